@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE — ctypes face of oracle/libfdc_oracle.so (the CPU restatement) and, when
+built, oracle/_ref/libref_windows.so (the reference's own lib/windows.h).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+package (gr-fdc_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfdc_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_windows.so")
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB) or (os.path.isdir("/root/reference") and not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def _load():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    lib.fdco_nextpow2.restype = C.c_long
+    lib.fdco_nextpow2.argtypes = [C.c_double]
+    lib.fdco_channel_params.restype = C.c_int
+    lib.fdco_channel_params.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _ip, _ip, _ip, _dp, _dp]
+    lib.fdco_window.restype = None
+    lib.fdco_window.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.fdco_overlap_save.restype = None
+    lib.fdco_overlap_save.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fdco_vector_cut.restype = None
+    lib.fdco_vector_cut.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fdco_phase_window.restype = None
+    lib.fdco_phase_window.argtypes = [C.c_int, C.c_int, C.c_int, _ip, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fdco_fft_vcc.restype = None
+    lib.fdco_fft_vcc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fdco_channelizer.restype = C.c_int
+    lib.fdco_channelizer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(_REF)
+
+
+def nextpow2(k):
+    r = lib().fdco_nextpow2(float(k))
+    if r < 0:
+        raise ValueError("Cannot evaluate next power 2 of {}".format(k))
+    return int(r)
+
+
+def channel_params(N, R, freq, bw):
+    """(f, l, lout, pbw, sbw) for an INTERNAL frequency/bandwidth pair."""
+    f, l, lo = C.c_int(), C.c_int(), C.c_int()
+    p, s = C.c_double(), C.c_double()
+    if lib().fdco_channel_params(N, R, float(freq), float(bw), f, l, lo, p, s) != 0:
+        raise ValueError("invalid channel ({}, {})".format(freq, bw))
+    return f.value, l.value, lo.value, p.value, s.value
+
+
+def window(wintype, blocksize, passbw, stopbw, R, step=1, normalize=False):
+    w = np.empty((R, blocksize), dtype=np.complex64)
+    lib().fdco_window(wintype, blocksize, passbw, stopbw, R, step, int(normalize), w.ctypes.data)
+    return w
+
+
+def ref_window(wintype, blocksize, passbw, stopbw, R, step=1, normalize=False):
+    """The reference's own cr_win (lib/windows.h:41), compiled into oracle/_ref."""
+    r = C.CDLL(_REF)
+    r.ref_cr_win.restype = None
+    r.ref_cr_win.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    w = np.empty((R, blocksize), dtype=np.complex64)
+    r.ref_cr_win(wintype, blocksize, passbw, stopbw, R, step, int(normalize), w.ctypes.data)
+    return w
+
+
+class OverlapSave:
+    """lib/overlap_save_impl.cc (stateful, byte-level)."""
+
+    def __init__(self, itemsize, outputlen, overlaplen):
+        self.itemsize, self.outlen, self.ovl = itemsize, outputlen, overlaplen
+        self.hist = np.zeros(itemsize * overlaplen, dtype=np.uint8)
+
+    def work(self, inp):
+        inp = np.ascontiguousarray(inp)
+        per = self.itemsize * (self.outlen - self.ovl)
+        n = inp.nbytes // per
+        out = np.empty(n * self.itemsize * self.outlen, dtype=np.uint8)
+        lib().fdco_overlap_save(self.itemsize, self.outlen, self.ovl, self.hist.ctypes.data,
+                                inp.ctypes.data, n, out.ctypes.data)
+        return out.view(inp.dtype)
+
+
+def vector_cut(itemsize, veclen, offset, blocklen, inp):
+    inp = np.ascontiguousarray(inp)
+    n = inp.nbytes // (itemsize * veclen)
+    out = np.empty(n * itemsize * blocklen, dtype=np.uint8)
+    lib().fdco_vector_cut(itemsize, veclen, offset, blocklen, inp.ctypes.data, n, out.ctypes.data)
+    return out.view(inp.dtype)
+
+
+class PhaseWindow:
+    """lib/phase_shifting_windowing_vcc_impl.cc (stateful)."""
+
+    def __init__(self, blocklen, numphasestates, shifts, passbw, stopbw, windowtype):
+        if passbw <= 0.0 or stopbw <= 0.0 or stopbw < passbw:
+            raise ValueError("invalid window bandwidths")
+        self.l, self.R = blocklen, numphasestates
+        self.shift = ((shifts % self.R) + self.R) % self.R
+        self.counter = C.c_int(0)
+        self.win = window(windowtype, blocklen, passbw, stopbw, self.R, 1, False)
+
+    def work(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.complex64)
+        n = inp.size // self.l
+        out = np.empty(n * self.l, dtype=np.complex64)
+        lib().fdco_phase_window(self.l, self.R, self.shift, self.counter, self.win.ctypes.data,
+                                inp.ctypes.data, n, out.ctypes.data)
+        return out
+
+
+def fft_vcc(n, forward, shift, inp):
+    inp = np.ascontiguousarray(inp, dtype=np.complex64)
+    out = np.empty_like(inp)
+    lib().fdco_fft_vcc(n, int(forward), int(shift), inp.ctypes.data, inp.size // n, out.ctypes.data)
+    return out
+
+
+def channelizer(N, R, wintype, chans, x, prefix=None, first_block=0, want_spectrum=False,
+                use_float=False, nthreads=1):
+    """chans: list of (f, l, pbw, sbw).  Returns (list of per-channel complex64 streams, spectrum|None)."""
+    H = N - N // R
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    nblocks = x.size // H
+    Cn = len(chans)
+    f = np.array([c[0] for c in chans], dtype=np.int32)
+    l = np.array([c[1] for c in chans], dtype=np.int32)
+    pbw = np.array([c[2] for c in chans], dtype=np.float32)
+    sbw = np.array([c[3] for c in chans], dtype=np.float32)
+    outs = [np.empty(nblocks * (int(li) - int(li) // R), dtype=np.complex64) for li in l]
+    ptrs = (C.c_void_p * max(Cn, 1))(*[o.ctypes.data for o in outs])
+    spec = np.empty(nblocks * N, dtype=np.complex64) if want_spectrum else None
+    if prefix is not None:
+        prefix = np.ascontiguousarray(prefix, dtype=np.complex64)
+        assert prefix.size == N // R
+    rc = lib().fdco_channelizer(N, R, wintype, Cn, f.ctypes.data, l.ctypes.data, pbw.ctypes.data,
+                                sbw.ctypes.data, first_block,
+                                prefix.ctypes.data if prefix is not None else None,
+                                x.ctypes.data, nblocks, ptrs,
+                                spec.ctypes.data if spec is not None else None,
+                                int(use_float), nthreads)
+    if rc != 0:
+        raise RuntimeError("oracle channelizer failed")
+    return outs, spec
