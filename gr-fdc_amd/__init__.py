@@ -1,0 +1,10 @@
+"""gr-fdc_amd — MI355X-native frequency-domain channelizer (the gr-FDC overlap-save hot path).
+
+Python host side: a mirror of the reference's Python face (python/FrequencyDomainChannelizer.py and the
+SWIG block factories of swig/FDC_swig.i) over the C-ABI in include/fdc_amd.h.  All signal processing
+runs in hand-written gfx950 HIP kernels (gr-fdc_amd/csrc); nothing here computes on the CPU.
+"""
+from ._lib import FdcError, lib, LIB_PATH                                   # noqa: F401
+from .blocks import overlap_save, vector_cut_vxx, phase_shifting_windowing_vcc, fft_vcc, window_table  # noqa: F401
+from .channelizer import (FrequencyDomainChannelizer, Pipeline, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
+                          nextpow2, get_opt_channelparams)

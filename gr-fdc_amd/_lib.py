@@ -1,0 +1,87 @@
+"""ctypes binding of libfdc_amd.so (the C-ABI in include/fdc_amd.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is visible the calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdc_amd.so")
+
+FDC_OK = 0
+STATUS_NAMES = {0: "FDC_OK", -1: "FDC_ERR_INVALID_ARGUMENT", -2: "FDC_ERR_HIP", -3: "FDC_ERR_NO_DEVICE",
+                -4: "FDC_ERR_UNSUPPORTED", -5: "FDC_ERR_NOMEM"}
+
+
+class FdcError(RuntimeError):
+    def __init__(self, status, text):
+        self.status = status
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), text))
+
+
+class fdc_channel(C.Structure):
+    _fields_ = [("f", C.c_int32), ("l", C.c_int32), ("passbw", C.c_float), ("stopbw", C.c_float)]
+
+
+class fdc_pipeline_cfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("blocklen", C.c_int32), ("relinvovl", C.c_int32),
+                ("windowtype", C.c_int32), ("nchannels", C.c_int32), ("channels", C.POINTER(fdc_channel)),
+                ("max_blocks", C.c_int32), ("chunk_blocks", C.c_int32), ("keep_spectrum", C.c_int32)]
+
+
+# every symbol include/fdc_amd.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    "fdc_last_error": (C.c_char_p, []),
+    "fdc_version": (C.c_char_p, []),
+    "fdc_device_count": (C.c_int, []),
+    "fdc_pipeline_create": (C.c_int, [C.POINTER(fdc_pipeline_cfg), C.POINTER(_vp)]),
+    "fdc_pipeline_destroy": (None, [_vp]),
+    "fdc_pipeline_input_samples": (C.c_int64, [_vp, C.c_int]),
+    "fdc_pipeline_output_samples": (C.c_int64, [_vp, C.c_int]),
+    "fdc_pipeline_channel_offset": (C.c_int64, [_vp, C.c_int, C.c_int]),
+    "fdc_pipeline_channel_lout": (C.c_int32, [_vp, C.c_int]),
+    "fdc_pipeline_work": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_reset": (None, [_vp]),
+    "fdc_pipeline_process_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "fdc_pipeline_synchronize": (C.c_int, [_vp]),
+    "fdc_pipeline_stream": (_vp, [_vp]),
+    "fdc_pipeline_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "fdc_pipeline_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
+    "fdc_overlap_save_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fdc_overlap_save_work": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "fdc_overlap_save_destroy": (None, [_vp]),
+    "fdc_vector_cut_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fdc_vector_cut_work": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "fdc_vector_cut_destroy": (None, [_vp]),
+    "fdc_phase_window_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                          C.POINTER(_vp)]),
+    "fdc_phase_window_work": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "fdc_phase_window_destroy": (None, [_vp]),
+    "fdc_window_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp]),
+    "fdc_fft_vcc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libfdc_amd.so once.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("gr-fdc_amd: %s is missing — build it with `make -C gr-fdc_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)      # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(status):
+    if status < 0:
+        raise FdcError(status, lib().fdc_last_error().decode())
+    return status

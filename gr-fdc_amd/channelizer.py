@@ -1,0 +1,241 @@
+"""Host-side counterpart of the reference's Python caller, python/FrequencyDomainChannelizer.py.
+
+`FrequencyDomainChannelizer` takes the same constructor arguments as the reference hier block (:46-60),
+derives the same channel parameters (:322-345) and lowers the throughput part of the flowgraph
+(:200-231, :283-299) to ONE fused device pipeline behind the C-ABI (include/fdc_amd.h) instead of
+4 + 6*C GNU Radio blocks.  `Pipeline` is the thin object over fdc_pipeline_* used by it, by the tests
+and by bench.py.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+class FREQMODE:                      # python/FrequencyDomainChannelizer.py:31-32
+    normalized, basebandfs, centerfreqfs = range(3)
+
+
+class VERBOSEMODE:                   # python/FrequencyDomainChannelizer.py:34-35
+    NOLOG, LOGTOCONSOLE, LOGTOFILE = range(3)
+
+
+class WINDOWTYPES:                   # lib/windows.h:28-32
+    RECTANGULAR, HANN, RAMP = range(3)
+
+
+def nextpow2(k):
+    """Smallest power of two >= k (python/FrequencyDomainChannelizer.py:37-40); ValueError for k < 1."""
+    if k < 1:
+        raise ValueError('Cannot evaluate next power 2 of {}'.format(k))
+    return 1 << int(math.ceil(math.log2(k)))
+
+
+def get_opt_channelparams(blocksize, relinvovl, freq, bw):
+    """(freq, bw) in INTERNAL units -> (f, l, lout, passband, stopband).
+
+    Same decisions as the reference method (python/FrequencyDomainChannelizer.py:322-345): slice length =
+    next power of two of the occupied bins with at least 20 % head-room, pass band 10 % wider than the
+    signal, stop band at the slice edge unless the pass band is below 0.7, slice centred on the rounded
+    carrier bin, wrapped below zero and clamped at the upper band edge."""
+    occupied = blocksize * bw
+    l = nextpow2(occupied)
+    if l < 1.2 * occupied:
+        l *= 2
+    passband = float(occupied) / float(l) * 1.1
+    stopband = 1.0
+    if passband >= 1.0:
+        passband = 1.0
+    elif passband < 0.7:
+        stopband = passband + 0.25
+    centre = int(round(freq * blocksize)) % blocksize
+    first = centre - l / 2
+    if first < 0:
+        first = (first + blocksize) % blocksize
+    if first + l > blocksize:
+        first = blocksize - l
+    return int(first), int(l), int(l) - int(l) // relinvovl, float(passband), float(stopband)
+
+
+class Pipeline:
+    """fdc_pipeline handle: channels = [(f, l, passbw, stopbw), ...]."""
+
+    def __init__(self, blocklen, relinvovl, channels, windowtype=WINDOWTYPES.HANN, max_blocks=64,
+                 device_id=0, chunk_blocks=0, keep_spectrum=False):
+        self._h = C.c_void_p()
+        self.N, self.R = int(blocklen), int(relinvovl)
+        self.channels = [(int(f), int(l), float(p), float(s)) for (f, l, p, s) in channels]
+        arr = (_lib.fdc_channel * max(1, len(self.channels)))()
+        for i, (f, l, p, s) in enumerate(self.channels):
+            arr[i].f, arr[i].l, arr[i].passbw, arr[i].stopbw = f, l, p, s
+        cfg = _lib.fdc_pipeline_cfg(device_id, self.N, self.R, int(windowtype), len(self.channels), arr,
+                                    int(max_blocks), int(chunk_blocks), int(bool(keep_spectrum)))
+        rc = _lib.lib().fdc_pipeline_create(C.byref(cfg), C.byref(self._h))
+        if rc == -1:
+            raise ValueError(_lib.lib().fdc_last_error().decode())
+        _lib.check(rc)
+        self.max_blocks = int(max_blocks)
+        self.keep_spectrum = bool(keep_spectrum)
+        self.ovl = self.N // self.R if self.N >= self.R else 0
+        self.H = self.N - self.ovl
+        self.lout = [_lib.lib().fdc_pipeline_channel_lout(self._h, c) for c in range(len(self.channels))]
+
+    # -- sizes
+    def output_samples(self, nblocks):
+        return int(_lib.lib().fdc_pipeline_output_samples(self._h, nblocks))
+
+    def channel_offset(self, c, nblocks):
+        return int(_lib.lib().fdc_pipeline_channel_offset(self._h, c, nblocks))
+
+    # -- host path (what sync_block::work() would call)
+    def work(self, x, want_spectrum=False):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if x.size % self.H:
+            raise ValueError("input must be a whole number of (N - N/R)-sample items")
+        nb = x.size // self.H
+        outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
+        spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
+        _lib.check(_lib.lib().fdc_pipeline_work(self._h, x.ctypes.data, nb, ptrs,
+                                               spec.ctypes.data if spec is not None else None))
+        return (outs, spec) if want_spectrum else outs
+
+    def reset(self):
+        _lib.lib().fdc_pipeline_reset(self._h)
+
+    # -- device path
+    def process_device(self, d_ring, first_block, nblocks, d_out, d_spectrum=None, stream=None):
+        _lib.check(_lib.lib().fdc_pipeline_process_device(self._h, d_ring, int(first_block), int(nblocks), d_out,
+                                                         d_spectrum, stream))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().fdc_pipeline_synchronize(self._h))
+
+    def stream(self):
+        return _lib.lib().fdc_pipeline_stream(self._h)
+
+    def enable_timing(self, on=True):
+        _lib.check(_lib.lib().fdc_pipeline_enable_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 3)()
+        _lib.check(_lib.lib().fdc_pipeline_last_kernel_ms(self._h, ms, 3))
+        return [float(v) for v in ms]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().fdc_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FrequencyDomainChannelizer:
+    """Same constructor as FDC.FrequencyDomainChannelizer (python/FrequencyDomainChannelizer.py:46-60).
+
+    work(samples) takes a whole number of (blocksize - blocksize/relinvovl)-sample items of the input
+    stream and returns the list of hier-block output ports: [spectrum (only if debug)] + one stream per
+    throughput channel (:292-299, :314-315).  State (overlap history, window phase) carries over calls.
+    """
+
+    def __init__(self, inptype, inpveclen, blocksize, relinvovl,
+                 throughput_channels,
+                 activity_controlled_channels,
+                 act_contr_threshold,
+                 fs, centerfrequency, freqmode,
+                 windowtype,
+                 msgoutput, fileoutput, outputpath,
+                 threaded,
+                 activity_detection_segments, act_det_threshold, minchandist,
+                 act_det_deactivation_delay, minchanflankpuffer, verbose,
+                 pow_act_deactivation_delay,
+                 pow_act_maxblocks, act_det_maxblocks,
+                 debug, device_id=0, max_blocks=64):
+        self.verbose = int(verbose)
+        self.itemsize = inptype
+        self.debug = bool(debug)
+        if self.itemsize != 8:
+            raise ValueError('Unknown input type. ')            # only gr_complex is reachable (:205-210)
+
+        # frequency conventions (:70-91): everything is stored normalised to [0, 1) with DC at 0.5
+        if freqmode in (FREQMODE.normalized, 'normalized'):
+            self.freqmode = FREQMODE.normalized
+            self.get_freq = lambda f: (f + 0.5) % 1.0
+            self.set_freq = lambda f: f - 0.5
+            self.get_bw = lambda bw: bw % 1.0
+            self.set_bw = lambda bw: bw
+        elif freqmode in (FREQMODE.basebandfs, 'basebandfs'):
+            self.freqmode = FREQMODE.basebandfs
+            self.get_freq = lambda f: (f / fs + 0.5) % 1.0
+            self.set_freq = lambda f: (f - 0.5) * fs
+            self.get_bw = lambda bw: (bw / fs) % 1.0
+            self.set_bw = lambda bw: bw * fs
+        elif freqmode in (FREQMODE.centerfreqfs, 'centerfreqfs'):
+            self.freqmode = FREQMODE.centerfreqfs
+            self.get_freq = lambda f: ((f - centerfrequency) / fs + 0.5) % 1.0
+            self.set_freq = lambda f: (f - 0.5) * fs + centerfrequency
+            self.get_bw = lambda bw: (bw / fs) % 1.0
+            self.set_bw = lambda bw: bw * fs
+        else:
+            raise ValueError('Unknown Frequency mode. Exiting...')
+
+        self.throughput_channels = self._convert(throughput_channels, self.get_channel, 'Throughput channels')
+        self.activity_controlled_channels = self._convert(activity_controlled_channels, self.get_channel,
+                                                          'Activity controlled channels')
+        self.activity_detection_segments = self._convert(activity_detection_segments, self.get_segment,
+                                                         'Activity detection segments')
+
+        self.inpveclen = int(inpveclen) if int(inpveclen) > 0 else 1
+        self.blocksize = nextpow2(blocksize)                    # :138
+        self.relinvovl = nextpow2(relinvovl)                    # :139
+        self.ovllen = self.blocksize // self.relinvovl          # :140
+        self.inpblocklen = self.blocksize - self.ovllen         # :141
+        if self.inpveclen != 1:
+            raise NotImplementedError("inpveclen > 1 (input already transformed, :284-290) is not built yet")
+
+        self.channel_params = [get_opt_channelparams(self.blocksize, self.relinvovl, fr, bw)
+                               for (fr, bw) in self.throughput_channels]
+        self.pipeline = Pipeline(self.blocksize, self.relinvovl,
+                                 [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
+                                 windowtype=int(windowtype), max_blocks=max_blocks, device_id=device_id,
+                                 keep_spectrum=self.debug)
+        self.N_throughput_channelizers = len(self.channel_params)
+
+    @staticmethod
+    def _convert(lst, conv, what):
+        out = []
+        if lst is None:
+            return out
+        if not isinstance(lst, (list, tuple)):
+            raise ValueError('{} are invalid. Exiting...'.format(what))
+        for k in lst:
+            c = conv(k)
+            if c is None:
+                raise ValueError('Cannot convert {} to channel/segment. must be list or tuple of two numbers. '.format(k))
+            out.append(c)
+        return out
+
+    def get_opt_channelparams(self, freq, bw):
+        return get_opt_channelparams(self.blocksize, self.relinvovl, freq, bw)
+
+    def get_channel(self, c):                                   # :349-352
+        if not isinstance(c, (list, tuple)) or len(c) != 2:
+            return None
+        return [self.get_freq(c[0]), self.get_bw(c[1])]
+
+    def get_segment(self, c):                                   # :354-357
+        if not isinstance(c, (list, tuple)) or len(c) != 2:
+            return None
+        return [self.get_freq(c[0]), self.get_freq(c[1])]
+
+    def work(self, samples):
+        if self.debug:
+            outs, spec = self.pipeline.work(samples, want_spectrum=True)
+            return [spec] + outs
+        return self.pipeline.work(samples)

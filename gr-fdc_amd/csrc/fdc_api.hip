@@ -1,0 +1,537 @@
+// C-ABI of the MI355X frequency-domain channelizer (include/fdc_amd.h): handles, device memory,
+// launch sequencing.  No CPU compute fallback exists: without a HIP device every create() fails.
+#include "../../include/fdc_amd.h"
+#include "fdc_kernels.h"
+#include "fdc_window.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+bool ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int select_device(int device_id)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(FDC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(FDC_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, n);
+    HIPCHK(hipSetDevice(device_id));
+    static std::once_flag once;
+    static hipError_t init_err = hipSuccess;
+    std::call_once(once, [] { init_err = fdc::init_kernels(); });
+    if (init_err != hipSuccess) return fail(FDC_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(init_err));
+    return FDC_OK;
+}
+
+// exp(-2 pi i k / n) designed in double, rounded once
+std::vector<float2> make_twiddles(int n)
+{
+    std::vector<float2> t(n);
+    for (int k = 0; k < n; k++) {
+        const double a = -2.0 * M_PI * double(k) / double(n);
+        t[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    }
+    return t;
+}
+
+}  // namespace
+
+struct fdc_pipeline {
+    fdc_pipeline_cfg cfg{};
+    int N = 0, R = 0, ovl = 0, H = 0, C = 0;
+    int chunk = 0;
+    int64_t sum_lout = 0;
+    std::vector<fdc::ChanDev> chans;
+    std::vector<std::pair<int, std::vector<int32_t>>> groups;   // (l, channel ids)
+    std::vector<size_t> group_off;
+    hipStream_t stream = nullptr;
+    // device memory
+    float2 *d_tw = nullptr; int ntab = 0;
+    float2 *d_wins = nullptr;
+    fdc::ChanDev *d_chans = nullptr;
+    int32_t *d_groups = nullptr;
+    float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
+    float2 *d_spec = nullptr;    // spectrum, chunk*N (or max_blocks*N with keep_spectrum)
+    float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
+    float2 *d_out = nullptr;     // work(): max_blocks*sum_lout
+    int64_t blockcount = 0;      // work(): blocks consumed so far
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    size_t ev_used = 0;
+    std::vector<std::array<size_t, 4>> ev_spans;   // start, mid, end-of-fft, end-of-channels
+};
+
+extern "C" {
+
+const char *fdc_last_error(void) { return g_err.c_str(); }
+const char *fdc_version(void) { return "gr-fdc_amd 0.1 (gfx950)"; }
+
+int fdc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fdc_window_table(int windowtype, int blocklen, float passbw, float stopbw, int numphasestates, int step,
+                     int normalize, float *w)
+{
+    if (blocklen < 1 || numphasestates < 1 || !w) return fail(FDC_ERR_INVALID_ARGUMENT, "bad window table arguments");
+    fdc::window_table(windowtype, blocklen, passbw, stopbw, numphasestates, step, normalize != 0,
+                      reinterpret_cast<std::complex<float> *>(w));
+    return FDC_OK;
+}
+
+void fdc_pipeline_destroy(fdc_pipeline *p)
+{
+    if (!p) return;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (auto e : p->events) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
+    (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
+{
+    if (!cfg || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const int N = cfg->blocklen, R = cfg->relinvovl;
+    if (!ispow2(N) || N < 2) return fail(FDC_ERR_INVALID_ARGUMENT, "blocklen %d must be a power of two >= 2", N);
+    if (!ispow2(R) || R < 2 || R > N) return fail(FDC_ERR_INVALID_ARGUMENT, "relinvovl %d must be a power of two in [2, blocklen]", R);
+    if (N > (1 << 24)) return fail(FDC_ERR_UNSUPPORTED, "blocklen %d above 2^24", N);
+    if (cfg->nchannels < 0 || (cfg->nchannels > 0 && !cfg->channels)) return fail(FDC_ERR_INVALID_ARGUMENT, "bad channel list");
+    if (cfg->max_blocks < 1) return fail(FDC_ERR_INVALID_ARGUMENT, "max_blocks must be >= 1");
+    for (int c = 0; c < cfg->nchannels; c++) {
+        const fdc_channel &ch = cfg->channels[c];
+        if (!ispow2(ch.l) || ch.l > N) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: l=%d must be a power of two <= blocklen", c, ch.l);
+        if (ch.f < 0 || ch.f + ch.l > N) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: slice [%d,%d) outside the spectrum", c, ch.f, ch.f + ch.l);
+        // predicates of phase_shifting_windowing_vcc_impl ctor (lib/phase_shifting_windowing_vcc_impl.cc:46-53)
+        if (ch.passbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: PassBw must not be <= 0", c);
+        if (ch.stopbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be <= 0", c);
+        if (ch.stopbw < ch.passbw) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be < PassBw", c);
+        if (ch.l > fdc::kMaxLdsFft) return fail(FDC_ERR_UNSUPPORTED, "channel %d: l=%d above %d not supported yet", c, ch.l, fdc::kMaxLdsFft);
+    }
+    int rc = select_device(cfg->device_id);
+    if (rc != FDC_OK) return rc;
+
+    fdc_pipeline *p = new fdc_pipeline();
+    p->cfg = *cfg; p->cfg.channels = nullptr;
+    p->N = N; p->R = R; p->ovl = N / R; p->H = N - p->ovl; p->C = cfg->nchannels;
+
+    // channel records + de-duplicated window tables
+    std::map<std::tuple<int, float, float>, int> winmap;
+    std::vector<std::complex<float>> pool;
+    int64_t off = 0;
+    for (int c = 0; c < p->C; c++) {
+        const fdc_channel &ch = cfg->channels[c];
+        fdc::ChanDev d{};
+        d.f = ch.f; d.l = ch.l; d.lout = ch.l - ch.l / R;
+        d.shift = ((ch.f % R) + R) % R;
+        d.out_off = off; off += d.lout;
+        auto key = std::make_tuple(ch.l, ch.passbw, ch.stopbw);
+        auto it = winmap.find(key);
+        if (it == winmap.end()) {
+            const int o = (int)pool.size();
+            pool.resize(pool.size() + (size_t)R * ch.l);
+            fdc::window_table(cfg->windowtype, ch.l, ch.passbw, ch.stopbw, R, 1, false, pool.data() + o);
+            it = winmap.emplace(key, o).first;
+        }
+        d.win_off = it->second;
+        p->chans.push_back(d);
+    }
+    p->sum_lout = off;
+    std::map<int, std::vector<int32_t>> bylen;
+    for (int c = 0; c < p->C; c++) bylen[p->chans[c].l].push_back(c);
+    std::vector<int32_t> flat;
+    for (auto &kv : bylen) {
+        p->group_off.push_back(flat.size());
+        p->groups.emplace_back(kv.first, kv.second);
+        flat.insert(flat.end(), kv.second.begin(), kv.second.end());
+    }
+
+    // chunking: keep tmp + spectrum of a chunk (2 * chunk*N*8 B) well inside the 256 MiB Infinity Cache
+    int chunk = cfg->chunk_blocks;
+    if (chunk <= 0) {
+        const int64_t budget = 96ll << 20;
+        chunk = (int)std::max<int64_t>(1, budget / (2ll * N * 8));
+    }
+    chunk = std::min(chunk, cfg->max_blocks);
+    p->chunk = chunk;
+
+#define CHK_OR_FREE(expr)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            int _rc = fail(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+            fdc_pipeline_destroy(p);                                                            \
+            return _rc;                                                                         \
+        }                                                                                       \
+    } while (0)
+
+    CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    p->ntab = N;
+    const std::vector<float2> tw = make_twiddles(N);
+    CHK_OR_FREE(hipMalloc(&p->d_tw, sizeof(float2) * (size_t)N));
+    CHK_OR_FREE(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
+    if (p->C > 0) {
+        CHK_OR_FREE(hipMalloc(&p->d_wins, sizeof(float2) * pool.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_wins, pool.data(), sizeof(float2) * pool.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_chans, sizeof(fdc::ChanDev) * p->chans.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_chans, p->chans.data(), sizeof(fdc::ChanDev) * p->chans.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_groups, sizeof(int32_t) * flat.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_groups, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+    }
+    if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
+    CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
+#undef CHK_OR_FREE
+    *out = p;
+    return FDC_OK;
+}
+
+int64_t fdc_pipeline_input_samples(const fdc_pipeline *p, int nblocks) { return p ? (int64_t)nblocks * p->H : 0; }
+int64_t fdc_pipeline_output_samples(const fdc_pipeline *p, int nblocks) { return p ? (int64_t)nblocks * p->sum_lout : 0; }
+int64_t fdc_pipeline_channel_offset(const fdc_pipeline *p, int c, int nblocks)
+{
+    if (!p || c < 0 || c >= p->C) return -1;
+    return (int64_t)nblocks * p->chans[c].out_off;
+}
+int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int c)
+{
+    if (!p || c < 0 || c >= p->C) return -1;
+    return p->chans[c].lout;
+}
+void *fdc_pipeline_stream(fdc_pipeline *p) { return p ? (void *)p->stream : nullptr; }
+
+int fdc_pipeline_synchronize(fdc_pipeline *p)
+{
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return FDC_OK;
+}
+
+int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable)
+{
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    p->timing = enable != 0;
+    return FDC_OK;
+}
+
+static int get_event(fdc_pipeline *p, size_t *idx)
+{
+    if (p->ev_used == p->events.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        p->events.push_back(e);
+    }
+    *idx = p->ev_used++;
+    return FDC_OK;
+}
+
+int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
+                                void *d_out, void *d_spectrum, void *stream)
+{
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0 || first_block < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative block count/index");
+    if (nblocks == 0) return FDC_OK;
+    if (!d_ring || (p->C > 0 && !d_out)) return fail(FDC_ERR_INVALID_ARGUMENT, "null device buffer");
+    if (d_spectrum && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    const float2 *ring = static_cast<const float2 *>(d_ring);
+    p->ev_used = 0; p->ev_spans.clear();
+    for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
+        const int nb = std::min(p->chunk, nblocks - m0);
+        float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
+        hipEvent_t ev[3]; hipEvent_t *evp = nullptr; std::array<size_t, 4> span{};
+        if (p->timing) {
+            for (int i = 0; i < 4; i++) { int rc = get_event(p, &span[i]); if (rc) return rc; }
+            for (int i = 0; i < 3; i++) ev[i] = p->events[span[i]];
+            evp = ev;
+        }
+        // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
+        HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
+                               1.0f / (float)p->N, p->d_tw, p->ntab, s, evp));
+        for (size_t g = 0; g < p->groups.size(); g++)
+            HIPCHK(fdc::launch_channels(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
+                                        (int)p->groups[g].second.size(), p->groups[g].first, p->N, p->R, nb, m0, nblocks,
+                                        first_block, p->d_wins, p->d_tw, p->ntab, s));
+        if (p->timing) {
+            HIPCHK(hipEventRecord(p->events[span[3]], s));
+            p->ev_spans.push_back(span);
+        }
+    }
+    return FDC_OK;
+}
+
+int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
+{
+    if (!p || !ms || n < 3) return fail(FDC_ERR_INVALID_ARGUMENT, "need room for 3 values");
+    ms[0] = ms[1] = ms[2] = 0.f;
+    for (auto &sp : p->ev_spans) {
+        float a = 0, b = 0, c = 0;
+        HIPCHK(hipEventSynchronize(p->events[sp[3]]));
+        HIPCHK(hipEventElapsedTime(&a, p->events[sp[0]], p->events[sp[1]]));
+        HIPCHK(hipEventElapsedTime(&b, p->events[sp[1]], p->events[sp[2]]));
+        HIPCHK(hipEventElapsedTime(&c, p->events[sp[2]], p->events[sp[3]]));
+        if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; } else { ms[0] += a; ms[1] += b; }
+        ms[2] += c;
+    }
+    return 3;
+}
+
+void fdc_pipeline_reset(fdc_pipeline *p)
+{
+    if (!p) return;
+    p->blockcount = 0;
+    if (p->d_ring) {
+        (void)hipSetDevice(p->cfg.device_id);
+        (void)hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream);
+        (void)hipStreamSynchronize(p->stream);
+    }
+}
+
+int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (nblocks == 0) return 0;
+    if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
+    if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    if (spectrum && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    if (!p->d_ring) {
+        HIPCHK(hipMalloc(&p->d_ring, sizeof(float2) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
+        HIPCHK(hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream));   // zero history (overlap_save_impl.cc:52)
+        if (p->sum_lout > 0) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
+    }
+    float2 *d_specfull = nullptr;
+    if (spectrum) HIPCHK(hipMalloc(&d_specfull, sizeof(float2) * (size_t)nblocks * p->N));
+    hipStream_t s = p->stream;
+    const size_t nin = (size_t)nblocks * p->H;
+    HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
+    int rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
+    if (rc != FDC_OK) { (void)hipFree(d_specfull); return rc; }
+    for (int c = 0; c < p->C; c++) {
+        if (!outs[c]) continue;
+        HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
+                              sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
+    }
+    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
+    // history <- last ovl samples of this call (overlap_save_impl.cc:78); src and dst never overlap (H >= ovl)
+    HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (d_specfull) HIPCHK(hipFree(d_specfull));
+    p->blockcount += nblocks;
+    return nblocks;
+}
+
+/* ---------------- single-block faces ---------------- */
+struct fdc_overlap_save {
+    int dev, itemsize, outlen, ovl; hipStream_t s; unsigned char *d_ring = nullptr, *d_out = nullptr; int cap = 0;
+};
+
+int fdc_overlap_save_create(int device_id, int itemsize, int outputlen, int overlaplen, fdc_overlap_save **out)
+{
+    if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (itemsize < 1 || outputlen < 1 || overlaplen < 0 || overlaplen >= outputlen)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "overlap_save: need itemsize>=1 and 0 <= overlaplen < outputlen");
+    if (2 * overlaplen > outputlen)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "overlap_save: overlaplen above outputlen/2 makes the reference read before its input buffer");
+    int rc = select_device(device_id); if (rc) return rc;
+    auto *b = new fdc_overlap_save{device_id, itemsize, outputlen, overlaplen, nullptr};
+    HIPCHK(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
+    *out = b;
+    return FDC_OK;
+}
+
+int fdc_overlap_save_work(fdc_overlap_save *b, const void *in, int nitems, void *out)
+{
+    if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    HIPCHK(hipSetDevice(b->dev));
+    const size_t isz = b->itemsize, inb = isz * (b->outlen - b->ovl), outb = isz * b->outlen, ovb = isz * b->ovl;
+    if (nitems > b->cap) {
+        unsigned char *nr = nullptr, *no = nullptr;
+        HIPCHK(hipMalloc(&nr, ovb + inb * nitems + 16));
+        HIPCHK(hipMalloc(&no, outb * nitems));
+        if (b->d_ring) HIPCHK(hipMemcpy(nr, b->d_ring, ovb, hipMemcpyDeviceToDevice));
+        else HIPCHK(hipMemset(nr, 0, ovb + 16));
+        (void)hipFree(b->d_ring); (void)hipFree(b->d_out);
+        b->d_ring = nr; b->d_out = no; b->cap = nitems;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_ring + ovb, in, inb * nitems, hipMemcpyHostToDevice, b->s));
+    HIPCHK(fdc::launch_overlap_save(b->d_ring, b->d_out, inb, outb, nitems, b->s));
+    HIPCHK(hipMemcpyAsync(out, b->d_out, outb * nitems, hipMemcpyDeviceToHost, b->s));
+    if (ovb) HIPCHK(hipMemcpyAsync(b->d_ring, b->d_ring + inb * nitems, ovb, hipMemcpyDeviceToDevice, b->s));
+    HIPCHK(hipStreamSynchronize(b->s));
+    return nitems;
+}
+
+void fdc_overlap_save_destroy(fdc_overlap_save *b)
+{
+    if (!b) return;
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_out);
+    if (b->s) (void)hipStreamDestroy(b->s);
+    delete b;
+}
+
+struct fdc_vector_cut {
+    int dev, itemsize, veclen, offset, blocklen; hipStream_t s; unsigned char *d_in = nullptr, *d_out = nullptr; int cap = 0;
+};
+
+int fdc_vector_cut_create(int device_id, int itemsize, int veclen, int offset, int blocklen, fdc_vector_cut **out)
+{
+    if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (itemsize < 1 || veclen < 1 || blocklen < 1 || offset < 0 || offset + blocklen > veclen)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "vector_cut: slice [offset, offset+blocklen) must lie inside the vector");
+    int rc = select_device(device_id); if (rc) return rc;
+    auto *b = new fdc_vector_cut{device_id, itemsize, veclen, offset, blocklen, nullptr};
+    HIPCHK(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
+    *out = b;
+    return FDC_OK;
+}
+
+int fdc_vector_cut_work(fdc_vector_cut *b, const void *in, int nitems, void *out)
+{
+    if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    HIPCHK(hipSetDevice(b->dev));
+    const size_t inb = (size_t)b->itemsize * b->veclen, outb = (size_t)b->itemsize * b->blocklen;
+    if (nitems > b->cap) {
+        (void)hipFree(b->d_in); (void)hipFree(b->d_out); b->d_in = b->d_out = nullptr; b->cap = 0;
+        HIPCHK(hipMalloc(&b->d_in, inb * nitems));
+        HIPCHK(hipMalloc(&b->d_out, outb * nitems));
+        b->cap = nitems;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_in, in, inb * nitems, hipMemcpyHostToDevice, b->s));
+    HIPCHK(fdc::launch_vector_cut(b->d_in, b->d_out, inb, (size_t)b->offset * b->itemsize, outb, nitems, b->s));
+    HIPCHK(hipMemcpyAsync(out, b->d_out, outb * nitems, hipMemcpyDeviceToHost, b->s));
+    HIPCHK(hipStreamSynchronize(b->s));
+    return nitems;
+}
+
+void fdc_vector_cut_destroy(fdc_vector_cut *b)
+{
+    if (!b) return;
+    (void)hipFree(b->d_in); (void)hipFree(b->d_out);
+    if (b->s) (void)hipStreamDestroy(b->s);
+    delete b;
+}
+
+struct fdc_phase_window {
+    int dev, l, R, shift, counter; hipStream_t s; float2 *d_win = nullptr, *d_in = nullptr, *d_out = nullptr; int cap = 0;
+};
+
+int fdc_phase_window_create(int device_id, int blocklen, int numphasestates, int shifts, float passbw, float stopbw,
+                            int windowtype, fdc_phase_window **out)
+{
+    if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    // lib/phase_shifting_windowing_vcc_impl.cc:46-53
+    if (passbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "PassBw in phase_shifting_windowing_vcc must not be <= 0");
+    if (stopbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "StopBw in phase_shifting_windowing_vcc must not be <= 0");
+    if (stopbw < passbw) return fail(FDC_ERR_INVALID_ARGUMENT, "StopBw must not be < PassBw in phase_shifting_windowing_vcc");
+    if (blocklen < 1 || numphasestates < 1) return fail(FDC_ERR_INVALID_ARGUMENT, "blocklen and numphasestates must be >= 1");
+    int rc = select_device(device_id); if (rc) return rc;
+    auto *b = new fdc_phase_window{device_id, blocklen, numphasestates,
+                                   ((shifts % numphasestates) + numphasestates) % numphasestates, 0, nullptr};
+    std::vector<std::complex<float>> w((size_t)numphasestates * blocklen);
+    fdc::window_table(windowtype, blocklen, passbw, stopbw, numphasestates, 1, false, w.data());
+    HIPCHK(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&b->d_win, sizeof(float2) * w.size()));
+    HIPCHK(hipMemcpy(b->d_win, w.data(), sizeof(float2) * w.size(), hipMemcpyHostToDevice));
+    *out = b;
+    return FDC_OK;
+}
+
+int fdc_phase_window_work(fdc_phase_window *b, const void *in, int nitems, void *out)
+{
+    if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    HIPCHK(hipSetDevice(b->dev));
+    const size_t nb = sizeof(float2) * (size_t)b->l * nitems;
+    if (nitems > b->cap) {
+        (void)hipFree(b->d_in); (void)hipFree(b->d_out); b->d_in = b->d_out = nullptr; b->cap = 0;
+        HIPCHK(hipMalloc(&b->d_in, nb));
+        HIPCHK(hipMalloc(&b->d_out, nb));
+        b->cap = nitems;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_in, in, nb, hipMemcpyHostToDevice, b->s));
+    HIPCHK(fdc::launch_phase_window(b->d_in, b->d_out, b->d_win, b->l, b->R, b->shift, b->counter, nitems, b->s));
+    HIPCHK(hipMemcpyAsync(out, b->d_out, nb, hipMemcpyDeviceToHost, b->s));
+    HIPCHK(hipStreamSynchronize(b->s));
+    b->counter = (int)(((long long)b->counter + (long long)(nitems % b->R) * b->shift) % b->R);
+    return nitems;
+}
+
+void fdc_phase_window_destroy(fdc_phase_window *b)
+{
+    if (!b) return;
+    (void)hipFree(b->d_win); (void)hipFree(b->d_in); (void)hipFree(b->d_out);
+    if (b->s) (void)hipStreamDestroy(b->s);
+    delete b;
+}
+
+int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, int nitems, void *out)
+{
+    if (!ispow2(n) || n < 2 || n > (1 << 24)) return fail(FDC_ERR_INVALID_ARGUMENT, "fft size %d must be a power of two in [2, 2^24]", n);
+    if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (!in || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null buffer");
+    int rc = select_device(device_id); if (rc) return rc;
+    const size_t nb = sizeof(float2) * (size_t)n * nitems;
+    float2 *d_in = nullptr, *d_out = nullptr, *d_tmp = nullptr, *d_tw = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_tmp); (void)hipFree(d_tw); };
+#define CHK2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    CHK2(hipMalloc(&d_in, nb));
+    CHK2(hipMalloc(&d_out, nb));
+    if (n > fdc::kMaxLdsFft) CHK2(hipMalloc(&d_tmp, nb));
+    const std::vector<float2> tw = make_twiddles(n);
+    CHK2(hipMalloc(&d_tw, sizeof(float2) * (size_t)n));
+    CHK2(hipMemcpy(d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice));
+    // forward+shift: halves of the output swapped; inverse+shift: halves of the input swapped
+    const int in_rot = (!forward && shift) ? n / 2 : 0, out_rot = (forward && shift) ? n / 2 : 0;
+    CHK2(fdc::launch_fft(d_in, (size_t)n, d_out, d_tmp, n, nitems, !forward, in_rot, out_rot, 1.0f, d_tw, n, nullptr, nullptr));
+    CHK2(hipDeviceSynchronize());
+    CHK2(hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost));
+#undef CHK2
+    cleanup();
+    return nitems;
+}
+
+}  // extern "C"

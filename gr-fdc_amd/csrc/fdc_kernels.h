@@ -1,0 +1,59 @@
+// Internal launcher interface between the C-ABI (fdc_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdc {
+
+constexpr int kThreads = 256;        // 4 wave64 per workgroup
+constexpr int kTileElems = 8192;     // complex points per LDS tile (64 KiB)
+constexpr int kMaxLdsFft = 8192;     // longest transform one workgroup does in LDS
+
+// Per-channel record in device memory.
+struct ChanDev {
+    int32_t f;          // first bin in the shifted spectrum
+    int32_t l;          // slice / IFFT length
+    int32_t lout;       // l - l/R
+    int32_t shift;      // ((f mod R)+R) mod R   (lib/phase_shifting_windowing_vcc_impl.cc:58)
+    int64_t out_off;    // sum of lout over preceding channels (samples per block)
+    int32_t win_off;    // offset of this channel's [R][l] table in the window pool (complex elements)
+    int32_t pad;
+};
+
+// Geometry of an LDS "column" FFT tile: TC independent transforms of length L, element (i, t) at i*ld + t.
+struct TileGeom {
+    int L, log2L, TC, log2TC, ld;
+    size_t lds_bytes() const { return (size_t)L * ld * sizeof(float2); }
+};
+TileGeom tile_geom(int L);
+
+// Two-pass split N = N1*N2 used above kMaxLdsFft.
+struct BigGeom { int N, N1, N2; TileGeom a /* length N2 */, b /* length N1 */; };
+BigGeom big_geom(int N);
+
+hipError_t init_kernels();   // raises the dynamic-LDS limits once per process
+
+// Forward/inverse batched FFT of `nitems` transforms of length N (any power of two >= 2).
+//   in : item m starts at in + m*in_stride (complex elements); element n is read at (n + in_rot) mod N
+//   out: item m at out + m*N; result bin k is stored at (k + out_rot) mod N, multiplied by scale
+//   tw : exp(-2 pi i k / ntab), k in [0, ntab), ntab >= N, ntab % N == 0
+//   tmp: nitems*N complex scratch (two-pass sizes only)
+hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,
+                      bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
+                      hipStream_t s, hipEvent_t *ev /* null or 3 events: start, after pass A, end */);
+
+// Fused slice + phase + window + ifftshift + IFFT(l) + overlap discard + *l for one group of channels of
+// equal l (<= kMaxLdsFft).  spec holds nb_chunk spectra; block m of the chunk is block mbase+m of the call.
+hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans, const int32_t *group,
+                           int ngroup, int l, int N, int R, int nb_chunk, int mbase, int nb_call,
+                           int64_t first_block, const float2 *wins, const float2 *tw, int ntab, hipStream_t s);
+
+// single-block faces
+hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,
+                               size_t out_item_bytes, int nitems, hipStream_t s);
+hipError_t launch_vector_cut(const unsigned char *in, unsigned char *out, size_t in_item_bytes, size_t shift_bytes,
+                             size_t out_item_bytes, int nitems, hipStream_t s);
+hipError_t launch_phase_window(const float2 *in, float2 *out, const float2 *win, int l, int R, int shift,
+                               int counter0, int nitems, hipStream_t s);
+
+}  // namespace fdc

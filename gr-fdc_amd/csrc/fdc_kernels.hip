@@ -1,0 +1,426 @@
+// gfx950 (MI355X, CDNA4) kernels of the frequency-domain channelizer — generic path.
+//
+// Everything here is wave64 / 256-thread workgroups, float32 complex (float2), Stockham autosort
+// radix-4 (+ one radix-2 pass when log2 L is odd) with the transform index on the SLOW axis of an LDS
+// tile: element i of transform t lives at lds[i*ld + t], lanes run over t (and then over butterflies),
+// so every LDS access of a wave is unit-stride.  One LDS buffer serves both sides of a pass: all reads
+// of a pass go to registers, barrier, then all writes (each point is read once and written once).
+//
+// Reference semantics implemented (paths in the reference tree):
+//   overlap-save gather     lib/overlap_save_impl.cc:70-78           (fused into the first FFT load)
+//   fft_vcc(N, fwd, shift)  python/FrequencyDomainChannelizer.py:206 (shift fused into the store index)
+//   multiply_const(1/N)     python/FrequencyDomainChannelizer.py:214 (fused into the store)
+//   vector_cut_vxx          lib/vector_cut_vxx_impl.cc:67-68         (fused into the channel load)
+//   phase-shifting window   lib/phase_shifting_windowing_vcc_impl.cc:80-83
+//   fft_vcc(l, inv, shift)  python/FrequencyDomainChannelizer.py:228 (ifftshift fused into the LDS index)
+//   cut + *l                python/FrequencyDomainChannelizer.py:229-231
+#include "fdc_kernels.h"
+
+namespace fdc {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem[];
+
+constexpr int kMaxB = kTileElems / 4 / kThreads;   // radix-4 butterflies per thread per pass (8)
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ float2 ldtw(const float2 *__restrict__ tw, int idx)
+{
+    float2 w = tw[idx];
+    if (INV) w.y = -w.y;
+    return w;
+}
+
+// TC = 2^log2TC transforms of length L = 2^log2L held in lds as [L][ld].  twstride = ntab / L.
+template <bool INV>
+__device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float2 *__restrict__ tw, int twstride)
+{
+    const int tid = threadIdx.x;
+    const int L = 1 << log2L;
+    const int cmask = (1 << log2TC) - 1;
+    int log2ns = 0;
+    for (; log2ns + 2 <= log2L; log2ns += 2) {
+        const int ns = 1 << log2ns;
+        const int q = L >> 2;
+        const int total = q << log2TC;
+        const int tstep = (L >> (log2ns + 2)) * twstride;
+        float2 o[kMaxB][4];
+#pragma unroll
+        for (int i = 0; i < kMaxB; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+                float2 v0 = lds[j * ld + c];
+                float2 v1 = lds[(j + q) * ld + c];
+                float2 v2 = lds[(j + 2 * q) * ld + c];
+                float2 v3 = lds[(j + 3 * q) * ld + c];
+                if (ns > 1) {
+                    v1 = cmulf(v1, ldtw<INV>(tw, k * tstep));
+                    v2 = cmulf(v2, ldtw<INV>(tw, 2 * k * tstep));
+                    v3 = cmulf(v3, ldtw<INV>(tw, 3 * k * tstep));
+                }
+                const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+                const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+                const float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
+                // forward: d * (-j) ; inverse: d * (+j)
+                const float2 a3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                o[i][0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+                o[i][1] = make_float2(a1.x + a3.x, a1.y + a3.y);
+                o[i][2] = make_float2(a0.x - a2.x, a0.y - a2.y);
+                o[i][3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kMaxB; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+                const int j0 = ((j >> log2ns) << (log2ns + 2)) + k;
+                lds[j0 * ld + c] = o[i][0];
+                lds[(j0 + ns) * ld + c] = o[i][1];
+                lds[(j0 + 2 * ns) * ld + c] = o[i][2];
+                lds[(j0 + 3 * ns) * ld + c] = o[i][3];
+            }
+        }
+        __syncthreads();
+    }
+    if (log2ns < log2L) {   // final radix-2 pass
+        const int ns = 1 << log2ns;
+        const int q = L >> 1;
+        const int total = q << log2TC;
+        const int tstep = (L >> (log2ns + 1)) * twstride;
+        float2 o[2 * kMaxB][2];
+#pragma unroll
+        for (int i = 0; i < 2 * kMaxB; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+                float2 v0 = lds[j * ld + c];
+                float2 v1 = lds[(j + q) * ld + c];
+                if (ns > 1) v1 = cmulf(v1, ldtw<INV>(tw, k * tstep));
+                o[i][0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                o[i][1] = make_float2(v0.x - v1.x, v0.y - v1.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * kMaxB; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+                const int j0 = ((j >> log2ns) << (log2ns + 1)) + k;
+                lds[j0 * ld + c] = o[i][0];
+                lds[(j0 + ns) * ld + c] = o[i][1];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- whole transform in one workgroup (N <= kMaxLdsFft): TC items per workgroup ------------------
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_small(const float2 *__restrict__ in, size_t in_stride,
+                                                        float2 *__restrict__ out, int log2N, int log2TC, int ld,
+                                                        int nitems, int in_rot, int out_rot, float scale,
+                                                        const float2 *__restrict__ tw, int twstride)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int N = 1 << log2N, TC = 1 << log2TC;
+    const int m0 = blockIdx.x * TC;
+    for (int e = threadIdx.x; e < (N << log2TC); e += kThreads) {
+        const int t = e >> log2N, i = e & (N - 1), m = m0 + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (m < nitems) v = in[(size_t)m * in_stride + ((i + in_rot) & (N - 1))];
+        lds[i * ld + t] = v;
+    }
+    __syncthreads();
+    fft_cols<INV>(lds, log2N, log2TC, ld, tw, twstride);
+    for (int e = threadIdx.x; e < (N << log2TC); e += kThreads) {
+        const int t = e >> log2N, kp = e & (N - 1), m = m0 + t;
+        if (m < nitems) {
+            const float2 v = lds[((kp - out_rot) & (N - 1)) * ld + t];
+            out[(size_t)m * N + kp] = make_float2(v.x * scale, v.y * scale);
+        }
+    }
+}
+
+// ---- two-pass transform N = N1*N2, n = n1 + N1*n2, k = N2*k1 + k2 -----------------------------------
+// Pass A: TC columns n1, length-N2 transforms over n2 (row stride N1 in memory), times W_N^(n1*k2),
+//         stored transposed-by-construction as T[k2][n1] (n1 contiguous).
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
+                                                         float2 *__restrict__ tmp, int log2N, int log2N1,
+                                                         int log2TC, int ld, int in_rot,
+                                                         const float2 *__restrict__ tw, int ntab)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int N = 1 << log2N, N1 = 1 << log2N1, log2N2 = log2N - log2N1, N2 = 1 << log2N2;
+    const int TC = 1 << log2TC;
+    const int c0 = blockIdx.x * TC;
+    const size_t m = blockIdx.y;
+    const float2 *src = in + m * in_stride;
+    for (int e = threadIdx.x; e < (N2 << log2TC); e += kThreads) {
+        const int r = e >> log2TC, c = e & (TC - 1);
+        const int n = c0 + c + (r << log2N1);
+        lds[r * ld + c] = src[(n + in_rot) & (N - 1)];
+    }
+    __syncthreads();
+    fft_cols<INV>(lds, log2N2, log2TC, ld, tw, ntab >> log2N2);
+    float2 *dst = tmp + m * (size_t)N;
+    const int twn = ntab >> log2N;
+    for (int e = threadIdx.x; e < (N2 << log2TC); e += kThreads) {
+        const int k2 = e >> log2TC, c = e & (TC - 1), n1 = c0 + c;
+        const float2 w = ldtw<INV>(tw, n1 * k2 * twn);
+        dst[((size_t)k2 << log2N1) + n1] = cmulf(lds[k2 * ld + c], w);
+    }
+}
+
+// Pass B: TR rows k2 of T, length-N1 transforms over n1 (contiguous in memory), result bin
+//         k = N2*k1 + k2 stored at (k + out_rot) mod N, scaled.
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_pass_b(const float2 *__restrict__ tmp, float2 *__restrict__ out,
+                                                         int log2N, int log2N1, int log2TR, int ld, int out_rot,
+                                                         float scale, const float2 *__restrict__ tw, int ntab)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int N = 1 << log2N, N1 = 1 << log2N1, log2N2 = log2N - log2N1;
+    const int TR = 1 << log2TR;
+    const int r0 = blockIdx.x * TR;
+    const size_t m = blockIdx.y;
+    const float2 *src = tmp + m * (size_t)N;
+    for (int e = threadIdx.x; e < (N1 << log2TR); e += kThreads) {
+        const int r = e >> log2N1, i = e & (N1 - 1);
+        lds[i * ld + r] = src[((size_t)(r0 + r) << log2N1) + i];
+    }
+    __syncthreads();
+    fft_cols<INV>(lds, log2N1, log2TR, ld, tw, ntab >> log2N1);
+    float2 *dst = out + m * (size_t)N;
+    for (int e = threadIdx.x; e < (N1 << log2TR); e += kThreads) {
+        const int k1 = e >> log2TR, r = e & (TR - 1);
+        const int k = (k1 << log2N2) + r0 + r;
+        const float2 v = lds[k1 * ld + r];
+        dst[(k + out_rot) & (N - 1)] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// ---- fused channel kernel ------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
+                                                       const ChanDev *__restrict__ chans,
+                                                       const int32_t *__restrict__ group, int ngroup, int log2l,
+                                                       int log2TC, int ld, int N, int R, int nb_chunk, int mbase,
+                                                       int nb_call, long long first_block,
+                                                       const float2 *__restrict__ wins,
+                                                       const float2 *__restrict__ tw, int twstride)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int l = 1 << log2l, TC = 1 << log2TC;
+    const long long ntrans = (long long)nb_chunk * ngroup;
+    const long long t0 = (long long)blockIdx.x * TC;
+    for (int e = threadIdx.x; e < (l << log2TC); e += kThreads) {
+        const int tl = e >> log2l, i = e & (l - 1);
+        const long long t = t0 + tl;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < ntrans) {
+            const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
+            const ChanDev ch = chans[group[gi]];
+            // vector_cut_vxx: bins [f, f+l) of block m's spectrum
+            const float2 x = spec[(size_t)m * N + ch.f + i];
+            // phase_shifting_windowing_vcc: counter_m = (m*shift) mod R in closed form
+            const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
+            const float2 w = wins[ch.win_off + cnt * l + i];
+            v = cmulf(x, w);
+        }
+        lds[((i + (l >> 1)) & (l - 1)) * ld + tl] = v;     // ifftshift of the IFFT input
+    }
+    __syncthreads();
+    fft_cols<true>(lds, log2l, log2TC, ld, tw, twstride);
+    const int lout = l - l / R, skip = l - lout;
+    const float scale = (float)l;
+    for (int e = threadIdx.x; e < lout * TC; e += kThreads) {
+        const int tl = e / lout, tt = e - tl * lout;
+        const long long t = t0 + tl;
+        if (t < ntrans) {
+            const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
+            const ChanDev ch = chans[group[gi]];
+            const float2 y = lds[(skip + tt) * ld + tl];
+            out[(size_t)nb_call * ch.out_off + (size_t)(mbase + m) * lout + tt] = make_float2(y.x * scale, y.y * scale);
+        }
+    }
+}
+
+// ---- single-block faces ----------------------------------------------------------------------------
+__global__ void k_copy_items(const unsigned char *__restrict__ in, unsigned char *__restrict__ out,
+                             size_t in_item_stride, size_t in_offset, size_t out_item_bytes)
+{
+    // one grid row per item; byte-granular so any itemsize works (the reference blocks are type-agnostic)
+    const size_t m = blockIdx.y;
+    const unsigned char *s = in + m * in_item_stride + in_offset;
+    unsigned char *d = out + m * out_item_bytes;
+    const size_t start = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const size_t step = (size_t)gridDim.x * blockDim.x * 16;
+    const bool aligned = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+    for (size_t b = start; b < out_item_bytes; b += step) {
+        if (aligned && b + 16 <= out_item_bytes) {
+            *reinterpret_cast<uint4 *>(d + b) = *reinterpret_cast<const uint4 *>(s + b);
+        } else {
+            const size_t e = b + 16 < out_item_bytes ? b + 16 : out_item_bytes;
+            for (size_t k = b; k < e; k++) d[k] = s[k];
+        }
+    }
+}
+
+__global__ void k_phase_window(const float2 *__restrict__ in, float2 *__restrict__ out,
+                               const float2 *__restrict__ win, int l, int R, int shift, int counter0)
+{
+    const int m = blockIdx.y;
+    const int cnt = (int)(((long long)counter0 + (long long)(m % R) * shift) % R);
+    const float2 *w = win + (size_t)cnt * l;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < l; i += gridDim.x * blockDim.x)
+        out[(size_t)m * l + i] = cmulf(in[(size_t)m * l + i], w[i]);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
+
+TileGeom tile_geom(int L)
+{
+    TileGeom g;
+    g.L = L; g.log2L = ilog2(L);
+    int tc = kTileElems / L; if (tc > 32) tc = 32; if (tc < 1) tc = 1;
+    g.TC = tc; g.log2TC = ilog2(tc);
+    g.ld = tc > 1 ? tc + 1 : 1;
+    return g;
+}
+
+BigGeom big_geom(int N)
+{
+    BigGeom g;
+    const int lg = ilog2(N);
+    const int lg1 = (lg + 1) / 2;          // N1 >= N2
+    g.N = N; g.N1 = 1 << lg1; g.N2 = 1 << (lg - lg1);
+    g.a = tile_geom(g.N2);
+    g.b = tile_geom(g.N1);
+    return g;
+}
+
+hipError_t init_kernels()
+{
+    const int maxlds = 160 * 1024;
+    hipError_t e;
+#define FDC_SETLDS(k) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
+    if (e != hipSuccess) return e;
+    FDC_SETLDS(k_fft_small<false>) FDC_SETLDS(k_fft_small<true>)
+    FDC_SETLDS(k_fft_pass_a<false>) FDC_SETLDS(k_fft_pass_a<true>)
+    FDC_SETLDS(k_fft_pass_b<false>) FDC_SETLDS(k_fft_pass_b<true>)
+    FDC_SETLDS(k_channels)
+#undef FDC_SETLDS
+    return hipSuccess;
+}
+
+hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,
+                      bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
+                      hipStream_t s, hipEvent_t *ev)
+{
+    if (nitems <= 0) return hipSuccess;
+    hipError_t e;
+    if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
+    if (N <= kMaxLdsFft) {
+        const TileGeom g = tile_geom(N);
+        dim3 grid((nitems + g.TC - 1) / g.TC);
+        if (inverse)
+            hipLaunchKernelGGL(k_fft_small<true>, grid, dim3(kThreads), g.lds_bytes(), s, in, in_stride, out, g.log2L,
+                               g.log2TC, g.ld, nitems, in_rot, out_rot, scale, tw, ntab / N);
+        else
+            hipLaunchKernelGGL(k_fft_small<false>, grid, dim3(kThreads), g.lds_bytes(), s, in, in_stride, out, g.log2L,
+                               g.log2TC, g.ld, nitems, in_rot, out_rot, scale, tw, ntab / N);
+        if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
+    } else {
+        const BigGeom g = big_geom(N);
+        const int lgN = ilog2(N), lgN1 = ilog2(g.N1);
+        for (int m0 = 0; m0 < nitems; m0 += 32768) {   // gridDim.y limit is 65535
+            const int nb = nitems - m0 < 32768 ? nitems - m0 : 32768;
+            dim3 ga(g.N1 / g.a.TC, nb), gb(g.N2 / g.b.TC, nb);
+            const float2 *src = in + (size_t)m0 * in_stride;
+            float2 *t = tmp + (size_t)m0 * N, *dst = out + (size_t)m0 * N;
+            if (inverse)
+                hipLaunchKernelGGL(k_fft_pass_a<true>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
+                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab);
+            else
+                hipLaunchKernelGGL(k_fft_pass_a<false>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
+                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab);
+            if (m0 == 0 && ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
+            if (inverse)
+                hipLaunchKernelGGL(k_fft_pass_b<true>, gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
+                                   g.b.log2TC, g.b.ld, out_rot, scale, tw, ntab);
+            else
+                hipLaunchKernelGGL(k_fft_pass_b<false>, gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
+                                   g.b.log2TC, g.b.ld, out_rot, scale, tw, ntab);
+        }
+    }
+    if (ev && (e = hipEventRecord(ev[2], s)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans, const int32_t *group,
+                           int ngroup, int l, int N, int R, int nb_chunk, int mbase, int nb_call,
+                           int64_t first_block, const float2 *wins, const float2 *tw, int ntab, hipStream_t s)
+{
+    if (nb_chunk <= 0 || ngroup <= 0) return hipSuccess;
+    const TileGeom g = tile_geom(l);
+    const long long ntrans = (long long)nb_chunk * ngroup;
+    dim3 grid((unsigned)((ntrans + g.TC - 1) / g.TC));
+    hipLaunchKernelGGL(k_channels, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
+                       g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    return hipGetLastError();
+}
+
+hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,
+                               size_t out_item_bytes, int nitems, hipStream_t s)
+{
+    // item i = ring bytes [i*in_item_bytes, i*in_item_bytes + out_item_bytes): the ring already starts
+    // with the history (lib/overlap_save_impl.cc:70-76)
+    if (nitems <= 0) return hipSuccess;
+    unsigned gx = (unsigned)((out_item_bytes / 16 + 255) / 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+    for (int m0 = 0; m0 < nitems; m0 += 32768) {
+        const int nb = nitems - m0 < 32768 ? nitems - m0 : 32768;
+        hipLaunchKernelGGL(k_copy_items, dim3(gx, nb), dim3(256), 0, s, ring + (size_t)m0 * in_item_bytes,
+                           out + (size_t)m0 * out_item_bytes, in_item_bytes, (size_t)0, out_item_bytes);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_vector_cut(const unsigned char *in, unsigned char *out, size_t in_item_bytes, size_t shift_bytes,
+                             size_t out_item_bytes, int nitems, hipStream_t s)
+{
+    if (nitems <= 0) return hipSuccess;
+    unsigned gx = (unsigned)((out_item_bytes / 16 + 255) / 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+    for (int m0 = 0; m0 < nitems; m0 += 32768) {
+        const int nb = nitems - m0 < 32768 ? nitems - m0 : 32768;
+        hipLaunchKernelGGL(k_copy_items, dim3(gx, nb), dim3(256), 0, s, in + (size_t)m0 * in_item_bytes,
+                           out + (size_t)m0 * out_item_bytes, in_item_bytes, shift_bytes, out_item_bytes);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_phase_window(const float2 *in, float2 *out, const float2 *win, int l, int R, int shift,
+                               int counter0, int nitems, hipStream_t s)
+{
+    if (nitems <= 0) return hipSuccess;
+    unsigned gx = (unsigned)((l + 255) / 256); if (gx > 64) gx = 64;
+    for (int m0 = 0; m0 < nitems; m0 += 32768) {
+        const int nb = nitems - m0 < 32768 ? nitems - m0 : 32768;
+        const int c0 = (int)(((long long)counter0 + (long long)(m0 % R) * shift) % R);
+        hipLaunchKernelGGL(k_phase_window, dim3(gx, nb), dim3(256), 0, s, in + (size_t)m0 * l, out + (size_t)m0 * l, win,
+                           l, R, shift, c0);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fdc

@@ -1,0 +1,148 @@
+/* fdc_amd.h — C-ABI of the MI355X (gfx950) frequency-domain channelizer.
+ *
+ * Drop-in boundary for the ONE hot path of gereonsuch/gr-FDC: overlap-save -> large forward FFT ->
+ * per-channel vector cut / phase-shifting window -> per-channel inverse FFT -> overlap discard.
+ * Plain pointers and sizes only; no C++ types, no exceptions, no torch types.  Every entry point names
+ * the reference interface it replaces (paths relative to the reference tree).  How the reference's
+ * blocks bind to these functions (C++ sync_block::work() bodies, ctypes stub) is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - samples are complex float32, interleaved (re, im): GNU Radio's gr_complex;
+ *  - every function returns FDC_OK (0) or a negative fdc_status; fdc_last_error() gives the text;
+ *  - a handle is used by one thread at a time (GNU Radio calls work() of one block instance from
+ *    one thread); distinct handles may be used concurrently;
+ *  - host pointers passed to *_work() are not retained after the call returns
+ *    (the runtime owns them only for the duration of work(): lib/overlap_save_impl.cc:62-81).
+ */
+#ifndef FDC_AMD_H
+#define FDC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FDC_OK = 0,
+    FDC_ERR_INVALID_ARGUMENT = -1, /* the predicates on which the reference ctors throw std::invalid_argument */
+    FDC_ERR_HIP = -2,              /* a HIP runtime call failed */
+    FDC_ERR_NO_DEVICE = -3,        /* no gfx950 device visible: the product path never falls back to the CPU */
+    FDC_ERR_UNSUPPORTED = -4,
+    FDC_ERR_NOMEM = -5
+} fdc_status;
+
+/* window shapes: lib/windows.h:28-32 */
+enum { FDC_WIN_RECTANGULAR = 0, FDC_WIN_HANN = 1, FDC_WIN_RAMP = 2 };
+
+const char *fdc_last_error(void);            /* thread-local text of the last failure */
+const char *fdc_version(void);
+int fdc_device_count(void);                  /* number of visible HIP devices (0 if none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused throughput pipeline = the chain python/FrequencyDomainChannelizer.py:200-231 wires:
+ *   stream_to_vector -> overlap_save (lib/overlap_save_impl.cc:62-81) -> fft_vcc(N, fwd, shift) (:206)
+ *   -> multiply_const_cc(1/N) (:214-216) -> per channel { vector_cut_vxx (lib/vector_cut_vxx_impl.cc:59-72)
+ *   -> phase_shifting_windowing_vcc (lib/phase_shifting_windowing_vcc_impl.cc:72-86) -> fft_vcc(l, inv, shift)
+ *   (:228) -> vector_cut_vxx(l, l-lout, lout) (:229) -> vector_to_stream (:230) -> multiply_const_cc(l) (:231) }.
+ * The spectrum stays in HBM; only input samples and channel outputs cross the boundary.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fdc_pipeline fdc_pipeline;
+
+typedef struct {
+    int32_t f;        /* first bin of the slice in the fftshifted spectrum (vector_cut_vxx offset) */
+    int32_t l;        /* slice / inverse-FFT length, power of two (vector_cut_vxx blocklen)          */
+    float passbw;     /* phase_shifting_windowing_vcc::make passbw                                   */
+    float stopbw;     /* phase_shifting_windowing_vcc::make stopbw                                   */
+} fdc_channel;
+
+typedef struct {
+    int32_t device_id;      /* HIP device ordinal */
+    int32_t blocklen;       /* N, power of two (hier block "blocksize", py:138)                      */
+    int32_t relinvovl;      /* R, power of two >= 2 (py:139); overlap = N/R                           */
+    int32_t windowtype;     /* FDC_WIN_* (hier block "windowtype", py:227)                            */
+    int32_t nchannels;
+    const fdc_channel *channels;
+    int32_t max_blocks;     /* largest nblocks a single work()/process call will carry               */
+    int32_t chunk_blocks;   /* blocks per internal launch group (0 = choose so intermediates stay in
+                               the 256 MiB Infinity Cache)                                           */
+    int32_t keep_spectrum;  /* != 0: keep the whole normalised spectrum of a call (debug port, py:314) */
+} fdc_pipeline_cfg;
+
+int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out);
+void fdc_pipeline_destroy(fdc_pipeline *p);
+
+/* sizes derived from the configuration */
+int64_t fdc_pipeline_input_samples(const fdc_pipeline *p, int nblocks);   /* nblocks*(N-N/R)            */
+int64_t fdc_pipeline_output_samples(const fdc_pipeline *p, int nblocks);  /* nblocks*sum_c lout_c       */
+int64_t fdc_pipeline_channel_offset(const fdc_pipeline *p, int channel, int nblocks); /* in d_out, samples */
+int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int channel);
+
+/* work()-shaped entry: host buffers, stateful like the block chain (overlap history + window counters
+ * persist across calls; lib/overlap_save_impl.h:33, lib/phase_shifting_windowing_vcc_impl.h:47).
+ *   in          nblocks*(N-N/R) new samples (what stream_to_vector hands overlap_save)
+ *   outs[c]     nblocks*lout_c samples for channel c (hier output port c)
+ *   spectrum    NULL, or nblocks*N samples of the normalised spectrum (needs keep_spectrum)
+ * Returns nblocks (items consumed, sync 1:1) or a negative fdc_status. */
+int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum);
+void fdc_pipeline_reset(fdc_pipeline *p);    /* history <- zeros, block counter <- 0 (fresh ctor state)  */
+
+/* Device-resident entry (stateless; the form bench.py and a device-side flowgraph use).
+ *   d_ring      device pointer: N/R halo samples preceding the span, then nblocks*(N-N/R) new samples
+ *   first_block global index of the span's first block (window phase = first_block*shift mod R)
+ *   d_out       device pointer, fdc_pipeline_output_samples() samples: channel c's stream of
+ *               nblocks*lout_c samples starts at fdc_pipeline_channel_offset(p, c, nblocks)
+ *   d_spectrum  NULL or device pointer for nblocks*N samples (needs keep_spectrum)
+ *   stream      hipStream_t (NULL = the handle's own stream).  Asynchronous: returns after enqueue. */
+int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
+                                void *d_out, void *d_spectrum, void *stream);
+int fdc_pipeline_synchronize(fdc_pipeline *p);
+void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
+
+/* Timing of the dominant kernels with HIP events on the stream they are launched on (bench.py's
+ * roofline leg).  After a process_device call with timing enabled, ms[] receives the summed duration of
+ * each kernel class: [0] forward FFT pass A, [1] forward FFT pass B (or the single-pass kernel),
+ * [2] fused channel kernel(s).  Returns the number of entries written. */
+int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable);
+int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-block faces (same arithmetic as the fused pipeline, one reference block each).
+ * ---------------------------------------------------------------------------------------------- */
+/* gr::FDC::overlap_save::make(itemsize, outputlen, overlaplen) — include/FDC/overlap_save.h:49,
+ * lib/overlap_save_impl.cc:41-81.  Type-agnostic byte copies on the device. */
+typedef struct fdc_overlap_save fdc_overlap_save;
+int fdc_overlap_save_create(int device_id, int itemsize, int outputlen, int overlaplen, fdc_overlap_save **out);
+int fdc_overlap_save_work(fdc_overlap_save *b, const void *in, int nitems, void *out);
+void fdc_overlap_save_destroy(fdc_overlap_save *b);
+
+/* gr::FDC::vector_cut_vxx::make(itemsize, veclen, offset, blocklen) — include/FDC/vector_cut_vxx.h:49,
+ * lib/vector_cut_vxx_impl.cc:41-72. */
+typedef struct fdc_vector_cut fdc_vector_cut;
+int fdc_vector_cut_create(int device_id, int itemsize, int veclen, int offset, int blocklen, fdc_vector_cut **out);
+int fdc_vector_cut_work(fdc_vector_cut *b, const void *in, int nitems, void *out);
+void fdc_vector_cut_destroy(fdc_vector_cut *b);
+
+/* gr::FDC::phase_shifting_windowing_vcc::make(blocklen, numphasestates, shifts, passbw, stopbw, windowtype)
+ * — include/FDC/phase_shifting_windowing_vcc.h:49, lib/phase_shifting_windowing_vcc_impl.cc:41-86.
+ * create fails with FDC_ERR_INVALID_ARGUMENT on the ctor's predicates (:46-53). */
+typedef struct fdc_phase_window fdc_phase_window;
+int fdc_phase_window_create(int device_id, int blocklen, int numphasestates, int shifts, float passbw,
+                            float stopbw, int windowtype, fdc_phase_window **out);
+int fdc_phase_window_work(fdc_phase_window *b, const void *in, int nitems, void *out);
+void fdc_phase_window_destroy(fdc_phase_window *b);
+
+/* Window table generator used by the faces above (lib/windows.h:41-78 cr_win): w receives
+ * [numphasestates][blocklen] complex float32.  Host-side, no device needed. */
+int fdc_window_table(int windowtype, int blocklen, float passbw, float stopbw, int numphasestates,
+                     int step, int normalize, float *w);
+
+/* Stand-alone batched FFT with the semantics of gr-fft fft_vcc(n, forward, rectangular, shift, *)
+ * (python/FrequencyDomainChannelizer.py:206,228) on host buffers: nitems transforms of length n. */
+int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, int nitems, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDC_AMD_H */

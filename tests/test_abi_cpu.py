@@ -1,0 +1,83 @@
+"""CPU tests (-m "not gpu") of the product's host side: the C-ABI library loads and exports every
+symbol include/fdc_amd.h declares, host-side window design and parameter derivation match the
+reference fixtures, and nothing silently computes on the CPU when no GPU is present."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gr_fdc_amd as G
+from gr_fdc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fdc_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fdc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    h = G.lib()
+    for name in sorted(declared):
+        assert hasattr(h, name), "libfdc_amd.so does not export " + name
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_no_oracle_in_product_sources():
+    """The product path must not import, link or call the oracle."""
+    pkg = os.path.join(ROOT, "gr-fdc_amd")
+    for dp, _dn, fn in os.walk(pkg):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "fdc_oracle" not in txt and "fdco_" not in txt and "oracle." not in txt.replace("oracle/", ""), f
+
+
+def test_window_table_bit_exact_vs_reference_fixture(golden_dir):
+    """fdc_window_table (product, host-side design) == the reference's own cr_win tables."""
+    z = np.load(os.path.join(golden_dir, "windows_ref.npz"))
+    for i, (t, l, p, s, R) in enumerate(z["params"]):
+        w = G.window_table(int(t), int(l), np.float32(p), np.float32(s), int(R))
+        assert (w.view(np.uint32) == z["case%02d" % i].view(np.uint32)).all(), i
+
+
+def test_get_opt_channelparams_golden(golden_dir):
+    for r in json.load(open(os.path.join(golden_dir, "channel_params.json"))):
+        got = G.get_opt_channelparams(r["N"], r["R"], (r["freq"] + 0.5) % 1.0, r["bw"] % 1.0)
+        assert list(got[:3]) == r["out"][:3]
+        assert abs(got[3] - r["out"][3]) < 1e-12 and abs(got[4] - r["out"][4]) < 1e-12
+
+
+def test_channelparams_match_oracle_on_a_sweep(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        N = int(2 ** rng.integers(6, 19)); R = int(2 ** rng.integers(1, 4))
+        fr = float(rng.uniform(0, 1)); bw = float(rng.uniform(2.0 / N, 0.3))
+        assert G.get_opt_channelparams(N, R, fr, bw) == oracle.channel_params(N, R, fr, bw)
+    with pytest.raises(ValueError):
+        G.nextpow2(0.5)
+
+
+@pytest.mark.skipif(G.lib().fdc_device_count() > 0, reason="a GPU is present")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(G.FdcError) as ei:
+        G.Pipeline(4096, 2, [(0, 256, 0.88, 1.0)])
+    assert "FDC_ERR_NO_DEVICE" in str(ei.value)
+    with pytest.raises(G.FdcError):
+        G.overlap_save(8, 16, 4)
+    with pytest.raises(G.FdcError):
+        G.fft_vcc(16, True, True, np.zeros(16, np.complex64))
+
+
+def test_argument_validation_precedes_device_use():
+    # predicates of the reference ctors (lib/phase_shifting_windowing_vcc_impl.cc:46-53) -> ValueError
+    with pytest.raises(ValueError):
+        G.phase_shifting_windowing_vcc(64, 2, 0, 0.9, 0.5, 1)
+    with pytest.raises(ValueError):
+        G.phase_shifting_windowing_vcc(64, 2, 0, 0.0, 0.5, 1)
+    with pytest.raises(ValueError):
+        G.Pipeline(4096, 2, [(4000, 256, 0.88, 1.0)])      # slice leaves the spectrum
+    with pytest.raises(ValueError):
+        G.Pipeline(1000, 2, [])                            # not a power of two

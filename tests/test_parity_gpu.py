@@ -1,0 +1,162 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same
+seeded inputs and against the committed golden fixtures.
+
+Tolerance (BASELINE.json north_star / SURVEY.md §8d): relative L2 error <= 1e-5 AND
+max|y - ref| / max|ref| <= 1e-5 on complex float32 streams; byte-copy blocks are bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gr_fdc_amd as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = a.astype(np.complex128); b = b.astype(np.complex128)
+    nb = np.linalg.norm(b)
+    if nb == 0:
+        return float(np.linalg.norm(a)), float(np.abs(a).max(initial=0))
+    return float(np.linalg.norm(a - b) / nb), float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def assert_close(a, b, what=""):
+    assert a.shape == b.shape, what
+    l2, mx = rel(a, b)
+    assert l2 <= TOL and mx <= TOL, "%s: l2=%.3g max=%.3g" % (what, l2, mx)
+
+
+def noise(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+# ---------------------------------------------------------------- single-block faces
+def test_overlap_save_block_bit_exact(oracle):
+    for itemsize, N, ovl in [(8, 64, 16), (4, 256, 128), (1, 40, 7), (8, 4096, 2048), (2, 10, 5)]:
+        H = N - ovl
+        raw = np.random.default_rng(N).integers(0, 256, size=7 * H * itemsize, dtype=np.uint8)
+        a, b = G.overlap_save(itemsize, N, ovl), oracle.OverlapSave(itemsize, N, ovl)
+        for lo, hi in [(0, 3), (3, 4), (4, 7)]:          # state carries across calls
+            x = raw[lo * H * itemsize:hi * H * itemsize]
+            assert (a.work(x) == b.work(x)).all()
+
+
+def test_vector_cut_block_bit_exact(oracle):
+    for itemsize, veclen, off, bl in [(8, 4096, 2413, 256), (8, 256, 64, 192), (1, 33, 5, 9), (4, 100, 0, 100)]:
+        x = np.random.default_rng(veclen).integers(0, 256, size=5 * veclen * itemsize, dtype=np.uint8)
+        got = G.vector_cut_vxx(itemsize, veclen, off, bl).work(x)
+        assert (got == oracle.vector_cut(itemsize, veclen, off, bl, x)).all()
+
+
+def test_phase_window_block(oracle):
+    for l, R, shifts, p, s, wt in [(256, 2, 1, 0.88, 1.0, 1), (64, 4, 7, 0.5, 0.8, 2), (16, 8, -3, 0.6, 0.85, 0),
+                                   (1024, 4, 2, 0.528, 0.778, 1)]:
+        a, b = G.phase_shifting_windowing_vcc(l, R, shifts, p, s, wt), oracle.PhaseWindow(l, R, shifts, p, s, wt)
+        for n in (3, 1, 5):
+            x = noise(n * l, l + n)
+            ya, yb = a.work(x), b.work(x)
+            assert np.abs(ya - yb).max() <= 1e-6 * np.abs(yb).max()
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 32, 128, 512, 2048, 8192, 16384, 65536, 262144])
+def test_fft_vcc_all_sizes(oracle, n):
+    items = 3 if n <= 65536 else 2
+    x = noise(items * n, n)
+    for fwd in (True, False):
+        for shift in (True, False):
+            assert_close(G.fft_vcc(n, fwd, shift, x), oracle.fft_vcc(n, fwd, shift, x), "n=%d fwd=%d shift=%d" % (n, fwd, shift))
+
+
+# ---------------------------------------------------------------- fused pipeline
+def test_golden_chain_fixtures(golden_dir):
+    """HIP pipeline vs the committed numpy.fft goldens (cfg1 plans incl. odd f, R=2/4/8, all windows)."""
+    z = np.load(os.path.join(golden_dir, "chain_numpy.npz"))
+    for case in json.loads(str(z["cases"])):
+        p = G.Pipeline(case["N"], case["R"], [tuple(c) for c in case["chans"]], windowtype=case["wintype"],
+                       max_blocks=case["nblocks"])
+        outs = p.work(z[case["name"] + "_x"])
+        for i, o in enumerate(outs):
+            assert_close(o, z[case["name"] + "_out%d" % i], "%s ch%d" % (case["name"], i))
+
+
+@pytest.mark.parametrize("N,R,nb", [(4096, 2, 9), (4096, 4, 9), (1024, 8, 5), (64, 2, 4), (16384, 2, 5),
+                                    (65536, 2, 4), (32768, 4, 3)])
+def test_pipeline_vs_oracle_mixed_plan(oracle, N, R, nb):
+    rng = np.random.default_rng(N + R)
+    chans = []
+    for _ in range(7):
+        l = int(2 ** rng.integers(1, min(12, int(np.log2(N))) + 1))
+        f = int(rng.integers(0, N - l + 1))
+        p = float(rng.uniform(0.3, 0.95)); s = float(min(1.0, p + rng.uniform(0.05, 0.4)))
+        chans.append((f, l, p, s))
+    chans.append((0, 1, 0.5, 1.0))                  # degenerate 1-bin channel
+    chans.append((N - 2, 2, 1.0, 1.0))              # touches the band edge, pass band 1 -> rectangular
+    H = N - N // R
+    x = noise(nb * H, N)
+    for wt in (0, 1, 2):
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, keep_spectrum=True)
+        outs, spec = p.work(x, want_spectrum=True)
+        ref, rspec = oracle.channelizer(N, R, wt, chans, x, want_spectrum=True)
+        assert_close(spec, rspec, "spectrum")
+        for c, (o, r) in enumerate(zip(outs, ref)):
+            assert_close(o, r, "N=%d R=%d wt=%d ch%d %s" % (N, R, wt, c, chans[c]))
+
+
+def test_state_carries_across_work_calls(oracle):
+    """Ragged call sizes: history (overlap_save_impl.h:33) and window counter (…windowing_vcc_impl.h:47)
+    persist; results equal one big call."""
+    N, R = 4096, 4
+    H = N - N // R
+    chans = [(2413, 256, 0.88, 1.0), (963, 1024, 0.528, 0.778), (7, 64, 0.6, 0.85)]
+    x = noise(11 * H, 99)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=6)
+    parts = [p.work(x[a * H:b * H]) for a, b in [(0, 1), (1, 6), (6, 6), (6, 8), (8, 11)]]
+    for c in range(len(chans)):
+        assert_close(np.concatenate([q[c] for q in parts]), ref[c], "ch%d" % c)
+    p.reset()
+    again = p.work(x[:3 * H])
+    for c in range(len(chans)):
+        assert_close(again[c], ref[c][:3 * p.lout[c]], "after reset ch%d" % c)
+
+
+def test_cfg2_tiled_256_channels_vs_oracle(oracle):
+    """BASELINE configs[1] at a size the oracle finishes in seconds: N=65536, R=2, 256 channels l=256."""
+    N, R, Cn, nb = 65536, 2, 256, 3
+    chans = [G.get_opt_channelparams(N, R, ((c + 0.5) / Cn - 0.5 + 0.5) % 1.0, 0.8 / Cn) for c in range(Cn)]
+    assert all(ch[:3] == (256 * c, 256, 128) for c, ch in enumerate(chans))
+    plan = [(f, l, p, s) for (f, l, _lo, p, s) in chans]
+    x = noise(nb * (N - N // R), 2025)
+    outs = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb).work(x)
+    ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+    for c in range(Cn):
+        assert_close(outs[c], ref[c], "ch%d" % c)
+
+
+def test_chunking_is_invisible(oracle):
+    N, R = 16384, 2
+    chans = [(100, 256, 0.88, 1.0), (5001, 512, 0.7, 0.95)]
+    x = noise(10 * (N - N // R), 5)
+    a = G.Pipeline(N, R, chans, max_blocks=10, chunk_blocks=3).work(x)
+    b = G.Pipeline(N, R, chans, max_blocks=10, chunk_blocks=10).work(x)
+    for p, q in zip(a, b):
+        assert (p.view(np.uint32) == q.view(np.uint32)).all()
+
+
+def test_hier_block_mirror(oracle):
+    """FrequencyDomainChannelizer face with the example flowgraph's parameters (examples/FDC_example.grc)."""
+    user = [[0.12, 0.05], [0.22, 0.1], [-0.14, 0.12], [0, 0.081]]
+    fdc = G.FrequencyDomainChannelizer(8, 1, 2 ** 12, 4, user, None, 6.0, 1.0, 0.0, 'normalized', 1,
+                                       False, False, "", False, None, 10.0, 0.005, 1, 0.2, 0, 0, 128, 128, True)
+    assert [cp[:3] for cp in fdc.channel_params] == [(2412, 256, 192), (2693, 512, 384), (963, 1024, 768), (1792, 512, 384)]
+    x = noise(6 * fdc.inpblocklen, 42)
+    ports = fdc.work(x)
+    plan = [(f, l, p, s) for (f, l, _lo, p, s) in fdc.channel_params]
+    ref, rspec = oracle.channelizer(4096, 4, 1, plan, x, want_spectrum=True)
+    assert_close(ports[0], rspec, "debug spectrum port")
+    for c in range(4):
+        assert_close(ports[1 + c], ref[c], "port %d" % (1 + c))
