@@ -120,9 +120,13 @@ class Pipeline:
         _lib.check(_lib.lib().fdc_pipeline_enable_timing(self._h, int(on)))
 
     def last_kernel_ms(self):
-        ms = (C.c_float * 3)()
-        _lib.check(_lib.lib().fdc_pipeline_last_kernel_ms(self._h, ms, 3))
+        """[ms pass A, ms pass B, ms channel kernels, launch groups] summed since enable/last readout."""
+        ms = (C.c_float * 4)()
+        _lib.check(_lib.lib().fdc_pipeline_last_kernel_ms(self._h, ms, 4))
         return [float(v) for v in ms]
+
+    def chunk_blocks(self):
+        return int(_lib.lib().fdc_pipeline_chunk_blocks(self._h))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -233,6 +233,7 @@ int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int c)
     return p->chans[c].lout;
 }
 void *fdc_pipeline_stream(fdc_pipeline *p) { return p ? (void *)p->stream : nullptr; }
+int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk : -1; }
 
 int fdc_pipeline_synchronize(fdc_pipeline *p)
 {
@@ -246,6 +247,7 @@ int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable)
 {
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     p->timing = enable != 0;
+    p->ev_used = 0; p->ev_spans.clear();
     return FDC_OK;
 }
 
@@ -271,7 +273,6 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const float2 *ring = static_cast<const float2 *>(d_ring);
-    p->ev_used = 0; p->ev_spans.clear();
     for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
         const int nb = std::min(p->chunk, nblocks - m0);
         float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
@@ -298,8 +299,9 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
 
 int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
 {
-    if (!p || !ms || n < 3) return fail(FDC_ERR_INVALID_ARGUMENT, "need room for 3 values");
+    if (!p || !ms || n < 4) return fail(FDC_ERR_INVALID_ARGUMENT, "need room for 4 values");
     ms[0] = ms[1] = ms[2] = 0.f;
+    ms[3] = (float)p->ev_spans.size();
     for (auto &sp : p->ev_spans) {
         float a = 0, b = 0, c = 0;
         HIPCHK(hipEventSynchronize(p->events[sp[3]]));
@@ -309,7 +311,8 @@ int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
         if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; } else { ms[0] += a; ms[1] += b; }
         ms[2] += c;
     }
-    return 3;
+    p->ev_used = 0; p->ev_spans.clear();
+    return 4;
 }
 
 void fdc_pipeline_reset(fdc_pipeline *p)

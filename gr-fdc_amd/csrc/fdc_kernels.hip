@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass_a(const float2 *__restric
                                                          const float2 *__restrict__ tw, int ntab)
 {
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
-    const int N = 1 << log2N, N1 = 1 << log2N1, log2N2 = log2N - log2N1, N2 = 1 << log2N2;
+    const int N = 1 << log2N, log2N2 = log2N - log2N1, N2 = 1 << log2N2;
     const int TC = 1 << log2TC;
     const int c0 = blockIdx.x * TC;
     const size_t m = blockIdx.y;

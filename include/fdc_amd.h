@@ -99,11 +99,14 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                 void *d_out, void *d_spectrum, void *stream);
 int fdc_pipeline_synchronize(fdc_pipeline *p);
 void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
+int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per internal launch group */
 
-/* Timing of the dominant kernels with HIP events on the stream they are launched on (bench.py's
- * roofline leg).  After a process_device call with timing enabled, ms[] receives the summed duration of
- * each kernel class: [0] forward FFT pass A, [1] forward FFT pass B (or the single-pass kernel),
- * [2] fused channel kernel(s).  Returns the number of entries written. */
+/* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's
+ * roofline leg).  While enabled, every process_device call brackets its launches with events; the readout
+ * synchronises on them, sums all launch groups since enable / the previous readout and clears them:
+ * ms[0] forward FFT pass A, ms[1] forward FFT pass B (or the single-pass kernel), ms[2] fused channel
+ * kernel(s), ms[3] = number of launch groups summed (each group = one chunk of fdc_pipeline_chunk_blocks
+ * blocks, the last of a call possibly shorter).  Needs n >= 4; returns the number of entries written. */
 int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable);
 int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n);
 
