@@ -8,6 +8,7 @@
 #include <array>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -77,6 +78,9 @@ struct fdc_pipeline {
     // device memory
     float2 *d_tw = nullptr; int ntab = 0;
     float2 *d_wins = nullptr;
+    float2 *d_tw256 = nullptr;   // fast path: exp(-2 pi i j/256)
+    float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
+    std::vector<char> g_aligned, g_out_aligned;   // per channel group
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
@@ -84,6 +88,7 @@ struct fdc_pipeline {
     float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
     float2 *d_out = nullptr;     // work(): max_blocks*sum_lout
     int64_t blockcount = 0;      // work(): blocks consumed so far
+    bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -117,6 +122,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (auto e : p->events) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -172,10 +178,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->chans.push_back(d);
     }
     p->sum_lout = off;
+    { const char *fg = getenv("FDC_FORCE_GENERIC"); p->cfg_generic = fg && fg[0] == '1'; }
     std::map<int, std::vector<int32_t>> bylen;
     for (int c = 0; c < p->C; c++) bylen[p->chans[c].l].push_back(c);
     std::vector<int32_t> flat;
     for (auto &kv : bylen) {
+        bool al = true, oal = true;
+        for (int c : kv.second) {
+            if (p->chans[c].f & 1) al = false;
+            if ((p->chans[c].out_off & 1) || (p->chans[c].lout & 1)) oal = false;
+        }
+        p->g_aligned.push_back(al); p->g_out_aligned.push_back(oal);
         p->group_off.push_back(flat.size());
         p->groups.emplace_back(kv.first, kv.second);
         flat.insert(flat.end(), kv.second.begin(), kv.second.end());
@@ -212,6 +225,25 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMemcpy(p->d_chans, p->chans.data(), sizeof(fdc::ChanDev) * p->chans.size(), hipMemcpyHostToDevice));
         CHK_OR_FREE(hipMalloc(&p->d_groups, sizeof(int32_t) * flat.size()));
         CHK_OR_FREE(hipMemcpy(p->d_groups, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<float2> t256(256);
+        for (int j = 0; j < 256; j++) {
+            const double a = -2.0 * M_PI * double(j) / 256.0;
+            t256[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        }
+        CHK_OR_FREE(hipMalloc(&p->d_tw256, sizeof(float2) * 256));
+        CHK_OR_FREE(hipMemcpy(p->d_tw256, t256.data(), sizeof(float2) * 256, hipMemcpyHostToDevice));
+    }
+    if (N == 65536) {
+        std::vector<float2> tf(65536);
+        for (int k2 = 0; k2 < 256; k2++)
+            for (int n1 = 0; n1 < 256; n1++) {
+                const double a = -2.0 * M_PI * double(n1 * k2) / 65536.0;
+                tf[k2 * 256 + n1] = make_float2(float(std::cos(a)), float(std::sin(a)));
+            }
+        CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * 65536));
+        CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * 65536, hipMemcpyHostToDevice));
     }
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
@@ -283,12 +315,24 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
-                               1.0f / (float)p->N, p->d_tw, p->ntab, s, evp));
-        for (size_t g = 0; g < p->groups.size(); g++)
-            HIPCHK(fdc::launch_channels(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
-                                        (int)p->groups[g].second.size(), p->groups[g].first, p->N, p->R, nb, m0, nblocks,
-                                        first_block, p->d_wins, p->d_tw, p->ntab, s));
+        if (p->N == 65536 && !p->cfg_generic)
+            HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
+                                        1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
+        else
+            HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
+                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp));
+        for (size_t g = 0; g < p->groups.size(); g++) {
+            const int l = p->groups[g].first;
+            if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
+                HIPCHK(fdc::launch_channels256(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
+                                               (int)p->groups[g].second.size(), p->g_aligned[g] != 0,
+                                               p->g_out_aligned[g] != 0, p->N, p->R, nb, m0, nblocks, first_block,
+                                               p->d_wins, p->d_tw256, s));
+            else
+                HIPCHK(fdc::launch_channels(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
+                                            (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks,
+                                            first_block, p->d_wins, p->d_tw, p->ntab, s));
+        }
         if (p->timing) {
             HIPCHK(hipEventRecord(p->events[span[3]], s));
             p->ev_spans.push_back(span);

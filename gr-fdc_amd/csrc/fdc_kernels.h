@@ -48,6 +48,17 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
                            int ngroup, int l, int N, int R, int nb_chunk, int mbase, int nb_call,
                            int64_t first_block, const float2 *wins, const float2 *tw, int ntab, hipStream_t s);
 
+// ---- fast path (fdc_fast256.hip): N = 65536 forward transform, l = 256 channels ------------------------
+//   tw256: exp(-2 pi i j/256), j in [0,256);  twf: [k2][n1] = exp(-2 pi i n1*k2/65536)
+hipError_t init_fast_kernels();
+hipError_t launch_fft65536(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int nitems, int out_rot,
+                           float scale, const float2 *tw256, const float2 *twf, hipStream_t s, hipEvent_t *ev);
+// needs an even discard length 256/R; aligned = all f even; out_aligned = all out_off and lout even
+hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *chans, const int32_t *group,
+                              int ngroup, bool aligned, bool out_aligned, int N, int R, int nb_chunk, int mbase,
+                              int nb_call, int64_t first_block, const float2 *wins, const float2 *tw256,
+                              hipStream_t s);
+
 // single-block faces
 hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,
                                size_t out_item_bytes, int nitems, hipStream_t s);

@@ -321,7 +321,7 @@ hipError_t init_kernels()
     FDC_SETLDS(k_fft_pass_b<false>) FDC_SETLDS(k_fft_pass_b<true>)
     FDC_SETLDS(k_channels)
 #undef FDC_SETLDS
-    return hipSuccess;
+    return init_fast_kernels();
 }
 
 hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,

@@ -160,3 +160,35 @@ def test_hier_block_mirror(oracle):
     assert_close(ports[0], rspec, "debug spectrum port")
     for c in range(4):
         assert_close(ports[1 + c], ref[c], "port %d" % (1 + c))
+
+
+@pytest.mark.parametrize("N,R", [(65536, 2), (65536, 4), (65536, 8), (4096, 2), (16384, 4)])
+def test_fast_l256_kernels_all_alignment_variants(oracle, N, R):
+    """The size-specialised kernels (N=65536 forward, l=256 channels): odd/even slice offsets, odd/even
+    output offsets (an l=1 channel in front makes every later offset odd), phase rotation for odd f."""
+    nb = 5
+    for lead in ([], [(0, 1, 0.5, 1.0)]):
+        chans = lead + [(3, 256, 0.88, 1.0), (512, 256, 0.6, 0.9), (1025, 256, 0.88, 1.0), (N - 256, 256, 0.7, 0.95),
+                        (2050, 256, 1.0, 1.0), (777, 128, 0.8, 1.0)]
+        x = noise(nb * (N - N // R), N + R + len(lead))
+        for wt in (1, 2):
+            outs = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).work(x)
+            ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
+            for c, (o, r) in enumerate(zip(outs, ref)):
+                assert_close(o, r, "N=%d R=%d lead=%d wt=%d ch%d" % (N, R, len(lead), wt, c))
+
+
+def test_fast_and_generic_paths_agree(oracle):
+    """FDC_FORCE_GENERIC=1 routes the same call through the generic LDS Stockham kernels."""
+    N, R, nb = 65536, 2, 3
+    chans = [(256 * c, 256, 0.88, 1.0) for c in range(0, 256, 17)] + [(1, 256, 0.88, 1.0)]
+    x = noise(nb * (N - N // R), 77)
+    fast = G.Pipeline(N, R, chans, max_blocks=nb, keep_spectrum=True).work(x, want_spectrum=True)
+    os.environ["FDC_FORCE_GENERIC"] = "1"
+    try:
+        slow = G.Pipeline(N, R, chans, max_blocks=nb, keep_spectrum=True).work(x, want_spectrum=True)
+    finally:
+        del os.environ["FDC_FORCE_GENERIC"]
+    assert_close(fast[1], slow[1], "spectrum")
+    for a, b in zip(fast[0], slow[0]):
+        assert_close(a, b)
