@@ -170,7 +170,9 @@ def main():
     chunk = pipe.chunk_blocks()
     ngroups = int(last[3])                      # launch groups timed = steps * ceil(nb / chunk)
     nlaunch = ngroups // a.steps
-    names = ["fft_pass_a", "fft_pass_b", "channels"]
+    path = pipe.path()
+    names = ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 else \
+            ["fft_pass_a", "fft_pass_b", "channels"]
     dom = max(range(3), key=lambda i: last[i])
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel
     blocks_per_launch = nb * a.steps / ngroups  # units one launch processes
@@ -183,7 +185,7 @@ def main():
         "config": {"workload": "configs[1]: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), "
                                "%d blocks/step/GPU" % (N, R, C, params[0][1], params[0][2], nb),
                    "blocklen": N, "relinvovl": R, "channels": C, "blocks_per_step_per_gpu": nb,
-                   "chunk_blocks": chunk, "parallelism": "block-span sharding x%d, no collective" % world},
+                   "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel_ms_per_step": {n: round(v / a.steps, 4) for n, v in zip(names, last)},

@@ -47,6 +47,7 @@ SYMBOLS = {
     "fdc_pipeline_synchronize": (C.c_int, [_vp]),
     "fdc_pipeline_stream": (_vp, [_vp]),
     "fdc_pipeline_chunk_blocks": (C.c_int32, [_vp]),
+    "fdc_pipeline_path": (C.c_int32, [_vp]),
     "fdc_pipeline_enable_timing": (C.c_int, [_vp, C.c_int]),
     "fdc_pipeline_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "fdc_overlap_save_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

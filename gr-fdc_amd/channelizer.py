@@ -125,6 +125,10 @@ class Pipeline:
         _lib.check(_lib.lib().fdc_pipeline_last_kernel_ms(self._h, ms, 4))
         return [float(v) for v in ms]
 
+    def path(self):
+        """0 generic kernels, 1 radix-16 kernels with a spectrum in memory, 2 uniform-plan two-stage path."""
+        return int(_lib.lib().fdc_pipeline_path(self._h))
+
     def chunk_blocks(self):
         return int(_lib.lib().fdc_pipeline_chunk_blocks(self._h))
 

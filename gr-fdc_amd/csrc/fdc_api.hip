@@ -81,6 +81,9 @@ struct fdc_pipeline {
     float2 *d_tw256 = nullptr;   // fast path: exp(-2 pi i j/256)
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
+    bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    float2 *d_twm = nullptr;     // [k2][n1] window * twiddle * sign / N
+    long long *d_slot_off = nullptr;
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
@@ -122,7 +125,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (auto e : p->events) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf);
+    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twm); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -194,11 +197,26 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         flat.insert(flat.end(), kv.second.begin(), kv.second.end());
     }
 
-    // chunking: keep tmp + spectrum of a chunk (2 * chunk*N*8 B) well inside the 256 MiB Infinity Cache
+    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*256 (fdc_fast256.hip)
+    {
+        const char *np = getenv("FDC_NO_POLY");
+        bool ok = N == 65536 && p->C > 0 && R <= 64 && !p->cfg_generic && !(np && np[0] == '1');
+        std::vector<char> used(256, 0);
+        for (int c = 0; ok && c < p->C; c++) {
+            const fdc_channel &ch = cfg->channels[c];
+            if (ch.l != 256 || (ch.f & 255) || used[ch.f >> 8] || ch.passbw != cfg->channels[0].passbw ||
+                ch.stopbw != cfg->channels[0].stopbw) ok = false;
+            else used[ch.f >> 8] = 1;
+        }
+        p->poly_ok = ok;
+    }
+    // launch groups.  The uniform path keeps its stage-1 output (256 KiB per block) inside the 256 MiB Infinity
+    // Cache between the two stages; the spectrum path streams through HBM anyway (measured: no gain from small
+    // groups, a loss from short launches), so it takes groups as large as a 2 GiB scratch budget allows.
     int chunk = cfg->chunk_blocks;
     if (chunk <= 0) {
-        const int64_t budget = 96ll << 20;
-        chunk = (int)std::max<int64_t>(1, budget / (2ll * N * 8));
+        if (p->poly_ok && !cfg->keep_spectrum) chunk = 256;
+        else chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
     }
     chunk = std::min(chunk, cfg->max_blocks);
     p->chunk = chunk;
@@ -245,6 +263,23 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * 65536));
         CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * 65536, hipMemcpyHostToDevice));
     }
+    if (p->poly_ok) {
+        std::vector<std::complex<float>> shape(256);
+        fdc::window_table(cfg->windowtype, 256, cfg->channels[0].passbw, cfg->channels[0].stopbw, 1, 0, true, shape.data());
+        std::vector<float2> tm(65536);
+        for (int k2 = 0; k2 < 256; k2++)
+            for (int n1 = 0; n1 < 256; n1++) {
+                const double a = -2.0 * M_PI * double(n1 * k2) / 65536.0;
+                const double g = double(shape[k2].real()) * ((n1 & 1) ? -1.0 : 1.0) / 65536.0;
+                tm[k2 * 256 + n1] = make_float2(float(g * std::cos(a)), float(g * std::sin(a)));
+            }
+        CHK_OR_FREE(hipMalloc(&p->d_twm, sizeof(float2) * 65536));
+        CHK_OR_FREE(hipMemcpy(p->d_twm, tm.data(), sizeof(float2) * 65536, hipMemcpyHostToDevice));
+        std::vector<long long> so(256, -1);
+        for (int c = 0; c < p->C; c++) so[p->chans[c].f >> 8] = p->chans[c].out_off;
+        CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * 256));
+        CHK_OR_FREE(hipMemcpy(p->d_slot_off, so.data(), sizeof(long long) * 256, hipMemcpyHostToDevice));
+    }
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
@@ -266,6 +301,13 @@ int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int c)
 }
 void *fdc_pipeline_stream(fdc_pipeline *p) { return p ? (void *)p->stream : nullptr; }
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk : -1; }
+int32_t fdc_pipeline_path(const fdc_pipeline *p)
+{
+    if (!p) return -1;
+    if (p->poly_ok) return 2;
+    if (p->N == 65536 && !p->cfg_generic) return 1;
+    return 0;
+}
 
 int fdc_pipeline_synchronize(fdc_pipeline *p)
 {
@@ -315,6 +357,16 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
+        if (p->poly_ok && !d_spectrum) {
+            // uniform plan: window + IFFT commuted in front of pass B; nothing but G (lout*N1 per block) in between
+            HIPCHK(fdc::launch_poly256(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_tmp, static_cast<float2 *>(d_out),
+                                       256, p->R, nb, m0, nblocks, p->d_tw256, p->d_twm, p->d_slot_off, s, evp));
+            if (p->timing) {
+                HIPCHK(hipEventRecord(p->events[span[3]], s));
+                p->ev_spans.push_back(span);
+            }
+            continue;
+        }
         if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));

@@ -208,6 +208,130 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
     }
 }
 
+// ---- uniform-plan path ("polyphase commutation") ------------------------------------------------------------
+// When every channel has l = 256 and f = 256*slot (the tiled plans of BASELINE configs[1] and [3]), pass B of the
+// forward transform (FFT over n1) commutes with the per-channel window + IFFT (which act on k2 only):
+//   y_c[t] = (-1)^t sum_n1 W_N1^(n1*k1) G[n1][t],   G[n1][t] = IFFT_k2{ W0[k2] W_N^(n1*k2) A[n1][k2] },  k1 = c + N1/2
+// so the spectrum never has to exist in memory.  Stage 1 (k_p1) does, per column n1: overlap-save gather,
+// FFT-256 over n2, times the combined table (window * inter-pass twiddle * (-1)^n1 * l/N), ifftshift, IFFT-256,
+// overlap discard, and stores G[t'][n1]; stage 2 (k_p2) is pass B on G: FFT over n1, result index = channel slot.
+// Exact algebra (SURVEY.md App. A.2-A.4 substituted into each other); rounding differs from the 3-kernel
+// path at the 1e-7 level.
+__global__ __launch_bounds__(256, 2) void k_p1(const float2 *__restrict__ in, size_t in_stride,
+                                               float2 *__restrict__ g, const float2 *__restrict__ tw256,
+                                               const float2 *__restrict__ twm, int N1, int skip, int lout)
+{
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
+    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + kTileBytes);
+    const int tid = threadIdx.x, cp = tid & 15, b = tid >> 4;
+    const int c0 = blockIdx.x * 32;
+    const size_t m = blockIdx.y;
+    const float2 *src = in + m * in_stride + c0 + 2 * cp;
+    float2 va[16], vb[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        const float4 t = ld4(src + (size_t)(16 * a + b) * N1);
+        va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
+    }
+    w256[tid] = tw256[tid];
+    dft16<false>(va); dft16<false>(vb);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const float2 w = w256[b * p];
+        st4(&tile[(16 * b + p) * 32 + 2 * cp], cmul(va[rev16(p)], w), cmul(vb[rev16(p)], w));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) {
+        const float4 t = ld4(&tile[(16 * bb + b) * 32 + 2 * cp]);
+        va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
+    }
+    dft16<false>(va); dft16<false>(vb);          // A[k2 = b + 16q] in va/vb[rev16(q)]
+    // window * twiddle * sign * scale, placed at the ifftshifted position (k2 ^ 128  <=>  q ^ 8).  The thread
+    // already holds exactly the inputs of ITS first inverse DFT-16 (fixed low digit b, all high digits q).
+    float2 ua[16], ub[16];
+    const float2 *twp = twm + c0 + 2 * cp;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float4 w = ld4(twp + (size_t)(b + 16 * q) * N1);
+        ua[q ^ 8] = cmul(va[rev16(q)], make_float2(w.x, w.y));
+        ub[q ^ 8] = cmul(vb[rev16(q)], make_float2(w.z, w.w));
+    }
+    dft16<true>(ua); dft16<true>(ub);
+    __syncthreads();                                // every thread has finished reading the first exchange
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        float2 w = w256[b * p];
+        w.y = -w.y;
+        st4(&tile[(16 * b + p) * 32 + 2 * cp], cmul(ua[rev16(p)], w), cmul(ub[rev16(p)], w));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) {
+        const float4 t = ld4(&tile[(16 * bb + b) * 32 + 2 * cp]);
+        ua[bb] = make_float2(t.x, t.y); ub[bb] = make_float2(t.z, t.w);
+    }
+    dft16<true>(ua); dft16<true>(ub);             // y[t = b + 16q]
+    float2 *dst = g + m * (size_t)lout * N1 + c0 + 2 * cp;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int t = b + 16 * q;
+        if (t >= skip) st4(dst + (size_t)(t - skip) * N1, ua[rev16(q)], ub[rev16(q)]);
+    }
+}
+
+// Stage 2 for N1 = 256 slots: rows rho = m*lout + t' of G (256 contiguous n1 each), FFT over n1, bin = slot c.
+__global__ __launch_bounds__(256, 2) void k_p2(const float2 *__restrict__ g, float2 *__restrict__ out,
+                                               const float2 *__restrict__ tw256,
+                                               const long long *__restrict__ slot_off, long long nrows,
+                                               long long out_base, long long nb_call)
+{
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
+    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + kTileBytes);
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 32;
+    float2 va[16], vb[16];
+    {
+        const int r = tid >> 3, bp = tid & 7;
+        const bool live = r0 + r < nrows;
+        const float2 *src = g + (size_t)(r0 + r) * 256 + 2 * bp;
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) t = ld4(src + 16 * a);
+            va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
+        }
+        w256[tid] = tw256[tid];
+        dft16<false>(va); dft16<false>(vb);
+        __syncthreads();
+        const int col = r ^ (bp << 1);
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            tile[(p * 16 + 2 * bp) * 32 + col] = cmul(va[rev16(p)], w256[(2 * bp) * p]);
+            tile[(p * 16 + 2 * bp + 1) * 32 + col] = cmul(vb[rev16(p)], w256[(2 * bp + 1) * p]);
+        }
+    }
+    __syncthreads();
+    {
+        const int rp = tid & 15, p = tid >> 4;
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) {
+            const float4 t = ld4(&tile[(p * 16 + bb) * 32 + ((2 * rp) ^ ((bb >> 1) << 1))]);
+            va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
+        }
+        dft16<false>(va); dft16<false>(vb);
+        const long long rho = r0 + 2 * rp;
+        if (rho < nrows) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const long long off = slot_off[p + 16 * q];     // per-block sample offset of the channel in this slot
+                if (off >= 0) st4(out + off * nb_call + out_base + rho, va[rev16(q)], vb[rev16(q)]);
+            }
+        }
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t init_fast_kernels()
 {
@@ -216,6 +340,10 @@ hipError_t init_fast_kernels()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_b256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
 #define FDC_SETC(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, c); \
@@ -257,6 +385,26 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
     else if (out_aligned) FDC_LC(false, true);
     else FDC_LC(false, false);
 #undef FDC_LC
+    return hipGetLastError();
+}
+
+hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 *out, int N1, int R, int nb_chunk,
+                          int mbase, int nb_call, const float2 *tw256, const float2 *twm,
+                          const long long *slot_off, hipStream_t s, hipEvent_t *ev)
+{
+    hipError_t e;
+    const int skip = 256 / R, lout = 256 - skip;
+    if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
+    for (int m0 = 0; m0 < nb_chunk; m0 += 32768) {
+        const int nb = nb_chunk - m0 < 32768 ? nb_chunk - m0 : 32768;
+        hipLaunchKernelGGL(k_p1, dim3(N1 / 32, nb), dim3(256), kTileBytes + 2048, s, in + (size_t)m0 * in_stride, in_stride,
+                           g + (size_t)m0 * lout * N1, tw256, twm, N1, skip, lout);
+    }
+    if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
+    const long long nrows = (long long)nb_chunk * lout;
+    hipLaunchKernelGGL(k_p2, dim3((unsigned)((nrows + 31) / 32)), dim3(256), kTileBytes + 2048, s, g, out, tw256, slot_off,
+                       nrows, (long long)mbase * lout, (long long)nb_call);
+    if (ev && (e = hipEventRecord(ev[2], s)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

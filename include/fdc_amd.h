@@ -100,6 +100,11 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
 int fdc_pipeline_synchronize(fdc_pipeline *p);
 void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per internal launch group */
+/* Which kernels a process call without spectrum output runs: 0 = generic LDS Stockham kernels (any size),
+ * 1 = radix-16 register kernels with the spectrum in memory (N = 65536), 2 = uniform-plan path (all channels
+ * l = 256 on the 256-bin grid: stage 1 = column FFT + window + IFFT, stage 2 = FFT across slots; timing
+ * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0). */
+int32_t fdc_pipeline_path(const fdc_pipeline *p);
 
 /* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's
  * roofline leg).  While enabled, every process_device call brackets its launches with events; the readout
