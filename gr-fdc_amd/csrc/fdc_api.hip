@@ -82,7 +82,8 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
-    float2 *d_twm = nullptr;     // [k2][n1] window * twiddle * sign / N
+    float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
+    float *d_shn = nullptr;                      // uniform path: shape[k2] / N
     long long *d_slot_off = nullptr;
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
@@ -125,7 +126,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (auto e : p->events) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twm); (void)hipFree(p->d_slot_off);
+    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -200,7 +201,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*256 (fdc_fast256.hip)
     {
         const char *np = getenv("FDC_NO_POLY");
-        bool ok = N == 65536 && p->C > 0 && R <= 64 && !p->cfg_generic && !(np && np[0] == '1');
+        bool ok = N == 65536 && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
         std::vector<char> used(256, 0);
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
@@ -210,14 +211,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         }
         p->poly_ok = ok;
     }
-    // launch groups.  The uniform path keeps its stage-1 output (256 KiB per block) inside the 256 MiB Infinity
-    // Cache between the two stages; the spectrum path streams through HBM anyway (measured: no gain from small
-    // groups, a loss from short launches), so it takes groups as large as a 2 GiB scratch budget allows.
+    // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
+    // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
+    // default takes groups as large as a 2 GiB scratch budget allows (1024 blocks at N = 65536).
     int chunk = cfg->chunk_blocks;
-    if (chunk <= 0) {
-        if (p->poly_ok && !cfg->keep_spectrum) chunk = 256;
-        else chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
-    }
+    if (chunk <= 0) chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
     chunk = std::min(chunk, cfg->max_blocks);
     p->chunk = chunk;
 
@@ -266,15 +264,24 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     if (p->poly_ok) {
         std::vector<std::complex<float>> shape(256);
         fdc::window_table(cfg->windowtype, 256, cfg->channels[0].passbw, cfg->channels[0].stopbw, 1, 0, true, shape.data());
-        std::vector<float2> tm(65536);
-        for (int k2 = 0; k2 < 256; k2++)
-            for (int n1 = 0; n1 < 256; n1++) {
-                const double a = -2.0 * M_PI * double(n1 * k2) / 65536.0;
-                const double g = double(shape[k2].real()) * ((n1 & 1) ? -1.0 : 1.0) / 65536.0;
-                tm[k2 * 256 + n1] = make_float2(float(g * std::cos(a)), float(g * std::sin(a)));
+        const int N1 = N / 256;
+        std::vector<float2> tq((size_t)N1 * 16), cb((size_t)N1 * 16);
+        std::vector<float> sn(256);
+        for (int n1 = 0; n1 < N1; n1++)
+            for (int j = 0; j < 16; j++) {
+                const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
+                const double ab = -2.0 * M_PI * double(n1 * j) / double(N);
+                const double sg = (n1 & 1) ? -1.0 : 1.0;
+                tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
+                cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
             }
-        CHK_OR_FREE(hipMalloc(&p->d_twm, sizeof(float2) * 65536));
-        CHK_OR_FREE(hipMemcpy(p->d_twm, tm.data(), sizeof(float2) * 65536, hipMemcpyHostToDevice));
+        for (int k2 = 0; k2 < 256; k2++) sn[k2] = float(double(shape[k2].real()) / double(N));
+        CHK_OR_FREE(hipMalloc(&p->d_twq, sizeof(float2) * tq.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_twq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_cbt, sizeof(float2) * cb.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_shn, sizeof(float) * 256));
+        CHK_OR_FREE(hipMemcpy(p->d_shn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
         std::vector<long long> so(256, -1);
         for (int c = 0; c < p->C; c++) so[p->chans[c].f >> 8] = p->chans[c].out_off;
         CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * 256));
@@ -357,10 +364,11 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        if (p->poly_ok && !d_spectrum) {
+        if (p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < (1ll << 32)) {
             // uniform plan: window + IFFT commuted in front of pass B; nothing but G (lout*N1 per block) in between
             HIPCHK(fdc::launch_poly256(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_tmp, static_cast<float2 *>(d_out),
-                                       256, p->R, nb, m0, nblocks, p->d_tw256, p->d_twm, p->d_slot_off, s, evp));
+                                       256, p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn,
+                                       p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), s, evp));
             if (p->timing) {
                 HIPCHK(hipEventRecord(p->events[span[3]], s));
                 p->ev_spans.push_back(span);

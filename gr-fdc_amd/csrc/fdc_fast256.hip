@@ -12,6 +12,7 @@
 // Index algebra: n = n1 + 256*n2, k = 256*k1 + k2 (same as the generic two-pass path in fdc_kernels.hip).
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
+#include <cstdlib>
 
 namespace fdc {
 
@@ -21,10 +22,30 @@ constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
 constexpr int kCTileBytes = 32 * 272 * 8;         // channel kernel: 32 rows padded to 272 points
 
 __device__ __forceinline__ float4 ld4(const float2 *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ void st4(float2 *p, float2 a, float2 b)
+__device__ __forceinline__ void st4(float2 *p, cf a, cf b)
 {
     *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, b.x, b.y);
 }
+__device__ __forceinline__ cf ld2(const float2 *p) { return *reinterpret_cast<const cf *>(p); }
+
+// Buffer addressing (SRD in SGPRs + 32-bit per-lane byte offset + scalar offset): no 64-bit VGPR address per access.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ cf bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cf v)
+{
+    u32x2 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+}
+__device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
 
 // ---- pass A -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, size_t in_stride,
@@ -37,25 +58,25 @@ __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, 
     const int c0 = blockIdx.x * 32;
     const size_t m = blockIdx.y;
     const float2 *src = in + m * in_stride + c0 + 2 * cp;
-    float2 va[16], vb[16];
+    cf va[16], vb[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) {          // rows n2 = 16a+b, two adjacent columns per lane
         const float4 t = ld4(src + (size_t)(16 * a + b) * 256);
-        va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
+        va[a] = mk(t.x, t.y); vb[a] = mk(t.z, t.w);
     }
     w256[tid] = tw256[tid];
     dft16<false>(va); dft16<false>(vb);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 16; p++) {          // W_256^(b*p), then row 16b+p of the exchange tile
-        const float2 w = w256[b * p];
+        const cf w = ld2(&w256[b * p]);
         st4(&tile[(16 * b + p) * 32 + 2 * cp], cmul(va[rev16(p)], w), cmul(vb[rev16(p)], w));
     }
     __syncthreads();
 #pragma unroll
     for (int bb = 0; bb < 16; bb++) {       // this thread now owns p' = b
         const float4 t = ld4(&tile[(16 * bb + b) * 32 + 2 * cp]);
-        va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
+        va[bb] = mk(t.x, t.y); vb[bb] = mk(t.z, t.w);
     }
     dft16<false>(va); dft16<false>(vb);
     float2 *dst = tmp + m * 65536 + c0 + 2 * cp;
@@ -64,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, 
     for (int q = 0; q < 16; q++) {          // k2 = b + 16q ; inter-pass twiddle W_N^(n1*k2)
         const int k2 = b + 16 * q;
         const float4 w = ld4(twp + k2 * 256);
-        st4(dst + k2 * 256, cmul(va[rev16(q)], make_float2(w.x, w.y)), cmul(vb[rev16(q)], make_float2(w.z, w.w)));
+        st4(dst + k2 * 256, cmul(va[rev16(q)], mk(w.x, w.y)), cmul(vb[rev16(q)], mk(w.z, w.w)));
     }
 }
 
@@ -77,14 +98,14 @@ __global__ __launch_bounds__(256, 2) void k_b256(const float2 *__restrict__ tmp,
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * 32;
     const size_t m = blockIdx.y;
-    float2 va[16], vb[16];
+    cf va[16], vb[16];
     {
         const int r = tid >> 3, bp = tid & 7;          // row k2 = r0+r, columns n1 = 16a + {2bp, 2bp+1}
         const float2 *src = tmp + m * 65536 + (size_t)(r0 + r) * 256 + 2 * bp;
 #pragma unroll
         for (int a = 0; a < 16; a++) {
             const float4 t = ld4(src + 16 * a);
-            va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
+            va[a] = mk(t.x, t.y); vb[a] = mk(t.z, t.w);
         }
         w256[tid] = tw256[tid];
         dft16<false>(va); dft16<false>(vb);
@@ -92,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void k_b256(const float2 *__restrict__ tmp,
         const int col = r ^ (bp << 1);                 // XOR swizzle: conflict-free b64 writes
 #pragma unroll
         for (int p = 0; p < 16; p++) {
-            tile[(p * 16 + 2 * bp) * 32 + col] = cmul(va[rev16(p)], w256[(2 * bp) * p]);
-            tile[(p * 16 + 2 * bp + 1) * 32 + col] = cmul(vb[rev16(p)], w256[(2 * bp + 1) * p]);
+            st2(&tile[(p * 16 + 2 * bp) * 32 + col], cmul(va[rev16(p)], ld2(&w256[(2 * bp) * p])));
+            st2(&tile[(p * 16 + 2 * bp + 1) * 32 + col], cmul(vb[rev16(p)], ld2(&w256[(2 * bp + 1) * p])));
         }
     }
     __syncthreads();
@@ -102,14 +123,14 @@ __global__ __launch_bounds__(256, 2) void k_b256(const float2 *__restrict__ tmp,
 #pragma unroll
         for (int bb = 0; bb < 16; bb++) {
             const float4 t = ld4(&tile[(p * 16 + bb) * 32 + ((2 * rp) ^ ((bb >> 1) << 1))]);
-            va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
+            va[bb] = mk(t.x, t.y); vb[bb] = mk(t.z, t.w);
         }
         dft16<false>(va); dft16<false>(vb);
         float2 *dst = spec + m * 65536;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int k = ((p + 16 * q) << 8) + r0 + 2 * rp;          // bin 256*k1 + k2
-            st4(dst + ((k + out_rot) & 65535), cscale(va[rev16(q)], scale), cscale(vb[rev16(q)], scale));
+            st4(dst + ((k + out_rot) & 65535), va[rev16(q)] * scale, vb[rev16(q)] * scale);
         }
     }
 }
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
         m = (int)(t / ngroup);
         ch = chans[group[(int)(t - (long long)m * ngroup)]];
     }
-    float2 va[16], vb[16];
+    cf va[16], vb[16];
     {
         // slice bins i = 16a + {2bp, 2bp+1} (vector_cut_vxx), times W[cnt][i] (phase_shifting_windowing_vcc),
         // stored at the ifftshifted position i ^ 128 — i.e. a -> a ^ 8
@@ -150,18 +171,18 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
         const float2 *wsrc = wins + ch.win_off + cnt * 256 + 2 * bp;
 #pragma unroll
         for (int a = 0; a < 16; a++) {
-            float2 x0 = make_float2(0.f, 0.f), x1 = x0;
+            cf x0 = mk(0.f, 0.f), x1 = x0;
             if (live) {
                 if (ALIGNED) {
                     const float4 tt = ld4(src + 16 * a);
-                    x0 = make_float2(tt.x, tt.y); x1 = make_float2(tt.z, tt.w);
+                    x0 = mk(tt.x, tt.y); x1 = mk(tt.z, tt.w);
                 } else {
-                    x0 = src[16 * a]; x1 = src[16 * a + 1];
+                    x0 = ld2(src + 16 * a); x1 = ld2(src + 16 * a + 1);
                 }
             }
             const float4 w = ld4(wsrc + 16 * a);
-            va[a ^ 8] = cmul(x0, make_float2(w.x, w.y));
-            vb[a ^ 8] = cmul(x1, make_float2(w.z, w.w));
+            va[a ^ 8] = cmul(x0, mk(w.x, w.y));
+            vb[a ^ 8] = cmul(x1, mk(w.z, w.w));
         }
         w256[tid] = tw256[tid];
         dft16<true>(va); dft16<true>(vb);
@@ -170,12 +191,11 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
         float2 *row = tile + r * 272;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            float2 w0 = w256[(2 * bp) * (2 * j)], w1 = w256[(2 * bp) * (2 * j + 1)];
-            w0.y = -w0.y; w1.y = -w1.y;                       // inverse transform: conjugate twiddles
-            st4(row + (2 * bp) * 16 + 2 * (j ^ bp), cmul(va[rev16(2 * j)], w0), cmul(va[rev16(2 * j + 1)], w1));
-            float2 w2 = w256[(2 * bp + 1) * (2 * j)], w3 = w256[(2 * bp + 1) * (2 * j + 1)];
-            w2.y = -w2.y; w3.y = -w3.y;
-            st4(row + (2 * bp + 1) * 16 + 2 * (j ^ bp), cmul(vb[rev16(2 * j)], w2), cmul(vb[rev16(2 * j + 1)], w3));
+            // inverse transform: conjugate twiddles
+            st4(row + (2 * bp) * 16 + 2 * (j ^ bp), cmulc(va[rev16(2 * j)], ld2(&w256[(2 * bp) * (2 * j)])),
+                cmulc(va[rev16(2 * j + 1)], ld2(&w256[(2 * bp) * (2 * j + 1)])));
+            st4(row + (2 * bp + 1) * 16 + 2 * (j ^ bp), cmulc(vb[rev16(2 * j)], ld2(&w256[(2 * bp + 1) * (2 * j)])),
+                cmulc(vb[rev16(2 * j + 1)], ld2(&w256[(2 * bp + 1) * (2 * j + 1)])));
         }
     }
     __syncthreads();
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
 #pragma unroll
         for (int bb = 0; bb < 16; bb++) {
             const float4 tt = ld4(row + bb * 16 + 2 * (pp ^ (bb >> 1)));
-            va[bb] = make_float2(tt.x, tt.y); vb[bb] = make_float2(tt.z, tt.w);
+            va[bb] = mk(tt.x, tt.y); vb[bb] = mk(tt.z, tt.w);
         }
         dft16<true>(va); dft16<true>(vb);
         if (live) {
@@ -197,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
                 const int tt = 2 * pp + 16 * q;
                 if (tt >= skip) {
                     if (OUT_ALIGNED) {
-                        st4(dst + (tt - skip), cscale(va[rev16(q)], 256.f), cscale(vb[rev16(q)], 256.f));
+                        st4(dst + (tt - skip), va[rev16(q)] * 256.f, vb[rev16(q)] * 256.f);
                     } else {
-                        dst[tt - skip] = cscale(va[rev16(q)], 256.f);
-                        dst[tt - skip + 1] = cscale(vb[rev16(q)], 256.f);
+                        st2(dst + (tt - skip), va[rev16(q)] * 256.f);
+                        st2(dst + (tt - skip + 1), vb[rev16(q)] * 256.f);
                     }
                 }
             }
@@ -217,118 +237,190 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
 // overlap discard, and stores G[t'][n1]; stage 2 (k_p2) is pass B on G: FFT over n1, result index = channel slot.
 // Exact algebra (SURVEY.md App. A.2-A.4 substituted into each other); rounding differs from the 3-kernel
 // path at the 1e-7 level.
-__global__ __launch_bounds__(256, 2) void k_p1(const float2 *__restrict__ in, size_t in_stride,
-                                               float2 *__restrict__ g, const float2 *__restrict__ tw256,
-                                               const float2 *__restrict__ twm, int N1, int skip, int lout)
+// Persistent: each workgroup (TC*16 threads, one column of 16 points per thread and layer) loops over tiles
+// (tile = block*N1/TC + column tile) and issues the NEXT tile's 16 global loads before it starts computing the
+// current one (register double buffer), so HBM latency hides under the four DFT-16 layers and two LDS
+// exchanges of the current tile.  TC = 32: 512 threads, 2 workgroups/CU; TC = 16: 256 threads, 4 workgroups/CU.
+// ABL (diagnostic builds only, FDC_ABLATE env): 0 = real kernel, 1 = memory only (loads -> stores, no math, no LDS),
+// 2 = math + LDS only (one load per thread, data kept live), results are garbage for ABL != 0.
+template <int TC, int ABL>
+__global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in, size_t in_stride,
+                                                   float2 *__restrict__ g, const float2 *__restrict__ tw256,
+                                                   const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
+                                                   const float *__restrict__ shn, int N1, int log2ct, int ntiles,
+                                                   int qskip, int lout)
 {
-    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
-    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + kTileBytes);
-    const int tid = threadIdx.x, cp = tid & 15, b = tid >> 4;
-    const int c0 = blockIdx.x * 32;
-    const size_t m = blockIdx.y;
-    const float2 *src = in + m * in_stride + c0 + 2 * cp;
-    float2 va[16], vb[16];
+    constexpr int NT = TC * 16;
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [256][TC]
+    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8);
+    float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8 + 2048);        // [q][col]
+    float *sh = reinterpret_cast<float *>(fdc_smem_fast + 256 * TC * 8 + 2048 + TC * 128);   // [k2]
+    const int tid = threadIdx.x, col = tid & (TC - 1), b = tid / TC;
+    int tl = blockIdx.x;
+    if (tl >= ntiles) return;
+    // The launcher keeps gridDim.x a multiple of the column tiles per block, so this workgroup always works on
+    // the same TC columns n1 = c0..c0+TC-1.  The factor the spectrum column is multiplied by,
+    //   shape[k2]/N * (-1)^n1 * W_N^(n1*k2),  k2 = b + 16q,
+    // is split into  shape[k2]/N (LDS, wave-uniform)  *  W_N^(16*n1*q) (LDS, TCx16 entries for this column tile)
+    // *  (-1)^n1 W_N^(n1*b) (one register pair per thread, applied AFTER the first inverse DFT-16, which is
+    // linear in it) — three short tables instead of a 64-register slice of the full N-entry table.
+    const int c0 = (tl & ((1 << log2ct) - 1)) * TC;
+    for (int i = tid; i < 256; i += NT) { w256[i] = tw256[i]; sh[i] = shn[i]; }
+    tq[tid] = twq[(size_t)(c0 + col) * 16 + b];            // b plays q here: tq[q*TC + col]
+    const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
+    // per-lane byte offset inside a block (row b, column c0+col); rows 16a+b add a*16*N1*8 bytes (scalar)
+    const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u;
+    const unsigned rowstep = 16u * (unsigned)N1 * 8u;
+    const unsigned inbytes = 256u * (unsigned)N1 * 8u;
+    const unsigned gtile = (unsigned)lout * TC * 8u;           // bytes of one (block, column tile) piece of G
+    const unsigned goff = (unsigned)(b * TC + col) * 8u;       // row b of a 16-row group, column col
+    const unsigned gstep = 16u * TC * 8u;                      // 16 rows further
+    // One tile: consume `cur` (loaded earlier), prefetch the next tile into `nbuf`.  Called with the two buffers
+    // swapped on alternate iterations (ping-pong), so no register copies are needed.
+    auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int t0, int nxt) {
+        const size_t m = t0 >> log2ct;
+        if (nxt < ntiles) {                                     // prefetch the next tile
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(nxt >> log2ct) * in_stride, inbytes);
+            if (ABL == 2) {
+                nbuf[0] = bld2(rin, voff, 0);
 #pragma unroll
-    for (int a = 0; a < 16; a++) {
-        const float4 t = ld4(src + (size_t)(16 * a + b) * N1);
-        va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
+                for (int a = 1; a < 16; a++) nbuf[a] = nbuf[0] * (float)a;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+            }
+        }
+        // G is stored tile-major, G[m][column tile][t'][TC]: this workgroup's whole output (lout*TC points) is
+        // one contiguous run, and stage 2 reads it back in runs of TC rows x TC columns.
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + (m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
+        if (ABL == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, cur[q]);
+            return;
+        }
+        dft16<false>(cur);
+        __syncthreads();                                        // tables ready / previous tile's LDS reads done
+        // twiddles first, as one batch: a table read between two tile writes would wait (lgkmcnt is in-order)
+        // for the write in front of it, once per element
+        cf w[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], cmul(cur[rev16(p)], w[p]));
+        __syncthreads();
+        cf v[16];
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+        dft16<false>(v);                              // A[k2 = b + 16q] in v[rev16(q)]
+        // window * twiddle, placed at the ifftshifted position (k2 ^ 128  <=>  q ^ 8).  The thread already
+        // holds exactly the inputs of ITS first inverse DFT-16 (fixed low digit b, all high digits q).
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b + 16 * q];
+        dft16<true>(u);
+#pragma unroll
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+#pragma unroll
+        for (int p = 0; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], w[p]), cb);
+        __syncthreads();                                // every thread has finished reading the first exchange
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], u[rev16(p)]);
+        __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+        dft16<true>(u);                               // y[t = b + 16q]
+        // row t - skip of this block's G, t = b + 16q; skip = 16*qskip, so the test is wave-uniform
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (q >= qskip && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+    };
+    cf L[16];
+    {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(tl >> log2ct) * in_stride, inbytes);
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
     }
-    w256[tid] = tw256[tid];
-    dft16<false>(va); dft16<false>(vb);
-    __syncthreads();
+    const int step = gridDim.x;
+    for (;;) {
+        cf cur[16];
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-        const float2 w = w256[b * p];
-        st4(&tile[(16 * b + p) * 32 + 2 * cp], cmul(va[rev16(p)], w), cmul(vb[rev16(p)], w));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int bb = 0; bb < 16; bb++) {
-        const float4 t = ld4(&tile[(16 * bb + b) * 32 + 2 * cp]);
-        va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
-    }
-    dft16<false>(va); dft16<false>(vb);          // A[k2 = b + 16q] in va/vb[rev16(q)]
-    // window * twiddle * sign * scale, placed at the ifftshifted position (k2 ^ 128  <=>  q ^ 8).  The thread
-    // already holds exactly the inputs of ITS first inverse DFT-16 (fixed low digit b, all high digits q).
-    float2 ua[16], ub[16];
-    const float2 *twp = twm + c0 + 2 * cp;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const float4 w = ld4(twp + (size_t)(b + 16 * q) * N1);
-        ua[q ^ 8] = cmul(va[rev16(q)], make_float2(w.x, w.y));
-        ub[q ^ 8] = cmul(vb[rev16(q)], make_float2(w.z, w.w));
-    }
-    dft16<true>(ua); dft16<true>(ub);
-    __syncthreads();                                // every thread has finished reading the first exchange
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
-        float2 w = w256[b * p];
-        w.y = -w.y;
-        st4(&tile[(16 * b + p) * 32 + 2 * cp], cmul(ua[rev16(p)], w), cmul(ub[rev16(p)], w));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int bb = 0; bb < 16; bb++) {
-        const float4 t = ld4(&tile[(16 * bb + b) * 32 + 2 * cp]);
-        ua[bb] = make_float2(t.x, t.y); ub[bb] = make_float2(t.z, t.w);
-    }
-    dft16<true>(ua); dft16<true>(ub);             // y[t = b + 16q]
-    float2 *dst = g + m * (size_t)lout * N1 + c0 + 2 * cp;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int t = b + 16 * q;
-        if (t >= skip) st4(dst + (size_t)(t - skip) * N1, ua[rev16(q)], ub[rev16(q)]);
+        for (int a = 0; a < 16; a++) cur[a] = L[a];
+        do_tile(cur, L, tl, tl + step);
+        tl += step;
+        if (tl >= ntiles) break;
     }
 }
 
 // Stage 2 for N1 = 256 slots: rows rho = m*lout + t' of G (256 contiguous n1 each), FFT over n1, bin = slot c.
-__global__ __launch_bounds__(256, 2) void k_p2(const float2 *__restrict__ g, float2 *__restrict__ out,
-                                               const float2 *__restrict__ tw256,
-                                               const long long *__restrict__ slot_off, long long nrows,
-                                               long long out_base, long long nb_call)
+// Persistent with next-tile prefetch like k_p1; a tile is TR consecutive rows (TR*2 KiB contiguous).
+template <int TR>
+__global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g, float2 *__restrict__ out,
+                                                   const float2 *__restrict__ tw256,
+                                                   const long long *__restrict__ slot_off, long long nrows,
+                                                   long long out_base, long long nb_call, unsigned out_bytes,
+                                                   int ntiles, int lout)
 {
-    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
-    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + kTileBytes);
+    constexpr int NT = TR * 16;
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [p][b][TR]
+    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TR * 8);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_fast + 256 * TR * 8 + 2048);
     const int tid = threadIdx.x;
-    const long long r0 = (long long)blockIdx.x * 32;
-    float2 va[16], vb[16];
-    {
-        const int r = tid >> 3, bp = tid & 7;
-        const bool live = r0 + r < nrows;
-        const float2 *src = g + (size_t)(r0 + r) * 256 + 2 * bp;
-#pragma unroll
-        for (int a = 0; a < 16; a++) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) t = ld4(src + 16 * a);
-            va[a] = make_float2(t.x, t.y); vb[a] = make_float2(t.z, t.w);
-        }
-        w256[tid] = tw256[tid];
-        dft16<false>(va); dft16<false>(vb);
-        __syncthreads();
-        const int col = r ^ (bp << 1);
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            tile[(p * 16 + 2 * bp) * 32 + col] = cmul(va[rev16(p)], w256[(2 * bp) * p]);
-            tile[(p * 16 + 2 * bp + 1) * 32 + col] = cmul(vb[rev16(p)], w256[(2 * bp + 1) * p]);
-        }
+    int tl = blockIdx.x;
+    if (tl >= ntiles) return;
+    for (int i = tid; i < 256; i += NT) {
+        w256[i] = tw256[i];
+        const long long o = slot_off[i];
+        // byte offset of row 0 of the slot's stream (the launcher guarantees the whole output spans < 4 GiB)
+        soff[i] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
-    __syncthreads();
-    {
-        const int rp = tid & 15, p = tid >> 4;
+    const int r = tid >> 4, b = tid & 15;            // layer 1: row r, points n1 = 16a + b
+    const int r2 = tid & (TR - 1), p2 = tid / TR;    // layer 2: row r2, outputs k1 = p2 + 16q
+    // G is tile-major (k_p1): G[m][ct][t'][TR] with TR columns per column tile.  Point n1 = 16a + b of row t'
+    // sits in column tile ct = n1 / TR at column n1 % TR.  A tile of this kernel = TR consecutive rows t' of one
+    // block (lout is a multiple of TR), i.e. for every ct a contiguous run of TR*TR points.
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    const int tpb = lout / TR;                                 // tiles per block
+    const unsigned ctstep = (unsigned)lout * TR * 8u;          // bytes between column tiles of one block
+    // TR = 16: ct = a, column = b.  TR = 32: ct = a >> 1, column = 16*(a & 1) + b.
+    const unsigned voff = (unsigned)(r * TR + b) * 8u;
+    cf L[16];
+    auto issue = [&](int t) {
+        const size_t m = t / tpb;
+        const int t0 = (t - (int)m * tpb) * TR;
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 256 + (size_t)t0 * TR, (unsigned)lout * 256u * 8u);
 #pragma unroll
-        for (int bb = 0; bb < 16; bb++) {
-            const float4 t = ld4(&tile[(p * 16 + bb) * 32 + ((2 * rp) ^ ((bb >> 1) << 1))]);
-            va[bb] = make_float2(t.x, t.y); vb[bb] = make_float2(t.z, t.w);
-        }
-        dft16<false>(va); dft16<false>(vb);
-        const long long rho = r0 + 2 * rp;
+        for (int a = 0; a < 16; a++)
+            L[a] = bld2(rg, voff + (TR == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TR == 32 ? a >> 1 : a) * ctstep);
+    };
+    issue(tl);
+    for (;;) {
+        cf v[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = L[a];
+        const int nxt = tl + gridDim.x;
+        if (nxt < ntiles) issue(nxt);
+        dft16<false>(v);
+        __syncthreads();
+        // element (row r, b, p) at (p*16 + b)*TR + (r ^ b) [mod TR]: conflict-free b64 writes and reads
+#pragma unroll
+        for (int p = 0; p < 16; p++)
+            st2(&tile[(p * 16 + b) * TR + ((r ^ b) & (TR - 1))], cmul(v[rev16(p)], ld2(&w256[b * p])));
+        __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(p2 * 16 + bb) * TR + ((r2 ^ bb) & (TR - 1))]);
+        dft16<false>(v);
+        const long long rho = (long long)tl * TR + r2;
         if (rho < nrows) {
+            const unsigned rbytes = (unsigned)rho * 8u;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const long long off = slot_off[p + 16 * q];     // per-block sample offset of the channel in this slot
-                if (off >= 0) st4(out + off * nb_call + out_base + rho, va[rev16(q)], vb[rev16(q)]);
+                const unsigned off = soff[p2 + 16 * q];         // start of the stream of the channel in this slot
+                if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[rev16(q)]);
             }
         }
+        if (nxt >= ntiles) break;
+        tl = nxt;
     }
 }
 
@@ -336,14 +428,20 @@ __global__ __launch_bounds__(256, 2) void k_p2(const float2 *__restrict__ g, flo
 hipError_t init_fast_kernels()
 {
     hipError_t e;
-    const int a = kTileBytes + 2048, c = kCTileBytes + 2048;
+    const int a = kTileBytes + 8192, c = kCTileBytes + 2048;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_b256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+#define FDC_SETP1(T, A) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1<T, A>), hipFuncAttributeMaxDynamicSharedMemorySize, a); \
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    FDC_SETP1(32, 0) FDC_SETP1(16, 0) FDC_SETP1(16, 1) FDC_SETP1(16, 2) FDC_SETP1(32, 1) FDC_SETP1(32, 2)
+#undef FDC_SETP1
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
 #define FDC_SETC(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, c); \
@@ -389,21 +487,49 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 }
 
 hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 *out, int N1, int R, int nb_chunk,
-                          int mbase, int nb_call, const float2 *tw256, const float2 *twm,
-                          const long long *slot_off, hipStream_t s, hipEvent_t *ev)
+                          int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
+                          const float *shn, const long long *slot_off, unsigned out_bytes, hipStream_t s,
+                          hipEvent_t *ev)
 {
     hipError_t e;
     const int skip = 256 / R, lout = 256 - skip;
-    if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
-    for (int m0 = 0; m0 < nb_chunk; m0 += 32768) {
-        const int nb = nb_chunk - m0 < 32768 ? nb_chunk - m0 : 32768;
-        hipLaunchKernelGGL(k_p1, dim3(N1 / 32, nb), dim3(256), kTileBytes + 2048, s, in + (size_t)m0 * in_stride, in_stride,
-                           g + (size_t)m0 * lout * N1, tw256, twm, N1, skip, lout);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
     }
+    static int tcfg = -1;                                   // FDC_POLY_TILE=16|32 (A/B testing); default 16
+    if (tcfg < 0) { const char *t = getenv("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
+    const int TC = (lout % tcfg) ? 16 : tcfg;              // stage-2 tiles are TC whole rows of one block
+    const int ct = N1 / TC;
+    int log2ct = 0;
+    while ((1 << log2ct) < ct) log2ct++;
+    int slots = (TC == 32 ? 2 : 4) * ncu;                   // resident workgroups: LDS-limited
+    slots -= slots % ct;                                    // k_p1 keeps a fixed column tile per workgroup
+    if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
+    const long long nt1 = (long long)nb_chunk * ct;
+    const unsigned g1 = (unsigned)(nt1 < slots ? nt1 : slots);
+    const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024, lds2 = 256 * TC * 8 + 2048 + 2048;
+    static int abl = -1;
+    if (abl < 0) { const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0; }
+#define FDC_LP1(T, A) \
+    hipLaunchKernelGGL((k_p1<T, A>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
+                       (int)nt1, skip / 16, lout)
+    if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else FDC_LP1(32, 0); }
+    else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else FDC_LP1(16, 0); }
+#undef FDC_LP1
     if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
     const long long nrows = (long long)nb_chunk * lout;
-    hipLaunchKernelGGL(k_p2, dim3((unsigned)((nrows + 31) / 32)), dim3(256), kTileBytes + 2048, s, g, out, tw256, slot_off,
-                       nrows, (long long)mbase * lout, (long long)nb_call);
+    const long long nt2 = (nrows + TC - 1) / TC;
+    const unsigned g2 = (unsigned)(nt2 < slots ? nt2 : slots);
+    if (TC == 32)
+        hipLaunchKernelGGL(k_p2<32>, dim3(g2), dim3(512), lds2, s, g, out, tw256, slot_off, nrows,
+                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt2, lout);
+    else
+        hipLaunchKernelGGL(k_p2<16>, dim3(g2), dim3(256), lds2, s, g, out, tw256, slot_off, nrows,
+                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt2, lout);
     if (ev && (e = hipEventRecord(ev[2], s)) != hipSuccess) return e;
     return hipGetLastError();
 }

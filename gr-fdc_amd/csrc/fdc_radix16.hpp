@@ -3,48 +3,89 @@
 // dft16<INV>(v): v[n], n = 4a+b, is replaced by the 16-point DFT X[k], k = p+4q, which is left in
 // DIGIT-REVERSED register order: X[k] sits in v[rev16(k)] with rev16(k) = 4*(k&3) + (k>>2).  Every index
 // below is a compile-time constant after unrolling, so the arrays live in VGPRs.
+//
+// Complex values are clang 2-vectors (cf = float x2) so that complex add/sub/scale lower to the packed
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 of gfx950 (one instruction for re and im).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace fdc {
 
+typedef float cf __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+__device__ __forceinline__ cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cf from2(float2 a) { return mk(a.x, a.y); }
+__device__ __forceinline__ float2 to2(cf a) { return make_float2(a.x, a.y); }
+
+// (a.x + j a.y)(b.x + j b.y) as two packed ops: t = a.xx*b ; r = a.yy*(-b.y, b.x) + t.  The half swap and the
+// sign of the second product are op_sel / neg modifiers (hipcc's C lowering spends a v_xor + v_mov on them).
+__device__ __forceinline__ cf cmul(cf a, cf b)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    cf r;   // one asm block: hipcc pads an s_nop between separate asm statements
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "v"(b));
+    return r;
 }
-__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
+{
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// multiply by -j (forward) / +j (inverse)
+template <bool INV>
+__device__ __forceinline__ cf mulj(cf d) { return INV ? mk(-d.y, d.x) : mk(d.y, -d.x); }
+
+// a + (-j)*d = (a.x + d.y, a.y - d.x)  and  a - (-j)*d = (a.x - d.y, a.y + d.x) in ONE packed add each: the
+// half swap of d is an op_sel, the sign a neg modifier (hipcc emits v_xor + v_mov + v_pk_add for the C form).
+__device__ __forceinline__ cf add_mj(cf a, cf d)     // a + (-j) d
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ cf add_pj(cf a, cf d)     // a + (+j) d
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
 
 template <bool INV>
-__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+__device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-    const float2 s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = csub(a1, a3);
-    // forward: -j*d1 ; inverse: +j*d1
-    const float2 jd = INV ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
-    a0 = cadd(s0, s1); a1 = cadd(d0, jd); a2 = csub(s0, s1); a3 = csub(d0, jd);
+    const cf s0 = a0 + a2, d0 = a0 - a2, s1 = a1 + a3, d1 = a1 - a3;
+    a0 = s0 + s1; a2 = s0 - s1;
+    // forward: a1 = d0 - j d1, a3 = d0 + j d1 ; inverse: the other way round
+    a1 = INV ? add_pj(d0, d1) : add_mj(d0, d1);
+    a3 = INV ? add_mj(d0, d1) : add_pj(d0, d1);
 }
 
 // multiply by exp(-/+ j*2*pi*e/16), e compile-time
 template <bool INV, int E>
-__device__ __forceinline__ float2 mul_w16(float2 v)
+__device__ __forceinline__ cf mul_w16(cf v)
 {
     constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
     constexpr int e = E & 15;
+    static_assert(e == 0 || e == 1 || e == 2 || e == 3 || e == 4 || e == 6 || e == 9, "unused twiddle");
     if constexpr (e == 0) return v;
-    // forward twiddle = (c, -s); inverse = (c, +s)
-    constexpr float c = e == 1 ? C1 : e == 2 ? H : e == 3 ? S1 : e == 4 ? 0.f : e == 6 ? -H : e == 9 ? -C1 : 0.f;
-    constexpr float s0 = e == 1 ? S1 : e == 2 ? H : e == 3 ? C1 : e == 4 ? 1.f : e == 6 ? H : e == 9 ? -S1 : 0.f;
-    static_assert(e == 1 || e == 2 || e == 3 || e == 4 || e == 6 || e == 9, "unused twiddle");
-    constexpr float s = INV ? s0 : -s0;   // imaginary part of the twiddle
-    if constexpr (e == 4) return INV ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x);
-    return make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+    else if constexpr (e == 4) return mulj<INV>(v);
+    else {
+        // forward twiddle = (c, -s0); inverse = (c, +s0)
+        constexpr float c = e == 1 ? C1 : e == 2 ? H : e == 3 ? S1 : e == 6 ? -H : -C1;
+        constexpr float s0 = e == 1 ? S1 : e == 2 ? H : e == 3 ? C1 : e == 6 ? H : -S1;
+        constexpr float s = INV ? s0 : -s0;
+        return __builtin_elementwise_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
+    }
 }
 
 template <bool INV>
-__device__ __forceinline__ void dft16(float2 (&v)[16])
+__device__ __forceinline__ void dft16(cf (&v)[16])
 {
     // layer 1: DFT-4 over a for each b; u[b][p] lands in v[4p+b]
 #pragma unroll

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects rocprofv3 counters for bench.py in separate --pmc passes (no trace domains combined with --pmc),
+# as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Usage: profiles/pmc_run.sh <tag> [bench args...]
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" 
+  echo "pass $i done"
+done
+python3 $ROOT/profiles/pmc_summarize.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
