@@ -120,7 +120,7 @@ def main():
     b_alg = 8 * H + 8 * sum_lout                       # SURVEY.md §8d, bytes per input block
 
     pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk)
-    first_block = rank * nb                            # each rank owns an independent span (§8e)
+    first_block, _n = G.span_for_rank(world * nb, rank, world)   # contiguous span per rank (§8e); weak scaling
     x = synth_input(torch, dev, N, R, C, nb, first_block, 2025 + rank)
     out = torch.empty(pipe.output_samples(nb), dtype=torch.complex64, device=dev)
     torch.cuda.synchronize()
@@ -177,6 +177,17 @@ def main():
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel
     blocks_per_launch = nb * a.steps / ngroups  # units one launch processes
     achieved = b_alg * blocks_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
+    # (profiles/pmc_run.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pt = json.load(fh)
+        ent = pt.get(names[dom])
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N:
+            traffic = ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
     res = {
         "metric": "complex Msamples/s in, 64k-FFT/256-ch overlap-save; achieved HBM GB/s vs peak",
         "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -187,7 +198,7 @@ def main():
                    "blocklen": N, "relinvovl": R, "channels": C, "blocks_per_step_per_gpu": nb,
                    "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel_ms_per_step": {n: round(v / a.steps, 4) for n, v in zip(names, last)},
                      "kernel_avg_launch_ms": round(dom_avg_ms, 5), "blocks_per_launch": blocks_per_launch,
                      "launches_per_step": nlaunch, "alg_bytes_per_block": b_alg,
@@ -195,8 +206,11 @@ def main():
                      "pipeline_frac": round(b_alg * nb * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        ncores = os.cpu_count() or 1
-        nthreads = min(ncores, 64)
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        nthreads = min(ncores, 16)          # a one-GPU box's CPU share
         cb = a.cpu_blocks or max(nthreads * 4, 128)
         v, secs, reps = cpu_baseline(N, R, plan, nthreads, cb)
         res["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": nthreads, "kind": "port",

@@ -8,3 +8,4 @@ from ._lib import FdcError, lib, LIB_PATH                                   # no
 from .blocks import overlap_save, vector_cut_vxx, phase_shifting_windowing_vcc, fft_vcc, window_table  # noqa: F401
 from .channelizer import (FrequencyDomainChannelizer, Pipeline, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
                           nextpow2, get_opt_channelparams)
+from .sharding import span_for_rank, ring_bounds, ring_for_span                       # noqa: F401

@@ -402,13 +402,19 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
         if (nxt < ntiles) issue(nxt);
         dft16<false>(v);
         __syncthreads();
-        // element (row r, b, p) at (p*16 + b)*TR + (r ^ b) [mod TR]: conflict-free b64 writes and reads
+        // element (row r, b, p) at (p*16 + (b ^ (p&1)))*TR + (r ^ b) [mod TR]: conflict-free b64 writes (the 16 lanes
+        // of a row r hit 16 different bank pairs) and reads (for TR = 16 a 32-lane read group spans two p, whose
+        // 128-B rows are put on opposite halves of the 64 banks by the b ^ (p&1) term)
+        cf w[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
 #pragma unroll
         for (int p = 0; p < 16; p++)
-            st2(&tile[(p * 16 + b) * TR + ((r ^ b) & (TR - 1))], cmul(v[rev16(p)], ld2(&w256[b * p])));
+            st2(&tile[(p * 16 + (b ^ (p & 1))) * TR + ((r ^ b) & (TR - 1))], cmul(v[rev16(p)], w[p]));
         __syncthreads();
 #pragma unroll
-        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(p2 * 16 + bb) * TR + ((r2 ^ bb) & (TR - 1))]);
+        for (int bb = 0; bb < 16; bb++)
+            v[bb] = ld2(&tile[(p2 * 16 + (bb ^ (p2 & 1))) * TR + ((r2 ^ bb) & (TR - 1))]);
         dft16<false>(v);
         const long long rho = (long long)tl * TR + r2;
         if (rho < nrows) {

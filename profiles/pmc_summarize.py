@@ -21,3 +21,20 @@ for k in sorted(acc):
     for c in sorted(acc[k]):
         v = acc[k][c]
         print("   %-28s mean/dispatch %.6g   (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# HBM traffic per dispatch for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
+# FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md §HBM) -> doubled.
+import json
+names = {"fdc::k_p1": "poly_stage1(colFFT+window+IFFT)", "fdc::k_p2": "poly_stage2(slotFFT)",
+         "fdc::k_a256": "fft_pass_a", "fdc::k_b256": "fft_pass_b", "fdc::k_c256": "channels"}
+out = {}
+for k in acc:
+    base = k.split("<")[0]
+    if base in names and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+        f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024
+        w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
+        out[names[base]] = {"kernel": k, "fetch_size_raw_bytes": f, "write_size_bytes": w,
+                            "hbm_bytes_per_launch": 2 * f + w, "blocks_per_launch": float(os.environ.get("PMC_BLOCKS", "1024")),
+                            "blocklen": int(os.environ.get("PMC_BLOCKLEN", "65536"))}
+with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
