@@ -29,6 +29,30 @@ class fdc_pipeline_cfg(C.Structure):
                 ("max_blocks", C.c_int32), ("chunk_blocks", C.c_int32), ("keep_spectrum", C.c_int32)]
 
 
+class fdc_pac_cfg(C.Structure):
+    _fields_ = [("cfreq", C.c_float), ("bw", C.c_float), ("id", C.c_int32)]
+
+
+class fdc_segment_cfg(C.Structure):
+    _fields_ = [("start", C.c_float), ("stop", C.c_float)]
+
+
+class fdc_sinks_cfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("blocklen", C.c_int32), ("relinvovl", C.c_int32),
+                ("npac", C.c_int32), ("pac", C.POINTER(fdc_pac_cfg)),
+                ("pac_thresh_db", C.c_float), ("pac_maxblocks", C.c_int32), ("pac_deactivation_delay", C.c_int32),
+                ("nseg", C.c_int32), ("seg", C.POINTER(fdc_segment_cfg)),
+                ("det_thresh_db", C.c_float), ("det_maxblocks", C.c_int32), ("minchandist", C.c_float),
+                ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32)]
+
+
+class fdc_pdu(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("source", C.c_int32), ("chan_id", C.c_int32), ("finalized", C.c_int32),
+                ("part", C.c_int32), ("has_part", C.c_int32), ("rel_bw", C.c_double), ("rel_cfreq", C.c_double),
+                ("blockstart", C.c_int64), ("blockend", C.c_int64), ("vectorstart", C.c_int64),
+                ("vectorend", C.c_int64), ("nsamples", C.c_int64), ("samples", C.c_void_p)]
+
+
 # every symbol include/fdc_amd.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -50,6 +74,16 @@ SYMBOLS = {
     "fdc_pipeline_path": (C.c_int32, [_vp]),
     "fdc_pipeline_enable_timing": (C.c_int, [_vp, C.c_int]),
     "fdc_pipeline_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
+    "fdc_sinks_create": (C.c_int, [C.POINTER(fdc_sinks_cfg), C.POINTER(_vp)]),
+    "fdc_sinks_destroy": (None, [_vp]),
+    "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),
+    "fdc_sinks_spectrum": (_vp, [_vp]),
+    "fdc_sinks_stream": (_vp, [_vp]),
+    "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),
+    "fdc_sinks_pdu_count": (C.c_int, [_vp]),
+    "fdc_sinks_pdu": (C.c_int, [_vp, C.c_int, C.POINTER(fdc_pdu)]),
+    "fdc_sinks_pac_params": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32)]),
+    "fdc_sinks_segment_params": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32)]),
     "fdc_overlap_save_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "fdc_overlap_save_work": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "fdc_overlap_save_destroy": (None, [_vp]),

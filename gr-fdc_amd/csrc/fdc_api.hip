@@ -66,6 +66,21 @@ std::vector<float2> make_twiddles(int n)
 
 }  // namespace
 
+namespace fdc {
+// shared with fdc_sinks.hip
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int pick_device(int device_id) { return select_device(device_id); }
+}  // namespace fdc
+
 struct fdc_pipeline {
     fdc_pipeline_cfg cfg{};
     int N = 0, R = 0, ovl = 0, H = 0, C = 0;

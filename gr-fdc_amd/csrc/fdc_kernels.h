@@ -20,6 +20,16 @@ struct ChanDev {
     int32_t pad;
 };
 
+// Sinks (PowerActivationChannel / activity_detection_channelizer_vcm): power cells and extraction tasks.
+struct PowerCell { int32_t start, len; float scale; int32_t pad; };
+struct ExtractTask {
+    int32_t slot;       // spectrum block slot (0 = history block of the previous call, 1.. = blocks of this call)
+    int32_t start;      // first bin of the slice
+    int32_t win_off;    // offset of the (phase-resolved) window in the pool, complex elements
+    int32_t pad;
+    int64_t out_off;    // where the w - skip output samples go, complex elements
+};
+
 // Geometry of an LDS "column" FFT tile: TC independent transforms of length L, element (i, t) at i*ld + t.
 struct TileGeom {
     int L, log2L, TC, log2TC, ld;
@@ -66,6 +76,12 @@ hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 
                           int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
                           const float *shn, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
                           hipStream_t s, hipEvent_t *ev);
+
+// sinks
+hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
+                             hipStream_t s);
+hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip,
+                          const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 
 // single-block faces
 hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,

@@ -254,6 +254,55 @@ __global__ __launch_bounds__(kThreads) void k_channels(const float2 *__restrict_
     }
 }
 
+// ---- sinks: power cells + task-list extraction (PowerActivationChannel / activity_detection_channelizer_vcm) ----
+// One wave per (block, cell): sum |X|^2 over [start, start+len), times scale.
+//   lib/PowerActivationChannel_impl.cc:289-291 (scale 1), lib/activity_detection_channelizer_vcm_impl.cc:641-648 (1/dec)
+__global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restrict__ spec, int N,
+                                                         const PowerCell *__restrict__ cells, int ncells,
+                                                         float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cell = blockIdx.x * (kThreads / 64) + wave;
+    const size_t m = blockIdx.y;
+    if (cell >= ncells) return;
+    const PowerCell pc = cells[cell];
+    const float2 *x = spec + m * (size_t)N + pc.start;
+    float acc = 0.f;
+    for (int i = lane; i < pc.len; i += 64) { const float2 v = x[i]; acc += v.x * v.x + v.y * v.y; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) out[m * (size_t)ncells + cell] = acc * pc.scale;
+}
+
+// Extraction of one width class: out = IFFT_w( halfswap( X[slot][start .. start+w) * win ) )[skip .. w)
+//   lib/PowerActivationChannel_impl.cc:260-284, lib/activity_detection_channelizer_vcm_impl.cc:373-397
+__global__ __launch_bounds__(kThreads) void k_extract(const float2 *__restrict__ spec, int N,
+                                                      const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
+                                                      int log2TC, int ld, int skip, const float2 *__restrict__ wins,
+                                                      float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                                      int twstride)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int w = 1 << log2w, TC = 1 << log2TC;
+    const int t0 = blockIdx.x * TC;
+    for (int e = threadIdx.x; e < (w << log2TC); e += kThreads) {
+        const int tl = e >> log2w, i = e & (w - 1), t = t0 + tl;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < ntasks) {
+            const ExtractTask tk = tasks[t];
+            v = cmulf(spec[(size_t)tk.slot * N + tk.start + i], wins[tk.win_off + i]);
+        }
+        lds[((i + (w >> 1)) & (w - 1)) * ld + tl] = v;       // fftshift(): halves swapped
+    }
+    __syncthreads();
+    fft_cols<true>(lds, log2w, log2TC, ld, tw, twstride);
+    const int olen = w - skip;
+    for (int e = threadIdx.x; e < olen * TC; e += kThreads) {
+        const int tl = e / olen, tt = e - tl * olen, t = t0 + tl;
+        if (t < ntasks) out[tasks[t].out_off + tt] = lds[(skip + tt) * ld + tl];
+    }
+}
+
 // ---- single-block faces ----------------------------------------------------------------------------
 __global__ void k_copy_items(const unsigned char *__restrict__ in, unsigned char *__restrict__ out,
                              size_t in_item_stride, size_t in_offset, size_t out_item_bytes)
@@ -319,7 +368,7 @@ hipError_t init_kernels()
     FDC_SETLDS(k_fft_small<false>) FDC_SETLDS(k_fft_small<true>)
     FDC_SETLDS(k_fft_pass_a<false>) FDC_SETLDS(k_fft_pass_a<true>)
     FDC_SETLDS(k_fft_pass_b<false>) FDC_SETLDS(k_fft_pass_b<true>)
-    FDC_SETLDS(k_channels)
+    FDC_SETLDS(k_channels) FDC_SETLDS(k_extract)
 #undef FDC_SETLDS
     return init_fast_kernels();
 }
@@ -378,6 +427,28 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
     dim3 grid((unsigned)((ntrans + g.TC - 1) / g.TC));
     hipLaunchKernelGGL(k_channels, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
                        g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    return hipGetLastError();
+}
+
+hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
+                             hipStream_t s)
+{
+    if (ncells <= 0 || nblocks <= 0) return hipSuccess;
+    for (int m0 = 0; m0 < nblocks; m0 += 32768) {
+        const int nb = nblocks - m0 < 32768 ? nblocks - m0 : 32768;
+        hipLaunchKernelGGL(k_cell_power, dim3((ncells + 3) / 4, nb), dim3(kThreads), 0, s, spec + (size_t)m0 * N, N, cells,
+                           ncells, out + (size_t)m0 * ncells);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip,
+                          const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s)
+{
+    if (ntasks <= 0) return hipSuccess;
+    const TileGeom g = tile_geom(w);
+    hipLaunchKernelGGL(k_extract, dim3((ntasks + g.TC - 1) / g.TC), dim3(kThreads), g.lds_bytes(), s, spec, N, tasks, ntasks,
+                       g.log2L, g.log2TC, g.ld, skip, wins, out, tw, ntab / w);
     return hipGetLastError();
 }
 

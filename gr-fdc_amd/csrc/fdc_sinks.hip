@@ -1,0 +1,539 @@
+// Stateful sinks fed with the normalised spectrum: a bank of PowerActivationChannel instances and the segments of an
+// activity_detection_channelizer_vcm, sharing one device-resident spectrum (the hier block feeds all of them from the
+// same normalize_input output, python/FrequencyDomainChannelizer.py:301-312).
+//
+// Split of work: the data-parallel parts run on the GPU for a whole batch of blocks —
+// per-(block, cell) power sums (k_cell_power) and the window * half-swap * IFFT * discard extractions (k_extract,
+// grouped by width) — while the per-block decision logic, which is inherently sequential over blocks and tiny
+// (a few hundred floats per block), runs on the host between the two GPU phases:
+//     GPU power cells -> D2H -> host state machines (one pass over the batch, emits an extraction task list and PDU
+//     records that reference tasks) -> GPU extractions -> D2H -> payload assembly.
+// Behaviour follows lib/PowerActivationChannel_impl.cc and lib/activity_detection_channelizer_vcm_impl.cc; line
+// references are given at each decision.  The `threads` flag of the reference is accepted and ignored (GPU batching
+// replaces the per-channel std::thread fan-out).
+#include "../../include/fdc_amd.h"
+#include "fdc_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+
+extern "C" const char *fdc_last_error(void);
+namespace fdc { int set_error(int code, const char *fmt, ...); int pick_device(int device_id); }
+
+namespace {
+
+using cfl = std::complex<float>;
+
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) return fdc::set_error(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+int pow2ceil(int k) { return (int)std::pow(2.0, std::ceil(std::log2((double)k))); }
+bool ispow2i(int k) { return k > 0 && (k & (k - 1)) == 0; }
+
+// A buffered output block of a channel: either still on the device as the result of a task of the current call, or a
+// host copy carried over from an earlier call.
+struct BlockRef {
+    int64_t task = -1;
+    std::vector<cfl> owned;
+};
+
+struct PduRec {
+    fdc_pdu meta{};
+    std::vector<BlockRef> blocks;
+    int blocklen = 0;               // samples per block
+    std::vector<cfl> payload;
+};
+
+struct Pac {
+    int ID = 0, extract_start = 0, extract_stop = 0, extract_width = 0, output_len = 0, ovl_offset = 0;
+    int measure_start = 0, measure_stop = 0, deltaphase = 0, win_off = 0, cell = 0;
+    bool active = false;
+    float lastpower = FLT_MAX;
+    int count = 0, phase = 0, part = 0, finished = 0, id_at_activation = 0;
+    std::deque<BlockRef> blocks;
+};
+
+struct DetChan {
+    int ID, detect_start, detect_stop, extract_start, extract_stop, extract_width, wclass, ovlskip, outputsamples;
+    int count, phase, phaseincrement, inactive, part;
+    std::deque<BlockRef> data;
+};
+
+struct Segment {
+    int ID = 0, start = 0, stop = 0, width = 0, ncell = 0, cell0 = 0, counter = 0;
+    std::deque<DetChan> chans;
+};
+
+}  // namespace
+
+struct fdc_sinks {
+    fdc_sinks_cfg cfg{};
+    int N = 0, R = 0, dec = 1;
+    float pac_thr = 0.f, det_thr = 0.f;
+    std::vector<Pac> pacs;
+    std::vector<Segment> segs;
+    std::vector<int> det_win_off;            // per width class
+    std::vector<fdc::PowerCell> cells;
+    int64_t blockcount = 1;                  // both reference blocks start counting at 1 (hist is block 0)
+    hipStream_t stream = nullptr;
+    float2 *d_spec = nullptr;                // (max_blocks + 1) * N: slot 0 = history block
+    float2 *d_wins = nullptr, *d_tw = nullptr;
+    fdc::PowerCell *d_cells = nullptr;
+    float *d_power = nullptr;
+    fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
+    float2 *d_ext = nullptr; size_t cap_ext = 0;
+    std::vector<float> h_power;
+    std::vector<PduRec> pdus;
+    // per-call scratch
+    std::vector<fdc::ExtractTask> tasks;
+    std::vector<int> task_w, task_skip;
+    int64_t ext_used = 0;
+};
+
+namespace {
+
+int64_t add_task(fdc_sinks *s, int slot, int start, int w, int skip, int win_off)
+{
+    fdc::ExtractTask t{};
+    t.slot = slot; t.start = start; t.win_off = win_off; t.out_off = s->ext_used;
+    s->ext_used += w - skip;
+    s->tasks.push_back(t);
+    s->task_w.push_back(w); s->task_skip.push_back(skip);
+    return (int64_t)s->tasks.size() - 1;
+}
+
+// ---------------------------------------------------------------- PowerActivationChannel
+void pac_process(fdc_sinks *s, Pac &p, int slot)            // process_channel, …_impl.cc:260-284
+{
+    BlockRef b;
+    b.task = add_task(s, slot, p.extract_start, p.extract_width, p.ovl_offset, p.win_off + p.phase * p.extract_width);
+    p.blocks.push_back(std::move(b));
+    p.count++;
+    p.phase = (p.phase + p.deltaphase) % s->R;
+}
+
+void pac_emit(fdc_sinks *s, Pac &p, bool fin)               // emit_data, :212-258
+{
+    PduRec r;
+    r.meta.kind = 0; r.meta.source = p.ID; r.meta.chan_id = p.id_at_activation;
+    r.meta.finalized = fin; r.meta.part = p.part; r.meta.has_part = 1;
+    r.meta.rel_cfreq = (double)(p.extract_start + p.extract_stop) / 2.0 / (double)s->N;
+    r.meta.rel_bw = (double)p.extract_width / (double)s->N;
+    r.meta.blockstart = s->blockcount - p.count; r.meta.blockend = s->blockcount;
+    r.meta.vectorstart = p.extract_start; r.meta.vectorend = p.extract_stop;
+    r.blocklen = p.output_len;
+    for (auto &b : p.blocks) r.blocks.push_back(std::move(b));
+    p.blocks.clear();
+    s->pdus.push_back(std::move(r));
+    p.part++;
+}
+
+void pac_step(fdc_sinks *s, Pac &p, float pwr, int slot)    // one item of work(), :146-170
+{
+    if (pwr == 0.0f) pwr = FLT_MIN;                                        // :293-294
+    bool changed = false;
+    if (!p.active && pwr / p.lastpower >= s->pac_thr) changed = true;      // :296-302
+    else if (p.active && p.lastpower / pwr >= s->pac_thr) changed = true;
+    p.lastpower = pwr;
+    if (changed) {
+        if (!p.active) {                                                   // activate(), :198-210
+            p.part = 0; p.count = 0; p.active = true; p.phase = 0; p.blocks.clear();
+            p.id_at_activation = p.finished;
+            pac_process(s, p, slot - 1);                                   // previous block (slot 0 = saved history)
+            pac_process(s, p, slot);
+        } else {
+            pac_process(s, p, slot);
+            p.active = false;                                              // deactivate(), :189-196
+            pac_emit(s, p, true);
+            p.finished++;
+        }
+    } else if (p.active) {
+        pac_process(s, p, slot);
+        const int mb = s->cfg.pac_maxblocks;
+        if (mb == 0 || (mb > 0 && p.count % mb == 0)) pac_emit(s, p, false);
+    }
+}
+
+// ---------------------------------------------------------------- activity_detection_channelizer_vcm
+void det_process(fdc_sinks *s, DetChan &c, int slot)        // process_channel, …vcm_impl.cc:373-397
+{
+    BlockRef b;
+    b.task = add_task(s, slot, c.extract_start, c.extract_width, c.ovlskip,
+                      s->det_win_off[c.wclass] + c.phase * c.extract_width);
+    c.data.push_back(std::move(b));
+    c.count++;
+    c.phase = (c.phase + c.phaseincrement) % s->R;
+}
+
+void det_emit(fdc_sinks *s, Segment &g, DetChan &c, bool fin, size_t nblk)   // :406-452 / :454-510
+{
+    PduRec r;
+    r.meta.kind = 1; r.meta.source = g.ID; r.meta.chan_id = c.ID;
+    r.meta.finalized = fin; r.meta.part = c.part; r.meta.has_part = fin ? (c.part > 0) : 1;
+    r.meta.rel_bw = (double)c.extract_width / (double)s->N;
+    r.meta.rel_cfreq = (double)(c.extract_start + c.extract_stop) / 2.0 / (double)s->N;
+    r.meta.blockstart = s->blockcount - c.count; r.meta.blockend = s->blockcount;
+    r.meta.vectorstart = c.extract_start; r.meta.vectorend = c.extract_stop;
+    r.blocklen = c.outputsamples;
+    for (size_t i = 0; i < nblk; i++) { r.blocks.push_back(std::move(c.data.front())); c.data.pop_front(); }
+    s->pdus.push_back(std::move(r));
+}
+
+void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, :617-628
+{
+    const int n = g.ncell, dec = s->dec;
+    // get_active_channels, :694-739
+    struct Edge { float r; int pos; };
+    std::vector<Edge> rise;
+    std::vector<int> fall;
+    const float inv = 1.0f / s->det_thr;
+    for (int i = 1; i < n; i++) {
+        const float pd = P[i - 1] == 0.0f ? P[i] / FLT_MIN : P[i] / P[i - 1];   // :703-706
+        if (pd > s->det_thr) rise.push_back({pd, (i - 1) * dec + g.start});
+        if (pd < inv) fall.push_back(i * dec + g.start);
+    }
+    std::stable_sort(rise.begin(), rise.end(), [](const Edge &a, const Edge &b) { return a.r > b.r; });   // :713
+    std::vector<std::pair<int, int>> cand;
+    for (const Edge &e : rise) {
+        int ne = -1;
+        for (int f : fall) if (f > e.pos) { ne = f; break; }                   // get_next_int, :678-692
+        if (ne <= e.pos) continue;
+        bool clash = false;
+        for (auto &a : cand) if (e.pos < a.second && ne >= a.first) { clash = true; break; }   // :727-734
+        if (!clash) cand.emplace_back(e.pos, ne);
+    }
+    // match_active_channels, :741-783
+    if (cand.empty()) {
+        for (auto &c : g.chans) c.inactive += 1;
+        return;
+    }
+    for (auto &c : g.chans) {
+        bool idle = true;
+        for (size_t i = 0; i < cand.size();) {
+            if (cand[i].first < c.detect_stop && cand[i].second >= c.detect_start) {
+                c.inactive = 0; idle = false;
+                cand.erase(cand.begin() + i);
+            } else i++;
+        }
+        if (idle) c.inactive += 1;
+    }
+    for (auto &pc : cand) {                                                    // activate, :785-841
+        const int dw = pc.second - pc.first, mid = pc.first + dw / 2;
+        const int ew = pow2ceil((int)std::ceil((double)dw * (1.0 + 2.0 * s->cfg.window_flank_puffer)));
+        if (ew > s->N) continue;                                               // logged and skipped in the reference
+        if (ew > fdc::kMaxLdsFft) continue;                                    // above the single-workgroup IFFT (documented gap)
+        int es = mid - ew / 2, ee = mid + ew / 2;
+        if (es < 0) { es = 0; ee = ew; }
+        if (ee > s->N) { ee = s->N; es = s->N - ew; }
+        DetChan c{};
+        c.ID = g.counter++;
+        c.detect_start = pc.first; c.detect_stop = pc.second; c.extract_start = es; c.extract_stop = ee;
+        c.extract_width = ew; c.wclass = (int)std::log2((double)ew);
+        c.ovlskip = ew / s->R; c.outputsamples = ew - c.ovlskip;
+        c.count = 0; c.phase = 0; c.phaseincrement = es % s->R; c.inactive = -1; c.part = 0;
+        g.chans.push_back(std::move(c));
+    }
+}
+
+void seg_extract(fdc_sinks *s, Segment &g, int slot)        // extract_channels_in_segments_singlethread, :306-337
+{
+    const int mb = s->cfg.det_maxblocks, delay = s->cfg.det_deactivation_delay;
+    for (auto &c : g.chans) {
+        if (c.inactive < 0) { det_process(s, c, slot - 1); det_process(s, c, slot); c.inactive = 0; }   // :399-403
+        else if (c.inactive > delay) det_emit(s, g, c, true, c.data.size());
+        else det_process(s, c, slot);
+        if (mb >= 0 && (int)c.data.size() >= mb) {                              // :317-318, :454-470
+            const size_t ntx = mb == 0 ? c.data.size() : (size_t)mb;
+            if (ntx > 0) { det_emit(s, g, c, false, ntx); c.part++; }
+        }
+    }
+    for (size_t i = 0; i < g.chans.size();)                                     // clear_inactive_channels, :512-524
+        if (g.chans[i].inactive > delay) g.chans.erase(g.chans.begin() + i); else i++;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fdc_sinks_destroy(fdc_sinks *s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_cells);
+    (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
+{
+    if (!cfg || !out) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const int N = cfg->blocklen, R = cfg->relinvovl;
+    // shared predicates: PowerActivationChannel_impl.cc:64-70, …vcm_impl.cc:106-107,122-123
+    if (N < 2 || !ispow2i(N)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Blocklen invalid.");
+    if (R < 1 || !ispow2i(R) || R > N) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Relative inverse overlap is invalid, must be >0 and a power of 2.");
+    if (cfg->npac < 0 || cfg->nseg < 0 || (cfg->npac && !cfg->pac) || (cfg->nseg && !cfg->seg) || cfg->max_blocks < 1)
+        return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad sink lists");
+    std::unique_ptr<fdc_sinks> s(new fdc_sinks());
+    s->cfg = *cfg; s->cfg.pac = nullptr; s->cfg.seg = nullptr;
+    s->N = N; s->R = R;
+    std::vector<cfl> pool;
+    // ---- PowerActivationChannel instances
+    if (cfg->npac > 0) {
+        if (cfg->pac_thresh_db <= 0.0f)                                        // set_thresh, :377-381
+            return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Threshold is interpreted as dB and must be >0.0");
+        s->pac_thr = (float)std::pow(10.0, (double)cfg->pac_thresh_db / 10.0);
+    }
+    for (int i = 0; i < cfg->npac; i++) {
+        float cfreq = cfg->pac[i].cfreq, bw = cfg->pac[i].bw;
+        bw = bw > 0.0f ? bw : -bw;                                              // set_startstop, :314-355
+        if (bw > 1.0 || cfreq - bw / 2.0f < 0.0f || cfreq + bw / 2.0f > 1.0f)
+            return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Desired channel is out of band: cfreq=%f, bw=%f", cfreq, bw);
+        const int k = (int)std::ceil((double)bw * (double)N);
+        if (k <= 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Can't eval nextpow2 from %d", k);
+        Pac p;
+        p.ID = cfg->pac[i].id;
+        p.extract_width = std::min(pow2ceil(k), N);
+        const int mid = (int)std::round((double)cfreq * (double)N);
+        p.extract_start = std::max(0, mid - p.extract_width / 2);
+        p.extract_stop = p.extract_start + p.extract_width;
+        if (p.extract_stop > N) { p.extract_stop = N; p.extract_start = p.extract_stop - N; }   // reference clamp (App. B.2)
+        p.measure_start = std::max((int)std::round((double)(cfreq - bw / 2.0f) * (double)N), p.extract_start);
+        p.measure_stop = std::min((int)std::round((double)(cfreq + bw / 2.0f) * (double)N), p.extract_stop);
+        if (p.extract_start + p.extract_width > N)
+            return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "PowerActivationChannel %d: the reference reads past the block here", i);
+        if (p.extract_width > fdc::kMaxLdsFft)
+            return fdc::set_error(FDC_ERR_UNSUPPORTED, "PowerActivationChannel %d: width %d above %d", i, p.extract_width, fdc::kMaxLdsFft);
+        p.deltaphase = p.extract_start % R;
+        p.ovl_offset = p.extract_width / R; p.output_len = p.extract_width - p.ovl_offset;
+        // cr_windows, :357-375: unit phasor (float polar) with a rising sine edge; only the first extract_width
+        // entries of the block-long table are ever used (:267), the mirrored far edge matters only when it falls inside.
+        const int ramp = ((p.extract_stop - p.extract_start) - (p.measure_stop - p.measure_start)) / 3;
+        p.win_off = (int)pool.size();
+        pool.resize(pool.size() + (size_t)R * p.extract_width);
+        for (int r = 0; r < R; r++) {
+            const float ang = (float)(2.0f * M_PI * (double)r / (double)R);
+            const cfl ph(std::cos(ang), std::sin(ang));
+            std::vector<cfl> full((size_t)N, ph);
+            for (int q = 0; q < ramp; q++) {
+                full[q] *= (float)std::sin(0.5 * M_PI * (double)q / (double)(ramp + 1));
+                full[N - q - 1] = full[q];
+            }
+            std::copy(full.begin(), full.begin() + p.extract_width, pool.begin() + p.win_off + (size_t)r * p.extract_width);
+        }
+        p.cell = (int)s->cells.size();
+        s->cells.push_back({p.measure_start, std::max(0, p.measure_stop - p.measure_start), 1.0f, 0});
+        s->pacs.push_back(std::move(p));
+    }
+    // ---- detection segments
+    if (cfg->nseg > 0) {
+        if (cfg->minchandist <= 0.0f || cfg->minchandist >= 1.0)               // :231-232
+            return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Minimum channel distance is invalid. Must be in (0,1)");
+        if (cfg->det_thresh_db < 0.0f) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Threshold is interpreted as dB and must be greater zero.");
+        if (cfg->det_deactivation_delay < 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Channel deactication delay must not be smaller 0.");
+        if (cfg->window_flank_puffer < 0.0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Window flank puffer must not be smaller 0.0.");
+        const double dd = (double)N * (double)cfg->minchandist / 2.0;           // :234-240
+        s->dec = dd < 2.0 ? 1 : (int)dd;
+        s->det_thr = (float)std::pow(10.0, (double)cfg->det_thresh_db / 10.0);
+        for (int i = 0; i < cfg->nseg; i++) {                                   // create_segment, :248-279
+            const float v0 = cfg->seg[i].start, v1 = cfg->seg[i].stop;
+            if (v0 >= v1 || v0 < 0.0f || v1 > 1.0f) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Segment is incorrect: [%f, %f]", v0, v1);
+            const int mid = std::abs((int)std::round(((double)v1 + (double)v0) * 0.5 * (double)N));
+            int width = std::abs((int)std::round(((double)v1 - (double)v0) * (double)N));
+            if (width % s->dec) width += s->dec - width % s->dec;
+            if (width >= N) {
+                if (N % s->dec == 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "segment %d spans the whole block (the reference does not terminate here)", i);
+                width = N - N % s->dec;
+            }
+            Segment g;
+            g.ID = i;
+            g.start = mid - width / 2 <= 0 ? 0 : mid - width / 2;
+            g.stop = g.start + width;
+            if (g.stop > N) { g.stop = N; g.start = N - width; }
+            if (g.start < 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Cannot evaluate start and stop of segment %d", i);
+            g.width = width; g.ncell = width / s->dec; g.cell0 = (int)s->cells.size();
+            const float norm = 1.0f / (float)s->dec;                            // :632
+            for (int c = 0; c < g.ncell; c++) s->cells.push_back({g.start + c * s->dec, s->dec, norm, 0});
+            s->segs.push_back(std::move(g));
+        }
+        // cr_windows, :199-228: every power-of-two width x R phases, unit amplitude, Hann flanks
+        const int nw = (int)std::log2((double)N) + 1;
+        s->det_win_off.resize(nw);
+        for (int k = 0; k < nw; k++) {
+            const int ww = 1 << k, puf = (int)(cfg->window_flank_puffer * (double)ww);
+            s->det_win_off[k] = (int)pool.size();
+            if (ww > fdc::kMaxLdsFft) continue;
+            pool.resize(pool.size() + (size_t)R * ww);
+            for (int r = 0; r < R; r++) {
+                cfl *w = pool.data() + s->det_win_off[k] + (size_t)r * ww;
+                const double ang = 2.0 * M_PI * (double)r / (double)R;
+                const cfl ph((float)std::cos(ang), (float)std::sin(ang));
+                for (int n = 0; n < ww; n++) w[n] = ph;
+                for (int q = 0; q < puf; q++) {
+                    const float fl = 0.5f - 0.5f * (float)std::cos(M_PI * (double)q / (double)puf);
+                    w[q] *= fl; w[ww - 1 - q] *= fl;
+                }
+            }
+        }
+    }
+    int rc = fdc::pick_device(cfg->device_id);
+    if (rc != FDC_OK) return rc;
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    fdc_sinks *raw = s.release();
+#define CHKF(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int _r = fdc::set_error(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fdc_sinks_destroy(raw); return _r; } } while (0)
+    CHKF(hipMalloc(&raw->d_spec, sizeof(float2) * ((size_t)cfg->max_blocks + 1) * N));
+    CHKF(hipMemset(raw->d_spec, 0, sizeof(float2) * (size_t)N));            // zero history block (…cc:89 / :111)
+    if (!pool.empty()) {
+        CHKF(hipMalloc(&raw->d_wins, sizeof(float2) * pool.size()));
+        CHKF(hipMemcpy(raw->d_wins, pool.data(), sizeof(float2) * pool.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<float2> tw((size_t)N);
+        for (int k = 0; k < N; k++) {
+            const double a = -2.0 * M_PI * (double)k / (double)N;
+            tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        CHKF(hipMalloc(&raw->d_tw, sizeof(float2) * (size_t)N));
+        CHKF(hipMemcpy(raw->d_tw, tw.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
+    }
+    if (!raw->cells.empty()) {
+        CHKF(hipMalloc(&raw->d_cells, sizeof(fdc::PowerCell) * raw->cells.size()));
+        CHKF(hipMemcpy(raw->d_cells, raw->cells.data(), sizeof(fdc::PowerCell) * raw->cells.size(), hipMemcpyHostToDevice));
+        CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
+    }
+#undef CHKF
+    *out = raw;
+    return FDC_OK;
+}
+
+void *fdc_sinks_spectrum(fdc_sinks *s) { return s ? (void *)(s->d_spec + s->N) : nullptr; }
+void *fdc_sinks_stream(fdc_sinks *s) { return s ? (void *)s->stream : nullptr; }
+
+int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v)
+{
+    if (!s || i < 0 || i >= (int)s->pacs.size() || !v) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad index");
+    const Pac &p = s->pacs[i];
+    v[0] = p.extract_start; v[1] = p.extract_stop; v[2] = p.extract_width; v[3] = p.measure_start; v[4] = p.measure_stop;
+    v[5] = p.output_len; v[6] = p.ovl_offset; v[7] = p.deltaphase;
+    return FDC_OK;
+}
+
+int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
+{
+    if (!s || i < 0 || i >= (int)s->segs.size() || !v) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad index");
+    const Segment &g = s->segs[i];
+    v[0] = g.start; v[1] = g.stop; v[2] = g.width; v[3] = s->dec; v[4] = g.ncell;
+    return FDC_OK;
+}
+
+int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
+    s->pdus.clear();
+    if (nblocks == 0) return 0;
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    const int N = s->N, ncells = (int)s->cells.size();
+    // phase 1: power of every cell of every block
+    if (ncells) {
+        HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
+        s->h_power.resize((size_t)ncells * nblocks);
+        HIPCHK(hipMemcpyAsync(s->h_power.data(), s->d_power, sizeof(float) * s->h_power.size(), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    // phase 2: decisions, one block after the other (work() loops of both reference blocks)
+    s->tasks.clear(); s->task_w.clear(); s->task_skip.clear(); s->ext_used = 0;
+    for (int m = 0; m < nblocks; m++) {
+        const float *P = s->h_power.data() + (size_t)m * ncells;
+        const int slot = m + 1;
+        for (auto &p : s->pacs) pac_step(s, p, P[p.cell], slot);
+        for (auto &g : s->segs) seg_detect(s, g, P + g.cell0);                  // …vcm_impl.cc:558
+        for (auto &g : s->segs) seg_extract(s, g, slot);                        // :562
+        s->blockcount++;
+    }
+    // phase 3: extractions, one launch per width class
+    const size_t nt = s->tasks.size();
+    std::vector<cfl> ext((size_t)s->ext_used);
+    if (nt) {
+        std::vector<size_t> order(nt);
+        for (size_t i = 0; i < nt; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s->task_w[a] < s->task_w[b]; });
+        std::vector<fdc::ExtractTask> sorted(nt);
+        for (size_t i = 0; i < nt; i++) sorted[i] = s->tasks[order[i]];
+        if (nt > s->cap_tasks) {
+            (void)hipFree(s->d_tasks); s->d_tasks = nullptr; s->cap_tasks = 0;
+            HIPCHK(hipMalloc(&s->d_tasks, sizeof(fdc::ExtractTask) * nt * 2));
+            s->cap_tasks = nt * 2;
+        }
+        if ((size_t)s->ext_used > s->cap_ext) {
+            (void)hipFree(s->d_ext); s->d_ext = nullptr; s->cap_ext = 0;
+            HIPCHK(hipMalloc(&s->d_ext, sizeof(float2) * (size_t)s->ext_used * 2));
+            s->cap_ext = (size_t)s->ext_used * 2;
+        }
+        HIPCHK(hipMemcpyAsync(s->d_tasks, sorted.data(), sizeof(fdc::ExtractTask) * nt, hipMemcpyHostToDevice, s->stream));
+        for (size_t i = 0; i < nt;) {
+            const int w = s->task_w[order[i]], skip = s->task_skip[order[i]];
+            size_t j = i;
+            while (j < nt && s->task_w[order[j]] == w) j++;
+            HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
+            i = j;
+        }
+        HIPCHK(hipMemcpyAsync(ext.data(), s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
+    }
+    // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
+    HIPCHK(hipMemcpyAsync(s->d_spec, s->d_spec + (size_t)nblocks * N, sizeof(float2) * (size_t)N, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    // phase 4: payloads; blocks still buffered in live channels become host copies
+    auto resolve = [&](BlockRef &b, int len) {
+        if (b.task >= 0) {
+            const cfl *src = ext.data() + s->tasks[(size_t)b.task].out_off;
+            b.owned.assign(src, src + len);
+            b.task = -1;
+        }
+    };
+    for (auto &r : s->pdus) {
+        r.payload.reserve(r.blocks.size() * (size_t)r.blocklen);
+        for (auto &b : r.blocks) { resolve(b, r.blocklen); r.payload.insert(r.payload.end(), b.owned.begin(), b.owned.end()); }
+        r.blocks.clear();
+        r.meta.nsamples = (int64_t)r.payload.size();
+        r.meta.samples = r.payload.data();
+    }
+    for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
+    for (auto &g : s->segs) for (auto &c : g.chans) for (auto &b : c.data) resolve(b, c.outputsamples);
+    return nblocks;
+}
+
+int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
+    if (nitems == 0) { s->pdus.clear(); return 0; }
+    if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(s->d_spec + s->N, spectrum, sizeof(float2) * (size_t)nitems * s->N, hipMemcpyHostToDevice, s->stream));
+    return fdc_sinks_work_device(s, nitems);
+}
+
+int fdc_sinks_pdu_count(const fdc_sinks *s) { return s ? (int)s->pdus.size() : 0; }
+
+int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out)
+{
+    if (!s || !out || i < 0 || i >= (int)s->pdus.size()) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad PDU index");
+    *out = s->pdus[(size_t)i].meta;
+    return FDC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Faces of the two stateful sink blocks of the reference over fdc_sinks_* (include/fdc_amd.h):
+
+  PowerActivationChannel(blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay, msg, fileoutput, path,
+                         verbose, ID)                         — include/FDC/PowerActivationChannel.h:49
+  activity_detection_channelizer_vcm(blocklen, segments, thresh, relinvovl, maxblocks, message, fileoutput, path,
+                         threads, minchandist, channel_deactivation_delay, window_flank_puffer, verbose)
+                                                              — include/FDC/activity_detection_channelizer_vcm.h:49
+
+work(items) takes normalised-spectrum items and returns the PDUs the reference would publish on "msgout" as
+(dict, complex64 array) pairs with the same keys (…vcm_impl.cc:415-430, PowerActivationChannel_impl.cc:222-233).
+The timestamp prefix of the ID strings is left out: "PowActChan.<ID>.<n>(.fin|.part)", "DETECTED.<seg>.<n>".
+`Sinks` is the shared-spectrum bank both faces (and the hier-block mirror) are built on.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class Sinks:
+    def __init__(self, blocklen, relinvovl, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
+                 segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
+                 max_blocks=64, device_id=0):
+        self._h = C.c_void_p()
+        self.N = int(blocklen)
+        pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
+        for i, (cf, bw, ident) in enumerate(pac):
+            pa[i].cfreq, pa[i].bw, pa[i].id = float(cf), float(bw), int(ident)
+        sg = (_lib.fdc_segment_cfg * max(1, len(segments)))()
+        for i, (a, b) in enumerate(segments):
+            sg[i].start, sg[i].stop = float(a), float(b)
+        cfg = _lib.fdc_sinks_cfg(device_id, self.N, int(relinvovl), len(pac), pa, float(pac_thresh), int(pac_maxblocks),
+                                 int(pac_delay), len(segments), sg, float(det_thresh), int(det_maxblocks),
+                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks))
+        rc = _lib.lib().fdc_sinks_create(C.byref(cfg), C.byref(self._h))
+        if rc == -1:
+            raise ValueError(_lib.lib().fdc_last_error().decode())
+        _lib.check(rc)
+        self.max_blocks = int(max_blocks)
+        self.npac, self.nseg = len(pac), len(segments)
+
+    def pac_params(self, i):
+        v = (C.c_int32 * 8)()
+        _lib.check(_lib.lib().fdc_sinks_pac_params(self._h, i, v))
+        return dict(zip(("extract_start", "extract_stop", "extract_width", "measure_start", "measure_stop",
+                         "output_len", "output_ovl_offset", "deltaphase"), list(v)))
+
+    def segment_params(self, i):
+        v = (C.c_int32 * 5)()
+        _lib.check(_lib.lib().fdc_sinks_segment_params(self._h, i, v))
+        return dict(zip(("start", "stop", "width", "dec", "npower"), list(v)))
+
+    def spectrum_ptr(self):
+        return _lib.lib().fdc_sinks_spectrum(self._h)
+
+    def _collect(self):
+        out = []
+        p = _lib.fdc_pdu()
+        for i in range(_lib.lib().fdc_sinks_pdu_count(self._h)):
+            _lib.check(_lib.lib().fdc_sinks_pdu(self._h, i, C.byref(p)))
+            if p.nsamples > 0:
+                buf = (C.c_float * (2 * p.nsamples)).from_address(p.samples)
+                data = np.frombuffer(buf, dtype=np.complex64).copy()
+            else:
+                data = np.zeros(0, np.complex64)
+            out.append((dict(kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                             has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq,
+                             blockstart=p.blockstart, blockend=p.blockend, vectorstart=p.vectorstart,
+                             vectorend=p.vectorend), data))
+        return out
+
+    def work(self, spectrum):
+        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        if spectrum.size % self.N:
+            raise ValueError("input is not a whole number of spectrum items")
+        n = spectrum.size // self.N
+        out = []
+        for a in range(0, n, self.max_blocks):          # batches of at most max_blocks items
+            b = min(n, a + self.max_blocks)
+            _lib.check(_lib.lib().fdc_sinks_work(self._h, spectrum[a * self.N:].ctypes.data, b - a))
+            out += self._collect()
+        return out
+
+    def work_device(self, nblocks):
+        _lib.check(_lib.lib().fdc_sinks_work_device(self._h, int(nblocks)))
+        return self._collect()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().fdc_sinks_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _pac_pdu(meta, data):
+    """dict keys of PowerActivationChannel_impl.cc:222-230"""
+    d = {"ID": "PowActChan.%d.%d%s" % (meta["source"], meta["chan_id"], ".fin" if meta["finalized"] else ".part"),
+         "finalized": meta["finalized"], "part": meta["part"], "rel_cfreq": meta["rel_cfreq"], "rel_bw": meta["rel_bw"],
+         "blockstart": meta["blockstart"], "blockend": meta["blockend"]}
+    return d, data
+
+
+def _det_pdu(meta, data):
+    """dict keys of activity_detection_channelizer_vcm_impl.cc:415-427 / :472-483"""
+    d = {"ID": "DETECTED.%d.%d" % (meta["source"], meta["chan_id"]), "finalized": meta["finalized"]}
+    if meta["has_part"]:
+        d["part"] = meta["part"]
+    d.update(rel_bw=meta["rel_bw"], rel_cfreq=meta["rel_cfreq"], blockstart=meta["blockstart"],
+             blockend=meta["blockend"], vectorstart=meta["vectorstart"], vectorend=meta["vectorend"])
+    return d, data
+
+
+def _write_files(path, pdus, pac):
+    """<path>/<ID>.fin and <path>/<ID>.parted.<n>, raw complex64 (…vcm_impl.cc:431-439,488-496;
+    PowerActivationChannel_impl.cc:235-244)."""
+    for d, data in pdus:
+        base = d["ID"]
+        if pac:
+            base = base.rsplit(".", 1)[0]
+        name = base + (".fin" if d["finalized"] else ".parted.%d" % d.get("part", 0))
+        try:
+            data.tofile(os.path.join(path, name))
+        except OSError as e:                       # the reference prints to cerr and carries on
+            print("Cannot write to file", name, e)
+
+
+class PowerActivationChannel:
+    def __init__(self, blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay, msg, fileoutput, path,
+                 verbose, ID, device_id=0, max_blocks=64):
+        self.msg, self.fileoutput, self.path = bool(msg), bool(fileoutput), str(path)
+        self.bank = Sinks(blocklen, relinvovl, pac=[(cfreq, bw, ID)], pac_thresh=thresh, pac_maxblocks=maxblocks,
+                          pac_delay=deactivation_delay, max_blocks=max_blocks, device_id=device_id)
+        self.params = self.bank.pac_params(0)
+
+    def work(self, spectrum):
+        pdus = [_pac_pdu(m, d) for (m, d) in self.bank.work(spectrum)]
+        if self.fileoutput:
+            _write_files(self.path, pdus, True)
+        return pdus
+
+
+class activity_detection_channelizer_vcm:
+    def __init__(self, blocklen, segments, thresh, relinvovl, maxblocks, message, fileoutput, path, threads,
+                 minchandist, channel_deactivation_delay, window_flank_puffer, verbose, device_id=0, max_blocks=64):
+        self.msg, self.fileoutput, self.path = bool(message), bool(fileoutput), str(path)
+        for s in segments:
+            if len(s) != 2:
+                raise ValueError("Segment is incorrect. must be of size 2")
+        self.bank = Sinks(blocklen, relinvovl, segments=[tuple(s) for s in segments], det_thresh=thresh,
+                          det_maxblocks=maxblocks, minchandist=minchandist, det_delay=channel_deactivation_delay,
+                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id)
+        self.segments = [self.bank.segment_params(i) for i in range(len(segments))]
+
+    def work(self, spectrum):
+        pdus = [_det_pdu(m, d) for (m, d) in self.bank.work(spectrum)]
+        if self.fileoutput:
+            _write_files(self.path, pdus, False)
+        return pdus

@@ -116,6 +116,63 @@ int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable);
 int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stateful sinks fed with the normalised spectrum (what the hier block connects to normalize_input,
+ * python/FrequencyDomainChannelizer.py:301-312): a bank of
+ *   gr::FDC::PowerActivationChannel::make(blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay,
+ *        msg, fileoutput, path, verbose, ID)                       — include/FDC/PowerActivationChannel.h:49
+ * instances and the segments of one
+ *   gr::FDC::activity_detection_channelizer_vcm::make(blocklen, segments, thresh, relinvovl, maxblocks, message,
+ *        fileoutput, path, threads, minchandist, channel_deactivation_delay, window_flank_puffer, verbose)
+ *                                                                  — include/FDC/activity_detection_channelizer_vcm.h:49
+ * sharing ONE device-resident spectrum.  Power sums and extractions (window, half swap, inverse FFT, overlap discard)
+ * run on the GPU for a whole batch; the per-block decisions run on the host (lib/PowerActivationChannel_impl.cc:137-306,
+ * lib/activity_detection_channelizer_vcm_impl.cc:542-841).  What the reference publishes as pmt PDUs
+ * (dict + c32vector, …vcm_impl.cc:415-430, PowerActivationChannel_impl.cc:222-233) comes back as POD records that the
+ * C++ face turns into pmt; `msg`, `fileoutput`, `path`, `verbose` and `threads` stay with that face.
+ * create() fails with FDC_ERR_INVALID_ARGUMENT exactly where the reference constructors throw.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fdc_sinks fdc_sinks;
+typedef struct { float cfreq, bw; int32_t id; } fdc_pac_cfg;           /* INTERNAL frequency units, [0,1) */
+typedef struct { float start, stop; } fdc_segment_cfg;                 /* INTERNAL frequency units        */
+typedef struct {
+    int32_t device_id, blocklen, relinvovl;
+    int32_t npac; const fdc_pac_cfg *pac;
+    float pac_thresh_db; int32_t pac_maxblocks, pac_deactivation_delay;
+    int32_t nseg; const fdc_segment_cfg *seg;
+    float det_thresh_db; int32_t det_maxblocks; float minchandist; int32_t det_deactivation_delay;
+    double window_flank_puffer;
+    int32_t max_blocks;                                                /* largest batch of one work call  */
+} fdc_sinks_cfg;
+typedef struct {
+    int32_t kind;        /* 0 = PowerActivationChannel, 1 = detected channel of a segment                       */
+    int32_t source;      /* PAC: its ID argument; detection: segment index                                      */
+    int32_t chan_id;     /* the running number inside the ID string: PAC finished_channels at activation
+                            (…PowActChan.<ID>.<n>), detection: channel counter of the segment (…DETECTED.<seg>.<n>) */
+    int32_t finalized, part, has_part;   /* has_part: whether the dict carries "part" (…vcm_impl.cc:419-420)   */
+    double rel_bw, rel_cfreq;
+    int64_t blockstart, blockend, vectorstart, vectorend;   /* vectorstart/end are in the dict for detection only */
+    int64_t nsamples;
+    const void *samples; /* complex float32, owned by the handle until its next work call                     */
+} fdc_pdu;
+
+int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
+void fdc_sinks_destroy(fdc_sinks *s);
+/* work()-shaped: nitems normalised-spectrum items of blocklen samples each on the host; returns nitems */
+int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems);
+/* device-resident: the producer (fdc_pipeline_process_device with d_spectrum = fdc_sinks_spectrum(s)) has written
+ * nblocks spectra there on a stream it has synchronised; no PCIe traffic for the spectrum */
+void *fdc_sinks_spectrum(fdc_sinks *s);
+void *fdc_sinks_stream(fdc_sinks *s);
+int fdc_sinks_work_device(fdc_sinks *s, int nblocks);
+/* PDUs emitted by the last work call, in emission order */
+int fdc_sinks_pdu_count(const fdc_sinks *s);
+int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);
+/* derived geometry (for logs and tests): v[8] = extract_start, extract_stop, extract_width, measure_start,
+ * measure_stop, output_len, output_ovl_offset, deltaphase;  v[5] = start, stop, width, decimation, power cells */
+int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v8);
+int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v5);
+
+/* ------------------------------------------------------------------------------------------------
  * Single-block faces (same arithmetic as the fused pipeline, one reference block each).
  * ---------------------------------------------------------------------------------------------- */
 /* gr::FDC::overlap_save::make(itemsize, outputlen, overlaplen) — include/FDC/overlap_save.h:49,

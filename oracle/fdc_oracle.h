@@ -66,6 +66,39 @@ int fdco_channelizer(int N, int R, int wintype, int C, const int *f, const int *
                      const float *prefix, const float *x, int nblocks,
                      float **out, float *spectrum, int use_float, int nthreads);
 
+/* ---- stateful sinks fed with the normalised spectrum (fdc_oracle_detect.c) ------------------------------------ */
+typedef struct {
+    int kind;            /* 0 = PowerActivationChannel, 1 = activity_detection_channelizer_vcm */
+    int source;          /* PAC: ID argument; vcm: segment index                                    */
+    int chan_id;         /* PAC: finished_channels at activation; vcm: channel counter in the segment (ID strings) */
+    int finalized, part, has_part;
+    double rel_bw, rel_cfreq;
+    long blockstart, blockend, vectorstart, vectorend;
+    long nsamples;
+    float *samples;      /* interleaved complex, owned by the list */
+} fdco_pdu;
+typedef struct { fdco_pdu *pdu; int n, cap; } fdco_pdu_list;
+void fdco_pdu_list_clear(fdco_pdu_list *L);
+
+typedef struct fdco_pac fdco_pac;
+/* PowerActivationChannel::make(blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay, …, ID)
+ * (include/FDC/PowerActivationChannel.h:49); NULL where the reference constructor throws. */
+fdco_pac *fdco_pac_create(int blocklen, float cfreq, float bw, int relinvovl, float thresh_db, int maxblocks,
+                          int deactivation_delay, int ID);
+void fdco_pac_destroy(fdco_pac *p);
+void fdco_pac_params(const fdco_pac *p, int *v8);   /* extract_start, extract_stop, extract_width, measure_start,
+                                                       measure_stop, output_len, output_ovl_offset, deltaphase */
+void fdco_pac_work(fdco_pac *p, const float *spectrum_items, int nitems, fdco_pdu_list *L);
+
+typedef struct fdco_vcm fdco_vcm;
+/* activity_detection_channelizer_vcm::make(blocklen, segments, thresh, relinvovl, maxblocks, …, minchandist,
+ * channel_deactivation_delay, window_flank_puffer, …) (include/FDC/activity_detection_channelizer_vcm.h:49) */
+fdco_vcm *fdco_vcm_create(int blocklen, int nseg, const float *segs, float thresh_db, int relinvovl, int maxblocks,
+                          float minchandist, int deactivation_delay, double window_flank_puffer);
+void fdco_vcm_destroy(fdco_vcm *v);
+int fdco_vcm_segment_params(const fdco_vcm *v, int s, int *out5);   /* start, stop, width, dec, npower */
+void fdco_vcm_work(fdco_vcm *v, const float *spectrum_items, int nitems, fdco_pdu_list *L);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,101 @@ def channelizer(N, R, wintype, chans, x, prefix=None, first_block=0, want_spectr
     if rc != 0:
         raise RuntimeError("oracle channelizer failed")
     return outs, spec
+
+
+# ---- stateful sinks ---------------------------------------------------------------------------------------------
+class _Pdu(C.Structure):
+    _fields_ = [("kind", C.c_int), ("source", C.c_int), ("chan_id", C.c_int), ("finalized", C.c_int),
+                ("part", C.c_int), ("has_part", C.c_int), ("rel_bw", C.c_double), ("rel_cfreq", C.c_double),
+                ("blockstart", C.c_long), ("blockend", C.c_long), ("vectorstart", C.c_long), ("vectorend", C.c_long),
+                ("nsamples", C.c_long), ("samples", C.POINTER(C.c_float))]
+
+
+class _PduList(C.Structure):
+    _fields_ = [("pdu", C.POINTER(_Pdu)), ("n", C.c_int), ("cap", C.c_int)]
+
+
+def _drain(L):
+    out = []
+    for i in range(L.n):
+        p = L.pdu[i]
+        d = dict(kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                 has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq, blockstart=p.blockstart,
+                 blockend=p.blockend, vectorstart=p.vectorstart, vectorend=p.vectorend)
+        d["samples"] = np.ctypeslib.as_array(p.samples, shape=(2 * p.nsamples,)).copy().view(np.complex64) \
+            if p.nsamples > 0 else np.zeros(0, np.complex64)
+        out.append(d)
+    lib().fdco_pdu_list_clear(C.byref(L))
+    return out
+
+
+def _sink_protos():
+    l = lib()
+    if getattr(l, "_sinks_ready", False):
+        return l
+    l.fdco_pdu_list_clear.argtypes = [C.POINTER(_PduList)]
+    l.fdco_pac_create.restype = C.c_void_p
+    l.fdco_pac_create.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    l.fdco_pac_destroy.argtypes = [C.c_void_p]
+    l.fdco_pac_params.argtypes = [C.c_void_p, _ip]
+    l.fdco_pac_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_PduList)]
+    l.fdco_vcm_create.restype = C.c_void_p
+    l.fdco_vcm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double]
+    l.fdco_vcm_destroy.argtypes = [C.c_void_p]
+    l.fdco_vcm_segment_params.argtypes = [C.c_void_p, C.c_int, _ip]
+    l.fdco_vcm_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_PduList)]
+    l._sinks_ready = True
+    return l
+
+
+class PowerActivationChannel:
+    """lib/PowerActivationChannel_impl.cc restated (stateful)."""
+
+    def __init__(self, blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay, ID=0):
+        self.N = blocklen
+        self._h = _sink_protos().fdco_pac_create(blocklen, cfreq, bw, relinvovl, thresh, maxblocks, deactivation_delay, ID)
+        if not self._h:
+            raise ValueError("invalid PowerActivationChannel arguments")
+        v = (C.c_int * 8)()
+        lib().fdco_pac_params(self._h, v)
+        (self.extract_start, self.extract_stop, self.extract_width, self.measure_start, self.measure_stop,
+         self.output_len, self.output_ovl_offset, self.deltaphase) = list(v)
+
+    def work(self, spectrum):
+        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        L = _PduList()
+        lib().fdco_pac_work(self._h, spectrum.ctypes.data, spectrum.size // self.N, C.byref(L))
+        return _drain(L)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().fdco_pac_destroy(self._h)
+            self._h = None
+
+
+class ActivityDetectionVcm:
+    """lib/activity_detection_channelizer_vcm_impl.cc restated (stateful)."""
+
+    def __init__(self, blocklen, segments, thresh, relinvovl, maxblocks, minchandist, deactivation_delay, puffer):
+        self.N = blocklen
+        seg = np.array(segments, dtype=np.float32).reshape(-1, 2)
+        self._h = _sink_protos().fdco_vcm_create(blocklen, len(seg), seg.ctypes.data, thresh, relinvovl, maxblocks,
+                                                 minchandist, deactivation_delay, puffer)
+        if not self._h:
+            raise ValueError("invalid activity_detection_channelizer_vcm arguments")
+        self.segments = []
+        for s in range(len(seg)):
+            v = (C.c_int * 5)()
+            lib().fdco_vcm_segment_params(self._h, s, v)
+            self.segments.append(dict(start=v[0], stop=v[1], width=v[2], dec=v[3], npower=v[4]))
+
+    def work(self, spectrum):
+        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        L = _PduList()
+        lib().fdco_vcm_work(self._h, spectrum.ctypes.data, spectrum.size // self.N, C.byref(L))
+        return _drain(L)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().fdco_vcm_destroy(self._h)
+            self._h = None

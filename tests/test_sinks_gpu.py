@@ -1,0 +1,141 @@
+"""GPU tests (-m gpu) of the stateful sinks against the oracle restatements: PDU metadata exact (ints) / 1e-12
+(doubles), emitted-sample counts exact, payload within 1e-5 relative (SURVEY.md §8d parity metric).
+Bursts sit >= 20 dB above the floor so threshold decisions do not depend on the float summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gr_fdc_amd as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+INTS = ("kind", "source", "chan_id", "finalized", "part", "has_part", "blockstart", "blockend")
+
+
+def burst_spectrum(N, nb, bursts, seed, floor=1e-3):
+    """normalised-spectrum items: white floor plus rectangular bursts (lo_bin, hi_bin, first_block, last_block, amp)"""
+    rng = np.random.default_rng(seed)
+    s = floor * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))
+    for lo, hi, b0, b1, amp in bursts:
+        s[b0:b1 + 1, lo:hi] += amp * (rng.standard_normal((b1 - b0 + 1, hi - lo)) + 1j * rng.standard_normal((b1 - b0 + 1, hi - lo)))
+    return s.astype(np.complex64)
+
+
+def compare(got, ref, vec=True):
+    assert len(got) == len(ref), (len(got), len(ref))
+    for (gm, gd), r in zip(got, ref):
+        for k in INTS:
+            assert int(gm[k]) == int(r[k]), (k, gm, {q: r[q] for q in r if q != "samples"})
+        if vec:
+            assert gm["vectorstart"] == r["vectorstart"] and gm["vectorend"] == r["vectorend"]
+        assert abs(gm["rel_bw"] - r["rel_bw"]) < 1e-12 and abs(gm["rel_cfreq"] - r["rel_cfreq"]) < 1e-12
+        assert gd.size == r["samples"].size
+        if gd.size:
+            d = gd.astype(np.complex128) - r["samples"].astype(np.complex128)
+            assert np.linalg.norm(d) <= TOL * np.linalg.norm(r["samples"])
+            assert np.abs(d).max() <= TOL * np.abs(r["samples"]).max()
+
+
+def test_pac_known_answer_from_survey(oracle, golden_dir):
+    """The scenario of SURVEY.md §8c: bins 1600-1799 active in blocks 3-7, N=4096, R=4 -> one finalised PDU."""
+    ka = json.load(open(os.path.join(golden_dir, "sink_known_answers.json")))["PowerActivationChannel"]
+    N, R = 4096, 4
+    spec = burst_spectrum(N, 12, [(1600, 1800, 3, 7, 1.0)], 0)
+    cf, bw = (1600 + 1800) / 2 / N, 200 / N
+    bank = G.Sinks(N, R, pac=[(cf, bw, 0)], pac_thresh=6.0, pac_maxblocks=-1, max_blocks=16)
+    got = bank.work(spec)
+    assert len(got) == 1
+    m, d = got[0]
+    assert m["finalized"] and abs(m["rel_bw"] - ka["rel_bw"]) < 1e-12
+    assert (m["blockstart"], m["blockend"], d.size) == (ka["blockstart"], ka["blockend"], ka["nsamples"])
+    compare(got, oracle.PowerActivationChannel(N, cf, bw, R, 6.0, -1, 0, 0).work(spec), vec=False)
+
+
+@pytest.mark.parametrize("maxblocks", [-1, 0, 3])
+def test_pac_bank_vs_oracle(oracle, maxblocks):
+    N, R, nb = 4096, 2, 40
+    plan = [(0.20, 0.03, 0), (0.41, 0.05, 1), (0.70, 0.011, 2), (0.9, 0.1, 7)]
+    bursts = []
+    rng = np.random.default_rng(3)
+    for cf, bw, _ in plan:
+        lo, hi = int(round((cf - bw / 2) * N)), int(round((cf + bw / 2) * N))
+        t = 2
+        while t < nb - 3:
+            ln = int(rng.integers(2, 9))
+            bursts.append((lo, hi, t, min(nb - 2, t + ln), 1.0))
+            t += ln + int(rng.integers(3, 7))
+    spec = burst_spectrum(N, nb, bursts, 11)
+    bank = G.Sinks(N, R, pac=plan, pac_thresh=6.0, pac_maxblocks=maxblocks, max_blocks=16)
+    got = bank.work(spec[:7].reshape(-1)) + bank.work(spec[7:].reshape(-1))       # state carries over calls and batches
+    assert len(got) > 4
+    for i, (cf, bw, ident) in enumerate(plan):
+        o = oracle.PowerActivationChannel(N, cf, bw, R, 6.0, maxblocks, 0, ident)
+        p = bank.pac_params(i)
+        assert (p["extract_start"], p["extract_stop"], p["extract_width"], p["measure_start"], p["measure_stop"],
+                p["output_len"]) == (o.extract_start, o.extract_stop, o.extract_width, o.measure_start, o.measure_stop, o.output_len)
+        ref = o.work(spec[:7]) + o.work(spec[7:])
+        compare([g for g in got if g[0]["source"] == ident], ref, vec=False)
+
+
+def test_pac_face_and_errors(oracle, tmp_path):
+    N, R = 1024, 2
+    spec = burst_spectrum(N, 10, [(300, 340, 2, 5, 1.0)], 5)
+    blk = G.PowerActivationChannel(N, 320 / N, 40 / N, R, 6.0, -1, 0, True, True, str(tmp_path), 0, 3)
+    pdus = blk.work(spec)
+    assert len(pdus) == 1 and pdus[0][0]["ID"] == "PowActChan.3.0.fin" and pdus[0][0]["finalized"] is True
+    assert set(pdus[0][0]) == {"ID", "finalized", "part", "rel_cfreq", "rel_bw", "blockstart", "blockend"}
+    f = np.fromfile(os.path.join(str(tmp_path), "PowActChan.3.0.fin"), dtype=np.complex64)
+    assert (f == pdus[0][1]).all()
+    with pytest.raises(ValueError):
+        G.PowerActivationChannel(N, 0.01, 0.1, R, 6.0, -1, 0, False, False, "", 0, 0)    # out of band (…cc:318-319)
+    with pytest.raises(ValueError):
+        G.PowerActivationChannel(N, 0.5, 0.1, R, 0.0, -1, 0, False, False, "", 0, 0)     # thresh <= 0 (:378-379)
+    with pytest.raises(ValueError):
+        G.PowerActivationChannel(N, 0.5, 0.1, 3, 6.0, -1, 0, False, False, "", 0, 0)     # relinvovl not 2^k (:68-69)
+
+
+@pytest.mark.parametrize("N,R,maxblocks,delay", [(4096, 4, -1, 1), (4096, 2, 0, 0), (16384, 2, 3, 2), (65536, 2, 128, 1)])
+def test_vcm_vs_oracle(oracle, N, R, maxblocks, delay):
+    nb = 36
+    segs = [[0.05, 0.45], [0.55, 0.95]]
+    rng = np.random.default_rng(N + R)
+    bursts = []
+    for s0, s1 in segs:
+        pos = s0 + 0.02
+        while pos < s1 - 0.06:
+            wdt = float(rng.uniform(0.004, 0.03))
+            lo, hi = int(pos * N), int((pos + wdt) * N)
+            t0 = int(rng.integers(1, 12)); ln = int(rng.integers(4, 16))
+            bursts.append((lo, hi, t0, min(nb - 3, t0 + ln), 1.0))
+            pos += wdt + float(rng.uniform(0.03, 0.06))
+    spec = burst_spectrum(N, nb, bursts, 17)
+    blk = G.Sinks(N, R, segments=[tuple(s) for s in segs], det_thresh=10.0, det_maxblocks=maxblocks, minchandist=0.005,
+                  det_delay=delay, puffer=0.2, max_blocks=16)
+    o = oracle.ActivityDetectionVcm(N, segs, 10.0, R, maxblocks, 0.005, delay, 0.2)
+    for i, g in enumerate(o.segments):
+        assert blk.segment_params(i) == g
+    got = blk.work(spec[:5].reshape(-1)) + blk.work(spec[5:].reshape(-1))
+    ref = o.work(spec[:5]) + o.work(spec[5:])
+    assert len(ref) >= 4
+    compare(got, ref)
+
+
+def test_vcm_known_answer_and_face(oracle, golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "sink_known_answers.json")))["activity_detection_channelizer_vcm"]
+    N, R = 4096, 4
+    spec = burst_spectrum(N, 12, [(1600, 1800, 3, 7, 1.0)], 0)
+    blk = G.activity_detection_channelizer_vcm(N, [[0.3, 0.55]], 10.0, R, -1, True, False, "", False, 0.005, 1, 0.2, 0)
+    pdus = blk.work(spec)
+    assert len(pdus) == 1
+    d, data = pdus[0]
+    assert d["ID"] == "DETECTED.0.0" and d["finalized"] is True and "part" not in d
+    assert (abs(d["rel_bw"] - ka["rel_bw"]) < 1e-12 and d["blockstart"] == ka["blockstart"] and d["blockend"] == ka["blockend"]
+            and data.size == ka["nsamples"])
+    # the survey run's segment geometry is not recorded: the detection grid (dec = 10 bins) may shift the slice
+    assert abs(d["vectorstart"] - ka["vectorstart"]) <= 10 and d["vectorend"] - d["vectorstart"] == 512
+    with pytest.raises(ValueError):
+        G.activity_detection_channelizer_vcm(N, [[0.5, 0.3]], 10.0, R, -1, True, False, "", False, 0.005, 1, 0.2, 0)
+    with pytest.raises(ValueError):
+        G.activity_detection_channelizer_vcm(N, [[0.1, 0.3]], 10.0, R, -1, True, False, "", False, 1.5, 1, 0.2, 0)
