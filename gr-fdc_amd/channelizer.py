@@ -90,7 +90,8 @@ class Pipeline:
         return int(_lib.lib().fdc_pipeline_channel_offset(self._h, c, nblocks))
 
     # -- host path (what sync_block::work() would call)
-    def work(self, x, want_spectrum=False):
+    def work(self, x, want_spectrum=False, sinks=None):
+        """sinks: a gr_fdc_amd.Sinks bank fed from the device-resident spectrum of this call (needs keep_spectrum)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if x.size % self.H:
             raise ValueError("input must be a whole number of (N - N/R)-sample items")
@@ -98,8 +99,12 @@ class Pipeline:
         outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
         ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
         spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
-        _lib.check(_lib.lib().fdc_pipeline_work(self._h, x.ctypes.data, nb, ptrs,
-                                               spec.ctypes.data if spec is not None else None))
+        if sinks is not None:
+            _lib.check(_lib.lib().fdc_pipeline_work_sinks(self._h, x.ctypes.data, nb, ptrs,
+                                                         spec.ctypes.data if spec is not None else None, sinks._h))
+        else:
+            _lib.check(_lib.lib().fdc_pipeline_work(self._h, x.ctypes.data, nb, ptrs,
+                                                   spec.ctypes.data if spec is not None else None))
         return (outs, spec) if want_spectrum else outs
 
     def reset(self):
@@ -209,11 +214,27 @@ class FrequencyDomainChannelizer:
 
         self.channel_params = [get_opt_channelparams(self.blocksize, self.relinvovl, fr, bw)
                                for (fr, bw) in self.throughput_channels]
+        # activity-controlled channels (:237-251) and detection segments (:261-278) share one spectrum on the device
+        self.msgoutput, self.fileoutput, self.outputpath = bool(msgoutput), bool(fileoutput), str(outputpath)
+        self.sinks = None
+        if self.activity_controlled_channels or self.activity_detection_segments:
+            from .sinks import Sinks
+            pad = int(pow_act_deactivation_delay) if int(pow_act_deactivation_delay) >= 0 else 0
+            add = int(act_det_deactivation_delay) if int(act_det_deactivation_delay) >= 0 else 0
+            puf = float(minchanflankpuffer) if 0.0 <= float(minchanflankpuffer) else 0.2
+            self.sinks = Sinks(self.blocksize, self.relinvovl,
+                               pac=[(cf, bw, i) for i, (cf, bw) in enumerate(self.activity_controlled_channels)],
+                               pac_thresh=float(act_contr_threshold), pac_maxblocks=int(pow_act_maxblocks), pac_delay=pad,
+                               segments=[tuple(sg) for sg in self.activity_detection_segments],
+                               det_thresh=float(act_det_threshold), det_maxblocks=int(act_det_maxblocks),
+                               minchandist=self.get_bw(minchandist) if self.activity_detection_segments else 0.005,
+                               det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id)
         self.pipeline = Pipeline(self.blocksize, self.relinvovl,
                                  [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
                                  windowtype=int(windowtype), max_blocks=max_blocks, device_id=device_id,
-                                 keep_spectrum=self.debug)
+                                 keep_spectrum=self.debug or self.sinks is not None)
         self.N_throughput_channelizers = len(self.channel_params)
+        self.messages = []          # PDUs published on "msgout" by the last work() call
 
     @staticmethod
     def _convert(lst, conv, what):
@@ -243,7 +264,22 @@ class FrequencyDomainChannelizer:
         return [self.get_freq(c[0]), self.get_freq(c[1])]
 
     def work(self, samples):
+        """Returns the hier block's stream ports; PDUs of the sink blocks ("msgout", :166-168) are left in
+        self.messages as (dict, complex64 array) pairs.  Detection segments run the vcm core (the reference hier block
+        instantiates its single-segment twin SegmentDetection, whose block numbers are one lower: SURVEY App. B.3)."""
+        res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
+        self.messages = []
+        if self.sinks is not None:
+            from .sinks import _pac_pdu, _det_pdu, _write_files
+            raw = self.sinks._collect()
+            pac = [_pac_pdu(m, d) for (m, d) in raw if m["kind"] == 0]
+            det = [_det_pdu(m, d) for (m, d) in raw if m["kind"] == 1]
+            if self.fileoutput:
+                _write_files(self.outputpath, pac, True)
+                _write_files(self.outputpath, det, False)
+            if self.msgoutput:
+                self.messages = pac + det
         if self.debug:
-            outs, spec = self.pipeline.work(samples, want_spectrum=True)
+            outs, spec = res
             return [spec] + outs
-        return self.pipeline.work(samples)
+        return res

@@ -445,27 +445,28 @@ void fdc_pipeline_reset(fdc_pipeline *p)
     }
 }
 
-int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
+                              float2 *d_spec_dst)
 {
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     if (nblocks == 0) return 0;
     if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
     if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
-    if (spectrum && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    if ((spectrum || d_spec_dst) && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
     HIPCHK(hipSetDevice(p->cfg.device_id));
     if (!p->d_ring) {
         HIPCHK(hipMalloc(&p->d_ring, sizeof(float2) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
         HIPCHK(hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream));   // zero history (overlap_save_impl.cc:52)
         if (p->sum_lout > 0) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
     }
-    float2 *d_specfull = nullptr;
-    if (spectrum) HIPCHK(hipMalloc(&d_specfull, sizeof(float2) * (size_t)nblocks * p->N));
+    float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
+    if (spectrum && !d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
     hipStream_t s = p->stream;
     const size_t nin = (size_t)nblocks * p->H;
     HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
     int rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
-    if (rc != FDC_OK) { (void)hipFree(d_specfull); return rc; }
+    if (rc != FDC_OK) { (void)hipFree(d_owned); return rc; }
     for (int c = 0; c < p->C; c++) {
         if (!outs[c]) continue;
         HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
@@ -475,9 +476,25 @@ int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const 
     // history <- last ovl samples of this call (overlap_save_impl.cc:78); src and dst never overlap (H >= ovl)
     HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (d_specfull) HIPCHK(hipFree(d_specfull));
+    if (d_owned) HIPCHK(hipFree(d_owned));
     p->blockcount += nblocks;
     return nblocks;
+}
+
+int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    return pipeline_work_impl(p, in, nblocks, outs, spectrum, nullptr);
+}
+
+int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
+                            fdc_sinks *sinks)
+{
+    if (!sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null sinks handle");
+    // the spectrum goes straight into the sinks' device buffer (no PCIe round trip), then the sinks run on it
+    int rc = pipeline_work_impl(p, in, nblocks, outs, spectrum, static_cast<float2 *>(fdc_sinks_spectrum(sinks)));
+    if (rc < 0) return rc;
+    const int rs = fdc_sinks_work_device(sinks, nblocks);
+    return rs < 0 ? rs : rc;
 }
 
 /* ---------------- single-block faces ---------------- */

@@ -156,6 +156,11 @@ typedef struct {
 } fdc_pdu;
 
 int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
+/* The whole hier block in one call: fdc_pipeline_work() whose spectrum lands directly in the sinks' device buffer,
+ * followed by the sinks' work on it (python/FrequencyDomainChannelizer.py:283-312).  The pipeline needs keep_spectrum,
+ * the same blocklen/device as the sinks and nblocks <= the sinks' max_blocks. */
+int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
+                            fdc_sinks *sinks);
 void fdc_sinks_destroy(fdc_sinks *s);
 /* work()-shaped: nitems normalised-spectrum items of blocklen samples each on the host; returns nitems */
 int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems);

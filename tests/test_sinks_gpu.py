@@ -139,3 +139,33 @@ def test_vcm_known_answer_and_face(oracle, golden_dir):
         G.activity_detection_channelizer_vcm(N, [[0.5, 0.3]], 10.0, R, -1, True, False, "", False, 0.005, 1, 0.2, 0)
     with pytest.raises(ValueError):
         G.activity_detection_channelizer_vcm(N, [[0.1, 0.3]], 10.0, R, -1, True, False, "", False, 1.5, 1, 0.2, 0)
+
+
+def test_hier_block_with_sinks_from_device_spectrum(oracle):
+    """FrequencyDomainChannelizer mirror with throughput channels + activity-controlled channels + detection segments:
+    the sinks are fed from the device-resident spectrum of the same call (fdc_pipeline_work_sinks)."""
+    N, R, nb = 4096, 4, 24
+    H = N - N // R
+    rng = np.random.default_rng(8)
+    n = np.arange(nb * H)
+    x = 0.01 * (rng.standard_normal(nb * H) + 1j * rng.standard_normal(nb * H))
+    # a bursty carrier inside the activity-controlled channel and one inside the detection segment
+    for fc, t0, t1 in [(-0.2, 5, 11), (0.31, 8, 17)]:
+        env = np.zeros(nb * H); env[t0 * H:t1 * H] = 1.0
+        sym = (rng.integers(0, 2, nb * H // 64 + 1) * 2 - 1) + 1j * (rng.integers(0, 2, nb * H // 64 + 1) * 2 - 1)
+        x += env * np.repeat(sym, 64)[:nb * H] * np.exp(2j * np.pi * fc * n)
+    x = x.astype(np.complex64)
+    fdc = G.FrequencyDomainChannelizer(8, 1, N, R, [[0.1, 0.05]], [[-0.2, 0.04]], 6.0, 1.0, 0.0, 'normalized', 1,
+                                       True, False, "", False, [[0.25, 0.4]], 10.0, 0.005, 1, 0.2, 0, 0, -1, -1, True,
+                                       max_blocks=nb)
+    ports = fdc.work(x)
+    spec = ports[0]
+    pac_ref = oracle.PowerActivationChannel(N, (-0.2 + 0.5) % 1.0, 0.04, R, 6.0, -1, 0, 0).work(spec)
+    det_ref = oracle.ActivityDetectionVcm(N, [[0.75, 0.9]], 10.0, R, -1, 0.005, 1, 0.2).work(spec)
+    got_pac = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("PowActChan")]
+    got_det = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("DETECTED")]
+    assert len(pac_ref) >= 1 and len(det_ref) >= 1
+    assert len(got_pac) == len(pac_ref) and len(got_det) == len(det_ref)
+    for (d, s), r in zip(got_pac + got_det, pac_ref + det_ref):
+        assert (d["blockstart"], d["blockend"], s.size) == (r["blockstart"], r["blockend"], r["samples"].size)
+        assert np.abs(s - r["samples"]).max() <= 1e-5 * np.abs(r["samples"]).max()
