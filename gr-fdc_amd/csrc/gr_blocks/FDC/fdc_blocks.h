@@ -1,0 +1,55 @@
+// gr::FDC block classes of the MI355X build: the reference's public block API (class names, namespaces, header paths
+// FDC/<block>.h, make() signatures — include/FDC/*.h:36-50 of gereonsuch/gr-FDC) over libfdc_amd.so.
+// work() stays C++ inside the GNU Radio scheduler thread and forwards to the C-ABI (include/fdc_amd.h).
+#pragma once
+#ifdef FDC_HAVE_GNURADIO
+#include <gnuradio/sync_block.h>
+#else
+#include "../compat/gnuradio/sync_block.h"
+#endif
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifndef FDC_API
+#define FDC_API __attribute__((visibility("default")))
+#endif
+
+namespace gr {
+namespace FDC {
+
+class FDC_API overlap_save : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<overlap_save> sptr;
+    static sptr make(int itemsize, int outputlen, int overlaplen);
+};
+
+class FDC_API vector_cut_vxx : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<vector_cut_vxx> sptr;
+    static sptr make(int itemsize, int veclen, int offset, int blocklen);
+};
+
+class FDC_API phase_shifting_windowing_vcc : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<phase_shifting_windowing_vcc> sptr;
+    static sptr make(int blocklen, int numphasestates, int shifts, float passbw, float stopbw, int windowtype);
+};
+
+class FDC_API PowerActivationChannel : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<PowerActivationChannel> sptr;
+    static sptr make(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
+                     int deactivation_delay, bool msg, bool fileoutput, std::string path, int verbose, int ID);
+};
+
+class FDC_API activity_detection_channelizer_vcm : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<activity_detection_channelizer_vcm> sptr;
+    static sptr make(int blocklen, std::vector<std::vector<float>> segments, float thresh, int relinvovl, int maxblocks,
+                     bool message, bool fileoutput, std::string path, bool threads, float minchandist,
+                     int channel_deactivation_delay, double window_flank_puffer, int verbose);
+};
+
+}  // namespace FDC
+}  // namespace gr

@@ -1,0 +1,84 @@
+// Exercises the C++ gr::FDC faces the way the GNU Radio scheduler would (make(), then work() on item buffers) and
+// writes the results as raw files that tests/test_cpp_blocks_gpu.py compares with the oracle.
+//   blocks_demo <dir>   reads <dir>/x.c64 (stream), <dir>/spec.c64 (spectrum items); writes <dir>/*.out
+#include "FDC/overlap_save.h"
+#include "FDC/vector_cut_vxx.h"
+#include "FDC/phase_shifting_windowing_vcc.h"
+#include "FDC/PowerActivationChannel.h"
+#include "FDC/activity_detection_channelizer_vcm.h"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+using namespace gr::FDC;
+
+static std::vector<gr_complex> slurp(const std::string &fn)
+{
+    std::ifstream f(fn, std::ios::binary | std::ios::ate);
+    std::vector<gr_complex> v((size_t)f.tellg() / sizeof(gr_complex));
+    f.seekg(0);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(v.size() * sizeof(gr_complex)));
+    return v;
+}
+static void dump(const std::string &fn, const std::vector<gr_complex> &v)
+{
+    std::ofstream f(fn, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(gr_complex)));
+}
+template <class B> static std::vector<gr_complex> run(B &blk, const std::vector<gr_complex> &in, int nitems, size_t outlen)
+{
+    std::vector<gr_complex> out(outlen * (size_t)nitems);
+    gr_vector_const_void_star i{in.data()};
+    gr_vector_void_star o{out.data()};
+    if (blk->work(nitems, i, o) != nitems) throw std::runtime_error("work() did not consume all items");
+    return out;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    const std::string dir = argv[1];
+    const int N = 1024, R = 4, ovl = N / R, H = N - ovl;
+    try {
+        const auto x = slurp(dir + "/x.c64");
+        const int nb = (int)(x.size() / (size_t)H);
+        auto os = overlap_save::make(sizeof(gr_complex), N, ovl);
+        auto blocks = run(os, x, nb, (size_t)N);
+        dump(dir + "/overlap_save.out", blocks);
+        auto cut = vector_cut_vxx::make(sizeof(gr_complex), N, 301, 64);
+        auto sl = run(cut, blocks, nb, 64);
+        dump(dir + "/vector_cut.out", sl);
+        auto win = phase_shifting_windowing_vcc::make(64, R, 301, 0.6f, 0.85f, 1);
+        dump(dir + "/phase_window.out", run(win, sl, nb, 64));
+        bool threw = false;
+        try { phase_shifting_windowing_vcc::make(64, R, 0, 0.9f, 0.5f, 1); } catch (const std::invalid_argument &) { threw = true; }
+        if (!threw) throw std::runtime_error("constructor predicate did not throw");
+
+        const auto spec = slurp(dir + "/spec.c64");
+        const int ns = (int)(spec.size() / (size_t)N);
+        gr_vector_const_void_star si{spec.data()};
+        gr_vector_void_star none;
+        auto pac = PowerActivationChannel::make(N, 320.0f / N, 40.0f / N, R, 6.0f, -1, 0, true, false, "", 0, 5);
+        pac->work(ns, si, none);
+        std::vector<gr_complex> all;
+        FILE *meta = std::fopen((dir + "/pdus.txt").c_str(), "w");
+        for (auto &m : pac->published()) {
+            std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
+            all.insert(all.end(), m.samples.begin(), m.samples.end());
+        }
+        auto det = activity_detection_channelizer_vcm::make(N, {{0.5f, 0.9f}}, 10.0f, R, -1, true, false, "", false, 0.01f, 1, 0.2, 0);
+        det->work(ns, si, none);
+        for (auto &m : det->published()) {
+            std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
+            all.insert(all.end(), m.samples.begin(), m.samples.end());
+        }
+        std::fclose(meta);
+        dump(dir + "/pdus.out", all);
+    } catch (const std::exception &e) {
+        std::cerr << "blocks_demo: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

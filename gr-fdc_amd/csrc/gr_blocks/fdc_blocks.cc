@@ -1,0 +1,209 @@
+// Implementations of the gr::FDC block faces: constructors validate through the C-ABI's create() (which applies the
+// reference constructors' predicates) and rethrow std::invalid_argument; work() forwards and never throws.
+#include "FDC/fdc_blocks.h"
+#include "../../../include/fdc_amd.h"
+
+#include <cstdio>
+#include <iostream>
+#include <stdexcept>
+
+namespace gr {
+namespace FDC {
+
+namespace {
+
+void check_create(int rc)
+{
+    if (rc == FDC_ERR_INVALID_ARGUMENT) throw std::invalid_argument(fdc_last_error());
+    if (rc != FDC_OK) throw std::runtime_error(fdc_last_error());
+}
+
+int report(const char *who, int n)
+{
+    if (n < 0) { std::cerr << who << ": " << fdc_last_error() << std::endl; return 0; }   // work() never throws
+    return n;
+}
+
+class overlap_save_impl : public overlap_save {
+    fdc_overlap_save *d_h = nullptr;
+public:
+    overlap_save_impl(int itemsize, int outputlen, int overlaplen)
+        : gr::sync_block("overlap_save", gr::io_signature::make(1, 1, itemsize * (outputlen - overlaplen)),
+                         gr::io_signature::make(1, 1, itemsize * outputlen))
+    {
+        check_create(fdc_overlap_save_create(0, itemsize, outputlen, overlaplen, &d_h));
+    }
+    ~overlap_save_impl() override { fdc_overlap_save_destroy(d_h); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return report("overlap_save", fdc_overlap_save_work(d_h, in[0], n, out[0]));
+    }
+};
+
+class vector_cut_vxx_impl : public vector_cut_vxx {
+    fdc_vector_cut *d_h = nullptr;
+public:
+    vector_cut_vxx_impl(int itemsize, int veclen, int offset, int blocklen)
+        : gr::sync_block("vector_cut_vxx", gr::io_signature::make(1, 1, itemsize * veclen),
+                         gr::io_signature::make(1, 1, itemsize * blocklen))
+    {
+        check_create(fdc_vector_cut_create(0, itemsize, veclen, offset, blocklen, &d_h));
+    }
+    ~vector_cut_vxx_impl() override { fdc_vector_cut_destroy(d_h); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return report("vector_cut_vxx", fdc_vector_cut_work(d_h, in[0], n, out[0]));
+    }
+};
+
+class phase_shifting_windowing_vcc_impl : public phase_shifting_windowing_vcc {
+    fdc_phase_window *d_h = nullptr;
+public:
+    phase_shifting_windowing_vcc_impl(int blocklen, int numphasestates, int shifts, float passbw, float stopbw, int windowtype)
+        : gr::sync_block("phase_shifting_windowing_vcc", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
+                         gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen))
+    {
+        check_create(fdc_phase_window_create(0, blocklen, numphasestates, shifts, passbw, stopbw, windowtype, &d_h));
+    }
+    ~phase_shifting_windowing_vcc_impl() override { fdc_phase_window_destroy(d_h); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return report("phase_shifting_windowing_vcc", fdc_phase_window_work(d_h, in[0], n, out[0]));
+    }
+};
+
+// shared by the two sink faces: PDU records -> messages on "msgout" and raw files
+class sink_base {
+protected:
+    fdc_sinks *d_s = nullptr;
+    bool d_msg = false, d_file = false;
+    std::string d_path;
+    void publish(gr::sync_block *blk, bool pac)
+    {
+        fdc_pdu p;
+        for (int i = 0; i < fdc_sinks_pdu_count(d_s); i++) {
+            if (fdc_sinks_pdu(d_s, i, &p) != FDC_OK) continue;
+            char id[96];
+            if (pac) std::snprintf(id, sizeof id, "PowActChan.%d.%d", p.source, p.chan_id);
+            else std::snprintf(id, sizeof id, "DETECTED.%d.%d", p.source, p.chan_id);
+            const gr_complex *d = static_cast<const gr_complex *>(p.samples);
+            if (d_msg) {
+                gr::fdc_message m;      // with GNU Radio: pmt::cons(dict, pmt::init_c32vector(n, d)), same keys
+                m.str["ID"] = pac ? std::string(id) + (p.finalized ? ".fin" : ".part") : std::string(id);
+                m.flag["finalized"] = p.finalized != 0;
+                if (p.has_part) m.num["part"] = p.part;
+                m.real["rel_bw"] = p.rel_bw; m.real["rel_cfreq"] = p.rel_cfreq;
+                m.num["blockstart"] = (long)p.blockstart; m.num["blockend"] = (long)p.blockend;
+                if (!pac) { m.num["vectorstart"] = (long)p.vectorstart; m.num["vectorend"] = (long)p.vectorend; }
+                m.samples.assign(d, d + p.nsamples);
+                blk->message_port_pub("msgout", m);
+            }
+            if (d_file) {
+                const std::string fn = d_path + "/" + id + (p.finalized ? std::string(".fin") : ".parted." + std::to_string(p.part));
+                FILE *fh = std::fopen(fn.c_str(), "wb");
+                if (!fh) std::cerr << "Cannot write to file " << fn << std::endl;
+                else { std::fwrite(d, sizeof(gr_complex), (size_t)p.nsamples, fh); std::fclose(fh); }
+            }
+        }
+    }
+};
+
+class PowerActivationChannel_impl : public PowerActivationChannel, sink_base {
+public:
+    PowerActivationChannel_impl(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
+                                int deactivation_delay, bool msg, bool fileoutput, std::string path, int, int ID)
+        : gr::sync_block("PowerActivationChannel", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
+                         gr::io_signature::make(0, 0, 0))
+    {
+        fdc_pac_cfg pc{cfreq, bw, ID};
+        fdc_sinks_cfg c{};
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.npac = 1; c.pac = &pc; c.pac_thresh_db = thresh;
+        c.pac_maxblocks = maxblocks; c.pac_deactivation_delay = deactivation_delay; c.max_blocks = 64;
+        check_create(fdc_sinks_create(&c, &d_s));
+        d_msg = msg; d_file = fileoutput; d_path = path;
+        if (msg) message_port_register_out("msgout");
+    }
+    ~PowerActivationChannel_impl() override { fdc_sinks_destroy(d_s); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
+    {
+        const char *p = static_cast<const char *>(in[0]);
+        const size_t item = sizeof(gr_complex) * (size_t)input_signature()->sizeof_stream_item / sizeof(gr_complex);
+        for (int a = 0; a < n; a += 64) {
+            const int k = n - a < 64 ? n - a : 64;
+            if (report("PowerActivationChannel", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+            publish(this, true);
+        }
+        return n;
+    }
+};
+
+class activity_detection_channelizer_vcm_impl : public activity_detection_channelizer_vcm, sink_base {
+public:
+    activity_detection_channelizer_vcm_impl(int blocklen, std::vector<std::vector<float>> segments, float thresh,
+                                            int relinvovl, int maxblocks, bool message, bool fileoutput, std::string path,
+                                            bool /*threads: GPU batching replaces the per-channel std::thread fan-out*/,
+                                            float minchandist, int channel_deactivation_delay, double window_flank_puffer, int)
+        : gr::sync_block("activity_detection_channelizer_vcm", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
+                         gr::io_signature::make(0, 0, 0))
+    {
+        std::vector<fdc_segment_cfg> sg;
+        for (auto &v : segments) {
+            if (v.size() != 2) throw std::invalid_argument("Segment is incorrect. must be of size 2");
+            sg.push_back({v[0], v[1]});
+        }
+        fdc_sinks_cfg c{};
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = (int)sg.size(); c.seg = sg.data(); c.det_thresh_db = thresh;
+        c.det_maxblocks = maxblocks; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
+        c.window_flank_puffer = window_flank_puffer; c.max_blocks = 64;
+        check_create(fdc_sinks_create(&c, &d_s));
+        d_msg = message; d_file = fileoutput; d_path = path;
+        if (message) message_port_register_out("msgout");
+    }
+    ~activity_detection_channelizer_vcm_impl() override { fdc_sinks_destroy(d_s); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
+    {
+        const char *p = static_cast<const char *>(in[0]);
+        const size_t item = (size_t)input_signature()->sizeof_stream_item;
+        for (int a = 0; a < n; a += 64) {
+            const int k = n - a < 64 ? n - a : 64;
+            if (report("activity_detection_channelizer_vcm", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+            publish(this, false);
+        }
+        return n;
+    }
+};
+
+}  // namespace
+
+overlap_save::sptr overlap_save::make(int itemsize, int outputlen, int overlaplen)
+{
+    return gnuradio::get_initial_sptr(new overlap_save_impl(itemsize, outputlen, overlaplen));
+}
+vector_cut_vxx::sptr vector_cut_vxx::make(int itemsize, int veclen, int offset, int blocklen)
+{
+    return gnuradio::get_initial_sptr(new vector_cut_vxx_impl(itemsize, veclen, offset, blocklen));
+}
+phase_shifting_windowing_vcc::sptr phase_shifting_windowing_vcc::make(int blocklen, int numphasestates, int shifts,
+                                                                      float passbw, float stopbw, int windowtype)
+{
+    return gnuradio::get_initial_sptr(new phase_shifting_windowing_vcc_impl(blocklen, numphasestates, shifts, passbw, stopbw, windowtype));
+}
+PowerActivationChannel::sptr PowerActivationChannel::make(int blocklen, float cfreq, float bw, int relinvovl, float thresh,
+                                                          int maxblocks, int deactivation_delay, bool msg, bool fileoutput,
+                                                          std::string path, int verbose, int ID)
+{
+    return gnuradio::get_initial_sptr(new PowerActivationChannel_impl(blocklen, cfreq, bw, relinvovl, thresh, maxblocks,
+                                                                      deactivation_delay, msg, fileoutput, path, verbose, ID));
+}
+activity_detection_channelizer_vcm::sptr activity_detection_channelizer_vcm::make(
+    int blocklen, std::vector<std::vector<float>> segments, float thresh, int relinvovl, int maxblocks, bool message,
+    bool fileoutput, std::string path, bool threads, float minchandist, int channel_deactivation_delay,
+    double window_flank_puffer, int verbose)
+{
+    return gnuradio::get_initial_sptr(new activity_detection_channelizer_vcm_impl(
+        blocklen, segments, thresh, relinvovl, maxblocks, message, fileoutput, path, threads, minchandist,
+        channel_deactivation_delay, window_flank_puffer, verbose));
+}
+
+}  // namespace FDC
+}  // namespace gr

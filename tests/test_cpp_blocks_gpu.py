@@ -1,0 +1,43 @@
+"""GPU test (-m gpu): the C++ gr::FDC block faces (gr-fdc_amd/csrc/gr_blocks, the reference's make()/work() API over the
+C-ABI) driven by blocks_demo the way the GNU Radio scheduler drives blocks; results compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "gr-fdc_amd", "csrc", "gr_blocks", "blocks_demo")
+
+
+def test_cpp_block_faces_against_oracle(oracle, tmp_path):
+    if not os.path.exists(DEMO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gr-fdc_amd", "csrc")])
+    N, R = 1024, 4
+    H = N - N // R
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal(6 * H) + 1j * rng.standard_normal(6 * H)).astype(np.complex64)
+    spec = (1e-3 * (rng.standard_normal((14, N)) + 1j * rng.standard_normal((14, N)))).astype(np.complex64)
+    spec[3:8, 300:340] += (rng.standard_normal((5, 40)) + 1j * rng.standard_normal((5, 40))).astype(np.complex64)
+    spec[5:11, 700:760] += (rng.standard_normal((6, 60)) + 1j * rng.standard_normal((6, 60))).astype(np.complex64)
+    x.tofile(tmp_path / "x.c64"); spec.tofile(tmp_path / "spec.c64")
+    subprocess.check_call([DEMO, str(tmp_path)])
+    rd = lambda n: np.fromfile(tmp_path / n, dtype=np.complex64)   # noqa: E731
+    blocks = oracle.OverlapSave(8, N, N // R).work(x)
+    assert (rd("overlap_save.out").view(np.uint32) == blocks.view(np.uint32)).all()
+    sl = oracle.vector_cut(8, N, 301, 64, blocks)
+    assert (rd("vector_cut.out").view(np.uint32) == sl.view(np.uint32)).all()
+    pw = oracle.PhaseWindow(64, R, 301, 0.6, 0.85, 1).work(sl)
+    assert np.abs(rd("phase_window.out") - pw).max() <= 1e-6 * np.abs(pw).max()
+    ref = oracle.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, -1, 0, 5).work(spec) + \
+        oracle.ActivityDetectionVcm(N, [[0.5, 0.9]], 10.0, R, -1, 0.01, 1, 0.2).work(spec)
+    lines = open(tmp_path / "pdus.txt").read().split("\n")[:-1]
+    assert len(lines) == len(ref) and len(ref) >= 2
+    assert lines[0].split()[0] == "PowActChan.5.0.fin" and lines[-1].split()[0].startswith("DETECTED.0.")
+    for ln, r in zip(lines, ref):
+        _id, b0, b1, ns = ln.split()
+        assert (int(b0), int(b1), int(ns)) == (r["blockstart"], r["blockend"], r["samples"].size)
+    allref = np.concatenate([r["samples"] for r in ref])
+    got = rd("pdus.out")
+    assert got.size == allref.size and np.abs(got - allref).max() <= 1e-5 * np.abs(allref).max()

@@ -222,3 +222,39 @@ def test_uniform_plan_two_stage_path(oracle, R, wt):
     parts = [p.work(x[a * p.H:b * p.H]) for a, b in [(0, 2), (2, 3), (3, 5)]]
     for c in range(len(chans)):
         assert_close(np.concatenate([q_[c] for q_ in parts]), ref[c])
+
+
+def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
+    """BASELINE configs[3] at a size the oracle finishes in seconds: N=262144, R=2, 1024 channels (l=256), processed as
+    two independent block spans (halo + global first-block index) exactly as the 8-GPU sharding does, through the
+    device-resident entry; spans concatenated == oracle on the whole stream."""
+    import ctypes as C
+    from gr_fdc_amd import _lib
+    N, R, Cn, nb = 262144, 2, 1024, 3
+    H = N - N // R
+    params = [G.get_opt_channelparams(N, R, ((c + 0.5) / Cn) % 1.0, 0.8 / Cn) for c in range(Cn)]
+    assert all(p[:3] == (256 * c, 256, 128) for c, p in enumerate(params))
+    plan = [(f, l, p, s) for (f, l, _lo, p, s) in params]
+    x = noise(nb * H, 2027)
+    ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+    pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+    whole = pipe.work(x)
+    for c in range(0, Cn, 37):
+        assert_close(whole[c], ref[c], "whole ch%d" % c)
+    # two spans as two "ranks" would run them (stateless device entry needs raw device buffers: use hip through torch-free ctypes)
+    hip = C.CDLL("libamdhip64.so")
+    for first, n in [G.span_for_rank(nb, r, 2) for r in range(2)]:
+        ring = np.ascontiguousarray(G.ring_for_span(x, first, n, N, R))
+        d_ring, d_out = C.c_void_p(), C.c_void_p()
+        nout = pipe.output_samples(n)
+        assert hip.hipMalloc(C.byref(d_ring), C.c_size_t(ring.nbytes)) == 0
+        assert hip.hipMalloc(C.byref(d_out), C.c_size_t(nout * 8)) == 0
+        assert hip.hipMemcpy(d_ring, C.c_void_p(ring.ctypes.data), C.c_size_t(ring.nbytes), 1) == 0
+        pipe.process_device(d_ring, first, n, d_out)
+        pipe.synchronize()
+        out = np.empty(nout, np.complex64)
+        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), d_out, C.c_size_t(out.nbytes), 2) == 0
+        hip.hipFree(d_ring); hip.hipFree(d_out)
+        for c in range(0, Cn, 41):
+            o = out[pipe.channel_offset(c, n):pipe.channel_offset(c, n) + n * 128]
+            assert_close(o, ref[c][first * 128:(first + n) * 128], "span first=%d ch%d" % (first, c))
