@@ -97,6 +97,12 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    hipStream_t stream2 = nullptr;               // uniform path: stage 2 runs here, beside stage 1 of the next group
+    float2 *d_g[2] = {nullptr, nullptr};         // uniform path: double-buffered stage-1 output
+    hipEvent_t ev_fork = nullptr, ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
+    int poly_split = 2;                          // stage-1 workgroups per CU when the stages overlap (of 4)
+    bool poly_overlap = false;                   // FDC_POLY_OVERLAP=1: measured slower on MI355X (profiles/r01/NOTES.md)
+    bool last_was_poly = false;
     float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
     float *d_shn = nullptr;                      // uniform path: shape[k2] / N
     long long *d_slot_off = nullptr;
@@ -140,6 +146,9 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
 {
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
+    for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]);
     for (auto e : p->events) (void)hipEventDestroy(e);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
@@ -230,7 +239,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
     // default takes groups as large as a 2 GiB scratch budget allows (1024 blocks at N = 65536).
     int chunk = cfg->chunk_blocks;
-    if (chunk <= 0) chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
+    {
+        const char *ov = getenv("FDC_POLY_OVERLAP"), *sp = getenv("FDC_POLY_SPLIT");
+        if (ov) p->poly_overlap = ov[0] != '0';
+        if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
+    }
+    if (chunk <= 0) {
+        // uniform path with overlapped stages (experimental): two G buffers of chunk*lout*N/256 samples must stay in
+        // the 256 MiB Infinity Cache next to the streams passing through -> 256 blocks
+        if (p->poly_ok && p->poly_overlap && !cfg->keep_spectrum) chunk = 256;
+        else chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
+    }
     chunk = std::min(chunk, cfg->max_blocks);
     p->chunk = chunk;
 
@@ -302,6 +321,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * 256));
         CHK_OR_FREE(hipMemcpy(p->d_slot_off, so.data(), sizeof(long long) * 256, hipMemcpyHostToDevice));
     }
+    if (p->poly_ok) {
+        const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
+        CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
+        CHK_OR_FREE(hipMalloc(&p->d_g[1], gsz));
+        CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+        CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) {
+            CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_s1[i], hipEventDisableTiming));
+            CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_s2[i], hipEventDisableTiming));
+        }
+    }
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
@@ -369,6 +399,8 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const float2 *ring = static_cast<const float2 *>(d_ring);
+    const bool use_poly = p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < (1ll << 32);
+    p->last_was_poly = use_poly;
     for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
         const int nb = std::min(p->chunk, nblocks - m0);
         float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
@@ -379,14 +411,33 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        if (p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < (1ll << 32)) {
-            // uniform plan: window + IFFT commuted in front of pass B; nothing but G (lout*N1 per block) in between
-            HIPCHK(fdc::launch_poly256(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_tmp, static_cast<float2 *>(d_out),
-                                       256, p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn,
-                                       p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), s, evp));
+        if (use_poly) {
+            // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the stages.
+            // Stage 1 on the caller's stream, stage 2 on stream2; group i's stage 2 overlaps group i+1's stage 1.
+            const int gi = (m0 / p->chunk) & 1;
+            const bool ovl = p->poly_overlap && nblocks > p->chunk;
+            hipStream_t s2 = ovl ? p->stream2 : s;
+            if (ovl && m0 >= 2 * p->chunk) HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi], 0));   // G[gi] free again
+            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[gi], p->N / 256, p->R, nb,
+                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, ovl ? p->poly_split : 0, s));
+            if (p->timing) HIPCHK(hipEventRecord(p->events[span[1]], s));
+            if (ovl) {
+                HIPCHK(hipEventRecord(p->ev_s1[gi], s));
+                HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
+            }
+            if (p->timing) HIPCHK(hipEventRecord(p->events[span[2]], s2));
+            HIPCHK(fdc::launch_poly_stage2(p->d_g[gi], static_cast<float2 *>(d_out), p->R, nb, m0, nblocks, p->d_tw256,
+                                           p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8),
+                                           ovl ? 4 - p->poly_split : 0, s2));
+            if (ovl) HIPCHK(hipEventRecord(p->ev_s2[gi], s2));
             if (p->timing) {
-                HIPCHK(hipEventRecord(p->events[span[3]], s));
+                HIPCHK(hipEventRecord(p->events[span[3]], s2));
                 p->ev_spans.push_back(span);
+            }
+            if (ovl && m0 + p->chunk >= nblocks) {           // join: the caller's stream waits for both stage-2 tails
+                HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi], 0));
+                if (m0 >= p->chunk) HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi ^ 1], 0));
             }
             continue;
         }
@@ -427,8 +478,9 @@ int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
         HIPCHK(hipEventElapsedTime(&a, p->events[sp[0]], p->events[sp[1]]));
         HIPCHK(hipEventElapsedTime(&b, p->events[sp[1]], p->events[sp[2]]));
         HIPCHK(hipEventElapsedTime(&c, p->events[sp[2]], p->events[sp[3]]));
-        if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; } else { ms[0] += a; ms[1] += b; }
-        ms[2] += c;
+        if (p->poly_ok && p->last_was_poly) { ms[0] += a; ms[1] += c; }        // stage 1, stage 2 (b = wait between them)
+        else if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; ms[2] += c; }
+        else { ms[0] += a; ms[1] += b; ms[2] += c; }
     }
     p->ev_used = 0; p->ev_spans.clear();
     return 4;

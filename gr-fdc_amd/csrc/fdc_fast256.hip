@@ -492,13 +492,17 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
     return hipGetLastError();
 }
 
-hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 *out, int N1, int R, int nb_chunk,
-                          int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
-                          const float *shn, const long long *slot_off, unsigned out_bytes, hipStream_t s,
-                          hipEvent_t *ev)
+// The two stages as separate launches so the caller can put them on two streams: stage 2 of launch group i then runs
+// beside stage 1 of group i+1 (k_p1 is VALU/LDS-heavy, k_p2 memory-heavy), each with `wg_per_cu` resident workgroups
+// per CU, and a group's G never leaves the Infinity Cache.
+static int poly_tile(int lout)
 {
-    hipError_t e;
-    const int skip = 256 / R, lout = 256 - skip;
+    static int tcfg = -1;                                   // FDC_POLY_TILE=16|32 (A/B testing); default 16
+    if (tcfg < 0) { const char *t = getenv("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
+    return (lout % tcfg) ? 16 : tcfg;                       // stage-2 tiles are TC whole rows of one block
+}
+static int cu_count()
+{
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -506,18 +510,24 @@ hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    static int tcfg = -1;                                   // FDC_POLY_TILE=16|32 (A/B testing); default 16
-    if (tcfg < 0) { const char *t = getenv("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
-    const int TC = (lout % tcfg) ? 16 : tcfg;              // stage-2 tiles are TC whole rows of one block
+    return ncu;
+}
+
+hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
+                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
+                              int wg_per_cu, hipStream_t s)
+{
+    const int skip = 256 / R, lout = 256 - skip;
+    const int TC = poly_tile(lout);
     const int ct = N1 / TC;
     int log2ct = 0;
     while ((1 << log2ct) < ct) log2ct++;
-    int slots = (TC == 32 ? 2 : 4) * ncu;                   // resident workgroups: LDS-limited
+    const int maxwg = TC == 32 ? 2 : 4;                     // resident workgroups per CU: LDS-limited
+    int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
     slots -= slots % ct;                                    // k_p1 keeps a fixed column tile per workgroup
-    if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
     const long long nt1 = (long long)nb_chunk * ct;
     const unsigned g1 = (unsigned)(nt1 < slots ? nt1 : slots);
-    const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024, lds2 = 256 * TC * 8 + 2048 + 2048;
+    const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024;
     static int abl = -1;
     if (abl < 0) { const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0; }
 #define FDC_LP1(T, A) \
@@ -526,7 +536,18 @@ hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 
     if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else FDC_LP1(32, 0); }
     else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else FDC_LP1(16, 0); }
 #undef FDC_LP1
-    if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk, int mbase, int nb_call,
+                              const float2 *tw256, const long long *slot_off, unsigned out_bytes, int wg_per_cu,
+                              hipStream_t s)
+{
+    const int skip = 256 / R, lout = 256 - skip;
+    const int TC = poly_tile(lout);
+    const int maxwg = TC == 32 ? 2 : 4;
+    const int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
+    const size_t lds2 = 256 * TC * 8 + 2048 + 2048;
     const long long nrows = (long long)nb_chunk * lout;
     const long long nt2 = (nrows + TC - 1) / TC;
     const unsigned g2 = (unsigned)(nt2 < slots ? nt2 : slots);
@@ -536,7 +557,6 @@ hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 
     else
         hipLaunchKernelGGL(k_p2<16>, dim3(g2), dim3(256), lds2, s, g, out, tw256, slot_off, nrows,
                            (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt2, lout);
-    if (ev && (e = hipEventRecord(ev[2], s)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -72,10 +72,12 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
 //   slot_off[c] = per-block sample offset of the channel sitting in slot c, or -1;  g: nb_chunk*lout*N1 scratch
-hipError_t launch_poly256(const float2 *in, size_t in_stride, float2 *g, float2 *out, int N1, int R, int nb_chunk,
-                          int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
-                          const float *shn, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
-                          hipStream_t s, hipEvent_t *ev);
+hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
+                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
+                              int wg_per_cu /* 0 = all the LDS admits */, hipStream_t s);
+hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk, int mbase, int nb_call,
+                              const float2 *tw256, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
+                              int wg_per_cu, hipStream_t s);
 
 // sinks
 hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
