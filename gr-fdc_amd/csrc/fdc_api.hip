@@ -103,6 +103,10 @@ struct fdc_pipeline {
     int poly_split = 2;                          // stage-1 workgroups per CU when the stages overlap (of 4)
     bool poly_overlap = false;                   // FDC_POLY_OVERLAP=1: measured slower on MI355X (profiles/r01/NOTES.md)
     bool last_was_poly = false;
+    bool poly_fused = false;                     // FDC_POLY_FUSED=1: one persistent dataflow launch (fdc_fused256.hip)
+    int fused_D = 48, fused_ring = 192;          // stage-2 lag and G ring length, in blocks
+    float2 *d_gring = nullptr;
+    void *d_ctl = nullptr;
     float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
     float *d_shn = nullptr;                      // uniform path: shape[k2] / N
     long long *d_slot_off = nullptr;
@@ -148,7 +152,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
     for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]);
+    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl);
     for (auto e : p->events) (void)hipEventDestroy(e);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
@@ -242,6 +246,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     {
         const char *ov = getenv("FDC_POLY_OVERLAP"), *sp = getenv("FDC_POLY_SPLIT");
         if (ov) p->poly_overlap = ov[0] != '0';
+        const char *fu = getenv("FDC_POLY_FUSED"), *fd = getenv("FDC_FUSED_D"), *fr = getenv("FDC_FUSED_RING");
+        if (fu) p->poly_fused = fu[0] != '0';
+        if (fd && atoi(fd) >= 0) p->fused_D = atoi(fd);
+        if (fr && atoi(fr) >= 1) p->fused_ring = atoi(fr);
+        if (p->fused_ring < p->fused_D + 8) p->fused_ring = p->fused_D + 8;
         if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
     }
     if (chunk <= 0) {
@@ -325,6 +334,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
         CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
         CHK_OR_FREE(hipMalloc(&p->d_g[1], gsz));
+        if (p->poly_fused) {
+            CHK_OR_FREE(hipMalloc(&p->d_gring, sizeof(float2) * (size_t)p->fused_ring * (size_t)(256 - 256 / R) * 256));
+            CHK_OR_FREE(hipMalloc(&p->d_ctl, fdc::fused_ctl_bytes(chunk)));
+        }
         CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
         CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) {
@@ -366,6 +379,11 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     HIPCHK(hipSetDevice(p->cfg.device_id));
     HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->d_ctl) {                                   // bounded spins of the fused dataflow kernel report here
+        unsigned ctl[2] = {0, 0};
+        HIPCHK(hipMemcpy(ctl, p->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl[1]) return fail(FDC_ERR_HIP, "fused dataflow kernel: dependency wait timed out (code %u)", ctl[1]);
+    }
     return FDC_OK;
 }
 
@@ -411,6 +429,20 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
+        if (use_poly && p->poly_fused) {
+            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            HIPCHK(fdc::launch_poly_fused(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_gring, static_cast<float2 *>(d_out),
+                                          p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
+                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl,
+                                          std::min(p->fused_D, std::max(0, nb - 1)), p->fused_ring, s));
+            if (p->timing) {
+                HIPCHK(hipEventRecord(p->events[span[1]], s));
+                HIPCHK(hipEventRecord(p->events[span[2]], s));
+                HIPCHK(hipEventRecord(p->events[span[3]], s));
+                p->ev_spans.push_back(span);
+            }
+            continue;
+        }
         if (use_poly) {
             // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the stages.
             // Stage 1 on the caller's stream, stage 2 on stream2; group i's stage 2 overlaps group i+1's stage 1.

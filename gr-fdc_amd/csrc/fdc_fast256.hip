@@ -12,6 +12,7 @@
 // Index algebra: n = n1 + 256*n2, k = 256*k1 + k2 (same as the generic two-pass path in fdc_kernels.hip).
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
+#include "fdc_devutil.hpp"
 #include <cstdlib>
 
 namespace fdc {
@@ -20,32 +21,6 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
 
 constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
 constexpr int kCTileBytes = 32 * 272 * 8;         // channel kernel: 32 rows padded to 272 points
-
-__device__ __forceinline__ float4 ld4(const float2 *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ void st4(float2 *p, cf a, cf b)
-{
-    *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, b.x, b.y);
-}
-__device__ __forceinline__ cf ld2(const float2 *p) { return *reinterpret_cast<const cf *>(p); }
-
-// Buffer addressing (SRD in SGPRs + 32-bit per-lane byte offset + scalar offset): no 64-bit VGPR address per access.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ cf bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
-}
-__device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cf v)
-{
-    u32x2 t;
-    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
-}
-__device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
 
 // ---- pass A -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, size_t in_stride,
@@ -433,7 +408,8 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t init_fast_kernels()
 {
-    hipError_t e;
+    hipError_t e = init_fused_kernels();
+    if (e != hipSuccess) return e;
     const int a = kTileBytes + 8192, c = kCTileBytes + 2048;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;

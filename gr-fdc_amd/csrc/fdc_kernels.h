@@ -79,6 +79,15 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk,
                               const float2 *tw256, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
                               int wg_per_cu, hipStream_t s);
 
+// uniform plan as one persistent dataflow launch (fdc_fused256.hip): stage-1 tiles and stage-2 blocks pulled from one
+// task queue, G in a ring of `ring` blocks, stage 2 of a block D blocks behind its stage 1
+hipError_t init_fused_kernels();
+size_t fused_ctl_bytes(int nb);
+hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, float2 *out, int R, int nb_chunk,
+                             int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
+                             const float *shn, const long long *slot_off, unsigned out_bytes, void *ctl, int D, int ring,
+                             hipStream_t s);
+
 // sinks
 hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
                              hipStream_t s);
