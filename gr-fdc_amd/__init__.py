@@ -9,4 +9,4 @@ from .blocks import overlap_save, vector_cut_vxx, phase_shifting_windowing_vcc, 
 from .channelizer import (FrequencyDomainChannelizer, Pipeline, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
                           nextpow2, get_opt_channelparams)
 from .sharding import span_for_rank, ring_bounds, ring_for_span                       # noqa: F401
-from .sinks import Sinks, PowerActivationChannel, activity_detection_channelizer_vcm      # noqa: F401
+from .sinks import Sinks, PowerActivationChannel, activity_detection_channelizer_vcm, SegmentDetection      # noqa: F401

@@ -43,7 +43,8 @@ class fdc_sinks_cfg(C.Structure):
                 ("pac_thresh_db", C.c_float), ("pac_maxblocks", C.c_int32), ("pac_deactivation_delay", C.c_int32),
                 ("nseg", C.c_int32), ("seg", C.POINTER(fdc_segment_cfg)),
                 ("det_thresh_db", C.c_float), ("det_maxblocks", C.c_int32), ("minchandist", C.c_float),
-                ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32)]
+                ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32),
+                ("det_variant", C.c_int32)]
 
 
 class fdc_pdu(C.Structure):

@@ -228,7 +228,8 @@ class FrequencyDomainChannelizer:
                                segments=[tuple(sg) for sg in self.activity_detection_segments],
                                det_thresh=float(act_det_threshold), det_maxblocks=int(act_det_maxblocks),
                                minchandist=self.get_bw(minchandist) if self.activity_detection_segments else 0.005,
-                               det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id)
+                               det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id,
+                               det_variant=1)      # the hier block instantiates SegmentDetection (:25, :261-278)
         self.pipeline = Pipeline(self.blocksize, self.relinvovl,
                                  [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
                                  windowtype=int(windowtype), max_blocks=max_blocks, device_id=device_id,
@@ -265,8 +266,8 @@ class FrequencyDomainChannelizer:
 
     def work(self, samples):
         """Returns the hier block's stream ports; PDUs of the sink blocks ("msgout", :166-168) are left in
-        self.messages as (dict, complex64 array) pairs.  Detection segments run the vcm core (the reference hier block
-        instantiates its single-segment twin SegmentDetection, whose block numbers are one lower: SURVEY App. B.3)."""
+        self.messages as (dict, complex64 array) pairs.  Detection segments run as SegmentDetection instances, like in
+        the reference hier block (:261-278)."""
         res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
         self.messages = []
         if self.sinks is not None:

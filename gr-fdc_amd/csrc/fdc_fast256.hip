@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
                                                    float2 *__restrict__ g, const float2 *__restrict__ tw256,
                                                    const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
                                                    const float *__restrict__ shn, int N1, int log2ct, int ntiles,
-                                                   int qskip, int lout)
+                                                   int qskip, int lout, int stagger)
 {
     constexpr int NT = TC * 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [256][TC]
@@ -233,6 +233,16 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     const int tid = threadIdx.x, col = tid & (TC - 1), b = tid / TC;
     int tl = blockIdx.x;
     if (tl >= ntiles) return;
+    if (stagger > 0) {
+        // Co-resident workgroups run the same program from the same start and stay in lock-step (all in their LDS
+        // phases together, then all in their VALU phases).  Delay each by a different fraction of a tile time, once.
+        // Which of the CU's LDS slots this workgroup got tells the co-resident ones apart (HW_REG_LDS_ALLOC).
+        const unsigned la = __builtin_amdgcn_s_getreg(6 | (31 << 11));
+        const unsigned base = la & 0xff, size = (la >> 12) & 0x1ff;
+        const unsigned k = size ? (base / (size ? size : 1)) & 3 : 0;
+        for (unsigned i = 0; i < k; i++)
+            for (int j = 0; j < stagger; j++) __builtin_amdgcn_s_sleep(16);
+    }
     // The launcher keeps gridDim.x a multiple of the column tiles per block, so this workgroup always works on
     // the same TC columns n1 = c0..c0+TC-1.  The factor the spectrum column is multiplied by,
     //   shape[k2]/N * (-1)^n1 * W_N^(n1*k2),  k2 = b + 16q,
@@ -504,11 +514,14 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     const long long nt1 = (long long)nb_chunk * ct;
     const unsigned g1 = (unsigned)(nt1 < slots ? nt1 : slots);
     const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024;
-    static int abl = -1;
-    if (abl < 0) { const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0; }
+    static int abl = -1, stg = 0;
+    if (abl < 0) {
+        const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
+        const char *g2 = getenv("FDC_STAGGER"); stg = g2 ? atoi(g2) : 0;
+    }
 #define FDC_LP1(T, A) \
     hipLaunchKernelGGL((k_p1<T, A>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
-                       (int)nt1, skip / 16, lout)
+                       (int)nt1, skip / 16, lout, stg)
     if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else FDC_LP1(32, 0); }
     else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else FDC_LP1(16, 0); }
 #undef FDC_LP1

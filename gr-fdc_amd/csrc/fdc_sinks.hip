@@ -184,7 +184,9 @@ void det_emit(fdc_sinks *s, Segment &g, DetChan &c, bool fin, size_t nblk)   // 
     r.meta.finalized = fin; r.meta.part = c.part; r.meta.has_part = fin ? (c.part > 0) : 1;
     r.meta.rel_bw = (double)c.extract_width / (double)s->N;
     r.meta.rel_cfreq = (double)(c.extract_start + c.extract_stop) / 2.0 / (double)s->N;
-    r.meta.blockstart = s->blockcount - c.count; r.meta.blockend = s->blockcount;
+    // the vcm block counts from 1 (…vcm_impl.cc:188), SegmentDetection from 0 (SegmentDetection_impl.cc:118)
+    const int64_t bc = s->blockcount - (s->cfg.det_variant == 1 ? 1 : 0);
+    r.meta.blockstart = bc - c.count; r.meta.blockend = bc;
     r.meta.vectorstart = c.extract_start; r.meta.vectorend = c.extract_stop;
     r.blocklen = c.outputsamples;
     for (size_t i = 0; i < nblk; i++) { r.blocks.push_back(std::move(c.data.front())); c.data.pop_front(); }
@@ -199,10 +201,13 @@ void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, 
     std::vector<Edge> rise;
     std::vector<int> fall;
     const float inv = 1.0f / s->det_thr;
+    const bool sd = s->cfg.det_variant == 1;
     for (int i = 1; i < n; i++) {
-        const float pd = P[i - 1] == 0.0f ? P[i] / FLT_MIN : P[i] / P[i - 1];   // :703-706
+        // vcm guards a zero denominator (:703-706); SegmentDetection divides as is (volk_32f_x2_divide_32f, :206)
+        const float pd = (!sd && P[i - 1] == 0.0f) ? P[i] / FLT_MIN : P[i] / P[i - 1];
         if (pd > s->det_thr) rise.push_back({pd, (i - 1) * dec + g.start});
-        if (pd < inv) fall.push_back(i * dec + g.start);
+        else if (sd) { if (pd < inv) fall.push_back(i * dec + g.start); }        // if / else if (:209-210)
+        if (!sd && pd < inv) fall.push_back(i * dec + g.start);                  // two independent ifs (:708-709)
     }
     std::stable_sort(rise.begin(), rise.end(), [](const Edge &a, const Edge &b) { return a.r > b.r; });   // :713
     std::vector<std::pair<int, int>> cand;
@@ -254,11 +259,17 @@ void seg_extract(fdc_sinks *s, Segment &g, int slot)        // extract_channels_
         if (c.inactive < 0) { det_process(s, c, slot - 1); det_process(s, c, slot); c.inactive = 0; }   // :399-403
         else if (c.inactive > delay) det_emit(s, g, c, true, c.data.size());
         else det_process(s, c, slot);
-        if (mb >= 0 && (int)c.data.size() >= mb) {                              // :317-318, :454-470
+        if (s->cfg.det_variant == 0 && mb >= 0 && (int)c.data.size() >= mb) {  // :317-318, :454-470
             const size_t ntx = mb == 0 ? c.data.size() : (size_t)mb;
             if (ntx > 0) { det_emit(s, g, c, false, ntx); c.part++; }
         }
     }
+    if (s->cfg.det_variant == 1 && mb >= 0)                                     // SegmentDetection: separate pass, :359-362
+        for (auto &c : g.chans)
+            if ((int)c.data.size() >= mb) {
+                const size_t ntx = mb == 0 ? c.data.size() : (size_t)mb;
+                if (ntx > 0) { det_emit(s, g, c, false, ntx); c.part++; }
+            }
     for (size_t i = 0; i < g.chans.size();)                                     // clear_inactive_channels, :512-524
         if (g.chans[i].inactive > delay) g.chans.erase(g.chans.begin() + i); else i++;
 }
@@ -339,7 +350,34 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         s->pacs.push_back(std::move(p));
     }
     // ---- detection segments
-    if (cfg->nseg > 0) {
+    if (cfg->nseg > 0 && cfg->det_variant == 1) {
+        // SegmentDetection face (lib/SegmentDetection_impl.cc:68-86, :592-637): one instance per segment in the hier block
+        auto mod_f = [](float x) { return (float)std::fmod(std::fmod((double)x, 1.0) + 1.0, 1.0); };   // :700-703
+        if (cfg->det_thresh_db < 0.0f) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Threshold is interpreted as dB and must be greater zero to detect channels accordingly.");
+        if (cfg->window_flank_puffer < 0.0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Window flank puffer must not be smaller 0.0.");
+        const float mcd = mod_f(cfg->minchandist);
+        const double dd = (double)N * (double)mcd / 2.0;
+        s->dec = dd < 2.0 ? 1 : (int)dd;
+        s->det_thr = (float)std::pow(10.0, (double)cfg->det_thresh_db / 10.0);
+        for (int i = 0; i < cfg->nseg; i++) {
+            float a = mod_f(cfg->seg[i].start), b = mod_f(cfg->seg[i].stop);
+            if (a == b) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Start must not be equal to stop.");
+            if (a > b) std::swap(a, b);
+            size_t width = (size_t)((double)(b - a) * (double)N);
+            if (width % (size_t)s->dec) width += (size_t)s->dec - width % (size_t)s->dec;
+            if (width > (size_t)N) width = (size_t)(N - N % s->dec);
+            const size_t mid = (size_t)((double)(0.5f * (a + b)) * (double)N);
+            size_t st = mid < width / 2 ? 0 : mid - width / 2, sp = st + width;
+            if (sp > (size_t)N) { sp = (size_t)N; st = sp - (size_t)N; }                 // reference clamp (App. B.2)
+            if (st + width > (size_t)N) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "segment %d: the reference reads past the block here", i);
+            Segment g;
+            g.ID = i; g.start = (int)st; g.stop = (int)sp; g.width = (int)width;
+            g.ncell = (int)width / s->dec; g.cell0 = (int)s->cells.size();
+            for (int c = 0; c < g.ncell; c++) s->cells.push_back({g.start + c * s->dec, s->dec, 1.0f, 0});   // raw sums (:185-190)
+            s->segs.push_back(std::move(g));
+        }
+    }
+    if (cfg->nseg > 0 && cfg->det_variant != 1) {
         if (cfg->minchandist <= 0.0f || cfg->minchandist >= 1.0)               // :231-232
             return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Minimum channel distance is invalid. Must be in (0,1)");
         if (cfg->det_thresh_db < 0.0f) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "Threshold is interpreted as dB and must be greater zero.");
@@ -369,7 +407,10 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
             for (int c = 0; c < g.ncell; c++) s->cells.push_back({g.start + c * s->dec, s->dec, norm, 0});
             s->segs.push_back(std::move(g));
         }
-        // cr_windows, :199-228: every power-of-two width x R phases, unit amplitude, Hann flanks
+    }
+    if (cfg->nseg > 0) {
+        // cr_windows (…vcm_impl.cc:199-228, identical in SegmentDetection_impl.cc:551-583): every power-of-two width
+        // x R phases, unit amplitude, Hann flanks
         const int nw = (int)std::log2((double)N) + 1;
         s->det_win_off.resize(nw);
         for (int k = 0; k < nw; k++) {

@@ -22,7 +22,7 @@ from . import _lib
 class Sinks:
     def __init__(self, blocklen, relinvovl, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
                  segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
-                 max_blocks=64, device_id=0):
+                 max_blocks=64, device_id=0, det_variant=0):
         self._h = C.c_void_p()
         self.N = int(blocklen)
         pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
@@ -33,7 +33,7 @@ class Sinks:
             sg[i].start, sg[i].stop = float(a), float(b)
         cfg = _lib.fdc_sinks_cfg(device_id, self.N, int(relinvovl), len(pac), pa, float(pac_thresh), int(pac_maxblocks),
                                  int(pac_delay), len(segments), sg, float(det_thresh), int(det_maxblocks),
-                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks))
+                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant))
         rc = _lib.lib().fdc_sinks_create(C.byref(cfg), C.byref(self._h))
         if rc == -1:
             raise ValueError(_lib.lib().fdc_last_error().decode())
@@ -160,6 +160,30 @@ class activity_detection_channelizer_vcm:
 
     def work(self, spectrum):
         pdus = [_det_pdu(m, d) for (m, d) in self.bank.work(spectrum)]
+        if self.fileoutput:
+            _write_files(self.path, pdus, False)
+        return pdus
+
+
+class SegmentDetection:
+    """gr::FDC::SegmentDetection::make(ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist,
+    window_flank_puffer, maxblocks_to_emit, channel_deactivation_delay, messageoutput, fileoutput, path, threads, verbose)
+    — include/FDC/SegmentDetection.h:49.  The single-segment twin of the vcm block that the hier block instantiates."""
+
+    def __init__(self, ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist, window_flank_puffer,
+                 maxblocks_to_emit, channel_deactivation_delay, messageoutput, fileoutput, path, threads, verbose,
+                 device_id=0, max_blocks=64):
+        self.ID, self.msg, self.fileoutput, self.path = int(ID), bool(messageoutput), bool(fileoutput), str(path)
+        self.bank = Sinks(blocklen, relinvovl, segments=[(seg_start, seg_stop)], det_thresh=thresh,
+                          det_maxblocks=maxblocks_to_emit, minchandist=minchandist, det_delay=channel_deactivation_delay,
+                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id, det_variant=1)
+        self.segment = self.bank.segment_params(0)
+
+    def work(self, spectrum):
+        pdus = []
+        for (m, d) in self.bank.work(spectrum):
+            m = dict(m, source=self.ID)
+            pdus.append(_det_pdu(m, d))
         if self.fileoutput:
             _write_files(self.path, pdus, False)
         return pdus

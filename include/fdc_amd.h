@@ -142,6 +142,12 @@ typedef struct {
     float det_thresh_db; int32_t det_maxblocks; float minchandist; int32_t det_deactivation_delay;
     double window_flank_puffer;
     int32_t max_blocks;                                                /* largest batch of one work call  */
+    int32_t det_variant;   /* 0 = activity_detection_channelizer_vcm (all segments in one block); 1 = one
+                              gr::FDC::SegmentDetection::make(ID, blocklen, relinvovl, seg_start, seg_stop, thresh,
+                              minchandist, window_flank_puffer, maxblocks_to_emit, channel_deactivation_delay, …)
+                              (include/FDC/SegmentDetection.h:49) per segment, ID = segment index — the twin the hier
+                              block instantiates (python/FrequencyDomainChannelizer.py:261-278): its own segment geometry,
+                              raw power sums, block counter from 0, partial emission after all channels */
 } fdc_sinks_cfg;
 typedef struct {
     int32_t kind;        /* 0 = PowerActivationChannel, 1 = detected channel of a segment                       */

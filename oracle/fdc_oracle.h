@@ -95,6 +95,10 @@ typedef struct fdco_vcm fdco_vcm;
  * channel_deactivation_delay, window_flank_puffer, …) (include/FDC/activity_detection_channelizer_vcm.h:49) */
 fdco_vcm *fdco_vcm_create(int blocklen, int nseg, const float *segs, float thresh_db, int relinvovl, int maxblocks,
                           float minchandist, int deactivation_delay, double window_flank_puffer);
+/* SegmentDetection::make(ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist, window_flank_puffer,
+ * maxblocks_to_emit, channel_deactivation_delay, …) (include/FDC/SegmentDetection.h:49); same handle type. */
+fdco_vcm *fdco_sd_create(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh_db,
+                         float minchandist, float window_flank_puffer, int maxblocks, int deactivation_delay);
 void fdco_vcm_destroy(fdco_vcm *v);
 int fdco_vcm_segment_params(const fdco_vcm *v, int s, int *out5);   /* start, stop, width, dec, npower */
 void fdco_vcm_work(fdco_vcm *v, const float *spectrum_items, int nitems, fdco_pdu_list *L);

@@ -231,6 +231,7 @@ typedef struct {
 } vcm_seg;
 
 struct fdco_vcm {
+    int variant;           /* 0 = activity_detection_channelizer_vcm, 1 = SegmentDetection (lib/SegmentDetection_impl.cc) */
     int blocklen, relinvovl, maxblocks, delay, dec;
     float thresh; double puffer;
     vcm_seg *seg; int nseg;
@@ -241,6 +242,70 @@ struct fdco_vcm {
 };
 
 static int ilog2d(double v) { return (int)log2(v); }
+
+static float sd_mod_f(float x, float y)      /* SegmentDetection_impl.cc:700-703 */
+{
+    return (float)fmod(fmod((double)x, (double)y) + 1.0, (double)y);
+}
+
+/* SegmentDetection::make(ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist, window_flank_puffer,
+ * maxblocks_to_emit, channel_deactivation_delay, …) — the single-segment twin the hier block instantiates
+ * (python/FrequencyDomainChannelizer.py:261-278).  Differences to the vcm block: segment geometry
+ * (lib/SegmentDetection_impl.cc:592-637), raw power sums and a plain divide (:178-193, :206), partial emission in a
+ * separate pass (:346-365), block counter starting at 0 (:118), the segment ID given by the caller. */
+fdco_vcm *fdco_sd_create(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh_db,
+                         float minchandist, float window_flank_puffer, int maxblocks, int deactivation_delay)
+{
+    if (blocklen < 1 || blocklen != ipow2ceil(blocklen)) return 0;             /* :68-69 */
+    if (relinvovl < 1 || relinvovl != ipow2ceil(relinvovl)) return 0;           /* :72-73 */
+    if (thresh_db < 0.0f) return 0;                                             /* :75-76 */
+    if ((double)window_flank_puffer < 0.0) return 0;                            /* :85-86 */
+    minchandist = sd_mod_f(minchandist, 1.0f);                                  /* :594-596 */
+    float start = sd_mod_f(seg_start, 1.0f), stop = sd_mod_f(seg_stop, 1.0f);
+    if (start == stop) return 0;                                                /* :598-599 */
+    if (start > stop) { float t = start; start = stop; stop = t; }
+    fdco_vcm *v = (fdco_vcm *)calloc(1, sizeof(*v));
+    v->variant = 1;
+    v->blocklen = blocklen; v->relinvovl = relinvovl; v->maxblocks = maxblocks; v->delay = deactivation_delay;
+    v->puffer = (double)window_flank_puffer;
+    v->hist = (float *)calloc(2 * (size_t)blocklen, sizeof(float));
+    const double dec = (double)blocklen * (double)minchandist / 2.0;            /* :608-614 */
+    v->dec = dec < 2.0 ? 1 : (int)dec;
+    v->thresh = (float)pow(10.0, (double)thresh_db / 10.0);
+    size_t width = (size_t)((double)(stop - start) * (double)blocklen);         /* :617-621 */
+    if (width % (size_t)v->dec) width += (size_t)v->dec - width % (size_t)v->dec;
+    if (width > (size_t)blocklen) width = (size_t)(blocklen - (blocklen % v->dec));
+    const size_t mid = (size_t)((double)(0.5f * (start + stop)) * (double)blocklen);   /* :626 */
+    size_t dstart = mid < width / 2 ? 0 : mid - width / 2, dstop = dstart + width;
+    if (dstop > (size_t)blocklen) { dstop = (size_t)blocklen; dstart = dstop - (size_t)blocklen; }   /* :629-632 (App. B.2) */
+    v->seg = (vcm_seg *)calloc(1, sizeof(vcm_seg));
+    v->nseg = 1;
+    v->seg[0].ID = ID; v->seg[0].start = (int)dstart; v->seg[0].stop = (int)dstop; v->seg[0].width = (int)width;
+    v->seg[0].npower = (int)width / v->dec;
+    v->seg[0].power = (float *)calloc((size_t)(v->seg[0].npower > 0 ? v->seg[0].npower : 1), sizeof(float));
+    if (dstart + width > (size_t)blocklen) { fdco_vcm_destroy(v); return 0; }   /* the reference would read past the block */
+    /* cr_windows, :551-583 — identical to the vcm tables */
+    v->nwin = ilog2d((double)blocklen) + 1;
+    v->windows = (float **)calloc((size_t)v->nwin, sizeof(float *));
+    for (int k = 0; k < v->nwin; k++) {
+        const int ww = 1 << k;
+        const int puffersamples = (int)(v->puffer * (double)ww);
+        v->windows[k] = (float *)malloc(sizeof(float) * 2 * (size_t)relinvovl * ww);
+        for (int i = 0; i < relinvovl; i++) {
+            float *w = v->windows[k] + 2 * (size_t)i * ww;
+            const double ang = 2.0 * M_PI * (double)i / (double)relinvovl;
+            const float cr = (float)(1.0 * cos(ang)), ci = (float)(1.0 * sin(ang));
+            for (int n = 0; n < ww; n++) { w[2 * n] = cr; w[2 * n + 1] = ci; }
+            for (int q = 0; q < puffersamples; q++) {
+                const float flank = 0.5f - 0.5f * (float)cos(M_PI * (double)q / (double)puffersamples);
+                w[2 * q] *= flank; w[2 * q + 1] *= flank;
+                w[2 * (ww - 1 - q)] *= flank; w[2 * (ww - 1 - q) + 1] *= flank;
+            }
+        }
+    }
+    v->blockcount = 0;                                                          /* :118 */
+    return v;
+}
 
 fdco_vcm *fdco_vcm_create(int blocklen, int nseg, const float *segs /* nseg pairs */, float thresh_db, int relinvovl,
                           int maxblocks, float minchandist, int deactivation_delay, double window_flank_puffer)
@@ -343,7 +408,8 @@ static void seg_detect(fdco_vcm *v, vcm_seg *g, const float *in)
             const float re = in[2 * (L + k)], im = in[2 * (L + k) + 1];
             t += re * re - im * (-im);
         }
-        g->power[i] = t * normfact;
+        /* SegmentDetection: volk_32fc_magnitude_squared_32f + volk_32f_accumulator_s32f, no normalisation (:185-190) */
+        g->power[i] = v->variant == 1 ? t : t * normfact;
     }
     /* get_active_channels, :694-739 */
     edge *rise = (edge *)malloc(sizeof(edge) * (size_t)(N > 0 ? N : 1));
@@ -352,9 +418,11 @@ static void seg_detect(fdco_vcm *v, vcm_seg *g, const float *in)
     const float inversethresh = 1.0f / v->thresh;
     for (int i = 1; i < N; i++) {
         float pd;
-        if (g->power[i - 1] == 0.0f) pd = g->power[i] / FLT_MIN; else pd = g->power[i] / g->power[i - 1];
+        if (v->variant == 1) pd = g->power[i] / g->power[i - 1];       /* volk_32f_x2_divide_32f, no zero guard (:206) */
+        else if (g->power[i - 1] == 0.0f) pd = g->power[i] / FLT_MIN; else pd = g->power[i] / g->power[i - 1];
         if (pd > v->thresh) { rise[nrise].r = pd; rise[nrise].pos = (i - 1) * dec + g->start; rise[nrise].ord = nrise; nrise++; }
-        if (pd < inversethresh) fall[nfall++] = i * dec + g->start;
+        else if (v->variant == 1) { if (pd < inversethresh) fall[nfall++] = i * dec + g->start; }   /* if / else if (:209-210) */
+        if (v->variant == 0 && pd < inversethresh) fall[nfall++] = i * dec + g->start;
     }
     qsort(rise, (size_t)nrise, sizeof(edge), edge_cmp);
     int (*pc)[2] = (int (*)[2])malloc(sizeof(int[2]) * (size_t)(nrise > 0 ? nrise : 1));
@@ -451,7 +519,7 @@ void fdco_vcm_work(fdco_vcm *v, const float *in, int nitems, fdco_pdu_list *L)  
                     pdu_push(L, &d, c->data, c->nblk * c->outputsamples);
                     c->nblk = 0;
                 } else vcm_process(v, sig, c);
-                if (v->maxblocks >= 0 && c->nblk >= v->maxblocks) {                 /* emit_unfinished_channel, :454-510 */
+                if (v->variant == 0 && v->maxblocks >= 0 && c->nblk >= v->maxblocks) {   /* emit_unfinished_channel, :454-510 */
                     const long ntx = v->maxblocks == 0 ? c->nblk : v->maxblocks;
                     if (ntx > 0) {
                         fdco_pdu d; vcm_fill(v, g, c, &d);
@@ -465,6 +533,21 @@ void fdco_vcm_work(fdco_vcm *v, const float *in, int nitems, fdco_pdu_list *L)  
                 }
             }
         }
+        if (v->variant == 1 && v->maxblocks >= 0)          /* SegmentDetection: partial emission after all channels, :359-362 */
+            for (int k = 0; k < v->seg[0].nch; k++) {
+                vcm_seg *g = &v->seg[0];
+                vcm_chan *c = &g->ch[k];
+                if (c->nblk < v->maxblocks) continue;
+                const long ntx = v->maxblocks == 0 ? c->nblk : v->maxblocks;
+                if (ntx <= 0) continue;
+                fdco_pdu d; vcm_fill(v, g, c, &d);
+                d.finalized = 0; d.part = c->part; d.has_part = 1;
+                pdu_push(L, &d, c->data, ntx * c->outputsamples);
+                memmove(c->data, c->data + 2 * (size_t)ntx * c->outputsamples,
+                        sizeof(float) * 2 * (size_t)(c->nblk - ntx) * c->outputsamples);
+                c->nblk -= ntx;
+                c->part++;
+            }
         for (int s = 0; s < v->nseg; s++) {                                         /* clear_inactive_channels, :512-524 */
             vcm_seg *g = &v->seg[s];
             int i = 0;

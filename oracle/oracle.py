@@ -214,6 +214,9 @@ def _sink_protos():
     l.fdco_pac_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_PduList)]
     l.fdco_vcm_create.restype = C.c_void_p
     l.fdco_vcm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_double]
+    l.fdco_sd_create.restype = C.c_void_p
+    l.fdco_sd_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int, C.c_int]
     l.fdco_vcm_destroy.argtypes = [C.c_void_p]
     l.fdco_vcm_segment_params.argtypes = [C.c_void_p, C.c_int, _ip]
     l.fdco_vcm_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_PduList)]
@@ -272,3 +275,17 @@ class ActivityDetectionVcm:
         if getattr(self, "_h", None):
             lib().fdco_vcm_destroy(self._h)
             self._h = None
+
+
+class SegmentDetection(ActivityDetectionVcm):
+    """lib/SegmentDetection_impl.cc restated (stateful): the single-segment twin of the vcm block."""
+
+    def __init__(self, ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist, puffer, maxblocks, delay):
+        self.N = blocklen
+        self._h = _sink_protos().fdco_sd_create(ID, blocklen, relinvovl, seg_start, seg_stop, thresh, minchandist, puffer,
+                                                maxblocks, delay)
+        if not self._h:
+            raise ValueError("invalid SegmentDetection arguments")
+        v = (C.c_int * 5)()
+        lib().fdco_vcm_segment_params(self._h, 0, v)
+        self.segments = [dict(start=v[0], stop=v[1], width=v[2], dec=v[3], npower=v[4])]

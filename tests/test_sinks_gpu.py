@@ -161,7 +161,7 @@ def test_hier_block_with_sinks_from_device_spectrum(oracle):
     ports = fdc.work(x)
     spec = ports[0]
     pac_ref = oracle.PowerActivationChannel(N, (-0.2 + 0.5) % 1.0, 0.04, R, 6.0, -1, 0, 0).work(spec)
-    det_ref = oracle.ActivityDetectionVcm(N, [[0.75, 0.9]], 10.0, R, -1, 0.005, 1, 0.2).work(spec)
+    det_ref = oracle.SegmentDetection(0, N, R, 0.75, 0.9, 10.0, 0.005, 0.2, -1, 1).work(spec)
     got_pac = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("PowActChan")]
     got_det = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("DETECTED")]
     assert len(pac_ref) >= 1 and len(det_ref) >= 1
@@ -169,3 +169,35 @@ def test_hier_block_with_sinks_from_device_spectrum(oracle):
     for (d, s), r in zip(got_pac + got_det, pac_ref + det_ref):
         assert (d["blockstart"], d["blockend"], s.size) == (r["blockstart"], r["blockend"], r["samples"].size)
         assert np.abs(s - r["samples"]).max() <= 1e-5 * np.abs(r["samples"]).max()
+
+
+@pytest.mark.parametrize("N,R,maxblocks,delay", [(4096, 4, -1, 1), (4096, 2, 0, 0), (16384, 2, 3, 2)])
+def test_segment_detection_face_vs_oracle(oracle, golden_dir, N, R, maxblocks, delay):
+    """SegmentDetection (the twin the hier block uses): own geometry, raw sums, counter from 0, separate partial pass."""
+    nb = 36
+    rng = np.random.default_rng(N + R + 5)
+    bursts = []
+    pos = 0.12
+    while pos < 0.78:
+        wdt = float(rng.uniform(0.004, 0.03))
+        t0 = int(rng.integers(1, 12)); ln = int(rng.integers(4, 16))
+        bursts.append((int(pos * N), int((pos + wdt) * N), t0, min(nb - 3, t0 + ln), 1.0))
+        pos += wdt + float(rng.uniform(0.03, 0.06))
+    spec = burst_spectrum(N, nb, bursts, 23)
+    blk = G.SegmentDetection(3, N, R, 0.1, 0.8, 10.0, 0.005, 0.2, maxblocks, delay, True, False, "", False, 0, max_blocks=16)
+    o = oracle.SegmentDetection(3, N, R, 0.1, 0.8, 10.0, 0.005, 0.2, maxblocks, delay)
+    assert blk.segment == o.segments[0]
+    got = blk.work(spec[:5].reshape(-1)) + blk.work(spec[5:].reshape(-1))
+    ref = o.work(spec[:5]) + o.work(spec[5:])
+    assert len(ref) >= 3 and len(got) == len(ref)
+    for (d, s), r in zip(got, ref):
+        assert d["ID"] == "DETECTED.3.%d" % r["chan_id"]
+        assert (d["finalized"], d["blockstart"], d["blockend"], d["vectorstart"], d["vectorend"]) == \
+            (r["finalized"], r["blockstart"], r["blockend"], r["vectorstart"], r["vectorend"])
+        assert ("part" in d) == r["has_part"] and s.size == r["samples"].size
+        if s.size:
+            assert np.abs(s - r["samples"]).max() <= TOL * np.abs(r["samples"]).max()
+    ka = json.load(open(os.path.join(golden_dir, "sink_known_answers.json")))["SegmentDetection"]
+    spec2 = burst_spectrum(4096, 12, [(1600, 1800, 3, 7, 1.0)], 0)
+    (d, s), = G.SegmentDetection(0, 4096, 4, 0.3, 0.55, 10.0, 0.005, 0.2, -1, 1, True, False, "", False, 0).work(spec2)
+    assert (d["blockstart"], d["blockend"], s.size) == (ka["blockstart"], ka["blockend"], ka["nsamples"]) and abs(d["rel_bw"] - ka["rel_bw"]) < 1e-12
