@@ -77,6 +77,7 @@ SYMBOLS = {
     "fdc_pipeline_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "fdc_sinks_create": (C.c_int, [C.POINTER(fdc_sinks_cfg), C.POINTER(_vp)]),
     "fdc_sinks_destroy": (None, [_vp]),
+    "fdc_pipeline_work_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_pipeline_work_sinks": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),
     "fdc_sinks_spectrum": (_vp, [_vp]),

@@ -107,6 +107,20 @@ class Pipeline:
                                                    spec.ctypes.data if spec is not None else None))
         return (outs, spec) if want_spectrum else outs
 
+    def work_spectrum(self, spec_items, want_spectrum=False, sinks=None):
+        """Items that are already transformed (unnormalised, fftshifted): hier block with inpveclen > 1."""
+        spec_items = np.ascontiguousarray(spec_items, dtype=np.complex64)
+        if spec_items.size % self.N:
+            raise ValueError("input must be a whole number of N-sample spectrum items")
+        nb = spec_items.size // self.N
+        outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
+        spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
+        _lib.check(_lib.lib().fdc_pipeline_work_spectrum(self._h, spec_items.ctypes.data, nb, ptrs,
+                                                        spec.ctypes.data if spec is not None else None,
+                                                        sinks._h if sinks is not None else None))
+        return (outs, spec) if want_spectrum else outs
+
     def reset(self):
         _lib.lib().fdc_pipeline_reset(self._h)
 
@@ -209,8 +223,8 @@ class FrequencyDomainChannelizer:
         self.relinvovl = nextpow2(relinvovl)                    # :139
         self.ovllen = self.blocksize // self.relinvovl          # :140
         self.inpblocklen = self.blocksize - self.ovllen         # :141
-        if self.inpveclen != 1:
-            raise NotImplementedError("inpveclen > 1 (input already transformed, :284-290) is not built yet")
+        if self.inpveclen != 1 and self.inpveclen != self.blocksize:
+            raise ValueError("inpveclen must be 1 (sample stream) or blocksize (items already transformed, :284-290)")
 
         self.channel_params = [get_opt_channelparams(self.blocksize, self.relinvovl, fr, bw)
                                for (fr, bw) in self.throughput_channels]
@@ -268,7 +282,10 @@ class FrequencyDomainChannelizer:
         """Returns the hier block's stream ports; PDUs of the sink blocks ("msgout", :166-168) are left in
         self.messages as (dict, complex64 array) pairs.  Detection segments run as SegmentDetection instances, like in
         the reference hier block (:261-278)."""
-        res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
+        if self.inpveclen == 1:
+            res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
+        else:       # the front end (stream_to_vector, overlap_save, fft_vcc) is the caller's: :201, :284-290
+            res = self.pipeline.work_spectrum(samples, want_spectrum=self.debug, sinks=self.sinks)
         self.messages = []
         if self.sinks is not None:
             from .sinks import _pac_pdu, _det_pdu, _write_files

@@ -581,6 +581,51 @@ int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *
     return rs < 0 ? rs : rc;
 }
 
+int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
+                               fdc_sinks *sinks)
+{
+    // hier block with inpveclen > 1 (py:284-290): items are spectra already; only multiply_const(1/N) and the channel /
+    // sink branches remain.  The front-end state (overlap history) is untouched; the block counter advances.
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (nblocks == 0) return 0;
+    if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
+    if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    hipStream_t s = p->stream;
+    float2 *d_full = sinks ? static_cast<float2 *>(fdc_sinks_spectrum(sinks)) : nullptr, *d_owned = nullptr;
+    if (!d_full) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_full = d_owned; }
+    if (p->sum_lout > 0 && !p->d_out) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
+    const size_t n = (size_t)nblocks * p->N;
+    HIPCHK(hipMemcpyAsync(d_full, in, sizeof(float2) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(fdc::launch_scale(d_full, d_full, n, 1.0f / (float)p->N, s));
+    for (size_t g = 0; g < p->groups.size(); g++) {
+        const int l = p->groups[g].first;
+        if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
+            HIPCHK(fdc::launch_channels256(d_full, p->d_out, p->d_chans, p->d_groups + p->group_off[g],
+                                           (int)p->groups[g].second.size(), p->g_aligned[g] != 0, p->g_out_aligned[g] != 0,
+                                           p->N, p->R, nblocks, 0, nblocks, p->blockcount, p->d_wins, p->d_tw256, s));
+        else
+            HIPCHK(fdc::launch_channels(d_full, p->d_out, p->d_chans, p->d_groups + p->group_off[g],
+                                        (int)p->groups[g].second.size(), l, p->N, p->R, nblocks, 0, nblocks, p->blockcount,
+                                        p->d_wins, p->d_tw, p->ntab, s));
+    }
+    for (int c = 0; c < p->C; c++) {
+        if (!outs[c]) continue;
+        HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
+                              sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
+    }
+    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_full, sizeof(float2) * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (d_owned) HIPCHK(hipFree(d_owned));
+    p->blockcount += nblocks;
+    if (sinks) {
+        const int rs = fdc_sinks_work_device(sinks, nblocks);
+        if (rs < 0) return rs;
+    }
+    return nblocks;
+}
+
 /* ---------------- single-block faces ---------------- */
 struct fdc_overlap_save {
     int dev, itemsize, outlen, ovl; hipStream_t s; unsigned char *d_ring = nullptr, *d_out = nullptr; int cap = 0;

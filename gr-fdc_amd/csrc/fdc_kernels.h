@@ -88,6 +88,8 @@ hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, 
                              const float *shn, const long long *slot_off, unsigned out_bytes, void *ctl, int D, int ring,
                              hipStream_t s);
 
+hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
+
 // sinks
 hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
                              hipStream_t s);

@@ -303,6 +303,16 @@ __global__ __launch_bounds__(kThreads) void k_extract(const float2 *__restrict__
     }
 }
 
+// multiply_const_cc(1/N, N) on spectrum items that arrive already transformed (hier block with inpveclen > 1,
+// python/FrequencyDomainChannelizer.py:213-216, :289-290)
+__global__ void k_scale(const float2 *__restrict__ in, float2 *__restrict__ out, size_t n, float k)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = in[i];
+        out[i] = make_float2(v.x * k, v.y * k);
+    }
+}
+
 // ---- single-block faces ----------------------------------------------------------------------------
 __global__ void k_copy_items(const unsigned char *__restrict__ in, unsigned char *__restrict__ out,
                              size_t in_item_stride, size_t in_offset, size_t out_item_bytes)
@@ -427,6 +437,14 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
     dim3 grid((unsigned)((ntrans + g.TC - 1) / g.TC));
     hipLaunchKernelGGL(k_channels, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
                        g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    size_t g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)g), dim3(256), 0, s, in, out, n, k);
     return hipGetLastError();
 }
 

@@ -51,5 +51,13 @@ public:
                      int channel_deactivation_delay, double window_flank_puffer, int verbose);
 };
 
+class FDC_API SegmentDetection : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<SegmentDetection> sptr;
+    static sptr make(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh, float minchandist,
+                     float window_flank_puffer, int maxblocks_to_emit, int channel_deactivation_delay, bool messageoutput,
+                     bool fileoutput, std::string path, bool threads, int verbose);
+};
+
 }  // namespace FDC
 }  // namespace gr

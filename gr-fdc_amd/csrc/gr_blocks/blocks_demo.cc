@@ -6,6 +6,7 @@
 #include "FDC/phase_shifting_windowing_vcc.h"
 #include "FDC/PowerActivationChannel.h"
 #include "FDC/activity_detection_channelizer_vcm.h"
+#include "FDC/SegmentDetection.h"
 
 #include <cstdio>
 #include <fstream>
@@ -71,6 +72,12 @@ int main(int argc, char **argv)
         auto det = activity_detection_channelizer_vcm::make(N, {{0.5f, 0.9f}}, 10.0f, R, -1, true, false, "", false, 0.01f, 1, 0.2, 0);
         det->work(ns, si, none);
         for (auto &m : det->published()) {
+            std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
+            all.insert(all.end(), m.samples.begin(), m.samples.end());
+        }
+        auto sd = SegmentDetection::make(2, N, R, 0.5f, 0.9f, 10.0f, 0.01f, 0.2f, -1, 1, true, false, "", false, 0);
+        sd->work(ns, si, none);
+        for (auto &m : sd->published()) {
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
             all.insert(all.end(), m.samples.begin(), m.samples.end());
         }

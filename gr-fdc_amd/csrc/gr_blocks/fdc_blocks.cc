@@ -78,6 +78,7 @@ protected:
     fdc_sinks *d_s = nullptr;
     bool d_msg = false, d_file = false;
     std::string d_path;
+    int d_source_override = -1;      // SegmentDetection: the ID argument names the segment in the message IDs
     void publish(gr::sync_block *blk, bool pac)
     {
         fdc_pdu p;
@@ -85,7 +86,7 @@ protected:
             if (fdc_sinks_pdu(d_s, i, &p) != FDC_OK) continue;
             char id[96];
             if (pac) std::snprintf(id, sizeof id, "PowActChan.%d.%d", p.source, p.chan_id);
-            else std::snprintf(id, sizeof id, "DETECTED.%d.%d", p.source, p.chan_id);
+            else std::snprintf(id, sizeof id, "DETECTED.%d.%d", d_source_override >= 0 ? d_source_override : p.source, p.chan_id);
             const gr_complex *d = static_cast<const gr_complex *>(p.samples);
             if (d_msg) {
                 gr::fdc_message m;      // with GNU Radio: pmt::cons(dict, pmt::init_c32vector(n, d)), same keys
@@ -173,7 +174,49 @@ public:
     }
 };
 
+class SegmentDetection_impl : public SegmentDetection, sink_base {
+public:
+    SegmentDetection_impl(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh,
+                          float minchandist, float window_flank_puffer, int maxblocks_to_emit,
+                          int channel_deactivation_delay, bool messageoutput, bool fileoutput, std::string path, bool, int)
+        : gr::sync_block("SegmentDetection", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
+                         gr::io_signature::make(0, 0, 0))
+    {
+        fdc_segment_cfg sg{seg_start, seg_stop};
+        fdc_sinks_cfg c{};
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = 1; c.seg = &sg; c.det_thresh_db = thresh;
+        c.det_maxblocks = maxblocks_to_emit; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
+        c.window_flank_puffer = window_flank_puffer; c.max_blocks = 64; c.det_variant = 1;
+        check_create(fdc_sinks_create(&c, &d_s));
+        d_msg = messageoutput; d_file = fileoutput; d_path = path; d_source_override = ID;
+        if (messageoutput) message_port_register_out("msgout");
+    }
+    ~SegmentDetection_impl() override { fdc_sinks_destroy(d_s); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
+    {
+        const char *p = static_cast<const char *>(in[0]);
+        const size_t item = (size_t)input_signature()->sizeof_stream_item;
+        for (int a = 0; a < n; a += 64) {
+            const int k = n - a < 64 ? n - a : 64;
+            if (report("SegmentDetection", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+            publish(this, false);
+        }
+        return n;
+    }
+};
+
 }  // namespace
+
+SegmentDetection::sptr SegmentDetection::make(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop,
+                                              float thresh, float minchandist, float window_flank_puffer,
+                                              int maxblocks_to_emit, int channel_deactivation_delay, bool messageoutput,
+                                              bool fileoutput, std::string path, bool threads, int verbose)
+{
+    return gnuradio::get_initial_sptr(new SegmentDetection_impl(ID, blocklen, relinvovl, seg_start, seg_stop, thresh,
+                                                               minchandist, window_flank_puffer, maxblocks_to_emit,
+                                                               channel_deactivation_delay, messageoutput, fileoutput, path,
+                                                               threads, verbose));
+}
 
 overlap_save::sptr overlap_save::make(int itemsize, int outputlen, int overlaplen)
 {

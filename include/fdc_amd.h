@@ -161,6 +161,11 @@ typedef struct {
     const void *samples; /* complex float32, owned by the handle until its next work call                     */
 } fdc_pdu;
 
+/* Same, for a hier block fed with items that are ALREADY transformed (inpveclen = blocksize: the front end is skipped,
+ * python/FrequencyDomainChannelizer.py:201, :284-290): nblocks unnormalised, fftshifted spectrum items in; the 1/N of
+ * multiply_const_cc (:213-216), the channel branches and, if given, the sinks run on the device.  sinks may be NULL. */
+int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
+                               fdc_sinks *sinks);
 int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
 /* The whole hier block in one call: fdc_pipeline_work() whose spectrum lands directly in the sinks' device buffer,
  * followed by the sinks' work on it (python/FrequencyDomainChannelizer.py:283-312).  The pipeline needs keep_spectrum,

@@ -31,10 +31,11 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     pw = oracle.PhaseWindow(64, R, 301, 0.6, 0.85, 1).work(sl)
     assert np.abs(rd("phase_window.out") - pw).max() <= 1e-6 * np.abs(pw).max()
     ref = oracle.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, -1, 0, 5).work(spec) + \
-        oracle.ActivityDetectionVcm(N, [[0.5, 0.9]], 10.0, R, -1, 0.01, 1, 0.2).work(spec)
+        oracle.ActivityDetectionVcm(N, [[0.5, 0.9]], 10.0, R, -1, 0.01, 1, 0.2).work(spec) + \
+        oracle.SegmentDetection(2, N, R, 0.5, 0.9, 10.0, 0.01, 0.2, -1, 1).work(spec)
     lines = open(tmp_path / "pdus.txt").read().split("\n")[:-1]
     assert len(lines) == len(ref) and len(ref) >= 2
-    assert lines[0].split()[0] == "PowActChan.5.0.fin" and lines[-1].split()[0].startswith("DETECTED.0.")
+    assert lines[0].split()[0] == "PowActChan.5.0.fin" and lines[-1].split()[0].startswith("DETECTED.2.")
     for ln, r in zip(lines, ref):
         _id, b0, b1, ns = ln.split()
         assert (int(b0), int(b1), int(ns)) == (r["blockstart"], r["blockend"], r["samples"].size)

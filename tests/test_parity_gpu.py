@@ -258,3 +258,20 @@ def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
         for c in range(0, Cn, 41):
             o = out[pipe.channel_offset(c, n):pipe.channel_offset(c, n) + n * 128]
             assert_close(o, ref[c][first * 128:(first + n) * 128], "span first=%d ch%d" % (first, c))
+
+
+def test_hier_block_inpveclen_mode(oracle):
+    """inpveclen = blocksize: the caller did overlap-save + forward FFT (python/FrequencyDomainChannelizer.py:284-290)."""
+    N, R, nb = 4096, 4, 5
+    H = N - N // R
+    x = noise(nb * H, 71)
+    user = [[0.12, 0.05], [-0.14, 0.12]]
+    items = oracle.fft_vcc(N, True, True, oracle.OverlapSave(8, N, N // R).work(x))      # what the caller's front end delivers
+    fdc = G.FrequencyDomainChannelizer(8, N, N, R, user, None, 6.0, 1.0, 0.0, 'normalized', 2, False, False, "", False,
+                                       None, 10.0, 0.005, 1, 0.2, 0, 0, 128, 128, True, max_blocks=nb)
+    ports = fdc.work(items)
+    plan = [(f, l, p, s) for (f, l, _lo, p, s) in fdc.channel_params]
+    ref, rspec = oracle.channelizer(N, R, 2, plan, x, want_spectrum=True)
+    assert_close(ports[0], rspec, "normalised spectrum port")
+    for c in range(2):
+        assert_close(ports[1 + c], ref[c], "port %d" % (1 + c))
