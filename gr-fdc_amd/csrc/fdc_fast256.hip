@@ -270,6 +270,11 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
                 nbuf[0] = bld2(rin, voff, 0);
 #pragma unroll
                 for (int a = 1; a < 16; a++) nbuf[a] = nbuf[0] * (float)a;
+            } else if (ABL == 3) {           // what-if: only the NEW half of the rows is loaded (overlap kept on chip)
+#pragma unroll
+                for (int a = 8; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+#pragma unroll
+                for (int a = 0; a < 8; a++) nbuf[a] = cur[a + 8];
             } else {
 #pragma unroll
                 for (int a = 0; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         // G is stored tile-major, G[m][column tile][t'][TC]: this workgroup's whole output (lout*TC points) is
         // one contiguous run, and stage 2 reads it back in runs of TC rows x TC columns.
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + (m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
-        if (ABL == 1) {
+        if (ABL == 1 || ABL == 3) {
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, cur[q]);
@@ -429,6 +434,7 @@ hipError_t init_fast_kernels()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1<T, A>), hipFuncAttributeMaxDynamicSharedMemorySize, a); \
     if (e != hipSuccess) return e;
     FDC_SETP1(32, 0) FDC_SETP1(16, 0) FDC_SETP1(16, 1) FDC_SETP1(16, 2) FDC_SETP1(32, 1) FDC_SETP1(32, 2)
+    FDC_SETP1(16, 3) FDC_SETP1(32, 3)
 #undef FDC_SETP1
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
@@ -522,8 +528,8 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
 #define FDC_LP1(T, A) \
     hipLaunchKernelGGL((k_p1<T, A>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
                        (int)nt1, skip / 16, lout, stg)
-    if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else FDC_LP1(32, 0); }
-    else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else FDC_LP1(16, 0); }
+    if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else if (abl == 3) FDC_LP1(32, 3); else FDC_LP1(32, 0); }
+    else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else if (abl == 3) FDC_LP1(16, 3); else FDC_LP1(16, 0); }
 #undef FDC_LP1
     return hipGetLastError();
 }

@@ -41,7 +41,10 @@ __device__ __forceinline__ bool wait_geq(unsigned *p, unsigned want)
     return false;
 }
 
-__global__ __launch_bounds__(256, 4) void k_pf(const float2 *__restrict__ in, size_t in_stride,
+// One workgroup = a stream of TILES: a stage-1 task is one tile, a stage-2 task is lout/16 tiles.  While a tile is being
+// computed, the loads of the workgroup's next tile are already in flight (register double buffer) whenever that tile
+// has no unmet dependency: the next tile of the same stage-2 task, or the single tile of a stage-1 task.
+__global__ __launch_bounds__(256, 3) void k_pf(const float2 *__restrict__ in, size_t in_stride,
                                                float2 *__restrict__ gring, float2 *__restrict__ out,
                                                const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -68,94 +71,129 @@ __global__ __launch_bounds__(256, 4) void k_pf(const float2 *__restrict__ in, si
     const unsigned gblock = gtile * (N1 / TC);                       // bytes of one block of G
     const int n1full = 16 * D;                                       // tasks before the first stage-2 task
     const int total = 17 * nb;                                       // 16 stage-1 + 1 stage-2 task per block
+    const int s2tiles = lout / TC;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    // thread roles
+    const int col = tid & (TC - 1), b1 = tid / TC;                   // stage 1: column col, rows 16a + b1
+    const int r = tid >> 4, b2 = tid & 15;                           // stage 2 layer 1: row r, points n1 = 16a + b2
+    const int r2 = tid & (TC - 1), p2 = tid / TC;                    // stage 2 layer 2: row r2, outputs k1 = p2 + 16q
+    const unsigned v1row = (unsigned)b1 * N1 * 8u + (unsigned)col * 8u, rowstep = 16u * N1 * 8u;
+    const unsigned v2off = (unsigned)(r * TC + b2) * 8u;
 
-    for (;;) {
-        __syncthreads();                                             // previous task's LDS traffic is over
+    // queue order: steps s = 0 .. nb+D-1; step s holds S1(s, 0..15) if s < nb, then S2(s - D) if s >= D
+    auto decode = [&](int t, int &m, int &idx) {
+        if (t < n1full) { m = t >> 4; idx = t & 15; return; }
+        const int u = t - n1full, mid = 17 * (nb - D);
+        if (u < mid) {
+            const int s = D + u / 17, rr = u - (s - D) * 17;
+            if (rr < 16) { m = s; idx = rr; } else { m = s - D; idx = 16; }
+        } else { m = nb - D + (u - mid); idx = 16; }
+    };
+    auto fetch_task = [&]() -> int {                                 // uniform result; two barriers
+        __syncthreads();
         if (tid == 0) bcast[0] = (int)__hip_atomic_fetch_add(&ctl->next_task, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        const int t = bcast[0];
-        if (t >= total) break;
-        // queue order: steps s = 0 .. nb+D-1; step s holds S1(s, 0..15) if s < nb, then S2(s - D) if s >= D
-        int m, idx;                                                  // idx 0..15 = stage-1 column tile, 16 = stage 2
-        if (t < n1full) { m = t >> 4; idx = t & 15; }
-        else {
-            const int u = t - n1full, mid = 17 * (nb - D);
-            if (u < mid) { const int s = D + u / 17; const int r = u - (s - D) * 17; if (r < 16) { m = s; idx = r; } else { m = s - D; idx = 16; } }
-            else { m = nb - D + (u - mid); idx = 16; }
-        }
+        return bcast[0];
+    };
+    cf L[16];
+    auto load_s1 = [&](int m, int idx) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)m * in_stride, 256u * N1 * 8u);
+        const unsigned vo = v1row + (unsigned)idx * TC * 8u;
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rin, vo, a * rowstep);
+    };
+    auto load_s2 = [&](int m, int tt) {
+        const unsigned char *gb = reinterpret_cast<const unsigned char *>(gring) + (size_t)(m % ring) * gblock;
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(gb + (size_t)tt * TC * TC * 8, gblock);
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rg, v2off, (unsigned)a * gtile);
+    };
+
+    int t = fetch_task();
+    bool have = false;                                               // L already holds the loads of the coming tile
+    while (t < total) {
+        int m, idx;
+        decode(t, m, idx);
         if (idx < 16) {
-            // ------------------------------------------------------------------ stage 1: column tile idx of block m
-            const int col = tid & (TC - 1), b = tid / TC, c0 = idx * TC;
-            const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u, rowstep = 16u * N1 * 8u;
-            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)m * in_stride, 256u * N1 * 8u);
+            // ============================================================ stage-1 task: column tile idx of block m
+            const int c0 = idx * TC;
+            if (!have) load_s1(m, idx);
+            tq[tid] = twq[(size_t)(c0 + col) * 16 + b1];
+            const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b1]);
+            if (m >= ring && tid == 0 && !wait_geq(&s2done[m - ring], 1u))      // the ring slot must have been read out
+                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tn = fetch_task();                             // next task; also orders the tq writes
+            int mn = 0, idn = 16;
+            if (tn < total) decode(tn, mn, idn);
             cf v[16];
 #pragma unroll
-            for (int a = 0; a < 16; a++) v[a] = bld2(rin, voff, a * rowstep);
-            tq[tid] = twq[(size_t)(c0 + col) * 16 + b];
-            const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
-            if (m >= ring) {                                         // the ring slot must have been read out
-                if (tid == 0 && !wait_geq(&s2done[m - ring], 1u)) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int a = 0; a < 16; a++) v[a] = L[a];
+            have = tn < total && idn < 16;
+            if (have) load_s1(mn, idn);                              // prefetch: a stage-1 tile has no dependency to wait for
             dft16<false>(v);
-            __syncthreads();
             cf w[16];
 #pragma unroll
-            for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+            for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b1 * p]);
 #pragma unroll
-            for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], cmul(v[rev16(p)], w[p]));
+            for (int p = 0; p < 16; p++) st2(&tile[(16 * b1 + p) * TC + col], cmul(v[rev16(p)], w[p]));
             __syncthreads();
 #pragma unroll
-            for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+            for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(16 * bb + b1) * TC + col]);
             dft16<false>(v);
             cf u[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b + 16 * q];
+            for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b1 + 16 * q];
             dft16<true>(u);
 #pragma unroll
-            for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+            for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b1 * p]);
 #pragma unroll
             for (int p = 0; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], w[p]), cb);
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], u[rev16(p)]);
+            for (int p = 0; p < 16; p++) st2(&tile[(16 * b1 + p) * TC + col], u[rev16(p)]);
             __syncthreads();
 #pragma unroll
-            for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+            for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b1) * TC + col]);
             dft16<true>(u);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(reinterpret_cast<unsigned char *>(gring) + (size_t)(m % ring) * gblock + (size_t)idx * gtile, gtile);
-            const unsigned goff = (unsigned)(b * TC + col) * 8u, gstep = 16u * TC * 8u;
+            const unsigned goff = (unsigned)(b1 * TC + col) * 8u, gstep = 16u * TC * 8u;
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 if (q >= qskip) bst2_sc1(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(&s1done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = tn;
         } else {
-            // ------------------------------------------------------------------ stage 2: all rows of block m
+            // ============================================================ stage-2 task: all rows of block m
             if (tid == 0) {
                 if (!wait_geq(&s1done[m], 16u)) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
-            const int r = tid >> 4, b = tid & 15;                    // layer 1: row r, points n1 = 16a + b (ct = a)
-            const int r2 = tid & (TC - 1), p2 = tid / TC;            // layer 2: row r2, outputs k1 = p2 + 16q
-            const unsigned voff = (unsigned)(r * TC + b) * 8u;
-            const unsigned char *gb = reinterpret_cast<const unsigned char *>(gring) + (size_t)(m % ring) * gblock;
-            for (int tt = 0; tt < lout / TC; tt++) {
-                const __amdgpu_buffer_rsrc_t rg = make_rsrc(gb + (size_t)tt * TC * TC * 8, gblock);
+            load_s2(m, 0);
+            int tn = total, mn = 0, idn = 16;
+            for (int tt = 0; tt < s2tiles; tt++) {
                 cf v[16];
 #pragma unroll
-                for (int a = 0; a < 16; a++) v[a] = bld2(rg, voff, (unsigned)a * gtile);
+                for (int a = 0; a < 16; a++) v[a] = L[a];
+                have = false;
+                if (tt + 1 < s2tiles) load_s2(m, tt + 1);            // next tile of this task
+                else {
+                    tn = fetch_task();
+                    if (tn < total) decode(tn, mn, idn);
+                    have = tn < total && idn < 16;
+                    if (have) load_s1(mn, idn);
+                }
                 dft16<false>(v);
                 __syncthreads();
                 cf w[16];
 #pragma unroll
-                for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+                for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b2 * p]);
 #pragma unroll
                 for (int p = 0; p < 16; p++)
-                    st2(&tile[(p * 16 + (b ^ (p & 1))) * TC + ((r ^ b) & (TC - 1))], cmul(v[rev16(p)], w[p]));
+                    st2(&tile[(p * 16 + (b2 ^ (p & 1))) * TC + ((r ^ b2) & (TC - 1))], cmul(v[rev16(p)], w[p]));
                 __syncthreads();
 #pragma unroll
                 for (int bb = 0; bb < 16; bb++)
@@ -170,6 +208,7 @@ __global__ __launch_bounds__(256, 4) void k_pf(const float2 *__restrict__ in, si
             }
             __syncthreads();                                         // every wave's G loads have returned (consumed)
             if (tid == 0) __hip_atomic_store(&s2done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = tn;
         }
     }
 }
@@ -196,7 +235,7 @@ hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         ncu = prop.multiProcessorCount;
     const long long total = 17ll * nb_chunk;
-    const unsigned grid = (unsigned)(total < 4ll * ncu ? total : 4ll * ncu);
+    const unsigned grid = (unsigned)(total < 3ll * ncu ? total : 3ll * ncu);   // 3 workgroups per CU: 168-VGPR budget
     const size_t lds = 256 * kFTC * 8 + 2048 + 2048 + 1024 + 1024 + 64;
     hipLaunchKernelGGL(k_pf, dim3(grid), dim3(256), lds, s, in, in_stride, gring, out, tw256, twq, cbt, shn, slot_off,
                        static_cast<FusedCtl *>(ctl), nb_chunk, D, ring, skip / 16, lout, (long long)mbase * lout,
