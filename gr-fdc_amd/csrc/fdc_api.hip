@@ -103,8 +103,8 @@ struct fdc_pipeline {
     int poly_split = 2;                          // stage-1 workgroups per CU when the stages overlap (of 4)
     bool poly_overlap = false;                   // FDC_POLY_OVERLAP=1: measured slower on MI355X (profiles/r01/NOTES.md)
     bool last_was_poly = false;
-    bool poly_fused = false;                     // FDC_POLY_FUSED=1: one persistent dataflow launch (fdc_fused256.hip)
-    int fused_D = 48, fused_ring = 192;          // stage-2 lag and G ring length, in blocks
+    bool poly_fused = false;                     // FDC_POLY_FUSED=1: XCD-local dataflow, G through L2 (fdc_fused256.hip)
+    int fused_ring = 8, fused_wg1 = 3;           // G ring per XCD in blocks (8 x 256 KiB = 2 MiB of the 4-MiB L2); stage-1 WGs/CU
     float2 *d_gring = nullptr;
     void *d_ctl = nullptr;
     float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
@@ -246,11 +246,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     {
         const char *ov = getenv("FDC_POLY_OVERLAP"), *sp = getenv("FDC_POLY_SPLIT");
         if (ov) p->poly_overlap = ov[0] != '0';
-        const char *fu = getenv("FDC_POLY_FUSED"), *fd = getenv("FDC_FUSED_D"), *fr = getenv("FDC_FUSED_RING");
+        const char *fu = getenv("FDC_POLY_FUSED"), *fw = getenv("FDC_FUSED_WG1"), *fr = getenv("FDC_FUSED_RING");
         if (fu) p->poly_fused = fu[0] != '0';
-        if (fd && atoi(fd) >= 0) p->fused_D = atoi(fd);
-        if (fr && atoi(fr) >= 1) p->fused_ring = atoi(fr);
-        if (p->fused_ring < p->fused_D + 8) p->fused_ring = p->fused_D + 8;
+        if (fw && atoi(fw) >= 1 && atoi(fw) <= 3) p->fused_wg1 = atoi(fw);
+        if (fr && atoi(fr) >= 2) p->fused_ring = atoi(fr);
         if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
     }
     if (chunk <= 0) {
@@ -335,7 +334,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
         CHK_OR_FREE(hipMalloc(&p->d_g[1], gsz));
         if (p->poly_fused) {
-            CHK_OR_FREE(hipMalloc(&p->d_gring, sizeof(float2) * (size_t)p->fused_ring * (size_t)(256 - 256 / R) * 256));
+            CHK_OR_FREE(hipMalloc(&p->d_gring, fdc::fused_ring_bytes(R, p->fused_ring)));
             CHK_OR_FREE(hipMalloc(&p->d_ctl, fdc::fused_ctl_bytes(chunk)));
         }
         CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
@@ -380,9 +379,9 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
     HIPCHK(hipSetDevice(p->cfg.device_id));
     HIPCHK(hipStreamSynchronize(p->stream));
     if (p->d_ctl) {                                   // bounded spins of the fused dataflow kernel report here
-        unsigned ctl[2] = {0, 0};
-        HIPCHK(hipMemcpy(ctl, p->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));
-        if (ctl[1]) return fail(FDC_ERR_HIP, "fused dataflow kernel: dependency wait timed out (code %u)", ctl[1]);
+        unsigned err = 0;
+        HIPCHK(hipMemcpy(&err, static_cast<char *>(p->d_ctl) + fdc::kFusedErrorOffset, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(FDC_ERR_HIP, "XCD-local dataflow: dependency wait timed out (code %u)", err);
     }
     return FDC_OK;
 }
@@ -430,17 +429,13 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
         if (use_poly && p->poly_fused) {
-            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            hipEvent_t ev4[4]; hipEvent_t *evp4 = nullptr;
+            if (p->timing) { for (int i = 0; i < 4; i++) ev4[i] = p->events[span[i]]; evp4 = ev4; }
             HIPCHK(fdc::launch_poly_fused(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_gring, static_cast<float2 *>(d_out),
                                           p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl,
-                                          std::min(p->fused_D, std::max(0, nb - 1)), p->fused_ring, s));
-            if (p->timing) {
-                HIPCHK(hipEventRecord(p->events[span[1]], s));
-                HIPCHK(hipEventRecord(p->events[span[2]], s));
-                HIPCHK(hipEventRecord(p->events[span[3]], s));
-                p->ev_spans.push_back(span);
-            }
+                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl, p->fused_ring,
+                                          p->fused_wg1, s, p->stream2, p->ev_fork, p->ev_s2[0], evp4));
+            if (p->timing) p->ev_spans.push_back(span);
             continue;
         }
         if (use_poly) {

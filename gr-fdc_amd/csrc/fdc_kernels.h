@@ -79,14 +79,17 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk,
                               const float2 *tw256, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
                               int wg_per_cu, hipStream_t s);
 
-// uniform plan as one persistent dataflow launch (fdc_fused256.hip): stage-1 tiles and stage-2 blocks pulled from one
-// task queue, G in a ring of `ring` blocks, stage 2 of a block D blocks behind its stage 1
+// uniform plan as an XCD-local dataflow (fdc_fused256.hip): stage 1 (3 workgroups/CU, stream s1) and stage 2
+// (1 workgroup/CU, stream s2) run concurrently; every block is owned by one XCD and its G stays in that XCD's L2
 hipError_t init_fused_kernels();
 size_t fused_ctl_bytes(int nb);
+size_t fused_ring_bytes(int R, int ringx);
+constexpr int kFusedErrorOffset = 1024;      // byte offset of the error word inside the control block
 hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, float2 *out, int R, int nb_chunk,
                              int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
-                             const float *shn, const long long *slot_off, unsigned out_bytes, void *ctl, int D, int ring,
-                             hipStream_t s);
+                             const float *shn, const long long *slot_off, unsigned out_bytes, void *ctl, int ringx,
+                             int wg1_per_cu, hipStream_t s1, hipStream_t s2, hipEvent_t fork, hipEvent_t join,
+                             hipEvent_t *ev);
 
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
 
