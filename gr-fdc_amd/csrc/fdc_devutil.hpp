@@ -24,6 +24,12 @@ __device__ __forceinline__ cf bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
     const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(t.x), __uint_as_float(t.y));
 }
+// sc1 load: bypasses this CU's L1 and is served by the XCD's L2 (MI355X_MICROARCH.md, "__hip_atomic_load/store ... sc1")
+__device__ __forceinline__ cf bld2_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16);
+    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
+}
 __device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cf v)
 {
     u32x2 t;

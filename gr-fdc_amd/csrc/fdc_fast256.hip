@@ -342,6 +342,88 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     }
 }
 
+// Two-group form of stage 1 (16-column tiles): a 512-thread workgroup holds TWO independent 256-thread groups, each
+// with its own tile, running the same four-barrier tile program HALF A TILE APART (group 1 enters two barriers late).
+// The shared s_barrier then pins one group's LDS-heavy exchanges against the other group's DFT-16 arithmetic, which
+// independent co-resident workgroups do not do by themselves (profiles/r01/NOTES.md: VALU and LDS phases convoy).
+__global__ __launch_bounds__(512, 4) void k_p1g(const float2 *__restrict__ in, size_t in_stride,
+                                                float2 *__restrict__ g, const float2 *__restrict__ tw256,
+                                                const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
+                                                const float *__restrict__ shn, int N1, int log2ct, int ntiles,
+                                                int qskip, int lout)
+{
+    constexpr int TC = 16;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, col = tid & (TC - 1), b = tid / TC;
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast + grp * (256 * TC * 8));    // [256][TC] per group
+    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + 2 * 256 * TC * 8);
+    float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 2 * 256 * TC * 8 + 2048 + grp * 2048);
+    float *sh = reinterpret_cast<float *>(fdc_smem_fast + 2 * 256 * TC * 8 + 2048 + 4096);
+    const int step = 2 * gridDim.x;
+    int tl = 2 * blockIdx.x + grp;
+    const int niter = (ntiles + step - 1) / step;                    // same for both groups (barrier counts must match)
+    const int c0 = (tl & ((1 << log2ct) - 1)) * TC;                  // step is a multiple of the column tiles per block
+    if (grp == 0) { w256[tid] = tw256[tid]; sh[tid] = shn[tid]; }
+    tq[tid] = twq[(size_t)(c0 + col) * 16 + b];
+    const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
+    const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u, rowstep = 16u * (unsigned)N1 * 8u;
+    const unsigned inbytes = 256u * (unsigned)N1 * 8u, gtile = (unsigned)lout * TC * 8u;
+    const unsigned goff = (unsigned)(b * TC + col) * 8u, gstep = 16u * TC * 8u;
+    cf L[16];
+    if (tl < ntiles) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(tl >> log2ct) * in_stride, inbytes);
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
+    }
+    __syncthreads();                                                 // tables of both groups are in LDS
+    if (grp == 1) { __syncthreads(); __syncthreads(); }              // half a tile late
+    for (int it = 0; it < niter; it++, tl += step) {
+        if (tl >= ntiles) {                                          // keep the barrier count of a real tile
+            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+            continue;
+        }
+        const size_t m = tl >> log2ct;
+        cf v[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = L[a];
+        if (tl + step < ntiles) {
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)((tl + step) >> log2ct) * in_stride, inbytes);
+#pragma unroll
+            for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
+        }
+        dft16<false>(v);
+        __syncthreads();                                             // (1) previous tile's exchange reads are done
+        cf w[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], cmul(v[rev16(p)], w[p]));
+        __syncthreads();                                             // (2)
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+        dft16<false>(v);
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b + 16 * q];
+        dft16<true>(u);
+#pragma unroll
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+#pragma unroll
+        for (int p = 0; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], w[p]), cb);
+        __syncthreads();                                             // (3)
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], u[rev16(p)]);
+        __syncthreads();                                             // (4)
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
+        dft16<true>(u);
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + (m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+    }
+    if (grp == 0) { __syncthreads(); __syncthreads(); }
+}
+
 // Stage 2 for N1 = 256 slots: rows rho = m*lout + t' of G (256 contiguous n1 each), FFT over n1, bin = slot c.
 // Persistent with next-tile prefetch like k_p1; a tile is TR consecutive rows (TR*2 KiB contiguous).
 template <int TR>
@@ -435,6 +517,8 @@ hipError_t init_fast_kernels()
     if (e != hipSuccess) return e;
     FDC_SETP1(32, 0) FDC_SETP1(16, 0) FDC_SETP1(16, 1) FDC_SETP1(16, 2) FDC_SETP1(32, 1) FDC_SETP1(32, 2)
     FDC_SETP1(16, 3) FDC_SETP1(32, 3)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
 #undef FDC_SETP1
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
@@ -520,10 +604,20 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     const long long nt1 = (long long)nb_chunk * ct;
     const unsigned g1 = (unsigned)(nt1 < slots ? nt1 : slots);
     const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024;
-    static int abl = -1, stg = 0;
+    static int abl = -1, stg = 0, twog = 0;
     if (abl < 0) {
         const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
         const char *g2 = getenv("FDC_STAGGER"); stg = g2 ? atoi(g2) : 0;
+        const char *g3 = getenv("FDC_POLY_2GROUP"); twog = g3 ? atoi(g3) : 0;
+    }
+    if (twog && TC == 16 && abl == 0) {                     // two phase-shifted groups per 512-thread workgroup
+        int wgs = (wg_per_cu > 0 && wg_per_cu < 4 ? (wg_per_cu + 1) / 2 : 2) * cu_count();
+        wgs -= wgs % (ct / 2 > 0 ? ct / 2 : 1);              // 2*grid must be a multiple of ct
+        const long long need = (nt1 + 1) / 2;
+        const unsigned gg = (unsigned)(need < wgs ? need : wgs);
+        hipLaunchKernelGGL(k_p1g, dim3(gg), dim3(512), 2 * 256 * 16 * 8 + 2048 + 4096 + 1024, s, in, in_stride, g, tw256,
+                           twq, cbt, shn, N1, log2ct, (int)nt1, skip / 16, lout);
+        return hipGetLastError();
     }
 #define FDC_LP1(T, A) \
     hipLaunchKernelGGL((k_p1<T, A>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \

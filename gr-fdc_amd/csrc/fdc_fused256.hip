@@ -11,8 +11,8 @@
 // Hand-off inside an XCD (L2 is the coherence point of its CUs; L1 is write-through and never refreshed):
 //   producer (stage-1 tile):  plain G stores -> every wave `s_waitcnt vmcnt(0)` -> __syncthreads() -> lane 0 agent-scope
 //                             fetch_add on the block's counter
-//   consumer (stage-2 block): lane 0 polls the counter (relaxed, agent) until 16 -> agent-scope acquire fence (drops this
-//                             CU's L1) -> `s_waitcnt vmcnt(0)` -> __syncthreads() -> plain loads (L2 hits)
+//   consumer (stage-2 tile):  lane 0 polls the counter (relaxed, agent) until 16 -> __syncthreads() -> every load of G is an
+//                             sc1 load (bypasses this CU's L1, served by the XCD's L2)
 //   ring reuse:               a stage-1 tile of local block j first waits for stage 2 of local block j - ring.
 // Same-XCD is guaranteed by construction (the hardware id, not by assuming a dispatch order), so no L2 write-back
 // (release) is needed; a workgroup never touches another XCD's G.  Queues are popped in order and waits only ever point
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 4) void k_p1x(const float2 *__restrict__ in, s
         for (int a = 0; a < 16; a++) v[a] = L[a];
         if (tn < ntl) issue(tn);                                     // prefetch
         st2(&tq[tid], tqv);                                          // tq[q*TC + col] with q = b
-        if (j >= ringx && tid == 0 && !wait_geq(&s2done[8 * (j - ringx) + x], 1u))      // ring slot read out?
+        if (j >= ringx && tid == 0 && !wait_geq(&s2done[8 * (j - ringx) + x], (unsigned)(lout / TC)))   // ring slot read out?
             __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dft16<false>(v);
         cf w[16];
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256, 4) void k_p1x(const float2 *__restrict__ in, s
     }
 }
 
-// ---- stage 2: whole blocks of this XCD, in queue order; G comes out of the XCD's L2
+// ---- stage 2: row tiles (16 rows t' of one block) of this XCD, in queue order; G comes out of the XCD's L2 through
+// sc1 loads (L1 bypass), so no fence is needed and a block's eight tiles run on eight workgroups at once — the
+// stage-2 latency of a block, which bounds how small the G ring can be, is one tile time.
 __global__ __launch_bounds__(256, 4) void k_p2x(const float2 *__restrict__ gring, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256,
                                                 const long long *__restrict__ slot_off, FusedCtl *ctl, int nb,
@@ -154,6 +156,8 @@ __global__ __launch_bounds__(256, 4) void k_p2x(const float2 *__restrict__ gring
     const int tid = threadIdx.x;
     const int x = (int)xcc_id();
     const int nbx = (nb - x + 7) >> 3;
+    const int s2tiles = lout / TC;
+    const int ntl = nbx * s2tiles;
     w256[tid] = tw256[tid];
     {
         const long long o = slot_off[tid];
@@ -166,55 +170,41 @@ __global__ __launch_bounds__(256, 4) void k_p2x(const float2 *__restrict__ gring
     const int r = tid >> 4, b = tid & 15;                            // layer 1: row r, points n1 = 16a + b (ct = a)
     const int r2 = tid & (TC - 1), p2 = tid / TC;                    // layer 2: row r2, outputs k1 = p2 + 16q
     const unsigned voff = (unsigned)(r * TC + b) * 8u;
-    const int s2tiles = lout / TC;
     for (;;) {
         __syncthreads();
-        if (tid == 0) bcast[0] = (int)__hip_atomic_fetch_add(&ctl->q2[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int j = bcast[0];
-        if (j >= nbx) break;
-        const int m = 8 * j + x;
         if (tid == 0) {
-            if (!wait_geq(&s1done[m], 16u)) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // buffer_inv sc1: this CU's L1 forgets old G lines
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = (int)__hip_atomic_fetch_add(&ctl->q2[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < ntl && !wait_geq(&s1done[8 * (t / s2tiles) + x], 16u))
+                __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bcast[0] = t;
         }
         __syncthreads();
-        const unsigned char *gb = gx + (size_t)(j % ringx) * gblock;
-        cf L[16];
-        auto issue = [&](int tt) {
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(gb + (size_t)tt * TC * TC * 8, gblock);
+        const int t = bcast[0];
+        if (t >= ntl) break;
+        const int j = t / s2tiles, tt = t - j * s2tiles, m = 8 * j + x;
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(gx + (size_t)(j % ringx) * gblock + (size_t)tt * TC * TC * 8, gblock);
+        cf v[16];
 #pragma unroll
-            for (int a = 0; a < 16; a++) L[a] = bld2(rg, voff, (unsigned)a * gtile);
-        };
-        issue(0);
-        for (int tt = 0; tt < s2tiles; tt++) {
-            cf v[16];
+        for (int a = 0; a < 16; a++) v[a] = bld2_sc1(rg, voff, (unsigned)a * gtile);
+        dft16<false>(v);
+        cf w[16];
 #pragma unroll
-            for (int a = 0; a < 16; a++) v[a] = L[a];
-            if (tt + 1 < s2tiles) issue(tt + 1);
-            dft16<false>(v);
-            __syncthreads();
-            cf w[16];
+        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
 #pragma unroll
-            for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+        for (int p = 0; p < 16; p++)
+            st2(&tile[(p * 16 + (b ^ (p & 1))) * TC + ((r ^ b) & (TC - 1))], cmul(v[rev16(p)], w[p]));
+        __syncthreads();                                             // all G loads of the tile have been consumed too
+        if (tid == 0) __hip_atomic_fetch_add(&s2done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int p = 0; p < 16; p++)
-                st2(&tile[(p * 16 + (b ^ (p & 1))) * TC + ((r ^ b) & (TC - 1))], cmul(v[rev16(p)], w[p]));
-            __syncthreads();
+        for (int bb = 0; bb < 16; bb++)
+            v[bb] = ld2(&tile[(p2 * 16 + (bb ^ (p2 & 1))) * TC + ((r2 ^ bb) & (TC - 1))]);
+        dft16<false>(v);
+        const unsigned rbytes = (unsigned)((long long)m * lout + tt * TC + r2) * 8u;
 #pragma unroll
-            for (int bb = 0; bb < 16; bb++)
-                v[bb] = ld2(&tile[(p2 * 16 + (bb ^ (p2 & 1))) * TC + ((r2 ^ bb) & (TC - 1))]);
-            dft16<false>(v);
-            const unsigned rbytes = (unsigned)((long long)m * lout + tt * TC + r2) * 8u;
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const unsigned off = soff[p2 + 16 * q];
-                if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[rev16(q)]);
-            }
+        for (int q = 0; q < 16; q++) {
+            const unsigned off = soff[p2 + 16 * q];
+            if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[rev16(q)]);
         }
-        __syncthreads();                                             // every wave's G loads have returned (consumed)
-        if (tid == 0) __hip_atomic_store(&s2done[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
