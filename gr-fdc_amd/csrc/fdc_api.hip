@@ -293,15 +293,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_tw256, sizeof(float2) * 256));
         CHK_OR_FREE(hipMemcpy(p->d_tw256, t256.data(), sizeof(float2) * 256, hipMemcpyHostToDevice));
     }
-    if (N == 65536) {
-        std::vector<float2> tf(65536);
-        for (int k2 = 0; k2 < 256; k2++)
-            for (int n1 = 0; n1 < 256; n1++) {
-                const double a = -2.0 * M_PI * double(n1 * k2) / 65536.0;
-                tf[k2 * 256 + n1] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    if (N > fdc::kMaxLdsFft) {
+        // inter-pass twiddles of the two-pass transform, laid out like pass A's output: [k2][n1] = W_N^(n1*k2)
+        const fdc::BigGeom bg = fdc::big_geom(N);
+        std::vector<float2> tf((size_t)N);
+        for (int k2 = 0; k2 < bg.N2; k2++)
+            for (int n1 = 0; n1 < bg.N1; n1++) {
+                const double a = -2.0 * M_PI * double((long long)n1 * k2) / double(N);
+                tf[(size_t)k2 * bg.N1 + n1] = make_float2(float(std::cos(a)), float(std::sin(a)));
             }
-        CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * 65536));
-        CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * 65536, hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * (size_t)N));
+        CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
     }
     if (p->poly_ok) {
         std::vector<std::complex<float>> shape(256);
@@ -473,7 +475,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
         else
             HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
-                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp));
+                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf));
         for (size_t g = 0; g < p->groups.size(); g++) {
             const int l = p->groups[g].first;
             if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)

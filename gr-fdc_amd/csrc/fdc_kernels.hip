@@ -15,6 +15,7 @@
 //   fft_vcc(l, inv, shift)  python/FrequencyDomainChannelizer.py:228 (ifftshift fused into the LDS index)
 //   cut + *l                python/FrequencyDomainChannelizer.py:229-231
 #include "fdc_kernels.h"
+#include "fdc_radix16.hpp"
 
 namespace fdc {
 
@@ -43,6 +44,43 @@ __device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float
     const int L = 1 << log2L;
     const int cmask = (1 << log2TC) - 1;
     int log2ns = 0;
+    // radix-16 passes first (two radix-4 layers in registers per LDS round trip, fdc_radix16.hpp)
+    for (; log2ns + 4 <= log2L; log2ns += 4) {
+        const int ns = 1 << log2ns;
+        const int q = L >> 4;
+        const int total = q << log2TC;
+        const int tstep = (L >> (log2ns + 4)) * twstride;
+        cf o[kMaxB / 4][16];
+#pragma unroll
+        for (int i = 0; i < kMaxB / 4; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float2 x = lds[(j + r * q) * ld + c];
+                    o[i][r] = mk(x.x, x.y);
+                    if (ns > 1 && r > 0) {
+                        const float2 w = ldtw<INV>(tw, k * r * tstep);
+                        o[i][r] = cmul(o[i][r], mk(w.x, w.y));
+                    }
+                }
+                dft16<INV>(o[i]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kMaxB / 4; i++) {
+            const int b = tid + i * kThreads;
+            if (b < total) {
+                const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
+                const int j0 = ((j >> log2ns) << (log2ns + 4)) + k;
+#pragma unroll
+                for (int r = 0; r < 16; r++) lds[(j0 + r * ns) * ld + c] = to2(o[i][rev16(r)]);
+            }
+        }
+        __syncthreads();
+    }
     for (; log2ns + 2 <= log2L; log2ns += 2) {
         const int ns = 1 << log2ns;
         const int q = L >> 2;
@@ -157,7 +195,8 @@ template <bool INV>
 __global__ __launch_bounds__(kThreads) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
                                                          float2 *__restrict__ tmp, int log2N, int log2N1,
                                                          int log2TC, int ld, int in_rot,
-                                                         const float2 *__restrict__ tw, int ntab)
+                                                         const float2 *__restrict__ tw, int ntab,
+                                                         const float2 *__restrict__ twf)
 {
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int N = 1 << log2N, log2N2 = log2N - log2N1, N2 = 1 << log2N2;
@@ -176,7 +215,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass_a(const float2 *__restric
     const int twn = ntab >> log2N;
     for (int e = threadIdx.x; e < (N2 << log2TC); e += kThreads) {
         const int k2 = e >> log2TC, c = e & (TC - 1), n1 = c0 + c;
-        const float2 w = ldtw<INV>(tw, n1 * k2 * twn);
+        // W_N^(n1*k2): from the [k2][n1] table when the caller has one (coalesced like the store), else gathered
+        float2 w;
+        if (twf) { w = twf[((size_t)k2 << log2N1) + n1]; if (INV) w.y = -w.y; }
+        else w = ldtw<INV>(tw, n1 * k2 * twn);
         dst[((size_t)k2 << log2N1) + n1] = cmulf(lds[k2 * ld + c], w);
     }
 }
@@ -385,7 +427,7 @@ hipError_t init_kernels()
 
 hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,
                       bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
-                      hipStream_t s, hipEvent_t *ev)
+                      hipStream_t s, hipEvent_t *ev, const float2 *twf)
 {
     if (nitems <= 0) return hipSuccess;
     hipError_t e;
@@ -410,10 +452,10 @@ hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *t
             float2 *t = tmp + (size_t)m0 * N, *dst = out + (size_t)m0 * N;
             if (inverse)
                 hipLaunchKernelGGL(k_fft_pass_a<true>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
-                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab);
+                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab, twf);
             else
                 hipLaunchKernelGGL(k_fft_pass_a<false>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
-                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab);
+                                   lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab, twf);
             if (m0 == 0 && ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
             if (inverse)
                 hipLaunchKernelGGL(k_fft_pass_b<true>, gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
