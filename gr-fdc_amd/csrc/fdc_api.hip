@@ -94,6 +94,7 @@ struct fdc_pipeline {
     float2 *d_tw = nullptr; int ntab = 0;
     float2 *d_wins = nullptr;
     float2 *d_tw256 = nullptr;   // fast path: exp(-2 pi i j/256)
+    float2 *d_tw1024 = nullptr;  // uniform path with 1024 slots: exp(-2 pi i j/1024)
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
@@ -154,7 +155,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
     (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl);
     for (auto e : p->events) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_tw256); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
+    (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -226,11 +227,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         flat.insert(flat.end(), kv.second.begin(), kv.second.end());
     }
 
-    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*256 (fdc_fast256.hip)
+    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*256 or 256*1024 (fdc_fast256.hip)
     {
         const char *np = getenv("FDC_NO_POLY");
-        bool ok = N == 65536 && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
-        std::vector<char> used(256, 0);
+        bool ok = (N == 65536 || N == 262144) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
+        std::vector<char> used(N / 256 + 1, 0);
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
             if (ch.l != 256 || (ch.f & 255) || used[ch.f >> 8] || ch.passbw != cfg->channels[0].passbw ||
@@ -247,7 +248,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const char *ov = getenv("FDC_POLY_OVERLAP"), *sp = getenv("FDC_POLY_SPLIT");
         if (ov) p->poly_overlap = ov[0] != '0';
         const char *fu = getenv("FDC_POLY_FUSED"), *fw = getenv("FDC_FUSED_WG1"), *fr = getenv("FDC_FUSED_RING");
-        if (fu) p->poly_fused = fu[0] != '0';
+        if (fu) p->poly_fused = fu[0] != '0' && N == 65536;
         if (fw && atoi(fw) >= 1 && atoi(fw) <= 3) p->fused_wg1 = atoi(fw);
         if (fr && atoi(fr) >= 2) p->fused_ring = atoi(fr);
         if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
@@ -326,10 +327,19 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMemcpy(p->d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
         CHK_OR_FREE(hipMalloc(&p->d_shn, sizeof(float) * 256));
         CHK_OR_FREE(hipMemcpy(p->d_shn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
-        std::vector<long long> so(256, -1);
+        std::vector<long long> so(N1, -1);
         for (int c = 0; c < p->C; c++) so[p->chans[c].f >> 8] = p->chans[c].out_off;
-        CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * 256));
-        CHK_OR_FREE(hipMemcpy(p->d_slot_off, so.data(), sizeof(long long) * 256, hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * N1));
+        CHK_OR_FREE(hipMemcpy(p->d_slot_off, so.data(), sizeof(long long) * N1, hipMemcpyHostToDevice));
+        if (N1 == 1024) {
+            std::vector<float2> t1k(1024);
+            for (int j = 0; j < 1024; j++) {
+                const double a = -2.0 * M_PI * double(j) / 1024.0;
+                t1k[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+            }
+            CHK_OR_FREE(hipMalloc(&p->d_tw1024, sizeof(float2) * 1024));
+            CHK_OR_FREE(hipMemcpy(p->d_tw1024, t1k.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
+        }
     }
     if (p->poly_ok) {
         const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
@@ -456,8 +466,9 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
             }
             if (p->timing) HIPCHK(hipEventRecord(p->events[span[2]], s2));
-            HIPCHK(fdc::launch_poly_stage2(p->d_g[gi], static_cast<float2 *>(d_out), p->R, nb, m0, nblocks, p->d_tw256,
-                                           p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8),
+            HIPCHK(fdc::launch_poly_stage2(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
+                                           p->d_tw256, p->d_tw1024, p->d_slot_off,
+                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8),
                                            ovl ? 4 - p->poly_split : 0, s2));
             if (ovl) HIPCHK(hipEventRecord(p->ev_s2[gi], s2));
             if (p->timing) {

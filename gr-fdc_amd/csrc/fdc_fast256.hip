@@ -21,6 +21,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
 
 constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
 constexpr int kCTileBytes = 32 * 272 * 8;         // channel kernel: 32 rows padded to 272 points
+constexpr int kP2kLds = 1024 * 16 * 8 + 8192 + 4096;   // k_p2k: 16-row tile + W_1024 table + slot offsets
 
 // ---- pass A -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, size_t in_stride,
@@ -502,6 +503,116 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
     }
 }
 
+// Stage 2 for N1 = 1024 slots (N = 262144, BASELINE configs[3]): FFT-1024 over n1 of every row (m, t') of G, as
+// 16 x 16 x 4: n1 = 64a + b' (layer 1, DFT-16 over a -> p), b' = 4c + d (layer 2, DFT-16 over c -> s; layer 3, DFT-4
+// over d -> u), slot k1 = p + 16 s + 256 u.  A tile is 16 consecutive rows t' of one block (128 KiB in LDS), one
+// 1024-thread workgroup per CU, 16 points per thread in every layer; persistent with next-tile prefetch like k_p2.
+// LDS exchange layouts (both conflict-free for b64 accesses, rows on the fast lanes at the store end):
+//   exchange 1: (r, p, b')    at (p*64 + b')*16 + ((r ^ b') & 15)
+//   exchange 2: (r, p, d, s)  at ((p*4 + d)*16 + (s ^ (d & 1)))*16 + r
+__global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, float2 *__restrict__ out,
+                                                  const float2 *__restrict__ tw1024,
+                                                  const long long *__restrict__ slot_off, long long nrows,
+                                                  long long out_base, long long nb_call, unsigned out_bytes,
+                                                  int ntiles, int lout)
+{
+    constexpr int TR = 16;
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // 16 rows x 1024 points
+    float2 *w1k = reinterpret_cast<float2 *>(fdc_smem_fast + 1024 * TR * 8);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_fast + 1024 * TR * 8 + 8192);
+    const int tid = threadIdx.x;
+    int tl = blockIdx.x;
+    if (tl >= ntiles) return;
+    {
+        w1k[tid] = tw1024[tid];
+        const long long o = slot_off[tid];
+        soff[tid] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+    }
+    const int col = tid & 15, r = (tid >> 4) & 15, j = tid >> 8;     // layer 1: row r, b' = 16j + col
+    const int bp = 16 * j + col;
+    const int r2 = tid & 15, d = (tid >> 4) & 3, p2 = tid >> 6;      // layer 2: row r2, (p2, d); layer 3: (p2, e = d)
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    const int tpb = lout / TR;                                       // tiles per block
+    // G[m][ct][t'][16]: point n1 = 64a + b' sits in column tile ct = 4a + j at column col
+    const unsigned voff = (unsigned)((j * lout + r) * 16 + col) * 8u;
+    const unsigned astep = 4u * (unsigned)lout * 16u * 8u;
+    // LDS addresses with the swizzles folded into a few base pointers (everything else is an immediate offset)
+    float2 *const wr1 = tile + bp * 16 + ((r ^ bp) & 15);                          // + p*1024
+    const float2 *rd1[4];                                                          // + c*64, base by c & 3
+#pragma unroll
+    for (int k = 0; k < 4; k++) rd1[k] = tile + (p2 * 64 + d) * 16 + ((r2 ^ d ^ (4 * k)) & 15);
+    float2 *wr2[2];                                                                // s even / odd: + (s>>1)*32
+    wr2[0] = tile + ((p2 * 4 + d) * 16 + (d & 1)) * 16 + r2;
+    wr2[1] = tile + ((p2 * 4 + d) * 16 + 1 - (d & 1)) * 16 + r2;
+    const float2 *rd2[2];                                                          // d' even / odd: + (d'*16 + 4f)*16
+    rd2[0] = tile + (p2 * 64 + d) * 16 + r2;
+    rd2[1] = tile + (p2 * 64 + (d ^ 1)) * 16 + r2;
+    cf L[16];
+    auto issue = [&](int t) {
+        const size_t m = t / tpb;
+        const int t0 = (t - (int)m * tpb) * TR;
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 1024 + (size_t)t0 * 16, (unsigned)lout * 1024u * 8u);
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rg, voff, (unsigned)a * astep);
+    };
+    issue(tl);
+    for (;;) {
+        cf v[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = L[a];
+        const int nxt = tl + gridDim.x;
+        if (nxt < ntiles) issue(nxt);
+        dft16<false>(v);                                            // Y_b'[p] in v[rev16(p)]
+        __syncthreads();                                            // tables ready / previous tile's reads done
+        // twiddles in batches of 8: a table read between two tile writes would wait for the write in front of it
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            cf w[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) w[p] = ld2(&w1k[bp * (8 * h + p)]);      // W_1024^(b' p)
+#pragma unroll
+            for (int p = 0; p < 8; p++) st2(wr1 + (8 * h + p) * 1024, cmul(v[rev16(8 * h + p)], w[p]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; c++) v[c] = ld2(rd1[c & 3] + c * 64);
+        dft16<false>(v);                                            // Z[s] in v[rev16(s)]
+        __syncthreads();                                            // every thread has read exchange 1
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            cf w[8];
+#pragma unroll
+            for (int sx = 0; sx < 8; sx++) w[sx] = ld2(&w1k[16 * d * (8 * h + sx)]);   // W_64^(d s)
+#pragma unroll
+            for (int sx = 0; sx < 8; sx++) {
+                const int sv = 8 * h + sx;
+                st2(wr2[sv & 1] + (sv >> 1) * 32, cmul(v[rev16(sv)], w[sx]));
+            }
+        }
+        __syncthreads();
+        // layer 3: this thread takes s = 4f + e (e = d), all four d of each
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) v[4 * f + dd] = ld2(rd2[dd & 1] + (dd * 16 + 4 * f) * 16);
+#pragma unroll
+        for (int f = 0; f < 4; f++) dft4<false>(v[4 * f], v[4 * f + 1], v[4 * f + 2], v[4 * f + 3]);
+        const long long rho = (long long)tl * TR + r2;
+        if (rho < nrows) {
+            const unsigned rbytes = (unsigned)rho * 8u;
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned off = soff[p2 + 16 * (4 * f + d) + 256 * u];
+                    if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[4 * f + u]);
+                }
+        }
+        if (nxt >= ntiles) break;
+        tl = nxt;
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t init_fast_kernels()
 {
@@ -524,6 +635,8 @@ hipError_t init_fast_kernels()
     if (e != hipSuccess) return e;
 
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2k), hipFuncAttributeMaxDynamicSharedMemorySize, kP2kLds);
     if (e != hipSuccess) return e;
 #define FDC_SETC(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, c); \
@@ -594,7 +707,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
                               int wg_per_cu, hipStream_t s)
 {
     const int skip = 256 / R, lout = 256 - skip;
-    const int TC = poly_tile(lout);
+    const int TC = N1 == 256 ? poly_tile(lout) : 16;        // k_p2k reads 16-column tiles
     const int ct = N1 / TC;
     int log2ct = 0;
     while ((1 << log2ct) < ct) log2ct++;
@@ -628,11 +741,20 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     return hipGetLastError();
 }
 
-hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk, int mbase, int nb_call,
-                              const float2 *tw256, const long long *slot_off, unsigned out_bytes, int wg_per_cu,
-                              hipStream_t s)
+hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
+                              const float2 *tw256, const float2 *tw1024, const long long *slot_off, unsigned out_bytes,
+                              int wg_per_cu, hipStream_t s)
 {
     const int skip = 256 / R, lout = 256 - skip;
+    if (N1 == 1024) {                                       // one 1024-thread workgroup per CU, 16-row tiles
+        const long long nrows = (long long)nb_chunk * lout;
+        const long long nt = (nrows + 15) / 16;
+        const int slots = cu_count();
+        const unsigned gk = (unsigned)(nt < slots ? nt : slots);
+        hipLaunchKernelGGL(k_p2k, dim3(gk), dim3(1024), kP2kLds, s, g, out, tw1024, slot_off, nrows,
+                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt, lout);
+        return hipGetLastError();
+    }
     const int TC = poly_tile(lout);
     const int maxwg = TC == 32 ? 2 : 4;
     const int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();

@@ -76,8 +76,9 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
                               const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                               int wg_per_cu /* 0 = all the LDS admits */, hipStream_t s);
-hipError_t launch_poly_stage2(const float2 *g, float2 *out, int R, int nb_chunk, int mbase, int nb_call,
-                              const float2 *tw256, const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
+hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 1024 slots */, int R, int nb_chunk, int mbase,
+                              int nb_call, const float2 *tw256, const float2 *tw1024 /* N1 = 1024 only */,
+                              const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
                               int wg_per_cu, hipStream_t s);
 
 // uniform plan as an XCD-local dataflow (fdc_fused256.hip): stage 1 (3 workgroups/CU, stream s1) and stage 2

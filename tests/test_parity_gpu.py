@@ -194,12 +194,13 @@ def test_fast_and_generic_paths_agree(oracle):
         assert_close(a, b)
 
 
-@pytest.mark.parametrize("R,wt", [(2, 1), (4, 2), (8, 0), (16, 1)])
-def test_uniform_plan_two_stage_path(oracle, R, wt):
-    """Uniform plans (l=256 on the 256-bin grid) take the two-stage path that never writes a spectrum; any
-    subset and any order of slots; result equals the oracle and the spectrum-in-memory path."""
-    N, nb = 65536, 5
-    slots = [200, 3, 255, 0, 17, 128, 127, 64]
+@pytest.mark.parametrize("N,R,wt", [(65536, 2, 1), (65536, 4, 2), (65536, 8, 0), (65536, 16, 1),
+                                    (262144, 2, 1), (262144, 4, 0), (262144, 16, 2)])
+def test_uniform_plan_two_stage_path(oracle, N, R, wt):
+    """Uniform plans (l=256 on the 256-bin grid; 256 slots at N=65536, 1024 at N=262144) take the two-stage path that
+    never writes a spectrum; any subset and any order of slots; result equals the oracle and the spectrum-in-memory path."""
+    nb = 5
+    slots = [200, 3, 255, 0, 17, 128, 127, 64] if N == 65536 else [200, 3, 1023, 0, 517, 512, 511, 64, 900, 256, 767]
     chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
@@ -211,7 +212,7 @@ def test_uniform_plan_two_stage_path(oracle, R, wt):
     os.environ["FDC_NO_POLY"] = "1"
     try:
         q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
-        assert q.path() == 1
+        assert q.path() == (1 if N == 65536 else 0)
         outs3 = q.work(x)
     finally:
         del os.environ["FDC_NO_POLY"]
@@ -238,6 +239,7 @@ def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
     x = noise(nb * H, 2027)
     ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
     pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+    assert pipe.path() == 2          # two-stage path with 1024 slots
     whole = pipe.work(x)
     for c in range(0, Cn, 37):
         assert_close(whole[c], ref[c], "whole ch%d" % c)
