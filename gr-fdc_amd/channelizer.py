@@ -59,6 +59,16 @@ def get_opt_channelparams(blocksize, relinvovl, freq, bw):
     return int(first), int(l), int(l) - int(l) // relinvovl, float(passband), float(stopband)
 
 
+def register_host(arr):
+    """Pin a numpy array for fdc_pipeline_work (fdc_host_register): calls whose input / outputs are slices of pinned
+    arrays are DMA'd in place.  Keep the array alive until unregister_host(arr)."""
+    _lib.check(_lib.lib().fdc_host_register(arr.ctypes.data, arr.nbytes))
+
+
+def unregister_host(arr):
+    _lib.check(_lib.lib().fdc_host_unregister(arr.ctypes.data))
+
+
 class Pipeline:
     """fdc_pipeline handle: channels = [(f, l, passbw, stopbw), ...]."""
 
@@ -90,13 +100,22 @@ class Pipeline:
         return int(_lib.lib().fdc_pipeline_channel_offset(self._h, c, nblocks))
 
     # -- host path (what sync_block::work() would call)
-    def work(self, x, want_spectrum=False, sinks=None):
-        """sinks: a gr_fdc_amd.Sinks bank fed from the device-resident spectrum of this call (needs keep_spectrum)."""
+    def work(self, x, want_spectrum=False, sinks=None, outs=None):
+        """sinks: a gr_fdc_amd.Sinks bank fed from the device-resident spectrum of this call (needs keep_spectrum).
+        outs: optional caller-owned complex64 arrays, one per channel with nblocks*lout_c samples (e.g. slices of
+        buffers pinned with register_host); allocated here when None."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if x.size % self.H:
             raise ValueError("input must be a whole number of (N - N/R)-sample items")
         nb = x.size // self.H
-        outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        if outs is None:
+            outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        else:
+            if len(outs) != len(self.lout):
+                raise ValueError("outs needs one array per channel")
+            for o, lo in zip(outs, self.lout):
+                if o.dtype != np.complex64 or not o.flags.c_contiguous or o.size != nb * lo:
+                    raise ValueError("outs[c] must be contiguous complex64 with nblocks*lout_c samples")
         ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
         spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
         if sinks is not None:
@@ -106,6 +125,11 @@ class Pipeline:
             _lib.check(_lib.lib().fdc_pipeline_work(self._h, x.ctypes.data, nb, ptrs,
                                                    spec.ctypes.data if spec is not None else None))
         return (outs, spec) if want_spectrum else outs
+
+    def work_raw(self, in_ptr, nblocks, out_ptrs):
+        """fdc_pipeline_work on raw addresses (out_ptrs: ctypes array of c_void_p, one per channel) — for callers that
+        keep their buffers and want no per-call Python work, e.g. timing the C entry itself."""
+        return _lib.check(_lib.lib().fdc_pipeline_work(self._h, in_ptr, int(nblocks), out_ptrs, None))
 
     def work_spectrum(self, spec_items, want_spectrum=False, sinks=None):
         """Items that are already transformed (unnormalised, fftshifted): hier block with inpveclen > 1."""

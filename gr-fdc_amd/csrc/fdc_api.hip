@@ -64,6 +64,24 @@ std::vector<float2> make_twiddles(int n)
     return t;
 }
 
+// Host ranges the caller pinned with fdc_host_register(): work() DMAs them directly; anything else goes through
+// the handle's own pinned staging buffers.
+struct HostRange { uintptr_t lo, hi, dev; };   // dev: device-side address of lo
+std::mutex g_reg_mu;
+std::vector<HostRange> g_reg;
+
+bool host_registered(const void *ptr, size_t bytes, void **devptr = nullptr)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (const HostRange &r : g_reg)
+        if (a >= r.lo && a + bytes <= r.hi) {
+            if (devptr) *devptr = reinterpret_cast<void *>(r.dev + (a - r.lo));
+            return true;
+        }
+    return false;
+}
+
 }  // namespace
 
 namespace fdc {
@@ -118,6 +136,12 @@ struct fdc_pipeline {
     float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
     float2 *d_out = nullptr;     // work(): max_blocks*sum_lout
     int64_t blockcount = 0;      // work(): blocks consumed so far
+    // work(): transfers and kernels of consecutive sub-batches overlap (H2D on s_in, kernels on stream, D2H on s_out)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    float2 *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // staging for unregistered host buffers
+    fdc::ScatterEnt *pin_tab = nullptr, *d_tab = nullptr;                        // registered outputs: scatter table
+    int sub = 0;                 // blocks per sub-batch
     bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
     // timing
     bool timing = false;
@@ -147,6 +171,34 @@ int fdc_window_table(int windowtype, int blocklen, float passbw, float stopbw, i
     return FDC_OK;
 }
 
+int fdc_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(FDC_ERR_INVALID_ARGUMENT, "fdc_host_register: empty range");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FDC_ERR_NO_DEVICE, "no HIP device visible");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void *dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess) { (void)hipHostUnregister(ptr); return fail(FDC_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg.push_back(HostRange{a, a + bytes, reinterpret_cast<uintptr_t>(dev)});
+    return FDC_OK;
+}
+
+int fdc_host_unregister(void *ptr)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [a](const HostRange &r) { return r.lo == a; });
+        if (it == g_reg.end()) return fail(FDC_ERR_INVALID_ARGUMENT, "fdc_host_unregister: range was not registered here");
+        g_reg.erase(it);
+    }
+    HIPCHK(hipHostUnregister(ptr));
+    return FDC_OK;
+}
+
 void fdc_pipeline_destroy(fdc_pipeline *p)
 {
     if (!p) return;
@@ -155,6 +207,13 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
     (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl);
     for (auto e : p->events) (void)hipEventDestroy(e);
+    for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (int i = 0; i < 2; i++) {
+        for (auto e : {p->ev_in[i], p->ev_k[i], p->ev_out[i]}) if (e) (void)hipEventDestroy(e);
+        if (p->pin_in[i]) (void)hipHostFree(p->pin_in[i]);
+        if (p->pin_out[i]) (void)hipHostFree(p->pin_out[i]);
+    }
+    if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
@@ -537,6 +596,37 @@ void fdc_pipeline_reset(fdc_pipeline *p)
     }
 }
 
+static int work_io_setup(fdc_pipeline *p)
+{
+    if (p->d_ring) return FDC_OK;
+    HIPCHK(hipMalloc(&p->d_ring, sizeof(float2) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
+    HIPCHK(hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream));   // zero history (overlap_save_impl.cc:52)
+    if (p->sum_lout > 0) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
+    HIPCHK(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_out[i], hipEventDisableTiming));
+    }
+    // sub-batch: about 8 MiB of input (measured best of 2-16 MiB on MI355X/PCIe5, staged and pinned): long against a
+    // transfer's launch cost, short against the call
+    int64_t sub = (8ll << 20) / ((int64_t)p->H * 8);
+    if (const char *e = getenv("FDC_HOST_SUB")) if (atoi(e) > 0) sub = atoi(e);
+    p->sub = (int)std::max<int64_t>(1, std::min<int64_t>(sub, p->cfg.max_blocks));
+    if (p->C > 0) {
+        // scatter table: pinned and device-mapped, the scatter kernel reads it in place (no per-call upload)
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_tab), sizeof(fdc::ScatterEnt) * p->C, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_tab), p->pin_tab, 0));
+    }
+    return FDC_OK;
+}
+
+// Host entry.  The call is cut into sub-batches; sub-batch k's H2D copy (stream s_in), its kernels (p->stream) and
+// its D2H leg (s_out) run beside the neighbouring sub-batches' other legs, so a long call moves at the rate of the
+// slower PCIe direction instead of the sum of all legs.  Caller buffers pinned with fdc_host_register() are DMA'd in
+// place (input: one async copy; outputs: one scatter kernel storing straight into the caller's per-channel buffers);
+// pageable ones go through two pinned staging slots per direction with a CPU copy on this thread.
 static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                               float2 *d_spec_dst)
 {
@@ -547,28 +637,113 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
     if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
     if ((spectrum || d_spec_dst) && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
     HIPCHK(hipSetDevice(p->cfg.device_id));
-    if (!p->d_ring) {
-        HIPCHK(hipMalloc(&p->d_ring, sizeof(float2) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
-        HIPCHK(hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream));   // zero history (overlap_save_impl.cc:52)
-        if (p->sum_lout > 0) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
-    }
-    float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
-    if (spectrum && !d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
+    int rc = work_io_setup(p);
+    if (rc != FDC_OK) return rc;
     hipStream_t s = p->stream;
     const size_t nin = (size_t)nblocks * p->H;
-    HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
-    int rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
-    if (rc != FDC_OK) { (void)hipFree(d_owned); return rc; }
-    for (int c = 0; c < p->C; c++) {
-        if (!outs[c]) continue;
-        HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
-                              sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
+    const float2 *hin = static_cast<const float2 *>(in);
+
+    if (spectrum || d_spec_dst) {
+        // spectrum wanted (debug port / sinks): one batch, the spectrum of the whole call in one buffer
+        float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
+        if (!d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
+        HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
+        rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
+        if (rc != FDC_OK) { (void)hipFree(d_owned); return rc; }
+        for (int c = 0; c < p->C; c++) {
+            if (!outs[c]) continue;
+            HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
+                                  sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
+        }
+        if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (d_owned) HIPCHK(hipFree(d_owned));
+        p->blockcount += nblocks;
+        return nblocks;
     }
-    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
+
+    const bool in_reg = host_registered(in, sizeof(float2) * nin);
+    bool out_reg = p->C > 0;
+    for (int c = 0; c < p->C && out_reg; c++) {
+        fdc::ScatterEnt &e = p->pin_tab[c];
+        e.dst = nullptr; e.out_off = p->chans[c].out_off; e.lout = p->chans[c].lout; e.pad = 0;
+        if (outs[c] && !host_registered(outs[c], sizeof(float2) * (size_t)nblocks * p->chans[c].lout, reinterpret_cast<void **>(&e.dst)))
+            out_reg = false;
+    }
+    const int sub = p->sub;
+    if (!in_reg && !p->pin_in[0])
+        for (int i = 0; i < 2; i++)
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_in[i]), sizeof(float2) * (size_t)sub * p->H, hipHostMallocDefault));
+    if (!out_reg && p->C > 0 && !p->pin_out[0])
+        for (int i = 0; i < 2; i++)
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_out[i]), sizeof(float2) * (size_t)sub * p->sum_lout, hipHostMallocDefault));
+    // staged outputs: wait for sub-batch j's D2H, then hand its pieces to the caller's per-channel buffers
+    auto drain = [&](int j) -> int {
+        const int b0 = j * sub, nb = std::min(sub, nblocks - b0);
+        HIPCHK(hipEventSynchronize(p->ev_out[j & 1]));
+        const float2 *src = p->pin_out[j & 1];
+        for (int c = 0; c < p->C; c++) {
+            if (!outs[c]) continue;
+            const size_t lo = (size_t)p->chans[c].lout;
+            std::memcpy(static_cast<float2 *>(outs[c]) + (size_t)b0 * lo, src + (size_t)nb * p->chans[c].out_off, sizeof(float2) * nb * lo);
+        }
+        return FDC_OK;
+    };
+    const int K = (nblocks + sub - 1) / sub;
+    if (K == 1) {
+        // short call (the usual work() of a running flowgraph): nothing to overlap, one stream, one synchronisation
+        const size_t bytes = sizeof(float2) * nin;
+        if (!in_reg) std::memcpy(p->pin_in[0], hin, bytes);
+        HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in_reg ? hin : p->pin_in[0], bytes, hipMemcpyHostToDevice, s));
+        rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, nullptr, s);
+        if (rc != FDC_OK) return rc;
+        if (p->C > 0) {
+            if (out_reg) HIPCHK(fdc::launch_scatter_out(p->d_out, p->d_tab, p->C, nblocks, 0, s));
+            else HIPCHK(hipMemcpyAsync(p->pin_out[0], p->d_out, sizeof(float2) * (size_t)nblocks * p->sum_lout, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (p->C > 0 && !out_reg)
+            for (int c = 0; c < p->C; c++)
+                if (outs[c])
+                    std::memcpy(outs[c], p->pin_out[0] + (size_t)nblocks * p->chans[c].out_off,
+                                sizeof(float2) * (size_t)nblocks * p->chans[c].lout);
+        p->blockcount += nblocks;
+        return nblocks;
+    }
+    for (int k = 0; k < K; k++) {
+        const int slot = k & 1, b0 = k * sub, nb = std::min(sub, nblocks - b0);
+        float2 *dst = p->d_ring + p->ovl + (size_t)b0 * p->H;
+        const size_t bytes = sizeof(float2) * (size_t)nb * p->H;
+        if (in_reg) {
+            HIPCHK(hipMemcpyAsync(dst, hin + (size_t)b0 * p->H, bytes, hipMemcpyHostToDevice, p->s_in));
+        } else {
+            if (k >= 2) HIPCHK(hipEventSynchronize(p->ev_in[slot]));          // this staging slot has left the host
+            std::memcpy(p->pin_in[slot], hin + (size_t)b0 * p->H, bytes);
+            HIPCHK(hipMemcpyAsync(dst, p->pin_in[slot], bytes, hipMemcpyHostToDevice, p->s_in));
+        }
+        HIPCHK(hipEventRecord(p->ev_in[slot], p->s_in));
+        HIPCHK(hipStreamWaitEvent(s, p->ev_in[slot], 0));
+        float2 *dok = p->d_out + (size_t)b0 * p->sum_lout;                    // [channel][nb*lout] of this sub-batch
+        rc = fdc_pipeline_process_device(p, p->d_ring + (size_t)b0 * p->H, p->blockcount + b0, nb, dok, nullptr, s);
+        if (rc != FDC_OK) return rc;
+        if (p->C == 0) continue;
+        HIPCHK(hipEventRecord(p->ev_k[slot], s));
+        HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[slot], 0));
+        if (out_reg) {
+            HIPCHK(fdc::launch_scatter_out(dok, p->d_tab, p->C, nb, b0, p->s_out));
+        } else {
+            HIPCHK(hipMemcpyAsync(p->pin_out[slot], dok, sizeof(float2) * (size_t)nb * p->sum_lout, hipMemcpyDeviceToHost, p->s_out));
+            HIPCHK(hipEventRecord(p->ev_out[slot], p->s_out));
+            if (k >= 1 && (rc = drain(k - 1)) != FDC_OK) return rc;
+        }
+    }
+    if (!out_reg && p->C > 0 && (rc = drain(K - 1)) != FDC_OK) return rc;
     // history <- last ovl samples of this call (overlap_save_impl.cc:78); src and dst never overlap (H >= ovl)
     HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (d_owned) HIPCHK(hipFree(d_owned));
+    HIPCHK(hipStreamSynchronize(p->s_out));
     p->blockcount += nblocks;
     return nblocks;
 }

@@ -73,6 +73,12 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
 //   slot_off[c] = per-block sample offset of the channel sitting in slot c, or -1;  g: nb_chunk*lout*N1 scratch
+// one entry per channel: where the caller's (pinned, device-mapped) buffer of that channel is
+struct ScatterEnt { float2 *dst; long long out_off; int lout; int pad; };
+// dst[c][row0*lout_c + i] = src[nb*out_off_c + i], i < nb*lout_c: the [channel][nb*lout] result of one sub-batch is
+// stored straight into the caller's per-channel host buffers (PCIe writes, 512 B per wave)
+hipError_t launch_scatter_out(const float2 *src, const ScatterEnt *tab, int nchan, int nb, long long row0, hipStream_t s);
+
 hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
                               const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                               int wg_per_cu /* 0 = all the LDS admits */, hipStream_t s);

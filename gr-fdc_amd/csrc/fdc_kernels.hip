@@ -482,6 +482,27 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_scatter_out(const float2 *__restrict__ src, const ScatterEnt *__restrict__ tab,
+                                                     int nb, long long row0)
+{
+    const ScatterEnt e = tab[blockIdx.y];
+    if (!e.dst) return;
+    const size_t n = (size_t)nb * e.lout;
+    const float2 *s = src + (size_t)nb * e.out_off;
+    float2 *d = e.dst + (size_t)row0 * e.lout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+
+hipError_t launch_scatter_out(const float2 *src, const ScatterEnt *tab, int nchan, int nb, long long row0, hipStream_t s)
+{
+    if (nchan <= 0 || nb <= 0) return hipSuccess;
+    for (int c0 = 0; c0 < nchan; c0 += 32768) {
+        const int nc = nchan - c0 < 32768 ? nchan - c0 : 32768;
+        hipLaunchKernelGGL(k_scatter_out, dim3(4, nc), dim3(256), 0, s, src, tab + c0, nb, row0);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s)
 {
     if (!n) return hipSuccess;

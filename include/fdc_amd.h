@@ -86,6 +86,14 @@ int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int channel);
  *   spectrum    NULL, or nblocks*N samples of the normalised spectrum (needs keep_spectrum)
  * Returns nblocks (items consumed, sync 1:1) or a negative fdc_status. */
 int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum);
+
+/* Optional: pin a host range that will be handed to fdc_pipeline_work() again and again (GNU Radio's circular buffers
+ * live as long as the flowgraph: register them in start(), unregister in stop()).  A call whose `in` lies in a
+ * registered range is DMA'd from it in place, and when every outs[c] does, the results are stored straight into
+ * them; other buffers are staged through pinned memory inside the handle.  Results are identical either way.
+ * The range must stay mapped until fdc_host_unregister(ptr) (same ptr as registered). */
+int fdc_host_register(void *ptr, size_t bytes);
+int fdc_host_unregister(void *ptr);
 void fdc_pipeline_reset(fdc_pipeline *p);    /* history <- zeros, block counter <- 0 (fresh ctor state)  */
 
 /* Device-resident entry (stateless; the form bench.py and a device-side flowgraph use).

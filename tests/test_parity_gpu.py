@@ -277,3 +277,41 @@ def test_hier_block_inpveclen_mode(oracle):
     assert_close(ports[0], rspec, "normalised spectrum port")
     for c in range(2):
         assert_close(ports[1 + c], ref[c], "port %d" % (1 + c))
+
+
+@pytest.mark.parametrize("sub", ["1", "2", "64"])
+def test_host_path_sub_batches_staged_and_pinned(oracle, sub):
+    """fdc_pipeline_work cuts a call into sub-batches whose transfers and kernels overlap; pageable buffers are staged,
+    buffers pinned with fdc_host_register are DMA'd in place (outputs stored by a scatter kernel).  Every combination
+    must give the oracle's samples, across calls (history + block counter carry over)."""
+    N, R, nb = 4096, 4, 7
+    H = N - N // R
+    chans = [(8, 512, 0.8, 1.0), (1031, 64, 0.7, 0.9), (3000, 1024, 0.5, 0.75), (777, 1, 0.5, 1.0), (2048, 256, 0.9, 1.0)]
+    x = noise(2 * nb * H, 77)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=2)
+    os.environ["FDC_HOST_SUB"] = sub
+    try:
+        p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+        los = p.lout
+        # call 1 staged (pageable numpy), call 2 pinned input + pinned outputs
+        o1 = p.work(x[:nb * H])
+        xin = np.empty(nb * H, np.complex64); xin[:] = x[nb * H:]
+        pool = np.empty(nb * sum(los), np.complex64)
+        G.register_host(xin); G.register_host(pool)
+        try:
+            outs, off = [], 0
+            for lo in los:
+                outs.append(pool[off:off + nb * lo]); off += nb * lo
+            o2 = p.work(xin, outs=outs)
+            o2 = [o.copy() for o in o2]
+            # pinned input, pageable outputs and the other way round
+            p.reset()
+            o3 = p.work(x[:nb * H], outs=outs); o3 = [o.copy() for o in o3]
+            o4 = p.work(xin)
+        finally:
+            G.unregister_host(xin); G.unregister_host(pool)
+    finally:
+        del os.environ["FDC_HOST_SUB"]
+    for c, lo in enumerate(los):
+        assert_close(np.concatenate([o1[c], o2[c]]), ref[c], "ch%d" % c)
+        assert_close(np.concatenate([o3[c], o4[c]]), ref[c], "ch%d (mixed)" % c)

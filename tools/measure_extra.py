@@ -43,7 +43,37 @@ def timeit(fn, reps=3):
 x = (rng.standard_normal(nb * H) + 1j * rng.standard_normal(nb * H)).astype(np.complex64)
 p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
 dt = timeit(lambda: p.work(x))
-print("cfg2 host path (fdc_pipeline_work, pageable host buffers, H2D+D2H included): %.1f Msamples/s in" % (nb * H / dt / 1e6))
+print("cfg2 host path (fdc_pipeline_work, pageable host buffers, fresh output arrays per call, H2D+D2H included): "
+      "%.1f Msamples/s in" % (nb * H / dt / 1e6))
+los = p.lout
+pool = np.zeros(nb * sum(los), np.complex64)
+
+
+def views(n):
+    out, off = [], 0
+    for lo in los:
+        out.append(pool[off:off + n * lo]); off += n * lo
+    return out
+
+
+import ctypes as ct
+
+
+def raw(n):
+    ptrs = (ct.c_void_p * len(los))(*[o.ctypes.data for o in views(n)])
+    return lambda: p.work_raw(x.ctypes.data, n, ptrs)
+
+
+for n in (nb, 64, 8, 1):
+    dt = timeit(raw(n), reps=10)
+    print("cfg2 host path, pageable buffers reused, %4d blocks/call: %.1f Msamples/s in (%.3f ms/call)"
+          % (n, n * H / dt / 1e6, dt * 1e3))
+G.register_host(x); G.register_host(pool)
+for n in (nb, 64, 8, 1):
+    dt = timeit(raw(n), reps=10)
+    print("cfg2 host path, buffers pinned with fdc_host_register, %4d blocks/call: %.1f Msamples/s in (%.3f ms/call)"
+          % (n, n * H / dt / 1e6, dt * 1e3))
+G.unregister_host(x); G.unregister_host(pool)
 
 xb = bursty(nb, 32, 1)
 pac = [(((c + 0.5) / C) % 1.0, 0.8 / C, c) for c in range(C)]
