@@ -59,5 +59,23 @@ public:
                      bool fileoutput, std::string path, bool threads, int verbose);
 };
 
+// The throughput chain of the FrequencyDomainChannelizer hier block as ONE sync block (what
+// python/FrequencyDomainChannelizer.py:200-231 wires from overlap_save + fft_vcc + multiply_const + per channel
+// vector_cut_vxx / phase_shifting_windowing_vcc / fft_vcc(inverse) / vector_cut_vxx / vector_to_stream): input items are
+// (blocklen - blocklen/relinvovl) new samples, output port c carries items of lout_c = l_c - l_c/relinvovl samples.
+// Not a class of the reference: it is the block a maintainer adds so that the fused device path is reachable from a
+// flowgraph.
+class FDC_API fdc_pipeline_vcc : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<fdc_pipeline_vcc> sptr;
+    // channels: rows (f, l, passbw, stopbw) as produced by get_opt_channelparams (py:322-345)
+    static sptr make(int blocklen, int relinvovl, std::vector<std::vector<float>> channels, int windowtype, int max_items);
+    // optional: pin the scheduler's buffers of this block's ports once the flowgraph has allocated them (start()), so
+    // that work() DMAs in place (fdc_host_register); call unpin_buffers() before they are freed (stop()).
+    virtual bool pin_buffer(void *base, size_t bytes) = 0;
+    virtual void unpin_buffers() = 0;
+    virtual int output_item_len(int port) const = 0;
+};
+
 }  // namespace FDC
 }  // namespace gr

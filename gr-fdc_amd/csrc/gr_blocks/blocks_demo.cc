@@ -7,6 +7,7 @@
 #include "FDC/PowerActivationChannel.h"
 #include "FDC/activity_detection_channelizer_vcm.h"
 #include "FDC/SegmentDetection.h"
+#include "FDC/fdc_pipeline_vcc.h"
 
 #include <cstdio>
 #include <fstream>
@@ -56,6 +57,33 @@ int main(int argc, char **argv)
         bool threw = false;
         try { phase_shifting_windowing_vcc::make(64, R, 0, 0.9f, 0.5f, 1); } catch (const std::invalid_argument &) { threw = true; }
         if (!threw) throw std::runtime_error("constructor predicate did not throw");
+
+        // the fused throughput chain as one block: two work() calls (state carries over), the second with the
+        // "scheduler buffers" pinned; port c -> <dir>/pipe<c>.out
+        {
+            const std::vector<std::vector<float>> chans = {{301.f, 64.f, 0.6f, 0.85f}, {0.f, 256.f, 0.8f, 1.0f}, {640.f, 128.f, 0.5f, 0.9f}};
+            auto pipe = fdc_pipeline_vcc::make(N, R, chans, 1, nb);
+            const int n1 = nb / 2, n2 = nb - n1;
+            std::vector<std::vector<gr_complex>> po(chans.size());
+            for (size_t c = 0; c < chans.size(); c++) po[c].resize((size_t)nb * pipe->output_item_len((int)c));
+            gr_vector_const_void_star pi{x.data()};
+            gr_vector_void_star pv;
+            for (auto &v : po) pv.push_back(v.data());
+            if (pipe->work(n1, pi, pv) != n1) throw std::runtime_error("fdc_pipeline_vcc: first work() failed");
+            std::vector<gr_complex> xin(x.begin() + (size_t)n1 * H, x.end());
+            bool pinned = pipe->pin_buffer(xin.data(), xin.size() * sizeof(gr_complex));
+            for (auto &v : po) pinned = pinned && pipe->pin_buffer(v.data(), v.size() * sizeof(gr_complex));
+            if (!pinned) throw std::runtime_error("fdc_pipeline_vcc: pin_buffer failed");
+            gr_vector_const_void_star pi2{xin.data()};
+            gr_vector_void_star pv2;
+            for (size_t c = 0; c < chans.size(); c++) pv2.push_back(po[c].data() + (size_t)n1 * pipe->output_item_len((int)c));
+            if (pipe->work(n2, pi2, pv2) != n2) throw std::runtime_error("fdc_pipeline_vcc: second work() failed");
+            pipe->unpin_buffers();
+            for (size_t c = 0; c < chans.size(); c++) dump(dir + "/pipe" + std::to_string(c) + ".out", po[c]);
+            bool threw2 = false;
+            try { fdc_pipeline_vcc::make(N, R, {{0.f, 64.f, 0.9f, 0.5f}}, 1, 4); } catch (const std::invalid_argument &) { threw2 = true; }
+            if (!threw2) throw std::runtime_error("fdc_pipeline_vcc: bad channel did not throw");
+        }
 
         const auto spec = slurp(dir + "/spec.c64");
         const int ns = (int)(spec.size() / (size_t)N);

@@ -21,7 +21,14 @@ public:
     {
         return sptr(new io_signature{min_streams, max_streams, sizeof_stream_item});
     }
+    static sptr makev(int min_streams, int max_streams, const std::vector<int> &sizeof_stream_items)
+    {
+        sptr p(new io_signature{min_streams, max_streams, sizeof_stream_items.empty() ? 0 : sizeof_stream_items[0]});
+        p->sizeof_stream_items = sizeof_stream_items;
+        return p;
+    }
     int min_streams, max_streams, sizeof_stream_item;
+    std::vector<int> sizeof_stream_items;      // per port, when built with makev
 };
 
 // what a PDU (pmt::cons(dict, c32vector)) carries, without pmt

@@ -72,6 +72,52 @@ public:
     }
 };
 
+class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc {
+    fdc_pipeline *d_p = nullptr;
+    std::vector<int> d_lout;
+    std::vector<void *> d_pinned;
+    static std::vector<int> out_sizes(int relinvovl, const std::vector<std::vector<float>> &ch)
+    {
+        std::vector<int> v;
+        for (const auto &c : ch) {
+            if (c.size() != 4) throw std::invalid_argument("fdc_pipeline_vcc: channel rows are (f, l, passbw, stopbw)");
+            const int l = (int)c[1];
+            v.push_back((int)sizeof(gr_complex) * (l - l / (relinvovl > 0 ? relinvovl : 1)));
+        }
+        return v;
+    }
+public:
+    fdc_pipeline_vcc_impl(int blocklen, int relinvovl, const std::vector<std::vector<float>> &channels, int windowtype, int max_items)
+        : gr::sync_block("fdc_pipeline_vcc",
+                         gr::io_signature::make(1, 1, (int)sizeof(gr_complex) * (blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1))),
+                         gr::io_signature::makev((int)channels.size(), (int)channels.size(), out_sizes(relinvovl, channels)))
+    {
+        std::vector<fdc_channel> ch(channels.size());
+        for (size_t i = 0; i < channels.size(); i++)
+            ch[i] = fdc_channel{(int32_t)channels[i][0], (int32_t)channels[i][1], channels[i][2], channels[i][3]};
+        fdc_pipeline_cfg cfg{0, blocklen, relinvovl, windowtype, (int32_t)ch.size(), ch.data(), max_items, 0, 0};
+        check_create(fdc_pipeline_create(&cfg, &d_p));
+        for (size_t i = 0; i < ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(d_p, (int)i));
+    }
+    ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return report("fdc_pipeline_vcc", fdc_pipeline_work(d_p, in[0], n, out.data(), nullptr));
+    }
+    bool pin_buffer(void *base, size_t bytes) override
+    {
+        if (fdc_host_register(base, bytes) != FDC_OK) { std::cerr << "fdc_pipeline_vcc: " << fdc_last_error() << std::endl; return false; }
+        d_pinned.push_back(base);
+        return true;
+    }
+    void unpin_buffers() override
+    {
+        for (void *b : d_pinned) fdc_host_unregister(b);
+        d_pinned.clear();
+    }
+    int output_item_len(int port) const override { return port >= 0 && port < (int)d_lout.size() ? d_lout[port] : -1; }
+};
+
 // shared by the two sink faces: PDU records -> messages on "msgout" and raw files
 class sink_base {
 protected:
@@ -218,6 +264,11 @@ SegmentDetection::sptr SegmentDetection::make(int ID, int blocklen, int relinvov
                                                                threads, verbose));
 }
 
+fdc_pipeline_vcc::sptr fdc_pipeline_vcc::make(int blocklen, int relinvovl, std::vector<std::vector<float>> channels,
+                                              int windowtype, int max_items)
+{
+    return gnuradio::get_initial_sptr(new fdc_pipeline_vcc_impl(blocklen, relinvovl, channels, windowtype, max_items));
+}
 overlap_save::sptr overlap_save::make(int itemsize, int outputlen, int overlaplen)
 {
     return gnuradio::get_initial_sptr(new overlap_save_impl(itemsize, outputlen, overlaplen));

@@ -30,6 +30,12 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     assert (rd("vector_cut.out").view(np.uint32) == sl.view(np.uint32)).all()
     pw = oracle.PhaseWindow(64, R, 301, 0.6, 0.85, 1).work(sl)
     assert np.abs(rd("phase_window.out") - pw).max() <= 1e-6 * np.abs(pw).max()
+    # fused block (fdc_pipeline_vcc): three channels, two work() calls, the second on pinned buffers
+    chans = [(301, 64, 0.6, 0.85), (0, 256, 0.8, 1.0), (640, 128, 0.5, 0.9)]
+    pref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=2)
+    for c in range(len(chans)):
+        got = rd("pipe%d.out" % c)
+        assert got.size == pref[c].size and np.abs(got - pref[c]).max() <= 1e-5 * np.abs(pref[c]).max()
     ref = oracle.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, -1, 0, 5).work(spec) + \
         oracle.ActivityDetectionVcm(N, [[0.5, 0.9]], 10.0, R, -1, 0.01, 1, 0.2).work(spec) + \
         oracle.SegmentDetection(2, N, R, 0.5, 0.9, 10.0, 0.01, 0.2, -1, 1).work(spec)
