@@ -10,9 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -139,7 +141,7 @@ struct fdc_pipeline {
     // work(): transfers and kernels of consecutive sub-batches overlap (H2D on s_in, kernels on stream, D2H on s_out)
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    float2 *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // staging for unregistered host buffers
+    float2 *pin_out[2] = {nullptr, nullptr};                                     // staging for unregistered output buffers
     fdc::ScatterEnt *pin_tab = nullptr, *d_tab = nullptr;                        // registered outputs: scatter table
     int sub = 0;                 // blocks per sub-batch
     bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
@@ -210,7 +212,6 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) {
         for (auto e : {p->ev_in[i], p->ev_k[i], p->ev_out[i]}) if (e) (void)hipEventDestroy(e);
-        if (p->pin_in[i]) (void)hipHostFree(p->pin_in[i]);
         if (p->pin_out[i]) (void)hipHostFree(p->pin_out[i]);
     }
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
@@ -625,8 +626,9 @@ static int work_io_setup(fdc_pipeline *p)
 // Host entry.  The call is cut into sub-batches; sub-batch k's H2D copy (stream s_in), its kernels (p->stream) and
 // its D2H leg (s_out) run beside the neighbouring sub-batches' other legs, so a long call moves at the rate of the
 // slower PCIe direction instead of the sum of all legs.  Caller buffers pinned with fdc_host_register() are DMA'd in
-// place (input: one async copy; outputs: one scatter kernel storing straight into the caller's per-channel buffers);
-// pageable ones go through two pinned staging slots per direction with a CPU copy on this thread.
+// place (input: one async copy; outputs: one scatter kernel storing straight into the caller's per-channel buffers).
+// Pageable input is copied by the runtime's pin-on-the-fly path from a feeder thread; pageable outputs come back
+// through two pinned staging slots and a CPU copy on this thread.
 static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                               float2 *d_spec_dst)
 {
@@ -643,25 +645,10 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
     const size_t nin = (size_t)nblocks * p->H;
     const float2 *hin = static_cast<const float2 *>(in);
 
-    if (spectrum || d_spec_dst) {
-        // spectrum wanted (debug port / sinks): one batch, the spectrum of the whole call in one buffer
-        float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
-        if (!d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
-        HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
-        rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
-        if (rc != FDC_OK) { (void)hipFree(d_owned); return rc; }
-        for (int c = 0; c < p->C; c++) {
-            if (!outs[c]) continue;
-            HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
-                                  sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
-        }
-        if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (d_owned) HIPCHK(hipFree(d_owned));
-        p->blockcount += nblocks;
-        return nblocks;
-    }
+    // spectrum wanted (debug port / sinks): every sub-batch writes its part of one whole-call buffer
+    float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
+    if (spectrum && !d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
+    struct OwnedGuard { float2 *p; ~OwnedGuard() { if (p) (void)hipFree(p); } } owned_guard{d_owned};
 
     const bool in_reg = host_registered(in, sizeof(float2) * nin);
     bool out_reg = p->C > 0;
@@ -672,9 +659,6 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
             out_reg = false;
     }
     const int sub = p->sub;
-    if (!in_reg && !p->pin_in[0])
-        for (int i = 0; i < 2; i++)
-            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_in[i]), sizeof(float2) * (size_t)sub * p->H, hipHostMallocDefault));
     if (!out_reg && p->C > 0 && !p->pin_out[0])
         for (int i = 0; i < 2; i++)
             HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_out[i]), sizeof(float2) * (size_t)sub * p->sum_lout, hipHostMallocDefault));
@@ -693,15 +677,14 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
     const int K = (nblocks + sub - 1) / sub;
     if (K == 1) {
         // short call (the usual work() of a running flowgraph): nothing to overlap, one stream, one synchronisation
-        const size_t bytes = sizeof(float2) * nin;
-        if (!in_reg) std::memcpy(p->pin_in[0], hin, bytes);
-        HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in_reg ? hin : p->pin_in[0], bytes, hipMemcpyHostToDevice, s));
-        rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, nullptr, s);
+        HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, hin, sizeof(float2) * nin, hipMemcpyHostToDevice, s));
+        rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
         if (rc != FDC_OK) return rc;
         if (p->C > 0) {
             if (out_reg) HIPCHK(fdc::launch_scatter_out(p->d_out, p->d_tab, p->C, nblocks, 0, s));
             else HIPCHK(hipMemcpyAsync(p->pin_out[0], p->d_out, sizeof(float2) * (size_t)nblocks * p->sum_lout, hipMemcpyDeviceToHost, s));
         }
+        if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         if (p->C > 0 && !out_reg)
@@ -712,21 +695,46 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
         p->blockcount += nblocks;
         return nblocks;
     }
+    // Pageable input: the runtime pins the pages of each copy on the fly and DMAs from them (measured faster than a CPU
+    // copy into pinned staging), but such a copy holds its calling thread until it is done — so a feeder thread issues
+    // them, and this thread spends that time launching kernels and draining finished outputs.
+    struct Feeder {
+        std::thread th; std::mutex mu; std::condition_variable cv; int done = 0; hipError_t err = hipSuccess;
+        ~Feeder() { if (th.joinable()) th.join(); }
+    } feeder;
+    if (!in_reg) {
+        const int dev = p->cfg.device_id, Hs = p->H;
+        float2 *ring_in = p->d_ring + p->ovl;
+        hipStream_t sin = p->s_in;
+        feeder.th = std::thread([&feeder, dev, Hs, ring_in, sin, hin, K, sub, nblocks] {
+            hipError_t e = hipSetDevice(dev);
+            for (int k = 0; k < K; k++) {
+                const int b0 = k * sub, nb = std::min(sub, nblocks - b0);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(ring_in + (size_t)b0 * Hs, hin + (size_t)b0 * Hs, sizeof(float2) * (size_t)nb * Hs,
+                                       hipMemcpyHostToDevice, sin);
+                if (e == hipSuccess) e = hipStreamSynchronize(sin);
+                std::lock_guard<std::mutex> lk(feeder.mu);
+                feeder.done = k + 1; feeder.err = e;
+                feeder.cv.notify_one();
+            }
+        });
+    }
     for (int k = 0; k < K; k++) {
         const int slot = k & 1, b0 = k * sub, nb = std::min(sub, nblocks - b0);
-        float2 *dst = p->d_ring + p->ovl + (size_t)b0 * p->H;
-        const size_t bytes = sizeof(float2) * (size_t)nb * p->H;
         if (in_reg) {
-            HIPCHK(hipMemcpyAsync(dst, hin + (size_t)b0 * p->H, bytes, hipMemcpyHostToDevice, p->s_in));
+            HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl + (size_t)b0 * p->H, hin + (size_t)b0 * p->H,
+                                  sizeof(float2) * (size_t)nb * p->H, hipMemcpyHostToDevice, p->s_in));
+            HIPCHK(hipEventRecord(p->ev_in[slot], p->s_in));
+            HIPCHK(hipStreamWaitEvent(s, p->ev_in[slot], 0));
         } else {
-            if (k >= 2) HIPCHK(hipEventSynchronize(p->ev_in[slot]));          // this staging slot has left the host
-            std::memcpy(p->pin_in[slot], hin + (size_t)b0 * p->H, bytes);
-            HIPCHK(hipMemcpyAsync(dst, p->pin_in[slot], bytes, hipMemcpyHostToDevice, p->s_in));
+            std::unique_lock<std::mutex> lk(feeder.mu);
+            feeder.cv.wait(lk, [&] { return feeder.done > k; });               // sub-batch k is on the device
+            if (feeder.err != hipSuccess) return fail(FDC_ERR_HIP, "input copy failed: %s", hipGetErrorString(feeder.err));
         }
-        HIPCHK(hipEventRecord(p->ev_in[slot], p->s_in));
-        HIPCHK(hipStreamWaitEvent(s, p->ev_in[slot], 0));
         float2 *dok = p->d_out + (size_t)b0 * p->sum_lout;                    // [channel][nb*lout] of this sub-batch
-        rc = fdc_pipeline_process_device(p, p->d_ring + (size_t)b0 * p->H, p->blockcount + b0, nb, dok, nullptr, s);
+        rc = fdc_pipeline_process_device(p, p->d_ring + (size_t)b0 * p->H, p->blockcount + b0, nb, dok,
+                                         d_specfull ? d_specfull + (size_t)b0 * p->N : nullptr, s);
         if (rc != FDC_OK) return rc;
         if (p->C == 0) continue;
         HIPCHK(hipEventRecord(p->ev_k[slot], s));
@@ -740,6 +748,7 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
         }
     }
     if (!out_reg && p->C > 0 && (rc = drain(K - 1)) != FDC_OK) return rc;
+    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
     // history <- last ovl samples of this call (overlap_save_impl.cc:78); src and dst never overlap (H >= ovl)
     HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
