@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -94,6 +95,7 @@ struct fdc_sinks {
     float *d_power = nullptr;
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
     float2 *d_ext = nullptr; size_t cap_ext = 0;
+    cfl *h_ext = nullptr; size_t cap_hext = 0;      // pinned landing buffer of the extractions
     std::vector<float> h_power;
     std::vector<PduRec> pdus;
     // per-call scratch
@@ -284,6 +286,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext);
+    if (s->h_ext) (void)hipHostFree(s->h_ext);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -488,6 +491,15 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     if (nblocks == 0) return 0;
     HIPCHK(hipSetDevice(s->cfg.device_id));
     const int N = s->N, ncells = (int)s->cells.size();
+    static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;      // phase times on stderr (diagnostics)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto t1 = now();
+        std::fprintf(stderr, "[fdc_sinks] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     // phase 1: power of every cell of every block
     if (ncells) {
         HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
@@ -495,6 +507,7 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         HIPCHK(hipMemcpyAsync(s->h_power.data(), s->d_power, sizeof(float) * s->h_power.size(), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
+    lap("cell power + D2H");
     // phase 2: decisions, one block after the other (work() loops of both reference blocks)
     s->tasks.clear(); s->task_w.clear(); s->task_skip.clear(); s->ext_used = 0;
     for (int m = 0; m < nblocks; m++) {
@@ -505,9 +518,9 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         for (auto &g : s->segs) seg_extract(s, g, slot);                        // :562
         s->blockcount++;
     }
+    lap("decisions (host)");
     // phase 3: extractions, one launch per width class
     const size_t nt = s->tasks.size();
-    std::vector<cfl> ext((size_t)s->ext_used);
     if (nt) {
         std::vector<size_t> order(nt);
         for (size_t i = 0; i < nt; i++) order[i] = i;
@@ -518,6 +531,12 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             (void)hipFree(s->d_tasks); s->d_tasks = nullptr; s->cap_tasks = 0;
             HIPCHK(hipMalloc(&s->d_tasks, sizeof(fdc::ExtractTask) * nt * 2));
             s->cap_tasks = nt * 2;
+        }
+        if ((size_t)s->ext_used > s->cap_hext) {
+            if (s->h_ext) (void)hipHostFree(s->h_ext);
+            s->h_ext = nullptr; s->cap_hext = 0;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->h_ext), sizeof(cfl) * (size_t)s->ext_used * 2, hipHostMallocDefault));
+            s->cap_hext = (size_t)s->ext_used * 2;
         }
         if ((size_t)s->ext_used > s->cap_ext) {
             (void)hipFree(s->d_ext); s->d_ext = nullptr; s->cap_ext = 0;
@@ -532,28 +551,34 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
             i = j;
         }
-        HIPCHK(hipMemcpyAsync(ext.data(), s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
     }
     // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
     HIPCHK(hipMemcpyAsync(s->d_spec, s->d_spec + (size_t)nblocks * N, sizeof(float2) * (size_t)N, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    lap("extractions + D2H");
     // phase 4: payloads; blocks still buffered in live channels become host copies
     auto resolve = [&](BlockRef &b, int len) {
         if (b.task >= 0) {
-            const cfl *src = ext.data() + s->tasks[(size_t)b.task].out_off;
+            const cfl *src = s->h_ext + s->tasks[(size_t)b.task].out_off;
             b.owned.assign(src, src + len);
             b.task = -1;
         }
     };
     for (auto &r : s->pdus) {
         r.payload.reserve(r.blocks.size() * (size_t)r.blocklen);
-        for (auto &b : r.blocks) { resolve(b, r.blocklen); r.payload.insert(r.payload.end(), b.owned.begin(), b.owned.end()); }
+        for (auto &b : r.blocks) {          // straight from the landing buffer, or from the copy an earlier call kept
+            const cfl *src = b.task >= 0 ? s->h_ext + s->tasks[(size_t)b.task].out_off : b.owned.data();
+            r.payload.insert(r.payload.end(), src, src + r.blocklen);
+        }
         r.blocks.clear();
         r.meta.nsamples = (int64_t)r.payload.size();
         r.meta.samples = r.payload.data();
     }
     for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
     for (auto &g : s->segs) for (auto &c : g.chans) for (auto &b : c.data) resolve(b, c.outputsamples);
+    lap("payload assembly");
+    if (trace) std::fprintf(stderr, "[fdc_sinks] %zu tasks, %lld samples extracted, %zu PDUs\n", nt, (long long)s->ext_used, s->pdus.size());
     return nblocks;
 }
 
