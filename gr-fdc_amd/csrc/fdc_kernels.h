@@ -6,7 +6,6 @@
 namespace fdc {
 
 constexpr int kThreads = 256;        // 4 wave64 per workgroup
-constexpr int kTileElems = 8192;     // complex points per LDS tile (64 KiB)
 constexpr int kMaxLdsFft = 8192;     // longest transform one workgroup does in LDS
 
 // Per-channel record in device memory.
@@ -32,7 +31,7 @@ struct ExtractTask {
 
 // Geometry of an LDS "column" FFT tile: TC independent transforms of length L, element (i, t) at i*ld + t.
 struct TileGeom {
-    int L, log2L, TC, log2TC, ld;
+    int L, log2L, TC, log2TC, ld, NB;   // NB: 4096-point units per tile (2 only for L = 8192)
     size_t lds_bytes() const { return (size_t)L * ld * sizeof(float2); }
 };
 TileGeom tile_geom(int L);

@@ -21,7 +21,10 @@ namespace fdc {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem[];
 
-constexpr int kMaxB = kTileElems / 4 / kThreads;   // radix-4 butterflies per thread per pass (8)
+// A tile holds 4096*NB complex points (NB = 1: 32 KiB, four workgroups per CU; NB = 2 only for L = 8192), every
+// thread owns PT = 16*NB of them in each pass and while a tile is loaded or stored (all PT global loads are issued
+// before the first is used).
+#define FDC_GENERIC_BOUNDS(NB) __launch_bounds__(kThreads, (NB) == 1 ? 4 : 2)
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
@@ -35,34 +38,46 @@ __device__ __forceinline__ float2 ldtw(const float2 *__restrict__ tw, int idx)
     if (INV) w.y = -w.y;
     return w;
 }
+template <bool INV>
+__device__ __forceinline__ cf ldtwc(const float2 *__restrict__ tw, int idx)
+{
+    const float2 w = tw[idx];
+    return mk(w.x, INV ? -w.y : w.y);
+}
 
 // TC = 2^log2TC transforms of length L = 2^log2L held in lds as [L][ld].  twstride = ntab / L.
-template <bool INV>
-__device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float2 *__restrict__ tw, int twstride)
+// Stockham autosort: radix-16 passes (two radix-4 layers in registers per LDS round trip, fdc_radix16.hpp), then
+// one radix-4 and/or one radix-2 pass for what is left of log2 L.
+template <bool INV, int NB>
+__device__ __forceinline__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float2 *__restrict__ tw, int twstride)
 {
     const int tid = threadIdx.x;
     const int L = 1 << log2L;
     const int cmask = (1 << log2TC) - 1;
     int log2ns = 0;
-    // radix-16 passes first (two radix-4 layers in registers per LDS round trip, fdc_radix16.hpp)
     for (; log2ns + 4 <= log2L; log2ns += 4) {
         const int ns = 1 << log2ns;
         const int q = L >> 4;
         const int total = q << log2TC;
         const int tstep = (L >> (log2ns + 4)) * twstride;
-        cf o[kMaxB / 4][16];
+        cf o[NB][16];
 #pragma unroll
-        for (int i = 0; i < kMaxB / 4; i++) {
+        for (int i = 0; i < NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float2 x = lds[(j + r * q) * ld + c];
-                    o[i][r] = mk(x.x, x.y);
-                    if (ns > 1 && r > 0) {
-                        const float2 w = ldtw<INV>(tw, k * r * tstep);
-                        o[i][r] = cmul(o[i][r], mk(w.x, w.y));
+                for (int r = 0; r < 16; r++) o[i][r] = from2(lds[(j + r * q) * ld + c]);
+                if (ns > 1) {
+                    // input r = 4a + b2 takes W^(k r) = W^(4 a k) * W^(b2 k): six table reads instead of fifteen
+                    const int kt = k * tstep;
+                    cf A[4], B[4];
+#pragma unroll
+                    for (int x = 1; x < 4; x++) { A[x] = ldtwc<INV>(tw, 4 * x * kt); B[x] = ldtwc<INV>(tw, x * kt); }
+#pragma unroll
+                    for (int r = 1; r < 16; r++) {
+                        if (r & 3) o[i][r] = cmul(o[i][r], B[r & 3]);
+                        if (r >> 2) o[i][r] = cmul(o[i][r], A[r >> 2]);
                     }
                 }
                 dft16<INV>(o[i]);
@@ -70,7 +85,7 @@ __device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < kMaxB / 4; i++) {
+        for (int i = 0; i < NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
@@ -81,80 +96,67 @@ __device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float
         }
         __syncthreads();
     }
-    for (; log2ns + 2 <= log2L; log2ns += 2) {
+    if (log2ns + 2 <= log2L) {
         const int ns = 1 << log2ns;
         const int q = L >> 2;
         const int total = q << log2TC;
         const int tstep = (L >> (log2ns + 2)) * twstride;
-        float2 o[kMaxB][4];
+        cf o[4 * NB][4];
 #pragma unroll
-        for (int i = 0; i < kMaxB; i++) {
+        for (int i = 0; i < 4 * NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
-                float2 v0 = lds[j * ld + c];
-                float2 v1 = lds[(j + q) * ld + c];
-                float2 v2 = lds[(j + 2 * q) * ld + c];
-                float2 v3 = lds[(j + 3 * q) * ld + c];
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[i][r] = from2(lds[(j + r * q) * ld + c]);
                 if (ns > 1) {
-                    v1 = cmulf(v1, ldtw<INV>(tw, k * tstep));
-                    v2 = cmulf(v2, ldtw<INV>(tw, 2 * k * tstep));
-                    v3 = cmulf(v3, ldtw<INV>(tw, 3 * k * tstep));
+#pragma unroll
+                    for (int r = 1; r < 4; r++) o[i][r] = cmul(o[i][r], ldtwc<INV>(tw, r * k * tstep));
                 }
-                const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-                const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-                const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-                const float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
-                // forward: d * (-j) ; inverse: d * (+j)
-                const float2 a3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
-                o[i][0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-                o[i][1] = make_float2(a1.x + a3.x, a1.y + a3.y);
-                o[i][2] = make_float2(a0.x - a2.x, a0.y - a2.y);
-                o[i][3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+                dft4<INV>(o[i][0], o[i][1], o[i][2], o[i][3]);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < kMaxB; i++) {
+        for (int i = 0; i < 4 * NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
                 const int j0 = ((j >> log2ns) << (log2ns + 2)) + k;
-                lds[j0 * ld + c] = o[i][0];
-                lds[(j0 + ns) * ld + c] = o[i][1];
-                lds[(j0 + 2 * ns) * ld + c] = o[i][2];
-                lds[(j0 + 3 * ns) * ld + c] = o[i][3];
+#pragma unroll
+                for (int r = 0; r < 4; r++) lds[(j0 + r * ns) * ld + c] = to2(o[i][r]);
             }
         }
         __syncthreads();
+        log2ns += 2;
     }
     if (log2ns < log2L) {   // final radix-2 pass
         const int ns = 1 << log2ns;
         const int q = L >> 1;
         const int total = q << log2TC;
-        const int tstep = (L >> (log2ns + 1)) * twstride;
-        float2 o[2 * kMaxB][2];
+        const int tstep = twstride;   // L / (2*ns) == 1 here
+        cf o[8 * NB][2];
 #pragma unroll
-        for (int i = 0; i < 2 * kMaxB; i++) {
+        for (int i = 0; i < 8 * NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
-                float2 v0 = lds[j * ld + c];
-                float2 v1 = lds[(j + q) * ld + c];
-                if (ns > 1) v1 = cmulf(v1, ldtw<INV>(tw, k * tstep));
-                o[i][0] = make_float2(v0.x + v1.x, v0.y + v1.y);
-                o[i][1] = make_float2(v0.x - v1.x, v0.y - v1.y);
+                const cf v0 = from2(lds[j * ld + c]);
+                cf v1 = from2(lds[(j + q) * ld + c]);
+                if (ns > 1) v1 = cmul(v1, ldtwc<INV>(tw, k * tstep));
+                o[i][0] = v0 + v1;
+                o[i][1] = v0 - v1;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2 * kMaxB; i++) {
+        for (int i = 0; i < 8 * NB; i++) {
             const int b = tid + i * kThreads;
             if (b < total) {
                 const int c = b & cmask, j = b >> log2TC, k = j & (ns - 1);
                 const int j0 = ((j >> log2ns) << (log2ns + 1)) + k;
-                lds[j0 * ld + c] = o[i][0];
-                lds[(j0 + ns) * ld + c] = o[i][1];
+                lds[j0 * ld + c] = to2(o[i][0]);
+                lds[(j0 + ns) * ld + c] = to2(o[i][1]);
             }
         }
         __syncthreads();
@@ -162,28 +164,38 @@ __device__ void fft_cols(float2 *lds, int log2L, int log2TC, int ld, const float
 }
 
 // ---- whole transform in one workgroup (N <= kMaxLdsFft): TC items per workgroup ------------------
-template <bool INV>
-__global__ __launch_bounds__(kThreads) void k_fft_small(const float2 *__restrict__ in, size_t in_stride,
-                                                        float2 *__restrict__ out, int log2N, int log2TC, int ld,
-                                                        int nitems, int in_rot, int out_rot, float scale,
-                                                        const float2 *__restrict__ tw, int twstride)
+template <bool INV, int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_fft_small(const float2 *__restrict__ in, size_t in_stride,
+                                                   float2 *__restrict__ out, int log2N, int log2TC, int ld,
+                                                   int nitems, int in_rot, int out_rot, float scale,
+                                                   const float2 *__restrict__ tw, int twstride)
 {
+    constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
-    const int N = 1 << log2N, TC = 1 << log2TC;
+    const int N = 1 << log2N, TC = 1 << log2TC, total = N << log2TC;
     const int m0 = blockIdx.x * TC;
-    for (int e = threadIdx.x; e < (N << log2TC); e += kThreads) {
+    float2 v[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int t = e >> log2N, i = e & (N - 1), m = m0 + t;
-        float2 v = make_float2(0.f, 0.f);
-        if (m < nitems) v = in[(size_t)m * in_stride + ((i + in_rot) & (N - 1))];
-        lds[i * ld + t] = v;
+        v[u] = make_float2(0.f, 0.f);
+        if (e < total && m < nitems) v[u] = in[(size_t)m * in_stride + ((i + in_rot) & (N - 1))];
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        if (e < total) lds[(e & (N - 1)) * ld + (e >> log2N)] = v[u];
     }
     __syncthreads();
-    fft_cols<INV>(lds, log2N, log2TC, ld, tw, twstride);
-    for (int e = threadIdx.x; e < (N << log2TC); e += kThreads) {
+    fft_cols<INV, NB>(lds, log2N, log2TC, ld, tw, twstride);
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int t = e >> log2N, kp = e & (N - 1), m = m0 + t;
-        if (m < nitems) {
-            const float2 v = lds[((kp - out_rot) & (N - 1)) * ld + t];
-            out[(size_t)m * N + kp] = make_float2(v.x * scale, v.y * scale);
+        if (e < total && m < nitems) {
+            const float2 y = lds[((kp - out_rot) & (N - 1)) * ld + t];
+            out[(size_t)m * N + kp] = make_float2(y.x * scale, y.y * scale);
         }
     }
 }
@@ -191,97 +203,137 @@ __global__ __launch_bounds__(kThreads) void k_fft_small(const float2 *__restrict
 // ---- two-pass transform N = N1*N2, n = n1 + N1*n2, k = N2*k1 + k2 -----------------------------------
 // Pass A: TC columns n1, length-N2 transforms over n2 (row stride N1 in memory), times W_N^(n1*k2),
 //         stored transposed-by-construction as T[k2][n1] (n1 contiguous).
-template <bool INV>
-__global__ __launch_bounds__(kThreads) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
-                                                         float2 *__restrict__ tmp, int log2N, int log2N1,
-                                                         int log2TC, int ld, int in_rot,
-                                                         const float2 *__restrict__ tw, int ntab,
-                                                         const float2 *__restrict__ twf)
+template <bool INV, int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
+                                                    float2 *__restrict__ tmp, int log2N, int log2N1,
+                                                    int log2TC, int ld, int in_rot,
+                                                    const float2 *__restrict__ tw, int ntab,
+                                                    const float2 *__restrict__ twf)
 {
+    constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int N = 1 << log2N, log2N2 = log2N - log2N1, N2 = 1 << log2N2;
-    const int TC = 1 << log2TC;
+    const int TC = 1 << log2TC, total = N2 << log2TC;
     const int c0 = blockIdx.x * TC;
     const size_t m = blockIdx.y;
     const float2 *src = in + m * in_stride;
-    for (int e = threadIdx.x; e < (N2 << log2TC); e += kThreads) {
+    float2 v[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int r = e >> log2TC, c = e & (TC - 1);
-        const int n = c0 + c + (r << log2N1);
-        lds[r * ld + c] = src[(n + in_rot) & (N - 1)];
+        v[u] = make_float2(0.f, 0.f);
+        if (e < total) v[u] = src[(c0 + c + (r << log2N1) + in_rot) & (N - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        if (e < total) lds[(e >> log2TC) * ld + (e & (TC - 1))] = v[u];
     }
     __syncthreads();
-    fft_cols<INV>(lds, log2N2, log2TC, ld, tw, ntab >> log2N2);
+    fft_cols<INV, NB>(lds, log2N2, log2TC, ld, tw, ntab >> log2N2);
     float2 *dst = tmp + m * (size_t)N;
     const int twn = ntab >> log2N;
-    for (int e = threadIdx.x; e < (N2 << log2TC); e += kThreads) {
+    // W_N^(n1*k2): from the [k2][n1] table when the caller has one (coalesced like the store), else gathered
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int k2 = e >> log2TC, c = e & (TC - 1), n1 = c0 + c;
-        // W_N^(n1*k2): from the [k2][n1] table when the caller has one (coalesced like the store), else gathered
-        float2 w;
-        if (twf) { w = twf[((size_t)k2 << log2N1) + n1]; if (INV) w.y = -w.y; }
-        else w = ldtw<INV>(tw, n1 * k2 * twn);
-        dst[((size_t)k2 << log2N1) + n1] = cmulf(lds[k2 * ld + c], w);
+        v[u] = make_float2(1.f, 0.f);
+        if (e < total) {
+            if (twf) { v[u] = twf[((size_t)k2 << log2N1) + n1]; if (INV) v[u].y = -v[u].y; }
+            else v[u] = ldtw<INV>(tw, n1 * k2 * twn);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int k2 = e >> log2TC, c = e & (TC - 1), n1 = c0 + c;
+        if (e < total) dst[((size_t)k2 << log2N1) + n1] = cmulf(lds[k2 * ld + c], v[u]);
     }
 }
 
 // Pass B: TR rows k2 of T, length-N1 transforms over n1 (contiguous in memory), result bin
 //         k = N2*k1 + k2 stored at (k + out_rot) mod N, scaled.
-template <bool INV>
-__global__ __launch_bounds__(kThreads) void k_fft_pass_b(const float2 *__restrict__ tmp, float2 *__restrict__ out,
-                                                         int log2N, int log2N1, int log2TR, int ld, int out_rot,
-                                                         float scale, const float2 *__restrict__ tw, int ntab)
+template <bool INV, int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ tmp, float2 *__restrict__ out,
+                                                    int log2N, int log2N1, int log2TR, int ld, int out_rot,
+                                                    float scale, const float2 *__restrict__ tw, int ntab)
 {
+    constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int N = 1 << log2N, N1 = 1 << log2N1, log2N2 = log2N - log2N1;
-    const int TR = 1 << log2TR;
+    const int TR = 1 << log2TR, total = N1 << log2TR;
     const int r0 = blockIdx.x * TR;
     const size_t m = blockIdx.y;
     const float2 *src = tmp + m * (size_t)N;
-    for (int e = threadIdx.x; e < (N1 << log2TR); e += kThreads) {
-        const int r = e >> log2N1, i = e & (N1 - 1);
-        lds[i * ld + r] = src[((size_t)(r0 + r) << log2N1) + i];
+    float2 v[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        v[u] = make_float2(0.f, 0.f);
+        if (e < total) v[u] = src[((size_t)(r0 + (e >> log2N1)) << log2N1) + (e & (N1 - 1))];
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        if (e < total) lds[(e & (N1 - 1)) * ld + (e >> log2N1)] = v[u];
     }
     __syncthreads();
-    fft_cols<INV>(lds, log2N1, log2TR, ld, tw, ntab >> log2N1);
+    fft_cols<INV, NB>(lds, log2N1, log2TR, ld, tw, ntab >> log2N1);
     float2 *dst = out + m * (size_t)N;
-    for (int e = threadIdx.x; e < (N1 << log2TR); e += kThreads) {
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int k1 = e >> log2TR, r = e & (TR - 1);
-        const int k = (k1 << log2N2) + r0 + r;
-        const float2 v = lds[k1 * ld + r];
-        dst[(k + out_rot) & (N - 1)] = make_float2(v.x * scale, v.y * scale);
+        if (e < total) {
+            const int k = (k1 << log2N2) + r0 + r;
+            const float2 y = lds[k1 * ld + r];
+            dst[(k + out_rot) & (N - 1)] = make_float2(y.x * scale, y.y * scale);
+        }
     }
 }
 
 // ---- fused channel kernel ------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
-                                                       const ChanDev *__restrict__ chans,
-                                                       const int32_t *__restrict__ group, int ngroup, int log2l,
-                                                       int log2TC, int ld, int N, int R, int nb_chunk, int mbase,
-                                                       int nb_call, long long first_block,
-                                                       const float2 *__restrict__ wins,
-                                                       const float2 *__restrict__ tw, int twstride)
+template <int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
+                                                  const ChanDev *__restrict__ chans,
+                                                  const int32_t *__restrict__ group, int ngroup, int log2l,
+                                                  int log2TC, int ld, int N, int R, int nb_chunk, int mbase,
+                                                  int nb_call, long long first_block,
+                                                  const float2 *__restrict__ wins,
+                                                  const float2 *__restrict__ tw, int twstride)
 {
+    constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
-    const int l = 1 << log2l, TC = 1 << log2TC;
+    const int l = 1 << log2l, TC = 1 << log2TC, total = l << log2TC;
     const long long ntrans = (long long)nb_chunk * ngroup;
     const long long t0 = (long long)blockIdx.x * TC;
-    for (int e = threadIdx.x; e < (l << log2TC); e += kThreads) {
+    float2 v[PT], w[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int tl = e >> log2l, i = e & (l - 1);
         const long long t = t0 + tl;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < ntrans) {
+        v[u] = make_float2(0.f, 0.f); w[u] = v[u];
+        if (e < total && t < ntrans) {
             const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
             const ChanDev ch = chans[group[gi]];
             // vector_cut_vxx: bins [f, f+l) of block m's spectrum
-            const float2 x = spec[(size_t)m * N + ch.f + i];
+            v[u] = spec[(size_t)m * N + ch.f + i];
             // phase_shifting_windowing_vcc: counter_m = (m*shift) mod R in closed form
             const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
-            const float2 w = wins[ch.win_off + cnt * l + i];
-            v = cmulf(x, w);
+            w[u] = wins[ch.win_off + cnt * l + i];
         }
-        lds[((i + (l >> 1)) & (l - 1)) * ld + tl] = v;     // ifftshift of the IFFT input
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int tl = e >> log2l, i = e & (l - 1);
+        if (e < total) lds[((i + (l >> 1)) & (l - 1)) * ld + tl] = cmulf(v[u], w[u]);     // ifftshift of the IFFT input
     }
     __syncthreads();
-    fft_cols<true>(lds, log2l, log2TC, ld, tw, twstride);
+    fft_cols<true, NB>(lds, log2l, log2TC, ld, tw, twstride);
     const int lout = l - l / R, skip = l - lout;
     const float scale = (float)l;
     for (int e = threadIdx.x; e < lout * TC; e += kThreads) {
@@ -318,7 +370,8 @@ __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restric
 
 // Extraction of one width class: out = IFFT_w( halfswap( X[slot][start .. start+w) * win ) )[skip .. w)
 //   lib/PowerActivationChannel_impl.cc:260-284, lib/activity_detection_channelizer_vcm_impl.cc:373-397
-__global__ __launch_bounds__(kThreads) void k_extract(const float2 *__restrict__ spec, int N,
+template <int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, int N,
                                                       const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
                                                       int log2TC, int ld, int skip, const float2 *__restrict__ wins,
                                                       float2 *__restrict__ out, const float2 *__restrict__ tw,
@@ -327,17 +380,28 @@ __global__ __launch_bounds__(kThreads) void k_extract(const float2 *__restrict__
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int w = 1 << log2w, TC = 1 << log2TC;
     const int t0 = blockIdx.x * TC;
-    for (int e = threadIdx.x; e < (w << log2TC); e += kThreads) {
+    constexpr int PT = 16 * NB;
+    const int total = w << log2TC;
+    float2 v[PT], ww[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
         const int tl = e >> log2w, i = e & (w - 1), t = t0 + tl;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < ntasks) {
+        v[u] = make_float2(0.f, 0.f); ww[u] = v[u];
+        if (e < total && t < ntasks) {
             const ExtractTask tk = tasks[t];
-            v = cmulf(spec[(size_t)tk.slot * N + tk.start + i], wins[tk.win_off + i]);
+            v[u] = spec[(size_t)tk.slot * N + tk.start + i];
+            ww[u] = wins[tk.win_off + i];
         }
-        lds[((i + (w >> 1)) & (w - 1)) * ld + tl] = v;       // fftshift(): halves swapped
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int tl = e >> log2w, i = e & (w - 1);
+        if (e < total) lds[((i + (w >> 1)) & (w - 1)) * ld + tl] = cmulf(v[u], ww[u]);       // fftshift(): halves swapped
     }
     __syncthreads();
-    fft_cols<true>(lds, log2w, log2TC, ld, tw, twstride);
+    fft_cols<true, NB>(lds, log2w, log2TC, ld, tw, twstride);
     const int olen = w - skip;
     for (int e = threadIdx.x; e < olen * TC; e += kThreads) {
         const int tl = e / olen, tt = e - tl * olen, t = t0 + tl;
@@ -393,7 +457,8 @@ TileGeom tile_geom(int L)
 {
     TileGeom g;
     g.L = L; g.log2L = ilog2(L);
-    int tc = kTileElems / L; if (tc > 32) tc = 32; if (tc < 1) tc = 1;
+    g.NB = L > 4096 ? 2 : 1;                    // tile = 4096*NB points
+    int tc = 4096 * g.NB / L; if (tc > 32) tc = 32; if (tc < 1) tc = 1;
     g.TC = tc; g.log2TC = ilog2(tc);
     g.ld = tc > 1 ? tc + 1 : 1;
     return g;
@@ -417,10 +482,8 @@ hipError_t init_kernels()
 #define FDC_SETLDS(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
-    FDC_SETLDS(k_fft_small<false>) FDC_SETLDS(k_fft_small<true>)
-    FDC_SETLDS(k_fft_pass_a<false>) FDC_SETLDS(k_fft_pass_a<true>)
-    FDC_SETLDS(k_fft_pass_b<false>) FDC_SETLDS(k_fft_pass_b<true>)
-    FDC_SETLDS(k_channels) FDC_SETLDS(k_extract)
+    FDC_SETLDS((k_fft_small<false, 2>)) FDC_SETLDS((k_fft_small<true, 2>))
+    FDC_SETLDS(k_channels<2>) FDC_SETLDS(k_extract<2>)
 #undef FDC_SETLDS
     return init_fast_kernels();
 }
@@ -435,12 +498,12 @@ hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *t
     if (N <= kMaxLdsFft) {
         const TileGeom g = tile_geom(N);
         dim3 grid((nitems + g.TC - 1) / g.TC);
-        if (inverse)
-            hipLaunchKernelGGL(k_fft_small<true>, grid, dim3(kThreads), g.lds_bytes(), s, in, in_stride, out, g.log2L,
-                               g.log2TC, g.ld, nitems, in_rot, out_rot, scale, tw, ntab / N);
-        else
-            hipLaunchKernelGGL(k_fft_small<false>, grid, dim3(kThreads), g.lds_bytes(), s, in, in_stride, out, g.log2L,
-                               g.log2TC, g.ld, nitems, in_rot, out_rot, scale, tw, ntab / N);
+#define FDC_LS(I, B) \
+    hipLaunchKernelGGL((k_fft_small<I, B>), grid, dim3(kThreads), g.lds_bytes(), s, in, in_stride, out, g.log2L, g.log2TC, g.ld, \
+                       nitems, in_rot, out_rot, scale, tw, ntab / N)
+        if (inverse) { if (g.NB == 2) FDC_LS(true, 2); else FDC_LS(true, 1); }
+        else { if (g.NB == 2) FDC_LS(false, 2); else FDC_LS(false, 1); }
+#undef FDC_LS
         if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
     } else {
         const BigGeom g = big_geom(N);
@@ -450,18 +513,19 @@ hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *t
             dim3 ga(g.N1 / g.a.TC, nb), gb(g.N2 / g.b.TC, nb);
             const float2 *src = in + (size_t)m0 * in_stride;
             float2 *t = tmp + (size_t)m0 * N, *dst = out + (size_t)m0 * N;
+            // N <= 2^24: both factors are <= 4096, one 4096-point tile per workgroup
             if (inverse)
-                hipLaunchKernelGGL(k_fft_pass_a<true>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
+                hipLaunchKernelGGL((k_fft_pass_a<true, 1>), ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
                                    lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab, twf);
             else
-                hipLaunchKernelGGL(k_fft_pass_a<false>, ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
+                hipLaunchKernelGGL((k_fft_pass_a<false, 1>), ga, dim3(kThreads), g.a.lds_bytes(), s, src, in_stride, t, lgN,
                                    lgN1, g.a.log2TC, g.a.ld, in_rot, tw, ntab, twf);
             if (m0 == 0 && ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
             if (inverse)
-                hipLaunchKernelGGL(k_fft_pass_b<true>, gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
+                hipLaunchKernelGGL((k_fft_pass_b<true, 1>), gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
                                    g.b.log2TC, g.b.ld, out_rot, scale, tw, ntab);
             else
-                hipLaunchKernelGGL(k_fft_pass_b<false>, gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
+                hipLaunchKernelGGL((k_fft_pass_b<false, 1>), gb, dim3(kThreads), g.b.lds_bytes(), s, t, dst, lgN, lgN1,
                                    g.b.log2TC, g.b.ld, out_rot, scale, tw, ntab);
         }
     }
@@ -477,8 +541,12 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
     const TileGeom g = tile_geom(l);
     const long long ntrans = (long long)nb_chunk * ngroup;
     dim3 grid((unsigned)((ntrans + g.TC - 1) / g.TC));
-    hipLaunchKernelGGL(k_channels, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
-                       g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    if (g.NB == 2)
+        hipLaunchKernelGGL(k_channels<2>, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
+                           g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    else
+        hipLaunchKernelGGL(k_channels<1>, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
+                           g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
     return hipGetLastError();
 }
 
@@ -528,8 +596,12 @@ hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, i
 {
     if (ntasks <= 0) return hipSuccess;
     const TileGeom g = tile_geom(w);
-    hipLaunchKernelGGL(k_extract, dim3((ntasks + g.TC - 1) / g.TC), dim3(kThreads), g.lds_bytes(), s, spec, N, tasks, ntasks,
-                       g.log2L, g.log2TC, g.ld, skip, wins, out, tw, ntab / w);
+    if (g.NB == 2)
+        hipLaunchKernelGGL(k_extract<2>, dim3((ntasks + g.TC - 1) / g.TC), dim3(kThreads), g.lds_bytes(), s, spec, N, tasks, ntasks,
+                           g.log2L, g.log2TC, g.ld, skip, wins, out, tw, ntab / w);
+    else
+        hipLaunchKernelGGL(k_extract<1>, dim3((ntasks + g.TC - 1) / g.TC), dim3(kThreads), g.lds_bytes(), s, spec, N, tasks, ntasks,
+                           g.log2L, g.log2TC, g.ld, skip, wins, out, tw, ntab / w);
     return hipGetLastError();
 }
 
