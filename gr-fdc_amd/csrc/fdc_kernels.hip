@@ -295,6 +295,10 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ t
 }
 
 // ---- fused channel kernel ------------------------------------------------------------------------
+// Per tile column (one transform = one (block, channel) pair): where its slice, window row and output run start.
+// Worked out once per column by the first TC threads, so the per-point loops carry no divisions or record fetches.
+struct ColInfo { long long src; long long dst; int win; int valid; };
+
 template <int NB>
 __global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
                                                   const ChanDev *__restrict__ chans,
@@ -305,25 +309,39 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spe
                                                   const float2 *__restrict__ tw, int twstride)
 {
     constexpr int PT = 16 * NB;
+    __shared__ ColInfo col[32];
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int l = 1 << log2l, TC = 1 << log2TC, total = l << log2TC;
+    const int lout = l - l / R, skip = l - lout;
     const long long ntrans = (long long)nb_chunk * ngroup;
     const long long t0 = (long long)blockIdx.x * TC;
+    if (threadIdx.x < TC) {
+        const long long t = t0 + threadIdx.x;
+        ColInfo ci{0, 0, 0, 0};
+        if (t < ntrans) {
+            const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
+            const ChanDev ch = chans[group[gi]];
+            // vector_cut_vxx: bins [f, f+l) of block m's spectrum
+            ci.src = (long long)m * N + ch.f;
+            // phase_shifting_windowing_vcc: counter_m = (m*shift) mod R in closed form
+            const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
+            ci.win = ch.win_off + cnt * l;
+            ci.dst = (long long)nb_call * ch.out_off + (long long)(mbase + m) * lout - skip;   // + output index i >= skip
+            ci.valid = 1;
+        }
+        col[threadIdx.x] = ci;
+    }
+    __syncthreads();
     float2 v[PT], w[PT];
 #pragma unroll
     for (int u = 0; u < PT; u++) {
         const int e = threadIdx.x + u * kThreads;
-        const int tl = e >> log2l, i = e & (l - 1);
-        const long long t = t0 + tl;
+        const int tl = (e >> log2l) & (TC - 1), i = e & (l - 1);
         v[u] = make_float2(0.f, 0.f); w[u] = v[u];
-        if (e < total && t < ntrans) {
-            const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
-            const ChanDev ch = chans[group[gi]];
-            // vector_cut_vxx: bins [f, f+l) of block m's spectrum
-            v[u] = spec[(size_t)m * N + ch.f + i];
-            // phase_shifting_windowing_vcc: counter_m = (m*shift) mod R in closed form
-            const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
-            w[u] = wins[ch.win_off + cnt * l + i];
+        const ColInfo ci = col[tl];
+        if (e < total && ci.valid) {
+            v[u] = spec[ci.src + i];
+            w[u] = wins[ci.win + i];
         }
     }
 #pragma unroll
@@ -334,16 +352,15 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spe
     }
     __syncthreads();
     fft_cols<true, NB>(lds, log2l, log2TC, ld, tw, twstride);
-    const int lout = l - l / R, skip = l - lout;
     const float scale = (float)l;
-    for (int e = threadIdx.x; e < lout * TC; e += kThreads) {
-        const int tl = e / lout, tt = e - tl * lout;
-        const long long t = t0 + tl;
-        if (t < ntrans) {
-            const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
-            const ChanDev ch = chans[group[gi]];
-            const float2 y = lds[(skip + tt) * ld + tl];
-            out[(size_t)nb_call * ch.out_off + (size_t)(mbase + m) * lout + tt] = make_float2(y.x * scale, y.y * scale);
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int tl = (e >> log2l) & (TC - 1), i = e & (l - 1);
+        const ColInfo ci = col[tl];
+        if (e < total && ci.valid && i >= skip) {                // overlap discard: the first l/R samples go
+            const float2 y = lds[i * ld + tl];
+            out[ci.dst + i] = make_float2(y.x * scale, y.y * scale);
         }
     }
 }
@@ -381,17 +398,28 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec
     const int w = 1 << log2w, TC = 1 << log2TC;
     const int t0 = blockIdx.x * TC;
     constexpr int PT = 16 * NB;
+    __shared__ ColInfo col[32];
     const int total = w << log2TC;
+    if (threadIdx.x < TC) {
+        const int t = t0 + threadIdx.x;
+        ColInfo ci{0, 0, 0, 0};
+        if (t < ntasks) {
+            const ExtractTask tk = tasks[t];
+            ci.src = (long long)tk.slot * N + tk.start; ci.win = tk.win_off; ci.dst = tk.out_off - skip; ci.valid = 1;
+        }
+        col[threadIdx.x] = ci;
+    }
+    __syncthreads();
     float2 v[PT], ww[PT];
 #pragma unroll
     for (int u = 0; u < PT; u++) {
         const int e = threadIdx.x + u * kThreads;
-        const int tl = e >> log2w, i = e & (w - 1), t = t0 + tl;
+        const int tl = (e >> log2w) & (TC - 1), i = e & (w - 1);
         v[u] = make_float2(0.f, 0.f); ww[u] = v[u];
-        if (e < total && t < ntasks) {
-            const ExtractTask tk = tasks[t];
-            v[u] = spec[(size_t)tk.slot * N + tk.start + i];
-            ww[u] = wins[tk.win_off + i];
+        const ColInfo ci = col[tl];
+        if (e < total && ci.valid) {
+            v[u] = spec[ci.src + i];
+            ww[u] = wins[ci.win + i];
         }
     }
 #pragma unroll
@@ -402,10 +430,12 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec
     }
     __syncthreads();
     fft_cols<true, NB>(lds, log2w, log2TC, ld, tw, twstride);
-    const int olen = w - skip;
-    for (int e = threadIdx.x; e < olen * TC; e += kThreads) {
-        const int tl = e / olen, tt = e - tl * olen, t = t0 + tl;
-        if (t < ntasks) out[tasks[t].out_off + tt] = lds[(skip + tt) * ld + tl];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int tl = (e >> log2w) & (TC - 1), i = e & (w - 1);
+        const ColInfo ci = col[tl];
+        if (e < total && ci.valid && i >= skip) out[ci.dst + i] = lds[i * ld + tl];
     }
 }
 
@@ -477,7 +507,7 @@ BigGeom big_geom(int N)
 
 hipError_t init_kernels()
 {
-    const int maxlds = 160 * 1024;
+    const int maxlds = 72 * 1024;      // largest generic tile: 8192 points (64 KiB) + static per-column records
     hipError_t e;
 #define FDC_SETLDS(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
