@@ -478,12 +478,17 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
         // element (row r, b, p) at (p*16 + (b ^ (p&1)))*TR + (r ^ b) [mod TR]: conflict-free b64 writes (the 16 lanes
         // of a row r hit 16 different bank pairs) and reads (for TR = 16 a 32-lane read group spans two p, whose
         // 128-B rows are put on opposite halves of the 64 banks by the b ^ (p&1) term)
-        cf w[16];
 #pragma unroll
-        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+        for (int h = 0; h < 2; h++) {                       // two batches of 8: the full 16 cost 3-6 spilled VGPRs
+            cf w[8];
 #pragma unroll
-        for (int p = 0; p < 16; p++)
-            st2(&tile[(p * 16 + (b ^ (p & 1))) * TR + ((r ^ b) & (TR - 1))], cmul(v[rev16(p)], w[p]));
+            for (int p = 0; p < 8; p++) w[p] = ld2(&w256[b * (8 * h + p)]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int pv = 8 * h + p;
+                st2(&tile[(pv * 16 + (b ^ (pv & 1))) * TR + ((r ^ b) & (TR - 1))], cmul(v[rev16(pv)], w[p]));
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int bb = 0; bb < 16; bb++)
