@@ -193,8 +193,10 @@ def main():
         "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), "
-                               "%d blocks/step/GPU" % (N, R, C, params[0][1], params[0][2], nb),
+        "config": {"workload": "%s: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), "
+                               "%d blocks/step/GPU" % ("configs[1]" if (N, R, C) == (65536, 2, 256) else
+                                                       "configs[3] per-GPU shape" if (N, R, C) == (262144, 2, 1024) else
+                                                       "non-default shape", N, R, C, params[0][1], params[0][2], nb),
                    "blocklen": N, "relinvovl": R, "channels": C, "blocks_per_step_per_gpu": nb,
                    "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
