@@ -133,6 +133,8 @@ struct fdc_pipeline {
     long long *d_slot_off = nullptr;
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
+    float2 *d_big = nullptr;     // channels wider than one workgroup's transform: 3 x chunk x (widest l) scratch
+    int big_l = 0;
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
     float2 *d_spec = nullptr;    // spectrum, chunk*N (or max_blocks*N with keep_spectrum)
     float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
@@ -217,7 +219,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
-    (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
+    (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -240,7 +242,6 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (ch.passbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: PassBw must not be <= 0", c);
         if (ch.stopbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be <= 0", c);
         if (ch.stopbw < ch.passbw) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be < PassBw", c);
-        if (ch.l > fdc::kMaxLdsFft) return fail(FDC_ERR_UNSUPPORTED, "channel %d: l=%d above %d not supported yet", c, ch.l, fdc::kMaxLdsFft);
     }
     int rc = select_device(cfg->device_id);
     if (rc != FDC_OK) return rc;
@@ -416,6 +417,8 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_s2[i], hipEventDisableTiming));
         }
     }
+    for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
+    if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
@@ -474,6 +477,30 @@ static int get_event(fdc_pipeline *p, size_t *idx)
         p->events.push_back(e);
     }
     *idx = p->ev_used++;
+    return FDC_OK;
+}
+
+// Channels wider than one workgroup's transform (l > kMaxLdsFft): the reference's block chain one step at a time on
+// scratch — vector_cut_vxx, phase_shifting_windowing_vcc, fft_vcc(l, inverse, shift) as the two-pass transform with the
+// ifftshift as input rotation and the *l in its store, vector_cut_vxx(l, l - lout, lout) — in pieces of `chunk` blocks.
+static int channels_wide(fdc_pipeline *p, const float2 *spec, float2 *d_out, const std::vector<int32_t> &ids, int l, int nb,
+                         int mbase, int nb_call, int64_t first_block, hipStream_t s)
+{
+    for (int c : ids) {
+        const fdc::ChanDev &ch = p->chans[(size_t)c];
+        for (int m0 = 0; m0 < nb; m0 += p->chunk) {
+            const int n = std::min(p->chunk, nb - m0);
+            float2 *A = p->d_big, *B = A + (size_t)p->chunk * p->big_l, *T = B + (size_t)p->chunk * p->big_l;
+            HIPCHK(fdc::launch_vector_cut(reinterpret_cast<const unsigned char *>(spec + (size_t)m0 * p->N), reinterpret_cast<unsigned char *>(A),
+                                          sizeof(float2) * (size_t)p->N, sizeof(float2) * (size_t)ch.f, sizeof(float2) * (size_t)l, n, s));
+            const int c0 = (int)((((first_block + mbase + m0) % p->R) * ch.shift) % p->R);
+            HIPCHK(fdc::launch_phase_window(A, A, p->d_wins + ch.win_off, l, p->R, ch.shift, c0, n, s));
+            HIPCHK(fdc::launch_fft(A, (size_t)l, B, T, l, n, true, l / 2, 0, (float)l, p->d_tw, p->ntab, s, nullptr));
+            HIPCHK(fdc::launch_vector_cut(reinterpret_cast<const unsigned char *>(B),
+                                          reinterpret_cast<unsigned char *>(d_out + (size_t)nb_call * ch.out_off + (size_t)(mbase + m0) * ch.lout),
+                                          sizeof(float2) * (size_t)l, sizeof(float2) * (size_t)(l - ch.lout), sizeof(float2) * (size_t)ch.lout, n, s));
+        }
+    }
     return FDC_OK;
 }
 
@@ -549,7 +576,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                    1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf));
         for (size_t g = 0; g < p->groups.size(); g++) {
             const int l = p->groups[g].first;
-            if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
+            if (l > fdc::kMaxLdsFft) {
+                const int rcw = channels_wide(p, spec, static_cast<float2 *>(d_out), p->groups[g].second, l, nb, m0, nblocks, first_block, s);
+                if (rcw != FDC_OK) return rcw;
+            } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
                 HIPCHK(fdc::launch_channels256(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
                                                (int)p->groups[g].second.size(), p->g_aligned[g] != 0,
                                                p->g_out_aligned[g] != 0, p->N, p->R, nb, m0, nblocks, first_block,
@@ -793,7 +823,10 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
     HIPCHK(fdc::launch_scale(d_full, d_full, n, 1.0f / (float)p->N, s));
     for (size_t g = 0; g < p->groups.size(); g++) {
         const int l = p->groups[g].first;
-        if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
+        if (l > fdc::kMaxLdsFft) {
+            const int rcw = channels_wide(p, d_full, p->d_out, p->groups[g].second, l, nblocks, 0, nblocks, p->blockcount, s);
+            if (rcw != FDC_OK) { if (d_owned) (void)hipFree(d_owned); return rcw; }
+        } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
             HIPCHK(fdc::launch_channels256(d_full, p->d_out, p->d_chans, p->d_groups + p->group_off[g],
                                            (int)p->groups[g].second.size(), p->g_aligned[g] != 0, p->g_out_aligned[g] != 0,
                                            p->N, p->R, nblocks, 0, nblocks, p->blockcount, p->d_wins, p->d_tw256, s));

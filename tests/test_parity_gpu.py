@@ -62,7 +62,7 @@ def test_phase_window_block(oracle):
             assert np.abs(ya - yb).max() <= 1e-6 * np.abs(yb).max()
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 32, 128, 512, 2048, 8192, 16384, 65536, 262144])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576])
 def test_fft_vcc_all_sizes(oracle, n):
     items = 3 if n <= 65536 else 2
     x = noise(items * n, n)
@@ -315,3 +315,29 @@ def test_host_path_sub_batches_staged_and_pinned(oracle, sub):
     for c, lo in enumerate(los):
         assert_close(np.concatenate([o1[c], o2[c]]), ref[c], "ch%d" % c)
         assert_close(np.concatenate([o3[c], o4[c]]), ref[c], "ch%d (mixed)" % c)
+
+
+def test_widest_channels_and_no_channels(oracle):
+    """Every channel width up to the whole band: l = 8192 takes the two-tile form of the generic kernels, wider ones the
+    block-by-block form with a two-pass inverse transform; a plan without any channel (spectrum only); an empty call."""
+    N, R, nb = 32768, 4, 3
+    H = N - N // R
+    chans = [(100, 8192, 0.7, 0.9), (12000, 4096, 0.5, 0.8), (20000, 2048, 0.9, 1.0), (30000, 8, 0.5, 1.0),
+             (16001, 16384, 0.6, 0.8), (0, 32768, 0.9, 1.0)]
+    x = noise(nb * H, 5)
+    ref, rspec = oracle.channelizer(N, R, 2, chans, x, want_spectrum=True, nthreads=2)
+    p = G.Pipeline(N, R, chans, windowtype=2, max_blocks=nb, keep_spectrum=True)
+    outs, spec = p.work(x, want_spectrum=True)
+    assert_close(spec, rspec, "spectrum")
+    for c in range(len(chans)):
+        assert_close(outs[c], ref[c], "l=%d" % chans[c][1])
+    assert [o.size for o in p.work(x[:0])] == [0] * len(chans)
+    q = G.Pipeline(N, R, [], windowtype=2, max_blocks=nb, keep_spectrum=True)
+    o2, s2 = q.work(x, want_spectrum=True)
+    assert o2 == [] and np.array_equal(s2, spec)
+    with pytest.raises(G.FdcError):
+        p.work(np.zeros((nb + 1) * H, np.complex64))          # above max_blocks
+    with pytest.raises(ValueError):
+        p.work(np.zeros(H + 1, np.complex64))                 # not a whole number of items
+    with pytest.raises(ValueError):
+        G.Pipeline(N, R, [(0, 3, 0.5, 1.0)], max_blocks=1)   # l not a power of two
