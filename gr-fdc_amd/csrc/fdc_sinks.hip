@@ -95,6 +95,7 @@ struct fdc_sinks {
     float *d_power = nullptr;
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
     float2 *d_ext = nullptr; size_t cap_ext = 0;
+    float2 *d_wide = nullptr;                       // scratch of extractions wider than kMaxLdsFft: 3 x N
     cfl *h_ext = nullptr; size_t cap_hext = 0;      // pinned landing buffer of the extractions
     std::vector<float> h_power;
     std::vector<PduRec> pdus;
@@ -240,7 +241,7 @@ void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, 
         const int dw = pc.second - pc.first, mid = pc.first + dw / 2;
         const int ew = pow2ceil((int)std::ceil((double)dw * (1.0 + 2.0 * s->cfg.window_flank_puffer)));
         if (ew > s->N) continue;                                               // logged and skipped in the reference
-        if (ew > fdc::kMaxLdsFft) continue;                                    // above the single-workgroup IFFT (documented gap)
+        if (s->det_win_off[(size_t)std::lround(std::log2((double)ew))] < 0) continue;   // no window table for this width (see create)
         int es = mid - ew / 2, ee = mid + ew / 2;
         if (es < 0) { es = 0; ee = ew; }
         if (ee > s->N) { ee = s->N; es = s->N - ew; }
@@ -285,7 +286,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_cells);
-    (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext);
+    (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -329,8 +330,6 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         p.measure_stop = std::min((int)std::round((double)(cfreq + bw / 2.0f) * (double)N), p.extract_stop);
         if (p.extract_start + p.extract_width > N)
             return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "PowerActivationChannel %d: the reference reads past the block here", i);
-        if (p.extract_width > fdc::kMaxLdsFft)
-            return fdc::set_error(FDC_ERR_UNSUPPORTED, "PowerActivationChannel %d: width %d above %d", i, p.extract_width, fdc::kMaxLdsFft);
         p.deltaphase = p.extract_start % R;
         p.ovl_offset = p.extract_width / R; p.output_len = p.extract_width - p.ovl_offset;
         // cr_windows, :357-375: unit phasor (float polar) with a rising sine edge; only the first extract_width
@@ -418,8 +417,11 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         s->det_win_off.resize(nw);
         for (int k = 0; k < nw; k++) {
             const int ww = 1 << k, puf = (int)(cfg->window_flank_puffer * (double)ww);
+            s->det_win_off[k] = -1;
+            // widths above one workgroup's transform get a table only while it stays small (<= 32 MiB); carriers wider
+            // than that are skipped at activation like the ones wider than the block
+            if (ww > fdc::kMaxLdsFft && (size_t)R * ww * sizeof(cfl) > ((size_t)32 << 20)) continue;
             s->det_win_off[k] = (int)pool.size();
-            if (ww > fdc::kMaxLdsFft) continue;
             pool.resize(pool.size() + (size_t)R * ww);
             for (int r = 0; r < R; r++) {
                 cfl *w = pool.data() + s->det_win_off[k] + (size_t)r * ww;
@@ -548,7 +550,21 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             const int w = s->task_w[order[i]], skip = s->task_skip[order[i]];
             size_t j = i;
             while (j < nt && s->task_w[order[j]] == w) j++;
-            HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
+            if (w <= fdc::kMaxLdsFft) {
+                HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
+            } else {
+                // wider than one workgroup's transform (rare: a carrier over 1/8 of a 65536-bin band): task by task on
+                // scratch — slice, window, two-pass inverse transform with the half swap as input rotation, discard
+                if (!s->d_wide) HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * (size_t)N));
+                float2 *A = s->d_wide, *B = A + N, *T = B + N;
+                for (size_t k = i; k < j; k++) {
+                    const fdc::ExtractTask &tk = sorted[k];
+                    HIPCHK(hipMemcpyAsync(A, s->d_spec + (size_t)tk.slot * N + tk.start, sizeof(float2) * (size_t)w, hipMemcpyDeviceToDevice, s->stream));
+                    HIPCHK(fdc::launch_phase_window(A, A, s->d_wins + tk.win_off, w, 1, 0, 0, 1, s->stream));
+                    HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, 1, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
+                    HIPCHK(hipMemcpyAsync(s->d_ext + tk.out_off, B + skip, sizeof(float2) * (size_t)(w - skip), hipMemcpyDeviceToDevice, s->stream));
+                }
+            }
             i = j;
         }
         HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));

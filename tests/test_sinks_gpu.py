@@ -201,3 +201,21 @@ def test_segment_detection_face_vs_oracle(oracle, golden_dir, N, R, maxblocks, d
     spec2 = burst_spectrum(4096, 12, [(1600, 1800, 3, 7, 1.0)], 0)
     (d, s), = G.SegmentDetection(0, 4096, 4, 0.3, 0.55, 10.0, 0.005, 0.2, -1, 1, True, False, "", False, 0).work(spec2)
     assert (d["blockstart"], d["blockend"], s.size) == (ka["blockstart"], ka["blockend"], ka["nsamples"]) and abs(d["rel_bw"] - ka["rel_bw"]) < 1e-12
+
+
+def test_sinks_wider_than_one_workgroup_transform(oracle):
+    """Extraction widths above 8192 bins (a PowerActivationChannel of 0.2 of a 65536-bin band -> 16384; a detected carrier
+    of ~11000 bins -> 16384) run task by task through the two-pass inverse transform; same PDUs as the oracle."""
+    N, R, nb = 65536, 2, 12
+    cf, bw = 0.30, 0.20
+    lo, hi = int(round((cf - bw / 2) * N)), int(round((cf + bw / 2) * N))
+    spec = burst_spectrum(N, nb, [(lo, hi, 2, 6, 1.0), (40000, 51000, 4, 9, 1.0)], 23)
+    bank = G.Sinks(N, R, pac=[(cf, bw, 4)], pac_thresh=6.0, pac_maxblocks=-1, segments=[(0.55, 0.95)], det_thresh=10.0,
+                   det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2, max_blocks=16)
+    assert bank.pac_params(0)["extract_width"] == 16384
+    got = bank.work(spec.reshape(-1))
+    rp = oracle.PowerActivationChannel(N, cf, bw, R, 6.0, -1, 0, 4).work(spec)
+    rd = oracle.ActivityDetectionVcm(N, [[0.55, 0.95]], 10.0, R, -1, 0.005, 1, 0.2).work(spec)
+    assert len(rp) >= 1 and len(rd) >= 1 and max(r["samples"].size for r in rd) >= 8192 * 3
+    compare([g for g in got if g[0]["kind"] == rp[0]["kind"]], rp, vec=False)
+    compare([g for g in got if g[0]["kind"] != rp[0]["kind"]], rd)
