@@ -104,12 +104,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # rehearsal on a one-GPU box (FDC_BENCH_REHEARSE=1): all ranks share cuda:0 and talk over gloo; the driver's real
+    # multi-GPU run is one rank per GPU over RCCL
+    rehearse = os.environ.get("FDC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     N, R, C, nb = a.blocklen, a.relinvovl, a.channels, a.blocks
     H = N - N // R
@@ -162,7 +170,7 @@ def main():
     last = pipe.last_kernel_ms()
     pipe.enable_timing(False)
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
