@@ -213,7 +213,10 @@ def main():
                      "kernel_avg_launch_ms": round(dom_avg_ms, 5), "blocks_per_launch": blocks_per_launch,
                      "launches_per_step": nlaunch, "alg_bytes_per_block": b_alg,
                      "pipeline_achieved": round(b_alg * nb * a.steps / dt / 1e9, 2),
-                     "pipeline_frac": round(b_alg * nb * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+                     "pipeline_frac": round(b_alg * nb * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                     # SURVEY.md §8d also asks for the fraction of the achievable float4-copy rate (6.3 TB/s per the guide)
+                     "frac_of_achievable_6300": round(achieved / 6300.0, 4),
+                     "pipeline_frac_of_achievable_6300": round(b_alg * nb * a.steps / dt / 1e9 / 6300.0, 4)},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -223,10 +226,13 @@ def main():
         nthreads = min(ncores, 16)          # a one-GPU box's CPU share
         cb = a.cpu_blocks or max(nthreads * 4, 128)
         v, secs, reps = cpu_baseline(N, R, plan, nthreads, cb)
+        import ctypes.util
+        have = [n for n in ("fftw3f", "volk") if ctypes.util.find_library(n)]      # SURVEY.md §8d start-up probe
         res["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": nthreads, "kind": "port",
                                "sample": "%d passes over %d blocks of the same workload (N=%d, %d channels), "
-                                         "float32 oracle port, OpenMP over blocks, %.1f s wall"
-                                         % (reps, cb, N, C, secs)}
+                                         "float32 oracle port, OpenMP over blocks, %.1f s wall; host libraries of the "
+                                         "reference's own CPU path found: %s"
+                                         % (reps, cb, N, C, secs, ", ".join(have) if have else "none (no FFTW3f, no VOLK)")}
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
