@@ -1,0 +1,101 @@
+"""GPU tests (-m gpu) at BASELINE.json's FULL sizes (cfg2 = 65536-pt FFT, 256 channels, 1024 blocks per
+launch; cfg4's per-GPU shape = 262144-pt FFT, 1024 channels, 256 blocks), through the C-ABI's host entry:
+  * the whole batch against the oracle (its OpenMP double-precision form finishes these sizes in seconds),
+  * size-independent properties: launch grouping is invisible (bit-exact), linearity, block-shift invariance
+    (bit-exact), unit gain and phase continuity of a bin-centred tone across every block boundary."""
+import os
+
+import numpy as np
+import pytest
+
+import gr_fdc_amd as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def plan_for(N, R, C):
+    params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C) % 1.0, 0.8 / C) for c in range(C)]
+    assert all(p[:3] == (256 * c, 256, 256 - 256 // R) for c, p in enumerate(params))
+    return [(f, l, p, s) for (f, l, _lo, p, s) in params]
+
+
+def noise(n, seed):
+    rng = np.random.default_rng(seed)
+    x = np.empty(n, np.complex64)
+    x.real = rng.standard_normal(n, dtype=np.float32)
+    x.imag = rng.standard_normal(n, dtype=np.float32)
+    return x
+
+
+def bits(a):
+    return a.view(np.uint32)
+
+
+def run(N, R, plan, x, nb, sub=None):
+    if sub is not None:
+        os.environ["FDC_HOST_SUB"] = str(sub)
+    try:
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+        assert p.path() == 2
+        return p.work(x)
+    finally:
+        os.environ.pop("FDC_HOST_SUB", None)
+
+
+@pytest.mark.parametrize("N,C,nb", [(65536, 256, 1024), (262144, 1024, 256)])
+def test_full_size_batch_vs_oracle_and_launch_grouping(oracle, N, C, nb):
+    R = 2
+    H = N - N // R
+    plan = plan_for(N, R, C)
+    x = noise(nb * H, N)
+    outs = run(N, R, plan, x, nb)                      # sub-batches of ~8 MiB, overlapped transfers
+    whole = run(N, R, plan, x, nb, sub=nb)             # one launch group for the whole batch
+    for c in range(C):
+        assert np.array_equal(bits(outs[c]), bits(whole[c])), "launch grouping changed channel %d" % c
+    ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=min(16, os.cpu_count() or 1))
+    worst_l2 = worst_mx = 0.0
+    for c in range(C):
+        d = outs[c].astype(np.complex128) - ref[c].astype(np.complex128)
+        worst_l2 = max(worst_l2, float(np.linalg.norm(d) / np.linalg.norm(ref[c])))
+        worst_mx = max(worst_mx, float(np.abs(d).max() / np.abs(ref[c]).max()))
+    assert worst_l2 <= TOL and worst_mx <= TOL, (worst_l2, worst_mx)
+
+
+def test_full_size_linearity_and_block_shift():
+    N, R, C, nb = 65536, 2, 256, 1024
+    H = N - N // R
+    plan = plan_for(N, R, C)
+    x1, x2 = noise(nb * H, 1), noise(nb * H, 2)
+    y1, y2, y12 = run(N, R, plan, x1, nb), run(N, R, plan, x2, nb), run(N, R, plan, x1 + x2, nb)
+    for c in range(0, C, 5):
+        s = y1[c].astype(np.complex128) + y2[c].astype(np.complex128)
+        d = y12[c].astype(np.complex128) - s
+        assert np.linalg.norm(d) <= TOL * np.linalg.norm(s) and np.abs(d).max() <= TOL * np.abs(s).max()
+    # drop the first block of the stream: every later block is the same block one index earlier (all f are multiples
+    # of R, so the window phase does not depend on the index); only the new first block sees a different history
+    ys = run(N, R, plan, x1[H:], nb - 1)
+    lout = 128
+    for c in range(C):
+        assert np.array_equal(bits(ys[c][lout:]), bits(y1[c][2 * lout:])), "block shift changed channel %d" % c
+
+
+def test_full_size_tone_gain_and_phase_continuity():
+    N, R, C, nb = 65536, 2, 256, 1024
+    H = N - N // R
+    plan = plan_for(N, R, C)
+    c0 = 77
+    k_shifted = 256 * c0 + 128 + 9                      # a bin inside channel c0's pass band (centre + 9)
+    k = (k_shifted - N // 2) % N                        # unshifted DFT bin
+    n = np.arange(nb * H + N // R, dtype=np.int64)      # the stream including the zero-history region's successor
+    ph = (k * n) % N
+    tone = np.exp(2j * np.pi * ph / N).astype(np.complex64)
+    y = run(N, R, plan, tone[N // R:], nb)              # history is zeros: the first block is a partial tone
+    lout = 128
+    z = y[c0][lout:].astype(np.complex128)              # from the second block on, every block holds the full tone
+    assert np.abs(np.abs(z) - 1.0).max() < 1e-4         # net gain exactly 1 in the pass band
+    step = z[1:] * np.conj(z[:-1])
+    expect = np.exp(2j * np.pi * 9 / 256)               # decimated tone: 9 bins off the channel centre, l = 256
+    assert np.abs(step - expect).max() < 2e-4           # same phase step inside blocks and across all 1022 boundaries
+    others = max(float(np.abs(y[c][lout:]).max()) for c in range(C) if c != c0)
+    assert others < 1e-4
