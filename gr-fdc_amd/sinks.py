@@ -71,6 +71,10 @@ class Sinks:
                              vectorend=p.vectorend), data))
         return out
 
+    def pdus(self):
+        """PDUs of the last work call (also of a fdc_pipeline_work_sinks call that fed this bank) as (meta, samples)."""
+        return self._collect()
+
     def work(self, spectrum):
         spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64)
         if spectrum.size % self.N:

@@ -99,3 +99,83 @@ def test_full_size_tone_gain_and_phase_continuity():
     assert np.abs(step - expect).max() < 2e-4           # same phase step inside blocks and across all 1022 boundaries
     others = max(float(np.abs(y[c][lout:]).max()) for c in range(C) if c != c0)
     assert others < 1e-4
+
+
+# ---------------------------------------------------------------- cfg3 / cfg5 at full size
+from test_sinks_gpu import compare  # noqa: E402  (same PDU comparison as the small cases)
+
+
+def bursty_stream(N, R, nb, carriers, seed, tone_amp, seg_blocks=8, floor=0.016):
+    """carriers: (first_even_bin, last_even_bin) in UNSHIFTED N-point bins.  Every carrier is a set of tones on even
+    bins (periodic in H = N/2, so a segment of seg_blocks blocks is one IFFT tiled) with fixed random phases, keyed on
+    and off per segment: phase-continuous.  Levels follow SURVEY.md section 8d (a carrier about 30 dB above the white floor in
+    its own band): with a far larger on/off ratio the payloads that hold only floor or the splatter of a switching
+    neighbour sit below what a float32 forward transform of the whole band resolves to 1e-5 of THEIR level."""
+    H = N - N // R
+    assert R == 2
+    g = np.random.default_rng(seed)
+    nseg = nb // seg_blocks
+    phases = [np.exp(2j * np.pi * g.random((hi - lo) // 2 + 1)) for lo, hi in carriers]
+    on = g.integers(0, 2, size=(len(carriers), nseg)).astype(bool)
+    on[:, 0] = False                                      # the stream starts idle
+    x = np.empty(nb * H, np.complex64)
+    for s in range(nseg):
+        S = np.zeros(H, np.complex128)
+        for k, (lo, hi) in enumerate(carriers):
+            if on[k, s]:
+                b = (np.arange(lo, hi + 1, 2) // 2) % H
+                S[b] = phases[k] * tone_amp
+        seg = np.fft.ifft(S) * H
+        x[s * seg_blocks * H:(s + 1) * seg_blocks * H] = np.tile(seg, seg_blocks).astype(np.complex64)
+    x += floor * noise(nb * H, seed + 1)
+    return x, on
+
+
+def test_cfg3_full_size_256_power_activation_channels(oracle):
+    N, R, C, nb = 65536, 2, 256, 1024
+    pac = [(((c + 0.5) / C) % 1.0, 0.8 / C, c) for c in range(C)]
+    carriers = []
+    for c in range(C):                                    # a 40-bin multitone at the centre of every channel
+        k = (256 * c + 128 - N // 2) % N
+        carriers.append((k - 20, k + 20))
+    x, on = bursty_stream(N, R, nb, carriers, 2026, tone_amp=8.7e-3)      # 21 tones: 30 dB over the in-band floor
+    p = G.Pipeline(N, R, [], windowtype=1, max_blocks=nb, keep_spectrum=True)
+    bank = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=nb)
+    p.work(x, sinks=bank)
+    got = bank.pdus()
+    _, spec = oracle.channelizer(N, R, 1, [], x, want_spectrum=True, nthreads=min(16, os.cpu_count() or 1))
+    spec = spec.reshape(nb, N)
+    total = 0
+    for c in range(0, C):
+        ref = oracle.PowerActivationChannel(N, pac[c][0], pac[c][1], R, 6.0, 128, 1, c).work(spec)
+        mine = [g for g in got if g[0]["source"] == c]
+        compare(mine, ref, vec=False)
+        total += len(ref)
+    assert total == len(got) and total > C                # every channel was active at least once on average
+
+
+def test_cfg5_full_size_activity_detection(oracle):
+    N, R, nb = 65536, 2, 1024
+    segs = [[0.05, 0.45], [0.55, 0.95]]
+    g = np.random.default_rng(2028)
+    carriers = []
+    for s0, s1 in segs:                                   # 12 carriers per segment, widths 0.002-0.03, non-overlapping
+        pos = s0 + 0.01
+        while pos < s1 - 0.04 and len(carriers) < 12 * (1 + segs.index([s0, s1])):
+            w = float(g.uniform(0.002, 0.03))
+            lo, hi = int(pos * N), int((pos + w) * N)
+            lo_u, hi_u = (lo - N // 2) % N, (hi - N // 2) % N
+            if lo_u < hi_u:
+                carriers.append((lo_u + (lo_u & 1), hi_u - (hi_u & 1)))
+            pos += w + float(g.uniform(0.01, 0.02))
+    x, on = bursty_stream(N, R, nb, carriers, 2029, tone_amp=4e-3)        # density 30 dB over the floor
+    p = G.Pipeline(N, R, [], windowtype=1, max_blocks=nb, keep_spectrum=True)
+    det = G.Sinks(N, R, segments=[tuple(s) for s in segs], det_thresh=10.0, det_maxblocks=128, minchandist=0.005,
+                  det_delay=1, puffer=0.2, max_blocks=nb)
+    assert det.segment_params(0)["dec"] == 163           # SURVEY.md §8d cfg5
+    p.work(x, sinks=det)
+    got = det.pdus()
+    _, spec = oracle.channelizer(N, R, 1, [], x, want_spectrum=True, nthreads=min(16, os.cpu_count() or 1))
+    ref = oracle.ActivityDetectionVcm(N, segs, 10.0, R, 128, 0.005, 1, 0.2).work(spec.reshape(nb, N))
+    assert len(ref) > 50
+    compare(got, ref)
