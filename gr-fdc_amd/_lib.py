@@ -84,6 +84,8 @@ SYMBOLS = {
     "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),
     "fdc_sinks_spectrum": (_vp, [_vp]),
     "fdc_sinks_stream": (_vp, [_vp]),
+    "fdc_sinks_blocklen": (C.c_int32, [_vp]),
+    "fdc_sinks_max_blocks": (C.c_int32, [_vp]),
     "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),
     "fdc_sinks_pdu_count": (C.c_int, [_vp]),
     "fdc_sinks_pdu": (C.c_int, [_vp, C.c_int, C.POINTER(fdc_pdu)]),

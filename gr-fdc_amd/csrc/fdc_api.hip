@@ -796,6 +796,9 @@ int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *
                             fdc_sinks *sinks)
 {
     if (!sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null sinks handle");
+    if (p && (fdc_sinks_blocklen(sinks) != p->N || nblocks > fdc_sinks_max_blocks(sinks)))
+        return fail(FDC_ERR_INVALID_ARGUMENT, "sinks were created for blocklen %d / %d blocks per call, pipeline call has %d / %d",
+                    fdc_sinks_blocklen(sinks), fdc_sinks_max_blocks(sinks), p->N, nblocks);
     // the spectrum goes straight into the sinks' device buffer (no PCIe round trip), then the sinks run on it
     int rc = pipeline_work_impl(p, in, nblocks, outs, spectrum, static_cast<float2 *>(fdc_sinks_spectrum(sinks)));
     if (rc < 0) return rc;
@@ -813,6 +816,9 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
     if (nblocks == 0) return 0;
     if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
     if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    if (sinks && (fdc_sinks_blocklen(sinks) != p->N || nblocks > fdc_sinks_max_blocks(sinks)))
+        return fail(FDC_ERR_INVALID_ARGUMENT, "sinks were created for blocklen %d / %d blocks per call, pipeline call has %d / %d",
+                    fdc_sinks_blocklen(sinks), fdc_sinks_max_blocks(sinks), p->N, nblocks);
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = p->stream;
     float2 *d_full = sinks ? static_cast<float2 *>(fdc_sinks_spectrum(sinks)) : nullptr, *d_owned = nullptr;

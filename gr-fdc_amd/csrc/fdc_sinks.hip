@@ -467,6 +467,8 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
 
 void *fdc_sinks_spectrum(fdc_sinks *s) { return s ? (void *)(s->d_spec + s->N) : nullptr; }
 void *fdc_sinks_stream(fdc_sinks *s) { return s ? (void *)s->stream : nullptr; }
+int32_t fdc_sinks_blocklen(const fdc_sinks *s) { return s ? s->N : -1; }
+int32_t fdc_sinks_max_blocks(const fdc_sinks *s) { return s ? s->cfg.max_blocks : -1; }
 
 int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v)
 {

@@ -187,6 +187,8 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems);
  * nblocks spectra there on a stream it has synchronised; no PCIe traffic for the spectrum */
 void *fdc_sinks_spectrum(fdc_sinks *s);
 void *fdc_sinks_stream(fdc_sinks *s);
+int32_t fdc_sinks_blocklen(const fdc_sinks *s);     /* N the bank was created for                                  */
+int32_t fdc_sinks_max_blocks(const fdc_sinks *s);   /* capacity of its device-resident spectrum buffer, in blocks   */
 int fdc_sinks_work_device(fdc_sinks *s, int nblocks);
 /* PDUs emitted by the last work call, in emission order */
 int fdc_sinks_pdu_count(const fdc_sinks *s);

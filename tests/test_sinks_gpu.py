@@ -219,3 +219,18 @@ def test_sinks_wider_than_one_workgroup_transform(oracle):
     assert len(rp) >= 1 and len(rd) >= 1 and max(r["samples"].size for r in rd) >= 8192 * 3
     compare([g for g in got if g[0]["kind"] == rp[0]["kind"]], rp, vec=False)
     compare([g for g in got if g[0]["kind"] != rp[0]["kind"]], rd)
+
+
+def test_pipeline_refuses_sinks_of_other_size():
+    """fdc_pipeline_work_sinks writes the spectrum into the sinks' device buffer: a bank made for fewer blocks per call or
+    another block length is refused before anything is written."""
+    N, R = 1024, 2
+    H = N - N // R
+    p = G.Pipeline(N, R, [], max_blocks=8, keep_spectrum=True)
+    small = G.Sinks(N, R, pac=[(0.5, 0.05, 0)], pac_thresh=6.0, pac_maxblocks=-1, max_blocks=4)
+    other = G.Sinks(2 * N, R, pac=[(0.5, 0.05, 0)], pac_thresh=6.0, pac_maxblocks=-1, max_blocks=8)
+    x = np.zeros(8 * H, np.complex64)
+    for bank in (small, other):
+        with pytest.raises(G.FdcError):
+            p.work(x, sinks=bank)
+    p.work(x[:4 * H], sinks=small)          # within capacity: fine
