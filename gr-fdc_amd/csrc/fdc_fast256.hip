@@ -213,18 +213,21 @@ __global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec
 // overlap discard, and stores G[t'][n1]; stage 2 (k_p2) is pass B on G: FFT over n1, result index = channel slot.
 // Exact algebra (SURVEY.md App. A.2-A.4 substituted into each other); rounding differs from the 3-kernel
 // path at the 1e-7 level.
-// Persistent: each workgroup (TC*16 threads, one column of 16 points per thread and layer) loops over tiles
-// (tile = block*N1/TC + column tile) and issues the NEXT tile's 16 global loads before it starts computing the
-// current one (register double buffer), so HBM latency hides under the four DFT-16 layers and two LDS
-// exchanges of the current tile.  TC = 32: 512 threads, 2 workgroups/CU; TC = 16: 256 threads, 4 workgroups/CU.
+// Persistent: each workgroup (TC*16 threads, one column of 16 points per thread and layer) owns ONE column tile and a run
+// of CONSECUTIVE blocks, and issues the next block's global loads before it starts computing the current one (register
+// double buffer), so HBM latency hides under the four DFT-16 layers and two LDS exchanges of the current tile.
+// Consecutive blocks overlap by N/R samples = 16*KEEP rows of the tile: with KEEP > 0 (= 16/R, the launcher picks it
+// when items are exactly N - N/R apart) those rows are handed over in registers — row 16a+b of the next block IS row
+// 16(a + 16 - KEEP) + b of this one — and only 16 - KEEP rows per thread are loaded (R = 2: half the input reads;
+// measured 0.144 -> 0.129 ms per 1024 blocks).  TC = 32: 512 threads, 2 workgroups/CU; TC = 16: 256 threads, 4/CU.
 // ABL (diagnostic builds only, FDC_ABLATE env): 0 = real kernel, 1 = memory only (loads -> stores, no math, no LDS),
 // 2 = math + LDS only (one load per thread, data kept live), results are garbage for ABL != 0.
-template <int TC, int ABL>
+template <int TC, int ABL, int KEEP>
 __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in, size_t in_stride,
                                                    float2 *__restrict__ g, const float2 *__restrict__ tw256,
                                                    const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
-                                                   const float *__restrict__ shn, int N1, int log2ct, int ntiles,
-                                                   int qskip, int lout, int stagger)
+                                                   const float *__restrict__ shn, int N1, int log2ct, int nb, int bpg,
+                                                   int qskip, int lout)
 {
     constexpr int NT = TC * 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [256][TC]
@@ -232,25 +235,15 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8 + 2048);        // [q][col]
     float *sh = reinterpret_cast<float *>(fdc_smem_fast + 256 * TC * 8 + 2048 + TC * 128);   // [k2]
     const int tid = threadIdx.x, col = tid & (TC - 1), b = tid / TC;
-    int tl = blockIdx.x;
-    if (tl >= ntiles) return;
-    if (stagger > 0) {
-        // Co-resident workgroups run the same program from the same start and stay in lock-step (all in their LDS
-        // phases together, then all in their VALU phases).  Delay each by a different fraction of a tile time, once.
-        // Which of the CU's LDS slots this workgroup got tells the co-resident ones apart (HW_REG_LDS_ALLOC).
-        const unsigned la = __builtin_amdgcn_s_getreg(6 | (31 << 11));
-        const unsigned base = la & 0xff, size = (la >> 12) & 0x1ff;
-        const unsigned k = size ? (base / (size ? size : 1)) & 3 : 0;
-        for (unsigned i = 0; i < k; i++)
-            for (int j = 0; j < stagger; j++) __builtin_amdgcn_s_sleep(16);
-    }
-    // The launcher keeps gridDim.x a multiple of the column tiles per block, so this workgroup always works on
-    // the same TC columns n1 = c0..c0+TC-1.  The factor the spectrum column is multiplied by,
+    // this workgroup: column tile (blockIdx mod ct) and runs of bpg consecutive blocks, run r = group, group + ngroups, ...
+    const int c0 = (blockIdx.x & ((1 << log2ct) - 1)) * TC;
+    const int grp = blockIdx.x >> log2ct, ngrp = gridDim.x >> log2ct;
+    if (grp * bpg >= nb) return;
+    // The factor the spectrum column is multiplied by,
     //   shape[k2]/N * (-1)^n1 * W_N^(n1*k2),  k2 = b + 16q,
     // is split into  shape[k2]/N (LDS, wave-uniform)  *  W_N^(16*n1*q) (LDS, TCx16 entries for this column tile)
     // *  (-1)^n1 W_N^(n1*b) (one register pair per thread, applied AFTER the first inverse DFT-16, which is
     // linear in it) — three short tables instead of a 64-register slice of the full N-entry table.
-    const int c0 = (tl & ((1 << log2ct) - 1)) * TC;
     for (int i = tid; i < 256; i += NT) { w256[i] = tw256[i]; sh[i] = shn[i]; }
     tq[tid] = twq[(size_t)(c0 + col) * 16 + b];            // b plays q here: tq[q*TC + col]
     const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
@@ -261,21 +254,20 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     const unsigned gtile = (unsigned)lout * TC * 8u;           // bytes of one (block, column tile) piece of G
     const unsigned goff = (unsigned)(b * TC + col) * 8u;       // row b of a 16-row group, column col
     const unsigned gstep = 16u * TC * 8u;                      // 16 rows further
-    // One tile: consume `cur` (loaded earlier), prefetch the next tile into `nbuf`.  Called with the two buffers
-    // swapped on alternate iterations (ping-pong), so no register copies are needed.
-    auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int t0, int nxt) {
-        const size_t m = t0 >> log2ct;
-        if (nxt < ntiles) {                                     // prefetch the next tile
-            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(nxt >> log2ct) * in_stride, inbytes);
+    // One tile: consume `cur` (block m), prefetch block mn (the next block of the run: overlap handed over in registers;
+    // or the first block of this workgroup's next run: all rows loaded; or none, mn < 0) into `nbuf`.
+    auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int m, int mn) {
+        if (mn >= 0) {
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mn * in_stride, inbytes);
             if (ABL == 2) {
                 nbuf[0] = bld2(rin, voff, 0);
 #pragma unroll
                 for (int a = 1; a < 16; a++) nbuf[a] = nbuf[0] * (float)a;
-            } else if (ABL == 3) {           // what-if: only the NEW half of the rows is loaded (overlap kept on chip)
+            } else if (KEEP > 0 && mn == m + 1) {
 #pragma unroll
-                for (int a = 8; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+                for (int a = 0; a < KEEP; a++) nbuf[a] = cur[a + 16 - KEEP];       // the overlap, already on chip
 #pragma unroll
-                for (int a = 0; a < 8; a++) nbuf[a] = cur[a + 8];
+                for (int a = KEEP; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
             } else {
 #pragma unroll
                 for (int a = 0; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
@@ -283,8 +275,8 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         }
         // G is stored tile-major, G[m][column tile][t'][TC]: this workgroup's whole output (lout*TC points) is
         // one contiguous run, and stage 2 reads it back in runs of TC rows x TC columns.
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + (m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
-        if (ABL == 1 || ABL == 3) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + ((size_t)m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
+        if (ABL == 1) {
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, cur[q]);
@@ -328,18 +320,19 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     };
     cf L[16];
     {
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(tl >> log2ct) * in_stride, inbytes);
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(grp * bpg) * in_stride, inbytes);
 #pragma unroll
         for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
     }
-    const int step = gridDim.x;
-    for (;;) {
-        cf cur[16];
+    for (int run = grp; run * bpg < nb; run += ngrp) {
+        const int m0 = run * bpg, m1 = m0 + bpg < nb ? m0 + bpg : nb;
+        const int nextrun = (run + ngrp) * bpg < nb ? (run + ngrp) * bpg : -1;
+        for (int m = m0; m < m1; m++) {
+            cf cur[16];
 #pragma unroll
-        for (int a = 0; a < 16; a++) cur[a] = L[a];
-        do_tile(cur, L, tl, tl + step);
-        tl += step;
-        if (tl >= ntiles) break;
+            for (int a = 0; a < 16; a++) cur[a] = L[a];
+            do_tile(cur, L, m, m + 1 < m1 ? m + 1 : nextrun);
+        }
     }
 }
 
@@ -628,11 +621,12 @@ hipError_t init_fast_kernels()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_b256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
-#define FDC_SETP1(T, A) \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1<T, A>), hipFuncAttributeMaxDynamicSharedMemorySize, a); \
+#define FDC_SETP1(T, A, K) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1<T, A, K>), hipFuncAttributeMaxDynamicSharedMemorySize, a); \
     if (e != hipSuccess) return e;
-    FDC_SETP1(32, 0) FDC_SETP1(16, 0) FDC_SETP1(16, 1) FDC_SETP1(16, 2) FDC_SETP1(32, 1) FDC_SETP1(32, 2)
-    FDC_SETP1(16, 3) FDC_SETP1(32, 3)
+    FDC_SETP1(32, 0, 0) FDC_SETP1(16, 0, 0) FDC_SETP1(16, 1, 0) FDC_SETP1(16, 2, 0) FDC_SETP1(32, 1, 0) FDC_SETP1(32, 2, 0)
+    FDC_SETP1(16, 0, 8) FDC_SETP1(16, 0, 4) FDC_SETP1(16, 0, 2) FDC_SETP1(16, 0, 1)
+    FDC_SETP1(32, 0, 8) FDC_SETP1(32, 0, 4) FDC_SETP1(32, 0, 2) FDC_SETP1(32, 0, 1)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) return e;
 #undef FDC_SETP1
@@ -718,17 +712,27 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     while ((1 << log2ct) < ct) log2ct++;
     const int maxwg = TC == 32 ? 2 : 4;                     // resident workgroups per CU: LDS-limited
     int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
-    slots -= slots % ct;                                    // k_p1 keeps a fixed column tile per workgroup
-    const long long nt1 = (long long)nb_chunk * ct;
-    const unsigned g1 = (unsigned)(nt1 < slots ? nt1 : slots);
+    slots -= slots % ct;
+    if (slots < ct) slots = ct;
+    // every workgroup keeps one column tile and takes runs of bpg consecutive blocks (FDC_POLY_BPG: run length, A/B testing)
+    static int bpg_cfg = -1;
+    if (bpg_cfg < 0) { const char *t = getenv("FDC_POLY_BPG"); bpg_cfg = t ? atoi(t) : 0; }
+    int groups = slots / ct;
+    if (groups > nb_chunk) groups = nb_chunk;
+    int bpg = (nb_chunk + groups - 1) / groups;
+    if (bpg_cfg > 0 && bpg_cfg < bpg) bpg = bpg_cfg;
+    const int runs = (nb_chunk + bpg - 1) / bpg;
+    if (groups > runs) groups = runs;
+    const unsigned g1 = (unsigned)(groups * ct);
     const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024;
-    static int abl = -1, stg = 0, twog = 0;
+    static int abl = -1, twog = 0, noreuse = 0;
     if (abl < 0) {
         const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
-        const char *g2 = getenv("FDC_STAGGER"); stg = g2 ? atoi(g2) : 0;
         const char *g3 = getenv("FDC_POLY_2GROUP"); twog = g3 ? atoi(g3) : 0;
+        const char *g4 = getenv("FDC_POLY_NOREUSE"); noreuse = g4 ? atoi(g4) : 0;
     }
-    if (twog && TC == 16 && abl == 0) {                     // two phase-shifted groups per 512-thread workgroup
+    if (twog && TC == 16 && abl == 0 && N1 == 256) {        // two phase-shifted groups per 512-thread workgroup
+        const long long nt1 = (long long)nb_chunk * ct;
         int wgs = (wg_per_cu > 0 && wg_per_cu < 4 ? (wg_per_cu + 1) / 2 : 2) * cu_count();
         wgs -= wgs % (ct / 2 > 0 ? ct / 2 : 1);              // 2*grid must be a multiple of ct
         const long long need = (nt1 + 1) / 2;
@@ -737,11 +741,17 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
                            twq, cbt, shn, N1, log2ct, (int)nt1, skip / 16, lout);
         return hipGetLastError();
     }
-#define FDC_LP1(T, A) \
-    hipLaunchKernelGGL((k_p1<T, A>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
-                       (int)nt1, skip / 16, lout, stg)
-    if (TC == 32) { if (abl == 1) FDC_LP1(32, 1); else if (abl == 2) FDC_LP1(32, 2); else if (abl == 3) FDC_LP1(32, 3); else FDC_LP1(32, 0); }
-    else { if (abl == 1) FDC_LP1(16, 1); else if (abl == 2) FDC_LP1(16, 2); else if (abl == 3) FDC_LP1(16, 3); else FDC_LP1(16, 0); }
+    // the overlap of consecutive blocks travels in registers when the items are exactly N - N/R apart
+    const bool reuse = !noreuse && abl == 0 && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
+#define FDC_LP1(T, A, K) \
+    hipLaunchKernelGGL((k_p1<T, A, K>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
+                       nb_chunk, bpg, skip / 16, lout)
+#define FDC_LP1K(T) \
+    do { if (!reuse) FDC_LP1(T, 0, 0); else if (R == 2) FDC_LP1(T, 0, 8); else if (R == 4) FDC_LP1(T, 0, 4); \
+         else if (R == 8) FDC_LP1(T, 0, 2); else FDC_LP1(T, 0, 1); } while (0)
+    if (TC == 32) { if (abl == 1) FDC_LP1(32, 1, 0); else if (abl == 2) FDC_LP1(32, 2, 0); else FDC_LP1K(32); }
+    else { if (abl == 1) FDC_LP1(16, 1, 0); else if (abl == 2) FDC_LP1(16, 2, 0); else FDC_LP1K(16); }
+#undef FDC_LP1K
 #undef FDC_LP1
     return hipGetLastError();
 }
