@@ -231,9 +231,11 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
 {
     constexpr int NT = TC * 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [256][TC]
-    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8);
-    float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8 + 2048);        // [q][col]
-    float *sh = reinterpret_cast<float *>(fdc_smem_fast + 256 * TC * 8 + 2048 + TC * 128);   // [k2]
+    // tables, laid out so that a thread reads ITS 16 entries as 16-byte pairs (half the LDS instructions of 8-byte reads);
+    // rows padded to 18 entries (144 B): the rows a wave touches then start in different bank groups
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8);             // [b][p] = W256^(b p), 16 x 18
+    float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 256 * TC * 8 + 2304);       // [col][q], TC x 18
+    float *sh = reinterpret_cast<float *>(fdc_smem_fast + 256 * TC * 8 + 2304 + TC * 144);   // [b][q] = shape[b + 16 q] / N
     const int tid = threadIdx.x, col = tid & (TC - 1), b = tid / TC;
     // this workgroup: column tile (blockIdx mod ct) and runs of bpg consecutive blocks, run r = group, group + ngroups, ...
     const int c0 = (blockIdx.x & ((1 << log2ct) - 1)) * TC;
@@ -244,8 +246,11 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     // is split into  shape[k2]/N (LDS, wave-uniform)  *  W_N^(16*n1*q) (LDS, TCx16 entries for this column tile)
     // *  (-1)^n1 W_N^(n1*b) (one register pair per thread, applied AFTER the first inverse DFT-16, which is
     // linear in it) — three short tables instead of a 64-register slice of the full N-entry table.
-    for (int i = tid; i < 256; i += NT) { w256[i] = tw256[i]; sh[i] = shn[i]; }
-    tq[tid] = twq[(size_t)(c0 + col) * 16 + b];            // b plays q here: tq[q*TC + col]
+    for (int i = tid; i < 256; i += NT) {
+        wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
+        sh[i] = shn[(i >> 4) + 16 * (i & 15)];
+    }
+    tq[col * 18 + b] = twq[(size_t)(c0 + col) * 16 + b];    // b plays q here
     const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
     // per-lane byte offset inside a block (row b, column c0+col); rows 16a+b add a*16*N1*8 bytes (scalar)
     const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u;
@@ -288,7 +293,10 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         // for the write in front of it, once per element
         cf w[16];
 #pragma unroll
-        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&wrow[b * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
 #pragma unroll
         for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], cmul(cur[rev16(p)], w[p]));
         __syncthreads();
@@ -300,10 +308,20 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         // holds exactly the inputs of ITS first inverse DFT-16 (fixed low digit b, all high digits q).
         cf u[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b + 16 * q];
+        for (int i = 0; i < 4; i++) {
+            const float4 t0 = ld4(&tq[col * 18 + 4 * i]), t1 = ld4(&tq[col * 18 + 4 * i + 2]);
+            const float4 sv = *reinterpret_cast<const float4 *>(&sh[b * 16 + 4 * i]);
+            u[(4 * i) ^ 8] = cmul(v[rev16(4 * i)], mk(t0.x, t0.y)) * sv.x;
+            u[(4 * i + 1) ^ 8] = cmul(v[rev16(4 * i + 1)], mk(t0.z, t0.w)) * sv.y;
+            u[(4 * i + 2) ^ 8] = cmul(v[rev16(4 * i + 2)], mk(t1.x, t1.y)) * sv.z;
+            u[(4 * i + 3) ^ 8] = cmul(v[rev16(4 * i + 3)], mk(t1.z, t1.w)) * sv.w;
+        }
         dft16<true>(u);
 #pragma unroll
-        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&wrow[b * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
 #pragma unroll
         for (int p = 0; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], w[p]), cb);
         __syncthreads();                                // every thread has finished reading the first exchange
@@ -724,7 +742,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     const int runs = (nb_chunk + bpg - 1) / bpg;
     if (groups > runs) groups = runs;
     const unsigned g1 = (unsigned)(groups * ct);
-    const size_t lds1 = 256 * TC * 8 + 2048 + TC * 128 + 1024;
+    const size_t lds1 = 256 * TC * 8 + 2304 + TC * 144 + 1024;
     static int abl = -1, twog = 0, noreuse = 0;
     if (abl < 0) {
         const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
