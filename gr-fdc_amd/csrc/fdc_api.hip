@@ -125,6 +125,9 @@ struct fdc_pipeline {
     bool poly_overlap = false;                   // FDC_POLY_OVERLAP=1: measured slower on MI355X (profiles/r01/NOTES.md)
     bool last_was_poly = false;
     bool poly_fused = false;                     // FDC_POLY_FUSED=1: XCD-local dataflow, G through L2 (fdc_fused256.hip)
+    bool poly_merged = false;                    // FDC_POLY_MERGED=1: both stages in one persistent launch (fdc_merged256.hip)
+    int merged_hints = 3, ncu = 0;
+    int *d_done = nullptr, *d_err = nullptr;
     int fused_ring = 8, fused_wg1 = 3;           // G ring per XCD in blocks (8 x 256 KiB = 2 MiB of the 4-MiB L2); stage-1 WGs/CU
     float2 *d_gring = nullptr;
     void *d_ctl = nullptr;
@@ -209,7 +212,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
     for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl);
+    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl); (void)hipFree(p->d_done);
     for (auto e : p->events) (void)hipEventDestroy(e);
     for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) {
@@ -310,6 +313,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (ov) p->poly_overlap = ov[0] != '0';
         const char *fu = getenv("FDC_POLY_FUSED"), *fw = getenv("FDC_FUSED_WG1"), *fr = getenv("FDC_FUSED_RING");
         if (fu) p->poly_fused = fu[0] != '0' && N == 65536;
+        const char *me = getenv("FDC_POLY_MERGED"), *mh = getenv("FDC_MERGED_HINTS");
+        if (me) p->poly_merged = me[0] != '0' && N == 65536;
+        if (mh) p->merged_hints = atoi(mh) & 127;
         if (fw && atoi(fw) >= 1 && atoi(fw) <= 3) p->fused_wg1 = atoi(fw);
         if (fr && atoi(fr) >= 2) p->fused_ring = atoi(fr);
         if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
@@ -406,6 +412,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
         CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
         CHK_OR_FREE(hipMalloc(&p->d_g[1], gsz));
+        if (p->poly_merged) {
+            hipDeviceProp_t prop;
+            CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
+            p->ncu = prop.multiProcessorCount;
+            if (p->ncu % 32) p->poly_merged = false;          // needs whole 16-workgroup groups per XCD at 4 per CU
+            else {
+                CHK_OR_FREE(hipMalloc(&p->d_done, sizeof(int) * ((size_t)chunk + 4)));
+                p->d_err = p->d_done + chunk;
+                CHK_OR_FREE(hipMemset(p->d_err, 0, 4 * sizeof(int)));
+            }
+        }
         if (p->poly_fused) {
             CHK_OR_FREE(hipMalloc(&p->d_gring, fdc::fused_ring_bytes(R, p->fused_ring)));
             CHK_OR_FREE(hipMalloc(&p->d_ctl, fdc::fused_ctl_bytes(chunk)));
@@ -457,6 +474,13 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
         unsigned err = 0;
         HIPCHK(hipMemcpy(&err, static_cast<char *>(p->d_ctl) + fdc::kFusedErrorOffset, sizeof err, hipMemcpyDeviceToHost));
         if (err) return fail(FDC_ERR_HIP, "XCD-local dataflow: dependency wait timed out (code %u)", err);
+    }
+    if (p->d_err) {                                   // merged uniform kernel: a hand-off wait timed out
+        int errw[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(errw, p->d_err, sizeof errw, hipMemcpyDeviceToHost));
+        if (p->merged_hints & 64) std::fprintf(stderr, "[fdc merged] short polls %d over %d waits\n", errw[1], errw[2]);
+        const int err = errw[0];
+        if (err) return fail(FDC_ERR_HIP, "merged uniform kernel: hand-off wait timed out; results of this handle are invalid");
     }
     return FDC_OK;
 }
@@ -535,6 +559,18 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl, p->fused_ring,
                                           p->fused_wg1, s, p->stream2, p->ev_fork, p->ev_s2[0], evp4));
             if (p->timing) p->ev_spans.push_back(span);
+            continue;
+        }
+        if (use_poly && p->poly_merged) {
+            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            HIPCHK(fdc::launch_poly_merged(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[0], static_cast<float2 *>(d_out), p->R, nb,
+                                           m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
+                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_done, p->d_err, p->ncu,
+                                           p->merged_hints, s));
+            if (p->timing) {
+                for (int i = 1; i < 4; i++) HIPCHK(hipEventRecord(p->events[span[i]], s));
+                p->ev_spans.push_back(span);
+            }
             continue;
         }
         if (use_poly) {

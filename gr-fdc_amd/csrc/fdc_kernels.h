@@ -89,6 +89,12 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 102
 // uniform plan as an XCD-local dataflow (fdc_fused256.hip): stage 1 (3 workgroups/CU, stream s1) and stage 2
 // (1 workgroup/CU, stream s2) run concurrently; every block is owned by one XCD and its G stays in that XCD's L2
 hipError_t init_fused_kernels();
+hipError_t init_merged_kernels();
+// uniform path, both stages in one persistent launch (fdc_merged256.hip); N = 65536 only.  hints: 1 = nt input loads, 2 = nt output stores
+hipError_t launch_poly_merged(const float2 *in, size_t in_stride, float2 *g, float2 *out, int R, int nb_chunk, int mbase,
+                              int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
+                              const long long *slot_off, unsigned out_bytes, int *done, int *err, int ncu, int hints,
+                              hipStream_t s);
 size_t fused_ctl_bytes(int nb);
 size_t fused_ring_bytes(int R, int ringx);
 constexpr int kFusedErrorOffset = 1024;      // byte offset of the error word inside the control block
