@@ -89,6 +89,7 @@ SYMBOLS = {
     "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),
     "fdc_sinks_pdu_count": (C.c_int, [_vp]),
     "fdc_sinks_pdu": (C.c_int, [_vp, C.c_int, C.POINTER(fdc_pdu)]),
+    "fdc_sinks_pdus": (C.c_int, [_vp, C.POINTER(fdc_pdu), C.c_int]),
     "fdc_sinks_pac_params": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32)]),
     "fdc_sinks_segment_params": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32)]),
     "fdc_overlap_save_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

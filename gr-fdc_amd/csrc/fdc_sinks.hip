@@ -523,6 +523,19 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         s->blockcount++;
     }
     lap("decisions (host)");
+    // Landing layout: the blocks of every PDU emitted in this call sit one behind the other (PDU order, block order),
+    // so a PDU whose blocks all come from this call needs no assembly — its payload IS a run of the landing buffer;
+    // blocks that stay buffered in live channels follow.
+    {
+        std::vector<int64_t> noff(s->tasks.size(), -1);
+        int64_t pos = 0;
+        for (auto &r : s->pdus)
+            for (auto &b : r.blocks)
+                if (b.task >= 0) { noff[(size_t)b.task] = pos; pos += r.blocklen; }
+        for (size_t i = 0; i < s->tasks.size(); i++)
+            if (noff[i] < 0) { noff[i] = pos; pos += s->task_w[i] - s->task_skip[i]; }
+        for (size_t i = 0; i < s->tasks.size(); i++) s->tasks[i].out_off = noff[i];
+    }
     // phase 3: extractions, one launch per width class
     const size_t nt = s->tasks.size();
     if (nt) {
@@ -584,14 +597,21 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         }
     };
     for (auto &r : s->pdus) {
-        r.payload.reserve(r.blocks.size() * (size_t)r.blocklen);
-        for (auto &b : r.blocks) {          // straight from the landing buffer, or from the copy an earlier call kept
-            const cfl *src = b.task >= 0 ? s->h_ext + s->tasks[(size_t)b.task].out_off : b.owned.data();
-            r.payload.insert(r.payload.end(), src, src + r.blocklen);
+        bool all_here = !r.blocks.empty();
+        for (auto &b : r.blocks) if (b.task < 0) { all_here = false; break; }
+        if (all_here) {                     // contiguous in the landing buffer by construction (layout above)
+            r.meta.nsamples = (int64_t)r.blocks.size() * r.blocklen;
+            r.meta.samples = s->h_ext + s->tasks[(size_t)r.blocks.front().task].out_off;
+        } else {                            // some blocks were kept from an earlier call: assemble
+            r.payload.reserve(r.blocks.size() * (size_t)r.blocklen);
+            for (auto &b : r.blocks) {
+                const cfl *src = b.task >= 0 ? s->h_ext + s->tasks[(size_t)b.task].out_off : b.owned.data();
+                r.payload.insert(r.payload.end(), src, src + r.blocklen);
+            }
+            r.meta.nsamples = (int64_t)r.payload.size();
+            r.meta.samples = r.payload.data();
         }
         r.blocks.clear();
-        r.meta.nsamples = (int64_t)r.payload.size();
-        r.meta.samples = r.payload.data();
     }
     for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
     for (auto &g : s->segs) for (auto &c : g.chans) for (auto &b : c.data) resolve(b, c.outputsamples);
@@ -618,6 +638,14 @@ int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out)
     if (!s || !out || i < 0 || i >= (int)s->pdus.size()) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad PDU index");
     *out = s->pdus[(size_t)i].meta;
     return FDC_OK;
+}
+
+int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap)
+{
+    if (!s || (cap > 0 && !out)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad PDU array");
+    const int n = (int)s->pdus.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = s->pdus[(size_t)i].meta;
+    return n;
 }
 
 }  // extern "C"

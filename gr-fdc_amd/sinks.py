@@ -56,19 +56,32 @@ class Sinks:
         return _lib.lib().fdc_sinks_spectrum(self._h)
 
     def _collect(self):
-        out = []
-        p = _lib.fdc_pdu()
-        for i in range(_lib.lib().fdc_sinks_pdu_count(self._h)):
-            _lib.check(_lib.lib().fdc_sinks_pdu(self._h, i, C.byref(p)))
-            if p.nsamples > 0:
-                buf = (C.c_float * (2 * p.nsamples)).from_address(p.samples)
-                data = np.frombuffer(buf, dtype=np.complex64).copy()
+        n = _lib.lib().fdc_sinks_pdu_count(self._h)
+        if n <= 0:
+            return []
+        arr = (_lib.fdc_pdu * n)()
+        _lib.check(_lib.lib().fdc_sinks_pdus(self._h, arr, n))
+        # payloads that sit one behind the other in the handle's buffer are copied out as ONE array and sliced
+        out, i = [], 0
+        while i < n:
+            j, base, end = i, arr[i].samples, (arr[i].samples or 0) + 8 * arr[i].nsamples
+            while j + 1 < n and arr[j + 1].samples == end and arr[j + 1].nsamples > 0:
+                j += 1
+                end += 8 * arr[j].nsamples
+            total = (end - (base or 0)) // 8
+            if total > 0:
+                blob = np.frombuffer((C.c_float * (2 * total)).from_address(base), dtype=np.complex64).copy()
             else:
-                data = np.zeros(0, np.complex64)
-            out.append((dict(kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
-                             has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq,
-                             blockstart=p.blockstart, blockend=p.blockend, vectorstart=p.vectorstart,
-                             vectorend=p.vectorend), data))
+                blob = np.zeros(0, np.complex64)
+            off = 0
+            for k in range(i, j + 1):
+                p = arr[k]
+                out.append((dict(kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                                 has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq,
+                                 blockstart=p.blockstart, blockend=p.blockend, vectorstart=p.vectorstart,
+                                 vectorend=p.vectorend), blob[off:off + p.nsamples]))
+                off += p.nsamples
+            i = j + 1
         return out
 
     def pdus(self):

@@ -193,6 +193,9 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks);
 /* PDUs emitted by the last work call, in emission order */
 int fdc_sinks_pdu_count(const fdc_sinks *s);
 int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);
+/* all of them at once: fills out[0 .. min(count, cap)) and returns the count.  PDUs whose blocks all come from the last call
+ * have their payloads one behind the other in one pinned buffer, in this order. */
+int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap);
 /* derived geometry (for logs and tests): v[8] = extract_start, extract_stop, extract_width, measure_start,
  * measure_stop, output_len, output_ovl_offset, deltaphase;  v[5] = start, stop, width, decimation, power cells */
 int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v8);
