@@ -32,15 +32,24 @@ def bits(a):
     return a.view(np.uint32)
 
 
-def run(N, R, plan, x, nb, sub=None):
+FORCED = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))     # the suite itself run under a forced path
+
+
+def run(N, R, plan, x, nb, sub=None, force=None):
+    """force: None = the default path (uniform two-stage), "FDC_NO_POLY" = spectrum in memory, "FDC_FORCE_GENERIC" = generic kernels"""
     if sub is not None:
         os.environ["FDC_HOST_SUB"] = str(sub)
+    if force:
+        os.environ[force] = "1"
     try:
         p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
-        assert p.path() == 2
+        if not FORCED:
+            assert p.path() == {None: 2, "FDC_NO_POLY": 1 if N == 65536 else 0, "FDC_FORCE_GENERIC": 0}[force]
         return p.work(x)
     finally:
         os.environ.pop("FDC_HOST_SUB", None)
+        if force:
+            os.environ.pop(force, None)
 
 
 @pytest.mark.parametrize("N,C,nb", [(65536, 256, 1024), (262144, 1024, 256)])
@@ -60,6 +69,12 @@ def test_full_size_batch_vs_oracle_and_launch_grouping(oracle, N, C, nb):
         worst_l2 = max(worst_l2, float(np.linalg.norm(d) / np.linalg.norm(ref[c])))
         worst_mx = max(worst_mx, float(np.abs(d).max() / np.abs(ref[c]).max()))
     assert worst_l2 <= TOL and worst_mx <= TOL, (worst_l2, worst_mx)
+    # the other two kernel paths on the same full-size batch (spectrum in memory; generic kernels) agree with the oracle too
+    for force in ("FDC_NO_POLY", "FDC_FORCE_GENERIC"):
+        alt = run(N, R, plan, x, nb, force=force)
+        for c in range(0, C, 7):
+            d = alt[c].astype(np.complex128) - ref[c].astype(np.complex128)
+            assert np.linalg.norm(d) <= TOL * np.linalg.norm(ref[c]) and np.abs(d).max() <= TOL * np.abs(ref[c]).max(), (force, c)
 
 
 def test_full_size_linearity_and_block_shift():

@@ -204,7 +204,8 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
-    assert p.path() == 2
+    forced = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
+    assert forced or p.path() == 2
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
@@ -212,7 +213,7 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     os.environ["FDC_NO_POLY"] = "1"
     try:
         q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
-        assert q.path() == (1 if N == 65536 else 0)
+        assert forced or q.path() == (1 if N == 65536 else 0)
         outs3 = q.work(x)
     finally:
         del os.environ["FDC_NO_POLY"]
@@ -239,7 +240,7 @@ def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
     x = noise(nb * H, 2027)
     ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
     pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
-    assert pipe.path() == 2          # two-stage path with 1024 slots
+    assert pipe.path() == 2 or any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # two-stage path, 1024 slots
     whole = pipe.work(x)
     for c in range(0, Cn, 37):
         assert_close(whole[c], ref[c], "whole ch%d" % c)
