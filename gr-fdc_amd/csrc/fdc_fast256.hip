@@ -20,7 +20,6 @@ namespace fdc {
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
 
 constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
-constexpr int kCTileBytes = 32 * 272 * 8;         // channel kernel: 32 rows padded to 272 points
 constexpr int kP2kLds = 1024 * 16 * 8 + 8192 + 4096;   // k_p2k: 16-row tile + W_1024 table + slot offsets
 
 // ---- pass A -------------------------------------------------------------------------------------------
@@ -112,94 +111,79 @@ __global__ __launch_bounds__(256, 2) void k_b256(const float2 *__restrict__ tmp,
 }
 
 // ---- fused channel kernel, l = 256 ------------------------------------------------------------------------
-// One row = one (block, channel) pair.  ALIGNED: every channel's f is even (16-B aligned slice loads);
-// OUT_ALIGNED: every channel's output offset and lout are even (16-B aligned stores).  Needs an even discard
-// length l/R (the launcher falls back to the generic kernel otherwise).
-template <bool ALIGNED, bool OUT_ALIGNED>
-__global__ __launch_bounds__(256, 2) void k_c256(const float2 *__restrict__ spec, float2 *__restrict__ out,
+// One row = one (block, channel) pair; 16 rows per workgroup, the 16 threads of a row are 16 neighbouring lanes, every
+// thread holds 16 points in both layers: slice bins i = 16a + b (vector_cut_vxx) times W[cnt][i]
+// (phase_shifting_windowing_vcc), ifftshift as a -> a ^ 8, DFT-16 over a, twiddle, 16x16 exchange INSIDE the row
+// (LDS, row-padded so two rows of a half-wave use different bank halves), DFT-16 over b, keep t >= l/R, times l.
+// Loads and stores are 128-byte runs per row; 32 KiB of LDS per workgroup, four workgroups per CU.
+struct RowInfo { long long src; long long dst; int win; int valid; };
+constexpr int kCRowPts = 272;
+constexpr int kCTileBytes = 16 * kCRowPts * 8;
+
+__global__ __launch_bounds__(256, 4) void k_c256(const float2 *__restrict__ spec, float2 *__restrict__ out,
                                                  const ChanDev *__restrict__ chans,
                                                  const int32_t *__restrict__ group, int ngroup, int N, int R,
                                                  int nb_chunk, int mbase, int nb_call, long long first_block,
                                                  const float2 *__restrict__ wins,
                                                  const float2 *__restrict__ tw256)
 {
+    __shared__ RowInfo rows[16];
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
-    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + kCTileBytes);
-    const int tid = threadIdx.x;
-    const int r = tid >> 3, lane8 = tid & 7;
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_fast + kCTileBytes);              // [b][p] = W256^(b p), 16 x 18
+    const int tid = threadIdx.x, r = tid >> 4, b = tid & 15;
     const long long ntrans = (long long)nb_chunk * ngroup;
-    const long long t = (long long)blockIdx.x * 32 + r;
-    const bool live = t < ntrans;
-    int m = 0;
-    ChanDev ch;
-    ch.f = 0; ch.l = 256; ch.lout = 128; ch.shift = 0; ch.out_off = 0; ch.win_off = 0; ch.pad = 0;
-    if (live) {
-        m = (int)(t / ngroup);
-        ch = chans[group[(int)(t - (long long)m * ngroup)]];
+    const int lout = 256 - 256 / R, skip = 256 - lout;
+    if (tid < 16) {
+        const long long t = (long long)blockIdx.x * 16 + tid;
+        RowInfo ri{0, 0, 0, 0};
+        if (t < ntrans) {
+            const int m = (int)(t / ngroup);
+            const ChanDev ch = chans[group[(int)(t - (long long)m * ngroup)]];
+            const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
+            ri.src = (long long)m * N + ch.f;
+            ri.win = ch.win_off + cnt * 256;
+            ri.dst = (long long)nb_call * ch.out_off + (long long)(mbase + m) * lout - skip;
+            ri.valid = 1;
+        }
+        rows[tid] = ri;
     }
-    cf va[16], vb[16];
+    wrow[(tid >> 4) * 18 + (tid & 15)] = tw256[((tid >> 4) * (tid & 15)) & 255];
+    __syncthreads();
+    const RowInfo ri = rows[r];
+    cf v[16];
     {
-        // slice bins i = 16a + {2bp, 2bp+1} (vector_cut_vxx), times W[cnt][i] (phase_shifting_windowing_vcc),
-        // stored at the ifftshifted position i ^ 128 — i.e. a -> a ^ 8
-        const int bp = lane8;
-        const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
-        const float2 *src = spec + (size_t)m * N + ch.f + 2 * bp;
-        const float2 *wsrc = wins + ch.win_off + cnt * 256 + 2 * bp;
+        cf x[16], w[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) {
-            cf x0 = mk(0.f, 0.f), x1 = x0;
-            if (live) {
-                if (ALIGNED) {
-                    const float4 tt = ld4(src + 16 * a);
-                    x0 = mk(tt.x, tt.y); x1 = mk(tt.z, tt.w);
-                } else {
-                    x0 = ld2(src + 16 * a); x1 = ld2(src + 16 * a + 1);
-                }
-            }
-            const float4 w = ld4(wsrc + 16 * a);
-            va[a ^ 8] = cmul(x0, mk(w.x, w.y));
-            vb[a ^ 8] = cmul(x1, mk(w.z, w.w));
+            x[a] = mk(0.f, 0.f); w[a] = x[a];
+            if (ri.valid) { x[a] = ld2(spec + ri.src + 16 * a + b); w[a] = ld2(wins + ri.win + 16 * a + b); }
         }
-        w256[tid] = tw256[tid];
-        dft16<true>(va); dft16<true>(vb);
-        __syncthreads();
-        // exchange layout: row r padded to 272 points; element (b, p) at b*16 + p, p-pairs swizzled by bp
-        float2 *row = tile + r * 272;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            // inverse transform: conjugate twiddles
-            st4(row + (2 * bp) * 16 + 2 * (j ^ bp), cmulc(va[rev16(2 * j)], ld2(&w256[(2 * bp) * (2 * j)])),
-                cmulc(va[rev16(2 * j + 1)], ld2(&w256[(2 * bp) * (2 * j + 1)])));
-            st4(row + (2 * bp + 1) * 16 + 2 * (j ^ bp), cmulc(vb[rev16(2 * j)], ld2(&w256[(2 * bp + 1) * (2 * j)])),
-                cmulc(vb[rev16(2 * j + 1)], ld2(&w256[(2 * bp + 1) * (2 * j + 1)])));
+        for (int a = 0; a < 16; a++) v[a ^ 8] = cmul(x[a], w[a]);
+    }
+    dft16<true>(v);
+    float2 *row = tile + r * kCRowPts;
+    {
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&wrow[b * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
         }
+        // element (b, p) of the row at p*16 + (b ^ p): writes of a fixed p and reads of a fixed b are both conflict-free
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&row[p * 16 + (b ^ p)], cmulc(v[rev16(p)], w[p]));   // inverse: conjugate twiddles
     }
     __syncthreads();
-    {
-        const int pp = lane8;                                  // this thread owns p = 2pp, 2pp+1 of row r
-        const float2 *row = tile + r * 272;
 #pragma unroll
-        for (int bb = 0; bb < 16; bb++) {
-            const float4 tt = ld4(row + bb * 16 + 2 * (pp ^ (bb >> 1)));
-            va[bb] = mk(tt.x, tt.y); vb[bb] = mk(tt.z, tt.w);
-        }
-        dft16<true>(va); dft16<true>(vb);
-        if (live) {
-            // y[t], t = p + 16q; keep t >= l/R (vector_cut_vxx(l, l-lout, lout)), times l (multiply_const_cc)
-            const int skip = 256 - ch.lout;
-            float2 *dst = out + (size_t)nb_call * ch.out_off + (size_t)(mbase + m) * ch.lout;
+    for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&row[b * 16 + (bb ^ b)]);      // this thread now plays p = b
+    dft16<true>(v);
+    if (ri.valid) {
+        // y[t], t = p + 16q; keep t >= l/R (vector_cut_vxx(l, l-lout, lout)), times l (multiply_const_cc)
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int tt = 2 * pp + 16 * q;
-                if (tt >= skip) {
-                    if (OUT_ALIGNED) {
-                        st4(dst + (tt - skip), va[rev16(q)] * 256.f, vb[rev16(q)] * 256.f);
-                    } else {
-                        st2(dst + (tt - skip), va[rev16(q)] * 256.f);
-                        st2(dst + (tt - skip + 1), vb[rev16(q)] * 256.f);
-                    }
-                }
-            }
+        for (int q = 0; q < 16; q++) {
+            const int tt = b + 16 * q;
+            if (tt >= skip) st2(out + ri.dst + tt, v[rev16(q)] * 256.f);
         }
     }
 }
@@ -636,7 +620,7 @@ hipError_t init_fast_kernels()
     if (e != hipSuccess) return e;
     e = init_merged_kernels();
     if (e != hipSuccess) return e;
-    const int a = kTileBytes + 8192, c = kCTileBytes + 2048;
+    const int a = kTileBytes + 8192, c = kCTileBytes + 2304;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_b256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
@@ -660,7 +644,7 @@ hipError_t init_fast_kernels()
 #define FDC_SETC(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, c); \
     if (e != hipSuccess) return e;
-    FDC_SETC((k_c256<true, true>)) FDC_SETC((k_c256<true, false>)) FDC_SETC((k_c256<false, true>)) FDC_SETC((k_c256<false, false>))
+    FDC_SETC(k_c256)
 #undef FDC_SETC
     return hipSuccess;
 }
@@ -686,17 +670,12 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
                               int ngroup, bool aligned, bool out_aligned, int N, int R, int nb_chunk, int mbase, int nb_call,
                               int64_t first_block, const float2 *wins, const float2 *tw256, hipStream_t s)
 {
+    (void)aligned; (void)out_aligned;                       // 8-byte accesses: no alignment classes any more
     const long long ntrans = (long long)nb_chunk * ngroup;
     if (ntrans <= 0) return hipSuccess;
-    dim3 grid((unsigned)((ntrans + 31) / 32));
-#define FDC_LC(A, B) \
-    hipLaunchKernelGGL((k_c256<A, B>), grid, dim3(256), kCTileBytes + 2048, s, spec, out, chans, group, ngroup, N, R, \
-                       nb_chunk, mbase, nb_call, (long long)first_block, wins, tw256)
-    if (aligned && out_aligned) FDC_LC(true, true);
-    else if (aligned) FDC_LC(true, false);
-    else if (out_aligned) FDC_LC(false, true);
-    else FDC_LC(false, false);
-#undef FDC_LC
+    dim3 grid((unsigned)((ntrans + 15) / 16));
+    hipLaunchKernelGGL(k_c256, grid, dim3(256), kCTileBytes + 2304, s, spec, out, chans, group, ngroup, N, R, nb_chunk, mbase,
+                       nb_call, (long long)first_block, wins, tw256);
     return hipGetLastError();
 }
 
