@@ -62,9 +62,9 @@ def test_phase_window_block(oracle):
             assert np.abs(ya - yb).max() <= 1e-6 * np.abs(yb).max()
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576, 4194304])
 def test_fft_vcc_all_sizes(oracle, n):
-    items = 3 if n <= 65536 else 2
+    items = 3 if n <= 65536 else 2 if n <= (1 << 20) else 1
     x = noise(items * n, n)
     for fwd in (True, False):
         for shift in (True, False):
@@ -342,3 +342,10 @@ def test_widest_channels_and_no_channels(oracle):
         p.work(np.zeros(H + 1, np.complex64))                 # not a whole number of items
     with pytest.raises(ValueError):
         G.Pipeline(N, R, [(0, 3, 0.5, 1.0)], max_blocks=1)   # l not a power of two
+
+
+def test_fft_vcc_largest_supported_size(oracle):
+    """N = 2^24, the largest block length fdc_pipeline_create accepts: forward, shifted."""
+    n = 1 << 24
+    x = noise(n, 24)
+    assert_close(G.fft_vcc(n, True, True, x), oracle.fft_vcc(n, True, True, x), "n=2^24")
