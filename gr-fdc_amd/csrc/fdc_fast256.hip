@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512, 4) void k_p1g(const float2 *__restrict__ in, s
 
 // Stage 2 for N1 = 256 slots: rows rho = m*lout + t' of G (256 contiguous n1 each), FFT over n1, bin = slot c.
 // Persistent with next-tile prefetch like k_p1; a tile is TR consecutive rows (TR*2 KiB contiguous).
-template <int TR>
+template <int TR, int TCG>
 __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g, float2 *__restrict__ out,
                                                    const float2 *__restrict__ tw256,
                                                    const long long *__restrict__ slot_off, long long nrows,
@@ -444,22 +444,22 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
     }
     const int r = tid >> 4, b = tid & 15;            // layer 1: row r, points n1 = 16a + b
     const int r2 = tid & (TR - 1), p2 = tid / TR;    // layer 2: row r2, outputs k1 = p2 + 16q
-    // G is tile-major (k_p1): G[m][ct][t'][TR] with TR columns per column tile.  Point n1 = 16a + b of row t'
-    // sits in column tile ct = n1 / TR at column n1 % TR.  A tile of this kernel = TR consecutive rows t' of one
-    // block (lout is a multiple of TR), i.e. for every ct a contiguous run of TR*TR points.
+    // G is tile-major (k_p1): G[m][ct][t'][TCG] with TCG columns per column tile.  Point n1 = 16a + b of row t'
+    // sits in column tile ct = n1 / TCG at column n1 % TCG.  A tile of this kernel = TR consecutive rows t' of one
+    // block (lout is a multiple of TR), i.e. for every ct a contiguous run of TR*TCG points.
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
     const int tpb = lout / TR;                                 // tiles per block
-    const unsigned ctstep = (unsigned)lout * TR * 8u;          // bytes between column tiles of one block
-    // TR = 16: ct = a, column = b.  TR = 32: ct = a >> 1, column = 16*(a & 1) + b.
-    const unsigned voff = (unsigned)(r * TR + b) * 8u;
+    const unsigned ctstep = (unsigned)lout * TCG * 8u;         // bytes between column tiles of one block
+    // TCG = 16: ct = a, column = b.  TCG = 32: ct = a >> 1, column = 16*(a & 1) + b.
+    const unsigned voff = (unsigned)(r * TCG + b) * 8u;
     cf L[16];
     auto issue = [&](int t) {
         const size_t m = t / tpb;
         const int t0 = (t - (int)m * tpb) * TR;
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 256 + (size_t)t0 * TR, (unsigned)lout * 256u * 8u);
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 256 + (size_t)t0 * TCG, (unsigned)lout * 256u * 8u);
 #pragma unroll
         for (int a = 0; a < 16; a++)
-            L[a] = bld2(rg, voff + (TR == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TR == 32 ? a >> 1 : a) * ctstep);
+            L[a] = bld2(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
     };
     issue(tl);
     for (;;) {
@@ -634,10 +634,12 @@ hipError_t init_fast_kernels()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) return e;
 #undef FDC_SETP1
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
 
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2k), hipFuncAttributeMaxDynamicSharedMemorySize, kP2kLds);
     if (e != hipSuccess) return e;
@@ -769,19 +771,25 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int n
                            (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt, lout);
         return hipGetLastError();
     }
-    const int TC = poly_tile(lout);
-    const int maxwg = TC == 32 ? 2 : 4;
+    const int TCG = poly_tile(lout);                        // column-tile width stage 1 wrote G with
+    static int rows_cfg = -1;                               // FDC_POLY_ROWS=16|32: rows per stage-2 tile (A/B testing)
+    if (rows_cfg < 0) { const char *t = getenv("FDC_POLY_ROWS"); rows_cfg = t ? atoi(t) : 0; }
+    int TR = rows_cfg == 16 || rows_cfg == 32 ? rows_cfg : TCG;
+    if (lout % TR) TR = 16;
+    if (TCG == 32 && TR == 16) TR = 32;                     // 32-column G tiles are read 32 rows at a time
+    const int maxwg = TR == 32 ? 2 : 4;
     const int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
-    const size_t lds2 = 256 * TC * 8 + 2048 + 2048;
+    const size_t lds2 = 256 * TR * 8 + 2048 + 2048;
     const long long nrows = (long long)nb_chunk * lout;
-    const long long nt2 = (nrows + TC - 1) / TC;
+    const long long nt2 = (nrows + TR - 1) / TR;
     const unsigned g2 = (unsigned)(nt2 < slots ? nt2 : slots);
-    if (TC == 32)
-        hipLaunchKernelGGL(k_p2<32>, dim3(g2), dim3(512), lds2, s, g, out, tw256, slot_off, nrows,
-                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt2, lout);
-    else
-        hipLaunchKernelGGL(k_p2<16>, dim3(g2), dim3(256), lds2, s, g, out, tw256, slot_off, nrows,
-                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt2, lout);
+#define FDC_LP2(A, B) \
+    hipLaunchKernelGGL((k_p2<A, B>), dim3(g2), dim3(A * 16), lds2, s, g, out, tw256, slot_off, nrows, (long long)mbase * lout, \
+                       (long long)nb_call, out_bytes, (int)nt2, lout)
+    if (TR == 32 && TCG == 32) FDC_LP2(32, 32);
+    else if (TR == 32) FDC_LP2(32, 16);
+    else FDC_LP2(16, 16);
+#undef FDC_LP2
     return hipGetLastError();
 }
 
