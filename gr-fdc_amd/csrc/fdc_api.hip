@@ -291,10 +291,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         flat.insert(flat.end(), kv.second.begin(), kv.second.end());
     }
 
-    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*256 or 256*1024 (fdc_fast256.hip)
+    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
+    // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
     {
         const char *np = getenv("FDC_NO_POLY");
-        bool ok = (N == 65536 || N == 262144) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
+        bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
         std::vector<char> used(N / 256 + 1, 0);
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
@@ -589,6 +590,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
             }
             if (p->timing) HIPCHK(hipEventRecord(p->events[span[2]], s2));
+            if (p->N != 65536 && p->N != 262144)
+                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
+                                                       p->d_slot_off, p->d_tw, p->ntab, s2));
+            else
             HIPCHK(fdc::launch_poly_stage2(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
                                            p->d_tw256, p->d_tw1024, p->d_slot_off,
                                            (unsigned)((int64_t)nblocks * p->sum_lout * 8),

@@ -86,6 +86,10 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 102
                               const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
                               int wg_per_cu, hipStream_t s);
 
+// stage 2 for any other slot count N1 = N/256 in [16, 4096] (generic LDS core, fdc_kernels.hip)
+hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
+                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s);
+
 // uniform plan as an XCD-local dataflow (fdc_fused256.hip): stage 1 (3 workgroups/CU, stream s1) and stage 2
 // (1 workgroup/CU, stream s2) run concurrently; every block is owned by one XCD and its G stays in that XCD's L2
 hipError_t init_fused_kernels();

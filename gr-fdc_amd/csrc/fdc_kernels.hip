@@ -294,6 +294,48 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ t
     }
 }
 
+// ---- uniform path, stage 2 for any number of slots N1 = N/256 (fdc_fast256.hip has the 256- and 1024-slot forms) ----
+// Rows rho = m*lout + t' of G (stage 1 writes them tile-major, G[m][ct][t'][16]), FFT over n1, bin k1 = channel slot.
+// A tile is TR consecutive rows of one block; lanes run over the rows at the store end, so every channel stream
+// receives TR*8-byte runs.
+__global__ FDC_GENERIC_BOUNDS(1) void k_p2g(const float2 *__restrict__ g, float2 *__restrict__ out, int log2N1, int log2TR,
+                                            int ld, int lout, const long long *__restrict__ slot_off, long long out_base,
+                                            long long nb_call, const float2 *__restrict__ tw, int twstride)
+{
+    constexpr int PT = 16;
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int N1 = 1 << log2N1, TR = 1 << log2TR, total = N1 << log2TR;
+    const int tpb = lout >> log2TR;                                   // tiles per block
+    const int m = blockIdx.x / tpb, t0 = (blockIdx.x - m * tpb) << log2TR;
+    const float2 *src = g + (size_t)m * (size_t)lout * N1 + (size_t)t0 * 16;
+    float2 v[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int col = e & 15, r = (e >> 4) & (TR - 1), ct = e >> (4 + log2TR);
+        v[u] = make_float2(0.f, 0.f);
+        if (e < total) v[u] = src[((size_t)ct * lout + r) * 16 + col];
+    }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int col = e & 15, r = (e >> 4) & (TR - 1), ct = e >> (4 + log2TR);
+        if (e < total) lds[(ct * 16 + col) * ld + r] = v[u];
+    }
+    __syncthreads();
+    fft_cols<false, 1>(lds, log2N1, log2TR, ld, tw, twstride);
+    const long long rho0 = (long long)m * lout + t0 + out_base;
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int r = e & (TR - 1), k1 = e >> log2TR;
+        if (e < total) {
+            const long long o = slot_off[k1];                         // start of the stream of the channel in this slot
+            if (o >= 0) out[o * nb_call + rho0 + r] = lds[k1 * ld + r];
+        }
+    }
+}
+
 // ---- fused channel kernel ------------------------------------------------------------------------
 // Per tile column (one transform = one (block, channel) pair): where its slice, window row and output run start.
 // Worked out once per column by the first TC threads, so the per-point loops carry no divisions or record fetches.
@@ -577,6 +619,20 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
     else
         hipLaunchKernelGGL(k_channels<1>, grid, dim3(kThreads), g.lds_bytes(), s, spec, out, chans, group, ngroup, g.log2L,
                            g.log2TC, g.ld, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / l);
+    return hipGetLastError();
+}
+
+hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
+                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s)
+{
+    const int lout = 256 - 256 / R;
+    int tr = 4096 / N1; if (tr > 32) tr = 32; if (tr < 1) tr = 1;
+    while (lout % tr) tr >>= 1;                                       // tiles are whole rows of one block
+    const TileGeom tg = tile_geom(N1);
+    const int log2TR = ilog2(tr), ld = tr > 1 ? tr + 1 : 1;
+    const long long ntiles = (long long)nb_chunk * (lout / tr);
+    hipLaunchKernelGGL(k_p2g, dim3((unsigned)ntiles), dim3(kThreads), (size_t)N1 * ld * sizeof(float2), s, g, out, tg.log2L,
+                       log2TR, ld, lout, slot_off, (long long)mbase * lout, (long long)nb_call, tw, ntab / N1);
     return hipGetLastError();
 }
 

@@ -195,12 +195,18 @@ def test_fast_and_generic_paths_agree(oracle):
 
 
 @pytest.mark.parametrize("N,R,wt", [(65536, 2, 1), (65536, 4, 2), (65536, 8, 0), (65536, 16, 1),
-                                    (262144, 2, 1), (262144, 4, 0), (262144, 16, 2)])
+                                    (262144, 2, 1), (262144, 4, 0), (262144, 16, 2),
+                                    (4096, 2, 1), (8192, 4, 2), (16384, 2, 0), (32768, 16, 1), (131072, 2, 1),
+                                    (524288, 8, 2), (1048576, 2, 1)])
 def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     """Uniform plans (l=256 on the 256-bin grid; 256 slots at N=65536, 1024 at N=262144) take the two-stage path that
     never writes a spectrum; any subset and any order of slots; result equals the oracle and the spectrum-in-memory path."""
     nb = 5
-    slots = [200, 3, 255, 0, 17, 128, 127, 64] if N == 65536 else [200, 3, 1023, 0, 517, 512, 511, 64, 900, 256, 767]
+    slots = {65536: [200, 3, 255, 0, 17, 128, 127, 64], 262144: [200, 3, 1023, 0, 517, 512, 511, 64, 900, 256, 767]}.get(N)
+    if slots is None:                                  # other slot counts: stage 2 on the generic core
+        n1 = N // 256
+        slots = [int(v) for v in np.random.default_rng(N).permutation(n1)[:min(n1, 9)]] + [0, n1 - 1, n1 // 2]
+        slots = list(dict.fromkeys(slots))
     chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
