@@ -65,8 +65,8 @@ typedef struct {
     int32_t nchannels;
     const fdc_channel *channels;
     int32_t max_blocks;     /* largest nblocks a single work()/process call will carry               */
-    int32_t chunk_blocks;   /* blocks per internal launch group (0 = choose so intermediates stay in
-                               the 256 MiB Infinity Cache)                                           */
+    int32_t chunk_blocks;   /* blocks per internal launch group (0 = as many as a 2 GiB scratch budget
+                               allows: long launches measured faster than cache-sized ones)          */
     int32_t keep_spectrum;  /* != 0: keep the whole normalised spectrum of a call (debug port, py:314) */
 } fdc_pipeline_cfg;
 
