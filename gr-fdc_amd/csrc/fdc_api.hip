@@ -589,7 +589,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 HIPCHK(hipEventRecord(p->ev_s1[gi], s));
                 HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
             }
-            if (p->timing) HIPCHK(hipEventRecord(p->events[span[2]], s2));
+            if (p->timing) {
+                if (ovl) HIPCHK(hipEventRecord(p->events[span[2]], s2));
+                else span[2] = span[1];                          // same stream: the end of stage 1 IS the start of stage 2
+            }
             if (p->N != 65536 && p->N != 262144)
                 HIPCHK(fdc::launch_poly_stage2_generic(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
                                                        p->d_slot_off, p->d_tw, p->ntab, s2));
