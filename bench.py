@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--relinvovl", type=int, default=2)
     ap.add_argument("--chunk", type=int, default=0, help="blocks per launch group (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostics: no HIP events inside the timed region (no roofline numbers)")
+    ap.add_argument("--timing-stride", type=int, default=4,
+                    help="HIP events around the kernels of every k-th launch group of the timed region (their packets cost "
+                         "7-17 us per group; 1 = every group)")
     ap.add_argument("--cpu-blocks", type=int, default=0, help="blocks in the CPU baseline sample (0 = auto)")
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     return ap.parse_args()
@@ -159,7 +163,7 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    pipe.enable_timing(True)
+    pipe.enable_timing(0 if a.no_kernel_timing else max(1, a.timing_stride))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -176,14 +180,14 @@ def main():
 
     msps = world * nb * H * a.steps / dt / 1e6
     chunk = pipe.chunk_blocks()
-    ngroups = int(last[3])                      # launch groups timed = steps * ceil(nb / chunk)
-    nlaunch = ngroups // a.steps
+    ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
+    nlaunch = (nb + chunk - 1) // chunk         # launch groups per step
     path = pipe.path()
     names = ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 else \
             ["fft_pass_a", "fft_pass_b", "channels"]
     dom = max(range(3), key=lambda i: last[i])
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel
-    blocks_per_launch = nb * a.steps / ngroups  # units one launch processes
+    blocks_per_launch = nb / nlaunch            # units one launch processes
     achieved = b_alg * blocks_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)
@@ -209,9 +213,10 @@ def main():
                    "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel_ms_per_step": {n: round(v / a.steps, 4) for n, v in zip(names, last)},
+                     "kernel_ms_per_step": {n: round(v / ngroups * nlaunch, 4) for n, v in zip(names, last)},
                      "kernel_avg_launch_ms": round(dom_avg_ms, 5), "blocks_per_launch": blocks_per_launch,
-                     "launches_per_step": nlaunch, "alg_bytes_per_block": b_alg,
+                     "launches_per_step": nlaunch, "timed_launches": ngroups, "timing_stride": max(1, a.timing_stride),
+                     "alg_bytes_per_block": b_alg,
                      "pipeline_achieved": round(b_alg * nb * a.steps / dt / 1e9, 2),
                      "pipeline_frac": round(b_alg * nb * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
                      # SURVEY.md §8d also asks for the fraction of the achievable float4-copy rate (6.3 TB/s per the guide)

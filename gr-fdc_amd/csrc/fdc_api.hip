@@ -152,6 +152,8 @@ struct fdc_pipeline {
     bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
     // timing
     bool timing = false;
+    int timing_stride = 1;       // events on every stride-th launch group (fdc_pipeline_enable_timing(p, stride))
+    long long timing_seq = 0;
     std::vector<hipEvent_t> events;
     size_t ev_used = 0;
     std::vector<std::array<size_t, 4>> ev_spans;   // start, mid, end-of-fft, end-of-channels
@@ -490,6 +492,8 @@ int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable)
 {
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     p->timing = enable != 0;
+    p->timing_stride = enable > 1 ? enable : 1;
+    p->timing_seq = 0;
     p->ev_used = 0; p->ev_spans.clear();
     return FDC_OK;
 }
@@ -546,7 +550,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         const int nb = std::min(p->chunk, nblocks - m0);
         float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
         hipEvent_t ev[3]; hipEvent_t *evp = nullptr; std::array<size_t, 4> span{};
-        if (p->timing) {
+        // events on every timing_stride-th launch group only: a sample of the launches, so that the packets between the
+        // kernels (measured 7-17 us per group) do not slow the region they time
+        const bool tg = p->timing && (p->timing_seq++ % p->timing_stride) == 0;
+        if (tg) {
             for (int i = 0; i < 4; i++) { int rc = get_event(p, &span[i]); if (rc) return rc; }
             for (int i = 0; i < 3; i++) ev[i] = p->events[span[i]];
             evp = ev;
@@ -554,21 +561,21 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
         if (use_poly && p->poly_fused) {
             hipEvent_t ev4[4]; hipEvent_t *evp4 = nullptr;
-            if (p->timing) { for (int i = 0; i < 4; i++) ev4[i] = p->events[span[i]]; evp4 = ev4; }
+            if (tg) { for (int i = 0; i < 4; i++) ev4[i] = p->events[span[i]]; evp4 = ev4; }
             HIPCHK(fdc::launch_poly_fused(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_gring, static_cast<float2 *>(d_out),
                                           p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl, p->fused_ring,
                                           p->fused_wg1, s, p->stream2, p->ev_fork, p->ev_s2[0], evp4));
-            if (p->timing) p->ev_spans.push_back(span);
+            if (tg) p->ev_spans.push_back(span);
             continue;
         }
         if (use_poly && p->poly_merged) {
-            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             HIPCHK(fdc::launch_poly_merged(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[0], static_cast<float2 *>(d_out), p->R, nb,
                                            m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
                                            (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_done, p->d_err, p->ncu,
                                            p->merged_hints, s));
-            if (p->timing) {
+            if (tg) {
                 for (int i = 1; i < 4; i++) HIPCHK(hipEventRecord(p->events[span[i]], s));
                 p->ev_spans.push_back(span);
             }
@@ -581,15 +588,15 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             const bool ovl = p->poly_overlap && nblocks > p->chunk;
             hipStream_t s2 = ovl ? p->stream2 : s;
             if (ovl && m0 >= 2 * p->chunk) HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi], 0));   // G[gi] free again
-            if (p->timing) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[gi], p->N / 256, p->R, nb,
                                            p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, ovl ? p->poly_split : 0, s));
-            if (p->timing) HIPCHK(hipEventRecord(p->events[span[1]], s));
+            if (tg) HIPCHK(hipEventRecord(p->events[span[1]], s));
             if (ovl) {
                 HIPCHK(hipEventRecord(p->ev_s1[gi], s));
                 HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
             }
-            if (p->timing) {
+            if (tg) {
                 if (ovl) HIPCHK(hipEventRecord(p->events[span[2]], s2));
                 else span[2] = span[1];                          // same stream: the end of stage 1 IS the start of stage 2
             }
@@ -602,7 +609,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                            (unsigned)((int64_t)nblocks * p->sum_lout * 8),
                                            ovl ? 4 - p->poly_split : 0, s2));
             if (ovl) HIPCHK(hipEventRecord(p->ev_s2[gi], s2));
-            if (p->timing) {
+            if (tg) {
                 HIPCHK(hipEventRecord(p->events[span[3]], s2));
                 p->ev_spans.push_back(span);
             }
@@ -633,7 +640,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                             (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks,
                                             first_block, p->d_wins, p->d_tw, p->ntab, s));
         }
-        if (p->timing) {
+        if (tg) {
             HIPCHK(hipEventRecord(p->events[span[3]], s));
             p->ev_spans.push_back(span);
         }
