@@ -81,3 +81,12 @@ def test_argument_validation_precedes_device_use():
         G.Pipeline(4096, 2, [(4000, 256, 0.88, 1.0)])      # slice leaves the spectrum
     with pytest.raises(ValueError):
         G.Pipeline(1000, 2, [])                            # not a power of two
+
+
+def test_header_is_plain_c_and_example_compiles(tmp_path):
+    """include/fdc_amd.h is a C header (C99, -pedantic) and the plain-C example builds against it without hipcc."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = str(tmp_path / "ex.o")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-c", os.path.join(root, "examples", "fdc_pipeline_example.c"), "-o", obj])

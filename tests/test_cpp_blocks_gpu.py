@@ -48,3 +48,15 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     allref = np.concatenate([r["samples"] for r in ref])
     got = rd("pdus.out")
     assert got.size == allref.size and np.abs(got - allref).max() <= 1e-5 * np.abs(allref).max()
+
+
+def test_plain_c_example_runs(tmp_path):
+    """examples/fdc_pipeline_example.c (gcc, C99, links only libfdc_amd.so): a tone at the centre of channel 0 comes out with
+    unit gain there and nowhere else."""
+    exe = str(tmp_path / "fdc_example")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "fdc_pipeline_example.c"), "-L", os.path.join(ROOT, "gr-fdc_amd"),
+                           "-lfdc_amd", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "gr-fdc_amd"), "-o", exe])
+    out = subprocess.check_output([exe], text=True).strip().split("\n")
+    rms = [float(ln.split("rms=")[1]) for ln in out]
+    assert len(rms) == 4 and abs(rms[0] - 1.0) < 1e-3 and max(rms[1:]) < 1e-3
