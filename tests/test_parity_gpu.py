@@ -355,3 +355,35 @@ def test_fft_vcc_largest_supported_size(oracle):
     n = 1 << 24
     x = noise(n, 24)
     assert_close(G.fft_vcc(n, True, True, x), oracle.fft_vcc(n, True, True, x), "n=2^24")
+
+
+def test_handles_release_their_device_memory(oracle):
+    """create / work / destroy in a loop: device memory in use returns to where it started (every path's scratch, tables,
+    streams, events, pinned staging and registrations are released)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    N, R, nb = 65536, 2, 8
+    H = N - N // R
+    uni = [(256 * c, 256, 0.88, 1.0) for c in range(0, 256, 3)]
+    mixed = [(100, 512, 0.7, 0.9), (5000, 16384, 0.6, 0.8), (40000, 256, 0.88, 1.0)]
+    x = noise(nb * H, 3)
+    pool = np.empty(nb * 128 * len(uni), np.complex64)
+    G.register_host(pool)
+    outs = [pool[i * nb * 128:(i + 1) * nb * 128] for i in range(len(uni))]
+    before = None
+    for it in range(6):
+        p = G.Pipeline(N, R, uni, max_blocks=nb); p.work(x, outs=outs); p.enable_timing(True); p.work(x); p.last_kernel_ms(); p.close()
+        q = G.Pipeline(N, R, mixed, max_blocks=nb, keep_spectrum=True)
+        s = G.Sinks(N, R, pac=[(0.3, 0.01, 1)], pac_thresh=6.0, pac_maxblocks=-1, segments=[(0.5, 0.9)], det_thresh=10.0,
+                    det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2, max_blocks=nb)
+        q.work(x, want_spectrum=True, sinks=s); s.close(); q.close()
+        if it == 1:
+            before = free_bytes()            # after the runtime's own pools have warmed up
+    G.unregister_host(pool)
+    assert before is not None and abs(free_bytes() - before) <= (64 << 20)
