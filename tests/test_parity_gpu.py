@@ -387,3 +387,36 @@ def test_handles_release_their_device_memory(oracle):
             before = free_bytes()            # after the runtime's own pools have warmed up
     G.unregister_host(pool)
     assert before is not None and abs(free_bytes() - before) <= (64 << 20)
+
+
+def test_distinct_handles_from_concurrent_threads(oracle):
+    """One handle per thread, used concurrently (GNU Radio's thread-per-block model): results equal the single-threaded ones."""
+    import threading
+    N, R, nb = 16384, 4, 6
+    H = N - N // R
+    plans = [[(256 * c, 256, 0.88, 1.0) for c in range(64)],                        # uniform path (64 slots)
+             [(100, 512, 0.7, 0.9), (5000, 2048, 0.6, 0.8), (12000, 64, 0.5, 1.0)],  # generic path
+             [(256 * c + 3, 256, 0.8, 1.0) for c in range(0, 60, 7)],                # off-grid l = 256
+             [(0, 16384, 0.9, 1.0)]]                                                 # one channel as wide as the band
+    xs = [noise(3 * nb * H, 50 + i) for i in range(len(plans))]
+    want = []
+    for pl, x in zip(plans, xs):
+        p = G.Pipeline(N, R, pl, max_blocks=nb)
+        want.append([np.concatenate(parts) for parts in zip(*[p.work(x[k * nb * H:(k + 1) * nb * H]) for k in range(3)])])
+        p.close()
+    got = [None] * len(plans)
+
+    def worker(i):
+        p = G.Pipeline(N, R, plans[i], max_blocks=nb)
+        got[i] = [np.concatenate(parts) for parts in zip(*[p.work(xs[i][k * nb * H:(k + 1) * nb * H]) for k in range(3)])]
+        p.close()
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(plans)):
+        assert got[i] is not None
+        for a, b in zip(got[i], want[i]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "plan %d differs under concurrency" % i
