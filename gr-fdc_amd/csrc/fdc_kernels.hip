@@ -357,7 +357,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spe
     const int lout = l - l / R, skip = l - lout;
     const long long ntrans = (long long)nb_chunk * ngroup;
     const long long t0 = (long long)blockIdx.x * TC;
-    if (threadIdx.x < TC) {
+    if ((int)threadIdx.x < TC) {
         const long long t = t0 + threadIdx.x;
         ColInfo ci{0, 0, 0, 0};
         if (t < ntrans) {
@@ -442,7 +442,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec
     constexpr int PT = 16 * NB;
     __shared__ ColInfo col[32];
     const int total = w << log2TC;
-    if (threadIdx.x < TC) {
+    if ((int)threadIdx.x < TC) {
         const int t = t0 + threadIdx.x;
         ColInfo ci{0, 0, 0, 0};
         if (t < ntasks) {

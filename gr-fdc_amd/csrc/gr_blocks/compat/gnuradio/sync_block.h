@@ -19,11 +19,11 @@ public:
     typedef std::shared_ptr<io_signature> sptr;
     static sptr make(int min_streams, int max_streams, int sizeof_stream_item)
     {
-        return sptr(new io_signature{min_streams, max_streams, sizeof_stream_item});
+        return sptr(new io_signature{min_streams, max_streams, sizeof_stream_item, {}});
     }
     static sptr makev(int min_streams, int max_streams, const std::vector<int> &sizeof_stream_items)
     {
-        sptr p(new io_signature{min_streams, max_streams, sizeof_stream_items.empty() ? 0 : sizeof_stream_items[0]});
+        sptr p(new io_signature{min_streams, max_streams, sizeof_stream_items.empty() ? 0 : sizeof_stream_items[0], {}});
         p->sizeof_stream_items = sizeof_stream_items;
         return p;
     }
