@@ -20,7 +20,7 @@ namespace fdc {
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
 
 constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
-constexpr int kP2kLds = 1024 * 16 * 8 + 8192 + 4096;   // k_p2k: 16-row tile + W_1024 table + slot offsets
+constexpr int kP2kLds = 1024 * 16 * 8 + 68 * 18 * 8 + 4096;   // k_p2k: 16-row tile + twiddle rows + slot offsets
 
 // ---- pass A -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_a256(const float2 *__restrict__ in, size_t in_stride,
@@ -518,13 +518,17 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
 {
     constexpr int TR = 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // 16 rows x 1024 points
-    float2 *w1k = reinterpret_cast<float2 *>(fdc_smem_fast + 1024 * TR * 8);
-    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_fast + 1024 * TR * 8 + 8192);
+    // twiddle tables as rows a thread reads 16 bytes at a time: tw1r[b'][p] = W_1024^(b' p) (64 rows), tw2r[d][s] = W_64^(d s)
+    // (4 rows); rows padded to 18 entries so that the rows of a wave start in different bank groups
+    float2 *tw1r = reinterpret_cast<float2 *>(fdc_smem_fast + 1024 * TR * 8);
+    float2 *tw2r = reinterpret_cast<float2 *>(fdc_smem_fast + 1024 * TR * 8 + 64 * 18 * 8);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_fast + 1024 * TR * 8 + 68 * 18 * 8);
     const int tid = threadIdx.x;
     int tl = blockIdx.x;
     if (tl >= ntiles) return;
     {
-        w1k[tid] = tw1024[tid];
+        tw1r[(tid >> 4) * 18 + (tid & 15)] = tw1024[((tid >> 4) * (tid & 15)) & 1023];
+        if (tid < 64) tw2r[(tid >> 4) * 18 + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
         const long long o = slot_off[tid];
         soff[tid] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
@@ -569,7 +573,10 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
         for (int h = 0; h < 2; h++) {
             cf w[8];
 #pragma unroll
-            for (int p = 0; p < 8; p++) w[p] = ld2(&w1k[bp * (8 * h + p)]);      // W_1024^(b' p)
+            for (int i = 0; i < 4; i++) {                                        // W_1024^(b' p)
+                const float4 t = ld4(&tw1r[bp * 18 + 8 * h + 2 * i]);
+                w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+            }
 #pragma unroll
             for (int p = 0; p < 8; p++) st2(wr1 + (8 * h + p) * 1024, cmul(v[rev16(8 * h + p)], w[p]));
         }
@@ -582,7 +589,10 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
         for (int h = 0; h < 2; h++) {
             cf w[8];
 #pragma unroll
-            for (int sx = 0; sx < 8; sx++) w[sx] = ld2(&w1k[16 * d * (8 * h + sx)]);   // W_64^(d s)
+            for (int i = 0; i < 4; i++) {                                        // W_64^(d s)
+                const float4 t = ld4(&tw2r[d * 18 + 8 * h + 2 * i]);
+                w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+            }
 #pragma unroll
             for (int sx = 0; sx < 8; sx++) {
                 const int sv = 8 * h + sx;
