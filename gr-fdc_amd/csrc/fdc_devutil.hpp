@@ -44,6 +44,18 @@ __device__ __forceinline__ void bst2_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 16);
 }
+// nt = streamed once: the line is not kept against data that will be re-read (aux bit 1)
+__device__ __forceinline__ cf bld2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cf v)
+{
+    u32x2 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 2);
+}
 __device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
 
 

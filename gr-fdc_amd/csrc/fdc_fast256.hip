@@ -20,6 +20,10 @@ namespace fdc {
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
 
 constexpr int kTileBytes = 256 * 32 * 8;          // 64 KiB of points
+// Default: the streams that are touched once (stage-1 input rows, stage-2 output samples) carry the nt hint, so that G — written by
+// stage 1 and read back by stage 2, about the size of the Infinity Cache per 1024-block launch — is what stays cached:
+// measured 0.236 -> 0.212 ms per step (bits 4 and 8, hints on G itself, lose: profiles/r01/NOTES.md)
+constexpr int kDefaultNtHints = 3;
 constexpr int kP2kLds = 1024 * 16 * 8 + 68 * 18 * 8 + 4096;   // k_p2k: 16-row tile + twiddle rows + slot offsets
 
 // ---- pass A -------------------------------------------------------------------------------------------
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
                                                    float2 *__restrict__ g, const float2 *__restrict__ tw256,
                                                    const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
                                                    const float *__restrict__ shn, int N1, int log2ct, int nb, int bpg,
-                                                   int qskip, int lout)
+                                                   int qskip, int lout, int hints)
 {
     constexpr int NT = TC * 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [256][TC]
@@ -255,8 +259,13 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
             } else if (KEEP > 0 && mn == m + 1) {
 #pragma unroll
                 for (int a = 0; a < KEEP; a++) nbuf[a] = cur[a + 16 - KEEP];       // the overlap, already on chip
+                if (hints & 2) {
 #pragma unroll
-                for (int a = KEEP; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+                    for (int a = KEEP; a < 16; a++) nbuf[a] = bld2_nt(rin, voff, a * rowstep);
+                } else {
+#pragma unroll
+                    for (int a = KEEP; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
@@ -316,9 +325,15 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
         dft16<true>(u);                               // y[t = b + 16q]
         // row t - skip of this block's G, t = b + 16q; skip = 16*qskip, so the test is wave-uniform
+        if (hints & 8) {
 #pragma unroll
-        for (int q = 0; q < 16; q++)
-            if (q >= qskip && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+            for (int q = 0; q < 16; q++)
+                if (q >= qskip && (ABL != 2 || q == 15)) bst2_nt(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                if (q >= qskip && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+        }
     };
     cf L[16];
     {
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
                                                    const float2 *__restrict__ tw256,
                                                    const long long *__restrict__ slot_off, long long nrows,
                                                    long long out_base, long long nb_call, unsigned out_bytes,
-                                                   int ntiles, int lout)
+                                                   int ntiles, int lout, int hints)
 {
     constexpr int NT = TR * 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // [p][b][TR]
@@ -457,9 +472,15 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
         const size_t m = t / tpb;
         const int t0 = (t - (int)m * tpb) * TR;
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 256 + (size_t)t0 * TCG, (unsigned)lout * 256u * 8u);
+        if (hints & 4) {
 #pragma unroll
-        for (int a = 0; a < 16; a++)
-            L[a] = bld2(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
+            for (int a = 0; a < 16; a++)
+                L[a] = bld2_nt(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; a++)
+                L[a] = bld2(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
+        }
     };
     issue(tl);
     for (;;) {
@@ -495,7 +516,10 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const unsigned off = soff[p2 + 16 * q];         // start of the stream of the channel in this slot
-                if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[rev16(q)]);
+                if (off != 0xFFFFFFFFu) {
+                    if (hints & 1) bst2_nt(rout, off + rbytes, 0, v[rev16(q)]);
+                    else bst2(rout, off + rbytes, 0, v[rev16(q)]);
+                }
             }
         }
         if (nxt >= ntiles) break;
@@ -514,7 +538,7 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
                                                   const float2 *__restrict__ tw1024,
                                                   const long long *__restrict__ slot_off, long long nrows,
                                                   long long out_base, long long nb_call, unsigned out_bytes,
-                                                  int ntiles, int lout)
+                                                  int ntiles, int lout, int hints)
 {
     constexpr int TR = 16;
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);                           // 16 rows x 1024 points
@@ -615,7 +639,10 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const unsigned off = soff[p2 + 16 * (4 * f + d) + 256 * u];
-                    if (off != 0xFFFFFFFFu) bst2(rout, off + rbytes, 0, v[4 * f + u]);
+                    if (off != 0xFFFFFFFFu) {
+                        if (hints & 1) bst2_nt(rout, off + rbytes, 0, v[4 * f + u]);
+                        else bst2(rout, off + rbytes, 0, v[4 * f + u]);
+                    }
                 }
         }
         if (nxt >= ntiles) break;
@@ -694,6 +721,13 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 // The two stages as separate launches so the caller can put them on two streams: stage 2 of launch group i then runs
 // beside stage 1 of group i+1 (k_p1 is VALU/LDS-heavy, k_p2 memory-heavy), each with `wg_per_cu` resident workgroups
 // per CU, and a group's G never leaves the Infinity Cache.
+// FDC_NT bits (A/B testing): 1 = stage-2 output stores nt, 2 = stage-1 input loads nt, 4 = stage-2 G loads nt, 8 = stage-1 G stores nt
+static int nt_hints()
+{
+    static int h = -1;
+    if (h < 0) { const char *t = getenv("FDC_NT"); h = t ? atoi(t) & 15 : kDefaultNtHints; }
+    return h;
+}
 static int poly_tile(int lout)
 {
     static int tcfg = -1;                                   // FDC_POLY_TILE=16|32 (A/B testing); default 16
@@ -756,7 +790,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     const bool reuse = !noreuse && abl == 0 && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
 #define FDC_LP1(T, A, K) \
     hipLaunchKernelGGL((k_p1<T, A, K>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
-                       nb_chunk, bpg, skip / 16, lout)
+                       nb_chunk, bpg, skip / 16, lout, nt_hints())
 #define FDC_LP1K(T) \
     do { if (!reuse) FDC_LP1(T, 0, 0); else if (R == 2) FDC_LP1(T, 0, 8); else if (R == 4) FDC_LP1(T, 0, 4); \
          else if (R == 8) FDC_LP1(T, 0, 2); else FDC_LP1(T, 0, 1); } while (0)
@@ -778,7 +812,7 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int n
         const int slots = cu_count();
         const unsigned gk = (unsigned)(nt < slots ? nt : slots);
         hipLaunchKernelGGL(k_p2k, dim3(gk), dim3(1024), kP2kLds, s, g, out, tw1024, slot_off, nrows,
-                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt, lout);
+                           (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt, lout, nt_hints());
         return hipGetLastError();
     }
     const int TCG = poly_tile(lout);                        // column-tile width stage 1 wrote G with
@@ -795,7 +829,7 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int n
     const unsigned g2 = (unsigned)(nt2 < slots ? nt2 : slots);
 #define FDC_LP2(A, B) \
     hipLaunchKernelGGL((k_p2<A, B>), dim3(g2), dim3(A * 16), lds2, s, g, out, tw256, slot_off, nrows, (long long)mbase * lout, \
-                       (long long)nb_call, out_bytes, (int)nt2, lout)
+                       (long long)nb_call, out_bytes, (int)nt2, lout, nt_hints())
     if (TR == 32 && TCG == 32) FDC_LP2(32, 32);
     else if (TR == 32) FDC_LP2(32, 16);
     else FDC_LP2(16, 16);

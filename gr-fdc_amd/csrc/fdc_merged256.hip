@@ -26,18 +26,6 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_merged[];
 
 constexpr int kMergedLds = 256 * 16 * 8 + 2304 + 2304 + 1024 + 1024;     // tile, wrow, tq, sh, soff = 39424 B
 
-__device__ __forceinline__ cf bld2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);      // aux 2 = nt (streamed once)
-    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
-}
-__device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cf v)
-{
-    u32x2 t;
-    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 2);
-}
-
 template <int KEEP>
 __global__ __launch_bounds__(256, 4) void k_pm(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ g,
                                                float2 *__restrict__ out, const float2 *__restrict__ tw256,
