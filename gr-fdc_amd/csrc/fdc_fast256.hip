@@ -650,6 +650,7 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
     }
 }
 
+static int nt_hints();
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t init_fast_kernels()
 {
