@@ -331,7 +331,8 @@ __global__ FDC_GENERIC_BOUNDS(1) void k_p2g(const float2 *__restrict__ g, float2
         const int r = e & (TR - 1), k1 = e >> log2TR;
         if (e < total) {
             const long long o = slot_off[k1];                         // start of the stream of the channel in this slot
-            if (o >= 0) out[o * nb_call + rho0 + r] = lds[k1 * ld + r];
+            // written once, never read back here: nt, so that G rather than the output stays cached (fdc_fast256.hip, nt_hints)
+            if (o >= 0) __builtin_nontemporal_store(from2(lds[k1 * ld + r]), reinterpret_cast<cf *>(out + o * nb_call + rho0 + r));
         }
     }
 }
