@@ -247,6 +247,9 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     const unsigned gtile = (unsigned)lout * TC * 8u;           // bytes of one (block, column tile) piece of G
     const unsigned goff = (unsigned)(b * TC + col) * 8u;       // row b of a 16-row group, column col
     const unsigned gstep = 16u * TC * 8u;                      // 16 rows further
+    // rows to discard, in units of 16: with the register hand-over it is the template constant (qskip == KEEP == 16/R), so
+    // the store predicates fold and the unused outputs of the last DFT-16 are never computed
+    const int qs = KEEP > 0 ? KEEP : qskip;
     // One tile: consume `cur` (block m), prefetch block mn (the next block of the run: overlap handed over in registers;
     // or the first block of this workgroup's next run: all rows loaded; or none, mn < 0) into `nbuf`.
     auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int m, int mn) {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         if (ABL == 1) {
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, cur[q]);
+                if (q >= qs) bst2(rg, goff, (unsigned)(q - qs) * gstep, cur[q]);
             return;
         }
         dft16<false>(cur);
@@ -328,11 +331,11 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         if (hints & 8) {
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (q >= qskip && (ABL != 2 || q == 15)) bst2_nt(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+                if (q >= qs && (ABL != 2 || q == 15)) bst2_nt(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (q >= qskip && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
+                if (q >= qs && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
         }
     };
     cf L[16];
