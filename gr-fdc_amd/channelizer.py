@@ -50,13 +50,29 @@ def get_opt_channelparams(blocksize, relinvovl, freq, bw):
         passband = 1.0
     elif passband < 0.7:
         stopband = passband + 0.25
-    centre = int(round(freq * blocksize)) % blocksize
+    # round(): the reference runs under Python 2 (half away from zero); Python 3's round() goes half to even
+    centre = int(math.floor(abs(freq * blocksize) + 0.5) * (1 if freq >= 0 else -1)) % blocksize
     first = centre - l / 2
     if first < 0:
         first = (first + blocksize) % blocksize
     if first + l > blocksize:
         first = blocksize - l
     return int(first), int(l), int(l) - int(l) // relinvovl, float(passband), float(stopband)
+
+
+def freq_converters(freqmode, fs=1.0, centerfrequency=0.0):
+    """(mode, get_freq, set_freq, get_bw, set_bw) of the three frequency conventions of the hier block
+    (python/FrequencyDomainChannelizer.py:70-91): user frequency -> internal [0, 1) with DC at 0.5, and back.
+    The mode may be given as the FREQMODE integer or as its name."""
+    if freqmode in (FREQMODE.normalized, 'normalized'):
+        return (FREQMODE.normalized, lambda f: (f + 0.5) % 1.0, lambda f: f - 0.5, lambda bw: bw % 1.0, lambda bw: bw)
+    if freqmode in (FREQMODE.basebandfs, 'basebandfs'):
+        return (FREQMODE.basebandfs, lambda f: (f / fs + 0.5) % 1.0, lambda f: (f - 0.5) * fs,
+                lambda bw: (bw / fs) % 1.0, lambda bw: bw * fs)
+    if freqmode in (FREQMODE.centerfreqfs, 'centerfreqfs'):
+        return (FREQMODE.centerfreqfs, lambda f: ((f - centerfrequency) / fs + 0.5) % 1.0,
+                lambda f: (f - 0.5) * fs + centerfrequency, lambda bw: (bw / fs) % 1.0, lambda bw: bw * fs)
+    raise ValueError('Unknown Frequency mode. Exiting...')
 
 
 def register_host(arr):
@@ -215,26 +231,7 @@ class FrequencyDomainChannelizer:
             raise ValueError('Unknown input type. ')            # only gr_complex is reachable (:205-210)
 
         # frequency conventions (:70-91): everything is stored normalised to [0, 1) with DC at 0.5
-        if freqmode in (FREQMODE.normalized, 'normalized'):
-            self.freqmode = FREQMODE.normalized
-            self.get_freq = lambda f: (f + 0.5) % 1.0
-            self.set_freq = lambda f: f - 0.5
-            self.get_bw = lambda bw: bw % 1.0
-            self.set_bw = lambda bw: bw
-        elif freqmode in (FREQMODE.basebandfs, 'basebandfs'):
-            self.freqmode = FREQMODE.basebandfs
-            self.get_freq = lambda f: (f / fs + 0.5) % 1.0
-            self.set_freq = lambda f: (f - 0.5) * fs
-            self.get_bw = lambda bw: (bw / fs) % 1.0
-            self.set_bw = lambda bw: bw * fs
-        elif freqmode in (FREQMODE.centerfreqfs, 'centerfreqfs'):
-            self.freqmode = FREQMODE.centerfreqfs
-            self.get_freq = lambda f: ((f - centerfrequency) / fs + 0.5) % 1.0
-            self.set_freq = lambda f: (f - 0.5) * fs + centerfrequency
-            self.get_bw = lambda bw: (bw / fs) % 1.0
-            self.set_bw = lambda bw: bw * fs
-        else:
-            raise ValueError('Unknown Frequency mode. Exiting...')
+        self.freqmode, self.get_freq, self.set_freq, self.get_bw, self.set_bw = freq_converters(freqmode, fs, centerfrequency)
 
         self.throughput_channels = self._convert(throughput_channels, self.get_channel, 'Throughput channels')
         self.activity_controlled_channels = self._convert(activity_controlled_channels, self.get_channel,

@@ -43,9 +43,10 @@ int fdco_channel_params(int N, int R, double freq, double bw,
     if (passband >= 1.0) passband = 1.0;                     /* :331-332 */
     else if (passband < 0.7) stopband = passband + 0.25;     /* :333-334 */
 
-    /* :336  int(round(freq*N)) % N — Python 3 round() = round-half-to-even = rint() in the
-     * default FP environment; Python's % is a floored modulo. */
-    long fs = (long)rint(freq * (double)N);
+    /* :336  int(round(freq*N)) % N — the reference is Python-2 code (python/__init__.py:29,34): its round()
+     * goes half AWAY from zero = C round(); Python's % is a floored modulo.  Pinned by the rows of
+     * tests/golden/channel_params.json, which come from running the reference's function (ties marked). */
+    long fs = (long)round(freq * (double)N);
     fs = ((fs % N) + N) % N;
     double fsd = (double)fs - (double)blocklen / 2.0;        /* :337 (true division) */
     if (fsd < 0) fsd = fmod(fsd + (double)N, (double)N);     /* :338-339 */

@@ -9,8 +9,9 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *  - window design (lib/windows.h): PINNED — compared bit-for-bit with the reference's own
  *    lib/windows.h compiled unmodified into oracle/_ref/ (oracle/Makefile, target ref).
- *  - channel parameter derivation (python/FrequencyDomainChannelizer.py:322-345): pinned on the
- *    reference outputs recorded in SURVEY.md section 8 row a8 (tests/golden/channel_params.json).
+ *  - channel parameter derivation (python/FrequencyDomainChannelizer.py:322-345): PINNED — compared with
+ *    ~1600 outputs of the reference's own function, recorded by tests/golden/make_params_from_reference.py
+ *    (which imports the reference's Python in the build container) in tests/golden/channel_params.json.
  *  - overlap_save / vector_cut_vxx / phase_shifting_windowing_vcc work(): restated from source;
  *    the reference .cc files need GNU Radio + VOLK headers that this image lacks => unbuildable here.
  *  - FFTs / multiply_const (GNU Radio + FFTW3f + VOLK, not under /root/reference, versions unpinned):

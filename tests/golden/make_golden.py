@@ -5,8 +5,8 @@ by oracle/Makefile) for the window tables.
 Fixtures are DATA (inputs + expected outputs):
   windows_ref.npz      tables produced by the reference's own cr_win (lib/windows.h:41-78), unmodified,
                        through oracle/ref_windows_driver.cpp.
-  channel_params.json  outputs of the reference's get_opt_channelparams
-                       (python/FrequencyDomainChannelizer.py:322-345) as recorded in SURVEY.md §8 row a8.
+  channel_params.json  NOT made here: tests/golden/make_params_from_reference.py produces it by running the
+                       reference's own get_opt_channelparams / frequency-mode lambdas.
   chain_numpy.npz      the throughput chain evaluated with numpy.fft in
                        complex128 — an implementation independent of oracle/fdc_oracle.c — on seeded
                        multicarrier input, float32-rounded at the reference's stage boundaries.
@@ -39,18 +39,6 @@ def make_windows():
         d["case%02d" % i] = O.ref_window(t, l, np.float32(p), np.float32(s), R)
     d["params"] = np.array(WINDOW_CASES, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "windows_ref.npz"), **d)
-
-
-def make_params():
-    rows = [  # SURVEY.md §8 row a8 (user-normalised freq, bw) -> (f, l, lout, pbw, sbw)
-        dict(N=4096, R=4, freq=0.12, bw=0.05, out=[2412, 256, 192, 0.88, 1.0]),
-        dict(N=4096, R=4, freq=0.22, bw=0.1, out=[2693, 512, 384, 0.88, 1.0]),
-        dict(N=4096, R=4, freq=-0.14, bw=0.12, out=[963, 1024, 768, 0.528, 0.778]),
-        dict(N=4096, R=4, freq=0.0, bw=0.081, out=[1792, 512, 384, 0.7128, 1.0]),
-        dict(N=65536, R=2, freq=0.5 / 256 - 0.5, bw=0.8 / 256, out=[0, 256, 128, 0.88, 1.0]),
-    ]
-    with open(os.path.join(HERE, "channel_params.json"), "w") as fh:
-        json.dump(rows, fh, indent=1)
 
 
 def multicarrier(N, chans, nsamp, seed, noise=0.1):
@@ -134,7 +122,6 @@ def make_sink_known_answers():
 
 if __name__ == "__main__":
     make_windows()
-    make_params()
-    make_chain()
+        make_chain()
     make_sink_known_answers()
     print("fixtures written to", HERE)

@@ -43,11 +43,59 @@ def test_window_table_bit_exact_vs_reference_fixture(golden_dir):
         assert (w.view(np.uint32) == z["case%02d" % i].view(np.uint32)).all(), i
 
 
-def test_get_opt_channelparams_golden(golden_dir):
-    for r in json.load(open(os.path.join(golden_dir, "channel_params.json"))):
-        got = G.get_opt_channelparams(r["N"], r["R"], (r["freq"] + 0.5) % 1.0, r["bw"] % 1.0)
-        assert list(got[:3]) == r["out"][:3]
-        assert abs(got[3] - r["out"][3]) < 1e-12 and abs(got[4] - r["out"][4]) < 1e-12
+def _params_fixture(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "channel_params.json")))
+
+
+def test_get_opt_channelparams_vs_reference_fixture(golden_dir):
+    """Product parameter derivation == the reference's own get_opt_channelparams on every row of the fixture that
+    tests/golden/make_params_from_reference.py produced by running python/FrequencyDomainChannelizer.py:322-345
+    (>= 1500 points: BASELINE plans, a random sweep, .5 ties, clamp / wrap edges, passband < 0.7, both fs modes)."""
+    fx = _params_fixture(golden_dir)
+    assert len(fx["rows"]) >= 1000 and "make_params_from_reference.py" in fx["generated_by"]
+    nties = 0
+    for r in fx["rows"]:
+        _m, get_freq, _sf, get_bw, _sb = G.freq_converters(r.get("freqmode", 0), r.get("fs", 1.0), r.get("centerfrequency", 0.0))
+        fr, bw = get_freq(r["freq"]), get_bw(r["bw"])
+        assert [fr, bw] == r["internal"], r                       # the mode lambdas (:70-91), bit for bit
+        N, R = G.nextpow2(r["N"]), G.nextpow2(r["R"])             # :138-139
+        if isinstance(r["out"], dict):
+            with pytest.raises(ValueError):
+                G.get_opt_channelparams(N, R, fr, bw)
+            continue
+        got = G.get_opt_channelparams(N, R, fr, bw)
+        assert list(got) == r["out"], (r, got)                    # ints exact, doubles bit-identical
+        if r.get("tie"):
+            nties += 1
+            assert list(got) != r["out_py3"]                      # Python-2 rounding is what the reference runs under
+    assert nties >= 5
+
+
+def test_nextpow2_vs_reference_fixture(golden_dir):
+    fx = _params_fixture(golden_dir)
+    for k, v in fx["nextpow2"]:
+        assert G.nextpow2(k) == v, k
+    assert fx["nextpow2_below_one_raises"]
+    with pytest.raises(ValueError):
+        G.nextpow2(0.5)
+
+
+def test_frequency_modes_vs_reference_fixture(golden_dir):
+    """normalized / basebandfs / centerfreqfs (integer and string spellings): channel and segment conversion and the
+    inverse lambdas, against what the reference's __init__ (:70-91, :349-357) produced."""
+    fx = _params_fixture(golden_dir)
+    assert len(fx["modes"]) == 6
+    for m in fx["modes"]:
+        mode, get_freq, set_freq, get_bw, set_bw = G.freq_converters(m["freqmode"], m["fs"], m["centerfrequency"])
+        assert mode == m["freqmode_int"]
+        assert [[get_freq(a), get_bw(b)] for a, b in m["channels"]] == m["throughput_channels"]
+        assert [[get_freq(a), get_freq(b)] for a, b in m["segments"]] == m["activity_detection_segments"]
+        assert [set_freq(v) for v in (0.0, 0.25, 0.5, 0.75)] == m["set_freq"]
+        assert [set_bw(v) for v in (0.01, 0.5)] == m["set_bw"]
+    with pytest.raises(ValueError):
+        G.freq_converters(3)
+    with pytest.raises(ValueError):
+        G.freq_converters("hz")
 
 
 def test_channelparams_match_oracle_on_a_sweep(oracle):
@@ -56,8 +104,6 @@ def test_channelparams_match_oracle_on_a_sweep(oracle):
         N = int(2 ** rng.integers(6, 19)); R = int(2 ** rng.integers(1, 4))
         fr = float(rng.uniform(0, 1)); bw = float(rng.uniform(2.0 / N, 0.3))
         assert G.get_opt_channelparams(N, R, fr, bw) == oracle.channel_params(N, R, fr, bw)
-    with pytest.raises(ValueError):
-        G.nextpow2(0.5)
 
 
 @pytest.mark.skipif(G.lib().fdc_device_count() > 0, reason="a GPU is present")
