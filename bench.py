@@ -183,7 +183,8 @@ def main():
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
     nlaunch = (nb + chunk - 1) // chunk         # launch groups per step
     path = pipe.path()
-    names = ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 else \
+    names = ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 else \
+            ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 else \
             ["fft_pass_a", "fft_pass_b", "channels"]
     dom = max(range(3), key=lambda i: last[i])
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel

@@ -118,6 +118,8 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
+    int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
     hipStream_t stream2 = nullptr;               // uniform path: stage 2 runs here, beside stage 1 of the next group
     float2 *d_g[2] = {nullptr, nullptr};         // uniform path: double-buffered stage-1 output
     hipEvent_t ev_fork = nullptr, ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
@@ -306,6 +308,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             else used[ch.f >> 8] = 1;
         }
         p->poly_ok = ok;
+        const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
+        p->poly_block = ok && N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
+        if (bh) p->block_hints = atoi(bh) & 3;
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
@@ -411,6 +416,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipMemcpy(p->d_tw1024, t1k.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
         }
     }
+    if (p->poly_block) {
+        hipDeviceProp_t prop;
+        CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
+        p->ncu = prop.multiProcessorCount;
+    }
     if (p->poly_ok) {
         const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
         CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
@@ -463,6 +473,7 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk :
 int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
+    if (p->poly_block && !p->poly_fused && !p->poly_merged) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -559,6 +570,19 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
+        if (use_poly && p->poly_block && !p->poly_fused && !p->poly_merged) {
+            // one launch: nothing but the input rows and the output samples crosses the memory interface
+            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
+                                          p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
+                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s));
+            if (tg) {
+                HIPCHK(hipEventRecord(p->events[span[1]], s));
+                span[2] = span[3] = span[1];
+                p->ev_spans.push_back(span);
+            }
+            continue;
+        }
         if (use_poly && p->poly_fused) {
             hipEvent_t ev4[4]; hipEvent_t *evp4 = nullptr;
             if (tg) { for (int i = 0; i < 4; i++) ev4[i] = p->events[span[i]]; evp4 = ev4; }

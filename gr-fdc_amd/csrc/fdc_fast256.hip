@@ -659,6 +659,8 @@ hipError_t init_fast_kernels()
 {
     hipError_t e = init_fused_kernels();
     if (e != hipSuccess) return e;
+    e = init_block_kernels();
+    if (e != hipSuccess) return e;
     e = init_merged_kernels();
     if (e != hipSuccess) return e;
     const int a = kTileBytes + 8192, c = kCTileBytes + 2304;

@@ -108,6 +108,13 @@ hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, 
                              int wg1_per_cu, hipStream_t s1, hipStream_t s2, hipEvent_t fork, hipEvent_t join,
                              hipEvent_t *ev);
 
+// uniform plan, N = 65536, R = 2: the whole path in one kernel, one block per CU, G kept in registers (fdc_block256.hip).
+// hints: 1 = nt output stores, 2 = nt input loads.  ncu: compute units of the device (grid size).
+hipError_t init_block_kernels();
+hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
+                             const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
+                             const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s);
+
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
 
 // sinks

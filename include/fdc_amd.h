@@ -111,7 +111,9 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
 /* Which kernels a process call without spectrum output runs: 0 = generic LDS Stockham kernels (any size),
  * 1 = radix-16 register kernels with the spectrum in memory (N = 65536), 2 = uniform-plan path (all channels
  * l = 256 on the 256-bin grid: stage 1 = column FFT + window + IFFT, stage 2 = FFT across slots; timing
- * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0). */
+ * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0), 3 = the uniform plan at N = 65536, R = 2 as ONE
+ * kernel (one block per compute unit, nothing between the input rows and the output samples touches memory;
+ * ms[0] = that kernel, ms[1] = ms[2] = 0). */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 
 /* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's

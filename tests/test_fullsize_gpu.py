@@ -32,11 +32,12 @@ def bits(a):
     return a.view(np.uint32)
 
 
-FORCED = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))     # the suite itself run under a forced path
+FORCED = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK"))     # the suite itself run under a forced path
 
 
 def run(N, R, plan, x, nb, sub=None, force=None):
-    """force: None = the default path (uniform two-stage), "FDC_NO_POLY" = spectrum in memory, "FDC_FORCE_GENERIC" = generic kernels"""
+    """force: None = the default path (uniform plan: one kernel at N = 65536, two launches otherwise), "FDC_NO_BLOCK" = the
+    two-launch uniform path, "FDC_NO_POLY" = spectrum in memory, "FDC_FORCE_GENERIC" = generic kernels"""
     if sub is not None:
         os.environ["FDC_HOST_SUB"] = str(sub)
     if force:
@@ -44,7 +45,8 @@ def run(N, R, plan, x, nb, sub=None, force=None):
     try:
         p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
         if not FORCED:
-            assert p.path() == {None: 2, "FDC_NO_POLY": 1 if N == 65536 else 0, "FDC_FORCE_GENERIC": 0}[force]
+            assert p.path() == {None: 3 if (N, R) == (65536, 2) else 2, "FDC_NO_BLOCK": 2,
+                                "FDC_NO_POLY": 1 if N == 65536 else 0, "FDC_FORCE_GENERIC": 0}[force]
         return p.work(x)
     finally:
         os.environ.pop("FDC_HOST_SUB", None)
@@ -70,7 +72,9 @@ def test_full_size_batch_vs_oracle_and_launch_grouping(oracle, N, C, nb):
         worst_mx = max(worst_mx, float(np.abs(d).max() / np.abs(ref[c]).max()))
     assert worst_l2 <= TOL and worst_mx <= TOL, (worst_l2, worst_mx)
     # the other two kernel paths on the same full-size batch (spectrum in memory; generic kernels) agree with the oracle too
-    for force in ("FDC_NO_POLY", "FDC_FORCE_GENERIC"):
+    for force in ("FDC_NO_BLOCK", "FDC_NO_POLY", "FDC_FORCE_GENERIC"):
+        if force == "FDC_NO_BLOCK" and N != 65536:
+            continue
         alt = run(N, R, plan, x, nb, force=force)
         for c in range(0, C, 7):
             d = alt[c].astype(np.complex128) - ref[c].astype(np.complex128)

@@ -211,7 +211,7 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
     forced = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
-    assert forced or p.path() == 2
+    assert forced or p.path() == (3 if (N, R) == (65536, 2) else 2)      # N = 65536, R = 2: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
@@ -230,6 +230,46 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     parts = [p.work(x[a * p.H:b * p.H]) for a, b in [(0, 2), (2, 3), (3, 5)]]
     for c in range(len(chans)):
         assert_close(np.concatenate([q_[c] for q_ in parts]), ref[c])
+
+
+@pytest.mark.parametrize("nslots,nb,chunk", [(256, 7, 0), (256, 300, 0), (256, 530, 256), (9, 261, 0), (1, 3, 0)])
+def test_uniform_plan_one_kernel_path(oracle, nslots, nb, chunk):
+    """N = 65536, R = 2, uniform plan: the one-block-per-CU kernel (path 3; G never leaves the compute unit) against the
+    oracle on the first and last blocks and against the two-launch path (FDC_NO_BLOCK=1) on every sample; block counts
+    below, at and above one round of workgroups, launch groups that end mid-round, any subset of slots."""
+    N, R = 65536, 2
+    H = N - N // R
+    rng = np.random.default_rng(nslots * 1000 + nb)
+    slots = [int(v) for v in rng.permutation(256)[:nslots]]
+    chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 77 + nb)
+    os.environ["FDC_HOST_SUB"] = str(nb)              # the whole call as one device batch (launch groups of `chunk` blocks)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    assert p.path() == 3
+    try:
+        outs = p.work(x)
+    finally:
+        os.environ.pop("FDC_HOST_SUB", None)
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x[:k * H], nthreads=8)
+    for c in range(len(chans)):
+        assert_close(outs[c][:k * 128], ref[c], "slot %d head" % slots[c])
+    if nb > k:                                        # last blocks, with the true history in front of them
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, 1, chans, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for c in range(len(chans)):
+            assert_close(outs[c][t0 * 128:], ref2[c], "slot %d tail" % slots[c])
+    os.environ["FDC_NO_BLOCK"] = "1"
+    try:
+        q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+        assert q.path() == 2
+        outs2 = q.work(x)
+    finally:
+        del os.environ["FDC_NO_BLOCK"]
+    for c in range(len(chans)):
+        assert_close(outs[c], outs2[c], "slot %d vs two-launch path" % slots[c])
 
 
 def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
