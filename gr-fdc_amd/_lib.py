@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdc_amd.so")
+LIB_PATH = os.environ.get("FDC_AMD_LIB") or os.path.join(_HERE, "libfdc_amd.so")    # FDC_AMD_LIB: A/B testing of builds
 
 FDC_OK = 0
 STATUS_NAMES = {0: "FDC_OK", -1: "FDC_ERR_INVALID_ARGUMENT", -2: "FDC_ERR_HIP", -3: "FDC_ERR_NO_DEVICE",

@@ -119,6 +119,7 @@ struct fdc_pipeline {
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
+    unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
     hipStream_t stream2 = nullptr;               // uniform path: stage 2 runs here, beside stage 1 of the next group
     float2 *d_g[2] = {nullptr, nullptr};         // uniform path: double-buffered stage-1 output
@@ -216,7 +217,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
     for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl); (void)hipFree(p->d_done);
+    (void)hipFree(p->d_dbg); (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl); (void)hipFree(p->d_done);
     for (auto e : p->events) (void)hipEventDestroy(e);
     for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) {
@@ -310,7 +311,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->poly_ok = ok;
         const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
         p->poly_block = ok && N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
-        if (bh) p->block_hints = atoi(bh) & 3;
+        if (bh) p->block_hints = atoi(bh) & 255;
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
@@ -420,6 +421,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         hipDeviceProp_t prop;
         CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
         p->ncu = prop.multiProcessorCount;
+        if (const char *dg = getenv("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
+            CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
+            CHK_OR_FREE(hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 32));
+        }
     }
     if (p->poly_ok) {
         const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
@@ -484,6 +489,19 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     HIPCHK(hipSetDevice(p->cfg.device_id));
     HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->d_dbg) {                                   // diagnostics: stage timeline of workgroup 0 of the last launch, cycles from block start
+        std::vector<unsigned long long> st(8 * 4 * 32);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(st.data(), p->d_dbg, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; k++)
+            for (int w = 0; w < 8; w++) {
+                const unsigned long long *q = st.data() + (w * 4 + k) * 32;
+                if (!q[0]) continue;
+                std::fprintf(stderr, "[fdc block] round %d wave %d t0=%llu :", k, w, q[0] - st[0]);
+                for (int i = 1; i < 31; i++) std::fprintf(stderr, " %lld", (long long)(q[i] - q[0]));
+                std::fprintf(stderr, "\n");
+            }
+    }
     if (p->d_ctl) {                                   // bounded spins of the fused dataflow kernel report here
         unsigned err = 0;
         HIPCHK(hipMemcpy(&err, static_cast<char *>(p->d_ctl) + fdc::kFusedErrorOffset, sizeof err, hipMemcpyDeviceToHost));
@@ -555,7 +573,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const float2 *ring = static_cast<const float2 *>(d_ring);
-    const bool use_poly = p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < (1ll << 32);
+    const bool use_poly = p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < 0xFFFFFF00ll;
     p->last_was_poly = use_poly;
     for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
         const int nb = std::min(p->chunk, nblocks - m0);
@@ -575,7 +593,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s));
+                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg));
             if (tg) {
                 HIPCHK(hipEventRecord(p->events[span[1]], s));
                 span[2] = span[3] = span[1];

@@ -113,7 +113,8 @@ hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, 
 hipError_t init_block_kernels();
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
-                             const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s);
+                             const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
+                             unsigned long long *dbg = nullptr /* diagnostics: 8 x 4 x 24 cycle stamps of workgroup 0 */);
 
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
 

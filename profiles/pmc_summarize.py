@@ -25,7 +25,7 @@ for k in sorted(acc):
 # HBM traffic per dispatch for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
 # FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md §HBM) -> doubled.
 import json
-names = {"fdc::k_p1": "poly_stage1(colFFT+window+IFFT)", "fdc::k_p2": "poly_stage2(slotFFT)",
+names = {"fdc::k_blk256": "block_kernel(colFFT+window+IFFT+slotFFT)", "fdc::k_p1": "poly_stage1(colFFT+window+IFFT)", "fdc::k_p2": "poly_stage2(slotFFT)",
          "fdc::k_a256": "fft_pass_a", "fdc::k_b256": "fft_pass_b", "fdc::k_c256": "channels"}
 out = {}
 for k in acc:
