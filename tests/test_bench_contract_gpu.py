@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-blocks", "32"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-blocks", "32",
+                          "--cpu-budget", "6"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -23,12 +24,51 @@ def test_bench_json_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["kernel_path"] == 2
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["kernel_path"] == 3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     # achieved = algorithmic bytes per launch / average launch duration of the dominant kernel
     assert abs(r["achieved"] - r["alg_bytes_per_block"] * r["blocks_per_launch"] / (r["kernel_avg_launch_ms"] * 1e-3) / 1e9) < 1.0
     assert d["value"] > 1e4 and abs(d["value"] - 1024 * 32768 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
+    # one kernel: the dominant kernel is the step, so the contract's frac and the whole-step fraction agree to the launch gaps
+    assert 0.8 < r["pipeline_frac"] / r["frac"] <= 1.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["one_thread"]["cores"] == 1 and 0 < c["one_thread"]["value"] <= c["value"] * 1.5
+    assert c["torch_fft"]["value"] > 0 and c["host"]["nproc"] >= c["cores"] and "cpu_model" in c["host"]
+
+
+def _line(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                         cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_config4_shape():
+    d = _line(["--config", "4", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["config"]["blocklen"] == 262144 and d["config"]["channels"] == 1024 and d["config"]["kernel_path"] == 2
+    assert d["roofline"]["alg_bytes_per_block"] == 2097152 and d["value"] > 1e4
+
+
+def test_bench_config3_and_5_sinks():
+    for cfg in (3, 5):
+        d = _line(["--config", str(cfg), "--blocks", "256", "--steps", "3", "--warmup", "1", "--cpu-blocks", "16", "--cpu-budget", "4"])
+        assert d["config"]["baseline_config"] == cfg and d["config"]["pdus_per_step"] > 0
+        assert d["config"]["extracted_samples_per_step"] > 0
+        # B_alg = input bytes + the samples really extracted (data dependent)
+        assert d["roofline"]["alg_bytes_per_block"] > 8 * 32768 and d["roofline"]["achieved"] > 0
+        assert d["cpu_baseline"]["value"] > 0 and d["value"] > 100.0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 started plainly: it spawns the two ranks itself; FDC_BENCH_REHEARSE=1 lets both use cuda:0 over gloo,
+    so the HIP path runs once per rank (span sharding with halo and global block index)."""
+    d = _line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "256", "--no-cpu-baseline"],
+              env={"FDC_BENCH_REHEARSE": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("block-span sharding x2") and d["value"] > 1e3
