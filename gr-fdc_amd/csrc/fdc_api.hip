@@ -48,10 +48,16 @@ int select_device(int device_id)
         return fail(FDC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device_id < 0 || device_id >= n) return fail(FDC_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, n);
     HIPCHK(hipSetDevice(device_id));
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] { init_err = fdc::init_kernels(); });
-    if (init_err != hipSuccess) return fail(FDC_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(init_err));
+    // the dynamic-LDS limits are function attributes PER DEVICE: set once for every device a handle is opened on
+    static std::mutex mu;
+    static std::vector<char> ready;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)ready.size() < n) ready.resize((size_t)n, 0);
+    if (!ready[(size_t)device_id]) {
+        const hipError_t e = fdc::init_kernels();
+        if (e != hipSuccess) return fail(FDC_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(e));
+        ready[(size_t)device_id] = 1;
+    }
     return FDC_OK;
 }
 
@@ -121,19 +127,9 @@ struct fdc_pipeline {
     bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
-    hipStream_t stream2 = nullptr;               // uniform path: stage 2 runs here, beside stage 1 of the next group
-    float2 *d_g[2] = {nullptr, nullptr};         // uniform path: double-buffered stage-1 output
-    hipEvent_t ev_fork = nullptr, ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
-    int poly_split = 2;                          // stage-1 workgroups per CU when the stages overlap (of 4)
-    bool poly_overlap = false;                   // FDC_POLY_OVERLAP=1: measured slower on MI355X (profiles/r01/NOTES.md)
+    float2 *d_g = nullptr;                       // uniform path (two launches): stage-1 output G, chunk*lout*N/256 samples
     bool last_was_poly = false;
-    bool poly_fused = false;                     // FDC_POLY_FUSED=1: XCD-local dataflow, G through L2 (fdc_fused256.hip)
-    bool poly_merged = false;                    // FDC_POLY_MERGED=1: both stages in one persistent launch (fdc_merged256.hip)
-    int merged_hints = 3, ncu = 0;
-    int *d_done = nullptr, *d_err = nullptr;
-    int fused_ring = 8, fused_wg1 = 3;           // G ring per XCD in blocks (8 x 256 KiB = 2 MiB of the 4-MiB L2); stage-1 WGs/CU
-    float2 *d_gring = nullptr;
-    void *d_ctl = nullptr;
+    int ncu = 0;                                 // compute units of the handle's device
     float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
     float *d_shn = nullptr;                      // uniform path: shape[k2] / N
     long long *d_slot_off = nullptr;
@@ -215,9 +211,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
 {
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
-    for (auto e : {p->ev_fork, p->ev_s1[0], p->ev_s1[1], p->ev_s2[0], p->ev_s2[1]}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_dbg); (void)hipFree(p->d_g[0]); (void)hipFree(p->d_g[1]); (void)hipFree(p->d_gring); (void)hipFree(p->d_ctl); (void)hipFree(p->d_done);
+    (void)hipFree(p->d_dbg); (void)hipFree(p->d_g);
     for (auto e : p->events) (void)hipEventDestroy(e);
     for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) {
@@ -317,24 +311,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
     // default takes groups as large as a 2 GiB scratch budget allows (1024 blocks at N = 65536).
     int chunk = cfg->chunk_blocks;
-    {
-        const char *ov = getenv("FDC_POLY_OVERLAP"), *sp = getenv("FDC_POLY_SPLIT");
-        if (ov) p->poly_overlap = ov[0] != '0';
-        const char *fu = getenv("FDC_POLY_FUSED"), *fw = getenv("FDC_FUSED_WG1"), *fr = getenv("FDC_FUSED_RING");
-        if (fu) p->poly_fused = fu[0] != '0' && N == 65536;
-        const char *me = getenv("FDC_POLY_MERGED"), *mh = getenv("FDC_MERGED_HINTS");
-        if (me) p->poly_merged = me[0] != '0' && N == 65536;
-        if (mh) p->merged_hints = atoi(mh) & 127;
-        if (fw && atoi(fw) >= 1 && atoi(fw) <= 3) p->fused_wg1 = atoi(fw);
-        if (fr && atoi(fr) >= 2) p->fused_ring = atoi(fr);
-        if (sp && atoi(sp) >= 1 && atoi(sp) <= 3) p->poly_split = atoi(sp);
-    }
-    if (chunk <= 0) {
-        // uniform path with overlapped stages (experimental): two G buffers of chunk*lout*N/256 samples must stay in
-        // the 256 MiB Infinity Cache next to the streams passing through -> 256 blocks
-        if (p->poly_ok && p->poly_overlap && !cfg->keep_spectrum) chunk = 256;
-        else chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
-    }
+    if (chunk <= 0) chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
     chunk = std::min(chunk, cfg->max_blocks);
     p->chunk = chunk;
 
@@ -417,41 +394,19 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipMemcpy(p->d_tw1024, t1k.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
         }
     }
-    if (p->poly_block) {
+    {
         hipDeviceProp_t prop;
         CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
-        p->ncu = prop.multiProcessorCount;
+        p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (p->poly_block) {
         if (const char *dg = getenv("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
             CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
             CHK_OR_FREE(hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 32));
         }
     }
-    if (p->poly_ok) {
-        const size_t gsz = sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256);
-        CHK_OR_FREE(hipMalloc(&p->d_g[0], gsz));
-        CHK_OR_FREE(hipMalloc(&p->d_g[1], gsz));
-        if (p->poly_merged) {
-            hipDeviceProp_t prop;
-            CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
-            p->ncu = prop.multiProcessorCount;
-            if (p->ncu % 32) p->poly_merged = false;          // needs whole 16-workgroup groups per XCD at 4 per CU
-            else {
-                CHK_OR_FREE(hipMalloc(&p->d_done, sizeof(int) * ((size_t)chunk + 4)));
-                p->d_err = p->d_done + chunk;
-                CHK_OR_FREE(hipMemset(p->d_err, 0, 4 * sizeof(int)));
-            }
-        }
-        if (p->poly_fused) {
-            CHK_OR_FREE(hipMalloc(&p->d_gring, fdc::fused_ring_bytes(R, p->fused_ring)));
-            CHK_OR_FREE(hipMalloc(&p->d_ctl, fdc::fused_ctl_bytes(chunk)));
-        }
-        CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
-        CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) {
-            CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_s1[i], hipEventDisableTiming));
-            CHK_OR_FREE(hipEventCreateWithFlags(&p->ev_s2[i], hipEventDisableTiming));
-        }
-    }
+    if (p->poly_ok)
+        CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
     for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
     if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
@@ -478,7 +433,7 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk :
 int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
-    if (p->poly_block && !p->poly_fused && !p->poly_merged) return 3;
+    if (p->poly_block) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -501,18 +456,6 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
                 for (int i = 1; i < 31; i++) std::fprintf(stderr, " %lld", (long long)(q[i] - q[0]));
                 std::fprintf(stderr, "\n");
             }
-    }
-    if (p->d_ctl) {                                   // bounded spins of the fused dataflow kernel report here
-        unsigned err = 0;
-        HIPCHK(hipMemcpy(&err, static_cast<char *>(p->d_ctl) + fdc::kFusedErrorOffset, sizeof err, hipMemcpyDeviceToHost));
-        if (err) return fail(FDC_ERR_HIP, "XCD-local dataflow: dependency wait timed out (code %u)", err);
-    }
-    if (p->d_err) {                                   // merged uniform kernel: a hand-off wait timed out
-        int errw[3] = {0, 0, 0};
-        HIPCHK(hipMemcpy(errw, p->d_err, sizeof errw, hipMemcpyDeviceToHost));
-        if (p->merged_hints & 64) std::fprintf(stderr, "[fdc merged] short polls %d over %d waits\n", errw[1], errw[2]);
-        const int err = errw[0];
-        if (err) return fail(FDC_ERR_HIP, "merged uniform kernel: hand-off wait timed out; results of this handle are invalid");
     }
     return FDC_OK;
 }
@@ -588,7 +531,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        if (use_poly && p->poly_block && !p->poly_fused && !p->poly_merged) {
+        if (use_poly && p->poly_block) {
             // one launch: nothing but the input rows and the output samples crosses the memory interface
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
@@ -601,63 +544,22 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        if (use_poly && p->poly_fused) {
-            hipEvent_t ev4[4]; hipEvent_t *evp4 = nullptr;
-            if (tg) { for (int i = 0; i < 4; i++) ev4[i] = p->events[span[i]]; evp4 = ev4; }
-            HIPCHK(fdc::launch_poly_fused(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_gring, static_cast<float2 *>(d_out),
-                                          p->R, nb, m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_ctl, p->fused_ring,
-                                          p->fused_wg1, s, p->stream2, p->ev_fork, p->ev_s2[0], evp4));
-            if (tg) p->ev_spans.push_back(span);
-            continue;
-        }
-        if (use_poly && p->poly_merged) {
-            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
-            HIPCHK(fdc::launch_poly_merged(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[0], static_cast<float2 *>(d_out), p->R, nb,
-                                           m0, nblocks, p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->d_done, p->d_err, p->ncu,
-                                           p->merged_hints, s));
-            if (tg) {
-                for (int i = 1; i < 4; i++) HIPCHK(hipEventRecord(p->events[span[i]], s));
-                p->ev_spans.push_back(span);
-            }
-            continue;
-        }
         if (use_poly) {
-            // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the stages.
-            // Stage 1 on the caller's stream, stage 2 on stream2; group i's stage 2 overlaps group i+1's stage 1.
-            const int gi = (m0 / p->chunk) & 1;
-            const bool ovl = p->poly_overlap && nblocks > p->chunk;
-            hipStream_t s2 = ovl ? p->stream2 : s;
-            if (ovl && m0 >= 2 * p->chunk) HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi], 0));   // G[gi] free again
+            // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the two launches
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
-            HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g[gi], p->N / 256, p->R, nb,
-                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, ovl ? p->poly_split : 0, s));
-            if (tg) HIPCHK(hipEventRecord(p->events[span[1]], s));
-            if (ovl) {
-                HIPCHK(hipEventRecord(p->ev_s1[gi], s));
-                HIPCHK(hipStreamWaitEvent(s2, p->ev_s1[gi], 0));
-            }
-            if (tg) {
-                if (ovl) HIPCHK(hipEventRecord(p->events[span[2]], s2));
-                else span[2] = span[1];                          // same stream: the end of stage 1 IS the start of stage 2
-            }
+            HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N / 256, p->R, nb,
+                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->ncu, s));
+            if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[1]; }   // the end of stage 1 IS the start of stage 2
             if (p->N != 65536 && p->N != 262144)
-                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
-                                                       p->d_slot_off, p->d_tw, p->ntab, s2));
+                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
+                                                       p->d_slot_off, p->d_tw, p->ntab, s));
             else
-            HIPCHK(fdc::launch_poly_stage2(p->d_g[gi], static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
-                                           p->d_tw256, p->d_tw1024, p->d_slot_off,
-                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8),
-                                           ovl ? 4 - p->poly_split : 0, s2));
-            if (ovl) HIPCHK(hipEventRecord(p->ev_s2[gi], s2));
+                HIPCHK(fdc::launch_poly_stage2(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
+                                               p->d_tw256, p->d_tw1024, p->d_slot_off,
+                                               (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, s));
             if (tg) {
-                HIPCHK(hipEventRecord(p->events[span[3]], s2));
+                HIPCHK(hipEventRecord(p->events[span[3]], s));
                 p->ev_spans.push_back(span);
-            }
-            if (ovl && m0 + p->chunk >= nblocks) {           // join: the caller's stream waits for both stage-2 tails
-                HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi], 0));
-                if (m0 >= p->chunk) HIPCHK(hipStreamWaitEvent(s, p->ev_s2[gi ^ 1], 0));
             }
             continue;
         }

@@ -356,88 +356,6 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     }
 }
 
-// Two-group form of stage 1 (16-column tiles): a 512-thread workgroup holds TWO independent 256-thread groups, each
-// with its own tile, running the same four-barrier tile program HALF A TILE APART (group 1 enters two barriers late).
-// The shared s_barrier then pins one group's LDS-heavy exchanges against the other group's DFT-16 arithmetic, which
-// independent co-resident workgroups do not do by themselves (profiles/r01/NOTES.md: VALU and LDS phases convoy).
-__global__ __launch_bounds__(512, 4) void k_p1g(const float2 *__restrict__ in, size_t in_stride,
-                                                float2 *__restrict__ g, const float2 *__restrict__ tw256,
-                                                const float2 *__restrict__ twq, const float2 *__restrict__ cbt,
-                                                const float *__restrict__ shn, int N1, int log2ct, int ntiles,
-                                                int qskip, int lout)
-{
-    constexpr int TC = 16;
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, col = tid & (TC - 1), b = tid / TC;
-    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast + grp * (256 * TC * 8));    // [256][TC] per group
-    float2 *w256 = reinterpret_cast<float2 *>(fdc_smem_fast + 2 * 256 * TC * 8);
-    float2 *tq = reinterpret_cast<float2 *>(fdc_smem_fast + 2 * 256 * TC * 8 + 2048 + grp * 2048);
-    float *sh = reinterpret_cast<float *>(fdc_smem_fast + 2 * 256 * TC * 8 + 2048 + 4096);
-    const int step = 2 * gridDim.x;
-    int tl = 2 * blockIdx.x + grp;
-    const int niter = (ntiles + step - 1) / step;                    // same for both groups (barrier counts must match)
-    const int c0 = (tl & ((1 << log2ct) - 1)) * TC;                  // step is a multiple of the column tiles per block
-    if (grp == 0) { w256[tid] = tw256[tid]; sh[tid] = shn[tid]; }
-    tq[tid] = twq[(size_t)(c0 + col) * 16 + b];
-    const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
-    const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u, rowstep = 16u * (unsigned)N1 * 8u;
-    const unsigned inbytes = 256u * (unsigned)N1 * 8u, gtile = (unsigned)lout * TC * 8u;
-    const unsigned goff = (unsigned)(b * TC + col) * 8u, gstep = 16u * TC * 8u;
-    cf L[16];
-    if (tl < ntiles) {
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(tl >> log2ct) * in_stride, inbytes);
-#pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
-    }
-    __syncthreads();                                                 // tables of both groups are in LDS
-    if (grp == 1) { __syncthreads(); __syncthreads(); }              // half a tile late
-    for (int it = 0; it < niter; it++, tl += step) {
-        if (tl >= ntiles) {                                          // keep the barrier count of a real tile
-            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
-            continue;
-        }
-        const size_t m = tl >> log2ct;
-        cf v[16];
-#pragma unroll
-        for (int a = 0; a < 16; a++) v[a] = L[a];
-        if (tl + step < ntiles) {
-            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)((tl + step) >> log2ct) * in_stride, inbytes);
-#pragma unroll
-            for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
-        }
-        dft16<false>(v);
-        __syncthreads();                                             // (1) previous tile's exchange reads are done
-        cf w[16];
-#pragma unroll
-        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
-#pragma unroll
-        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], cmul(v[rev16(p)], w[p]));
-        __syncthreads();                                             // (2)
-#pragma unroll
-        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
-        dft16<false>(v);
-        cf u[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) u[q ^ 8] = cmul(v[rev16(q)], ld2(&tq[q * TC + col])) * sh[b + 16 * q];
-        dft16<true>(u);
-#pragma unroll
-        for (int p = 0; p < 16; p++) w[p] = ld2(&w256[b * p]);
-#pragma unroll
-        for (int p = 0; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], w[p]), cb);
-        __syncthreads();                                             // (3)
-#pragma unroll
-        for (int p = 0; p < 16; p++) st2(&tile[(16 * b + p) * TC + col], u[rev16(p)]);
-        __syncthreads();                                             // (4)
-#pragma unroll
-        for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&tile[(16 * bb + b) * TC + col]);
-        dft16<true>(u);
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + (m * (size_t)(N1 / TC) + (c0 / TC)) * (size_t)lout * TC, gtile);
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-            if (q >= qskip) bst2(rg, goff, (unsigned)(q - qskip) * gstep, u[rev16(q)]);
-    }
-    if (grp == 0) { __syncthreads(); __syncthreads(); }
-}
-
 // Stage 2 for N1 = 256 slots: rows rho = m*lout + t' of G (256 contiguous n1 each), FFT over n1, bin = slot c.
 // Persistent with next-tile prefetch like k_p1; a tile is TR consecutive rows (TR*2 KiB contiguous).
 template <int TR, int TCG>
@@ -657,11 +575,7 @@ static int nt_hints();
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t init_fast_kernels()
 {
-    hipError_t e = init_fused_kernels();
-    if (e != hipSuccess) return e;
-    e = init_block_kernels();
-    if (e != hipSuccess) return e;
-    e = init_merged_kernels();
+    hipError_t e = init_block_kernels();
     if (e != hipSuccess) return e;
     const int a = kTileBytes + 8192, c = kCTileBytes + 2304;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
@@ -674,8 +588,6 @@ hipError_t init_fast_kernels()
     FDC_SETP1(32, 0, 0) FDC_SETP1(16, 0, 0) FDC_SETP1(16, 1, 0) FDC_SETP1(16, 2, 0) FDC_SETP1(32, 1, 0) FDC_SETP1(32, 2, 0)
     FDC_SETP1(16, 0, 8) FDC_SETP1(16, 0, 4) FDC_SETP1(16, 0, 2) FDC_SETP1(16, 0, 1)
     FDC_SETP1(32, 0, 8) FDC_SETP1(32, 0, 4) FDC_SETP1(32, 0, 2) FDC_SETP1(32, 0, 1)
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
 #undef FDC_SETP1
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p2<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
@@ -724,9 +636,6 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
     return hipGetLastError();
 }
 
-// The two stages as separate launches so the caller can put them on two streams: stage 2 of launch group i then runs
-// beside stage 1 of group i+1 (k_p1 is VALU/LDS-heavy, k_p2 memory-heavy), each with `wg_per_cu` resident workgroups
-// per CU, and a group's G never leaves the Infinity Cache.
 // FDC_NT bits (A/B testing): 1 = stage-2 output stores nt, 2 = stage-1 input loads nt, 4 = stage-2 G loads nt, 8 = stage-1 G stores nt
 static int nt_hints()
 {
@@ -740,21 +649,9 @@ static int poly_tile(int lout)
     if (tcfg < 0) { const char *t = getenv("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
     return (lout % tcfg) ? 16 : tcfg;                       // stage-2 tiles are TC whole rows of one block
 }
-static int cu_count()
-{
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
-
 hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
                               const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
-                              int wg_per_cu, hipStream_t s)
+                              int ncu, hipStream_t s)
 {
     const int skip = 256 / R, lout = 256 - skip;
     const int TC = N1 == 256 ? poly_tile(lout) : 16;        // k_p2k reads 16-column tiles
@@ -762,7 +659,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     int log2ct = 0;
     while ((1 << log2ct) < ct) log2ct++;
     const int maxwg = TC == 32 ? 2 : 4;                     // resident workgroups per CU: LDS-limited
-    int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
+    int slots = maxwg * (ncu > 0 ? ncu : 256);
     slots -= slots % ct;
     if (slots < ct) slots = ct;
     // every workgroup keeps one column tile and takes runs of bpg consecutive blocks (FDC_POLY_BPG: run length, A/B testing)
@@ -776,21 +673,10 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     if (groups > runs) groups = runs;
     const unsigned g1 = (unsigned)(groups * ct);
     const size_t lds1 = 256 * TC * 8 + 2304 + TC * 144 + 1024;
-    static int abl = -1, twog = 0, noreuse = 0;
+    static int abl = -1, noreuse = 0;
     if (abl < 0) {
         const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
-        const char *g3 = getenv("FDC_POLY_2GROUP"); twog = g3 ? atoi(g3) : 0;
         const char *g4 = getenv("FDC_POLY_NOREUSE"); noreuse = g4 ? atoi(g4) : 0;
-    }
-    if (twog && TC == 16 && abl == 0 && N1 == 256) {        // two phase-shifted groups per 512-thread workgroup
-        const long long nt1 = (long long)nb_chunk * ct;
-        int wgs = (wg_per_cu > 0 && wg_per_cu < 4 ? (wg_per_cu + 1) / 2 : 2) * cu_count();
-        wgs -= wgs % (ct / 2 > 0 ? ct / 2 : 1);              // 2*grid must be a multiple of ct
-        const long long need = (nt1 + 1) / 2;
-        const unsigned gg = (unsigned)(need < wgs ? need : wgs);
-        hipLaunchKernelGGL(k_p1g, dim3(gg), dim3(512), 2 * 256 * 16 * 8 + 2048 + 4096 + 1024, s, in, in_stride, g, tw256,
-                           twq, cbt, shn, N1, log2ct, (int)nt1, skip / 16, lout);
-        return hipGetLastError();
     }
     // the overlap of consecutive blocks travels in registers when the items are exactly N - N/R apart
     const bool reuse = !noreuse && abl == 0 && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
@@ -809,13 +695,13 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
 
 hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
                               const float2 *tw256, const float2 *tw1024, const long long *slot_off, unsigned out_bytes,
-                              int wg_per_cu, hipStream_t s)
+                              int ncu, hipStream_t s)
 {
     const int skip = 256 / R, lout = 256 - skip;
     if (N1 == 1024) {                                       // one 1024-thread workgroup per CU, 16-row tiles
         const long long nrows = (long long)nb_chunk * lout;
         const long long nt = (nrows + 15) / 16;
-        const int slots = cu_count();
+        const int slots = ncu > 0 ? ncu : 256;
         const unsigned gk = (unsigned)(nt < slots ? nt : slots);
         hipLaunchKernelGGL(k_p2k, dim3(gk), dim3(1024), kP2kLds, s, g, out, tw1024, slot_off, nrows,
                            (long long)mbase * lout, (long long)nb_call, out_bytes, (int)nt, lout, nt_hints());
@@ -828,7 +714,7 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int n
     if (lout % TR) TR = 16;
     if (TCG == 32 && TR == 16) TR = 32;                     // 32-column G tiles are read 32 rows at a time
     const int maxwg = TR == 32 ? 2 : 4;
-    const int slots = (wg_per_cu > 0 && wg_per_cu < maxwg ? wg_per_cu : maxwg) * cu_count();
+    const int slots = maxwg * (ncu > 0 ? ncu : 256);
     const size_t lds2 = 256 * TR * 8 + 2048 + 2048;
     const long long nrows = (long long)nb_chunk * lout;
     const long long nt2 = (nrows + TR - 1) / TR;

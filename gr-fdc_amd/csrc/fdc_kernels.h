@@ -80,33 +80,15 @@ hipError_t launch_scatter_out(const float2 *src, const ScatterEnt *tab, int ncha
 
 hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
                               const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
-                              int wg_per_cu /* 0 = all the LDS admits */, hipStream_t s);
+                              int ncu /* compute units of the device */, hipStream_t s);
 hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 1024 slots */, int R, int nb_chunk, int mbase,
                               int nb_call, const float2 *tw256, const float2 *tw1024 /* N1 = 1024 only */,
                               const long long *slot_off, unsigned out_bytes /* whole d_out, < 4 GiB */,
-                              int wg_per_cu, hipStream_t s);
+                              int ncu, hipStream_t s);
 
 // stage 2 for any other slot count N1 = N/256 in [16, 4096] (generic LDS core, fdc_kernels.hip)
 hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
                                       const long long *slot_off, const float2 *tw, int ntab, hipStream_t s);
-
-// uniform plan as an XCD-local dataflow (fdc_fused256.hip): stage 1 (3 workgroups/CU, stream s1) and stage 2
-// (1 workgroup/CU, stream s2) run concurrently; every block is owned by one XCD and its G stays in that XCD's L2
-hipError_t init_fused_kernels();
-hipError_t init_merged_kernels();
-// uniform path, both stages in one persistent launch (fdc_merged256.hip); N = 65536 only.  hints: 1 = nt input loads, 2 = nt output stores
-hipError_t launch_poly_merged(const float2 *in, size_t in_stride, float2 *g, float2 *out, int R, int nb_chunk, int mbase,
-                              int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
-                              const long long *slot_off, unsigned out_bytes, int *done, int *err, int ncu, int hints,
-                              hipStream_t s);
-size_t fused_ctl_bytes(int nb);
-size_t fused_ring_bytes(int R, int ringx);
-constexpr int kFusedErrorOffset = 1024;      // byte offset of the error word inside the control block
-hipError_t launch_poly_fused(const float2 *in, size_t in_stride, float2 *gring, float2 *out, int R, int nb_chunk,
-                             int mbase, int nb_call, const float2 *tw256, const float2 *twq, const float2 *cbt,
-                             const float *shn, const long long *slot_off, unsigned out_bytes, void *ctl, int ringx,
-                             int wg1_per_cu, hipStream_t s1, hipStream_t s2, hipEvent_t fork, hipEvent_t join,
-                             hipEvent_t *ev);
 
 // uniform plan, N = 65536, R = 2: the whole path in one kernel, one block per CU, G kept in registers (fdc_block256.hip).
 // hints: 1 = nt output stores, 2 = nt input loads.  ncu: compute units of the device (grid size).

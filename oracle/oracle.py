@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libfdc_oracle.so")
+_LIB = os.environ.get("FDC_ORACLE_LIB") or os.path.join(_HERE, "libfdc_oracle.so")    # FDC_ORACLE_LIB: the sanitizer build (oracle/_san)
 _REF = os.path.join(_HERE, "_ref", "libref_windows.so")
 
 _fp = C.POINTER(C.c_float)
