@@ -44,14 +44,14 @@ class fdc_sinks_cfg(C.Structure):
                 ("nseg", C.c_int32), ("seg", C.POINTER(fdc_segment_cfg)),
                 ("det_thresh_db", C.c_float), ("det_maxblocks", C.c_int32), ("minchandist", C.c_float),
                 ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32),
-                ("det_variant", C.c_int32)]
+                ("det_variant", C.c_int32), ("verbose", C.c_int32), ("det_id", C.c_int32)]
 
 
 class fdc_pdu(C.Structure):
     _fields_ = [("kind", C.c_int32), ("source", C.c_int32), ("chan_id", C.c_int32), ("finalized", C.c_int32),
                 ("part", C.c_int32), ("has_part", C.c_int32), ("rel_bw", C.c_double), ("rel_cfreq", C.c_double),
                 ("blockstart", C.c_int64), ("blockend", C.c_int64), ("vectorstart", C.c_int64),
-                ("vectorend", C.c_int64), ("nsamples", C.c_int64), ("samples", C.c_void_p)]
+                ("vectorend", C.c_int64), ("nsamples", C.c_int64), ("samples", C.c_void_p), ("id", C.c_char * 72)]
 
 
 # every symbol include/fdc_amd.h declares: (restype, argtypes)
@@ -87,6 +87,7 @@ SYMBOLS = {
     "fdc_sinks_blocklen": (C.c_int32, [_vp]),
     "fdc_sinks_max_blocks": (C.c_int32, [_vp]),
     "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),
+    "fdc_set_log_callback": (None, [_vp, _vp]),
     "fdc_sinks_pdu_count": (C.c_int, [_vp]),
     "fdc_sinks_pdu": (C.c_int, [_vp, C.c_int, C.POINTER(fdc_pdu)]),
     "fdc_sinks_pdus": (C.c_int, [_vp, C.POINTER(fdc_pdu), C.c_int]),

@@ -247,8 +247,24 @@ class FrequencyDomainChannelizer:
         if self.inpveclen != 1 and self.inpveclen != self.blocksize:
             raise ValueError("inpveclen must be 1 (sample stream) or blocksize (items already transformed, :284-290)")
 
+        if self.verbose:                                        # runtime information, :176-193
+            bar = '\n' + '#' * 32 + '\n'
+            for ln in (bar, '# gr-FDC Frequency Domain Channelizer Runtime Information', bar,
+                       'Blocksize     = {}'.format(self.blocksize), 'InputVecLen   = {}'.format(self.inpveclen),
+                       'Relinvovl     = {}'.format(self.relinvovl), 'Ovllen        = {}'.format(self.ovllen),
+                       'MsgOutput     = {}'.format(msgoutput), 'FileOutput    = {}'.format(fileoutput),
+                       'Outputpath    = {}'.format(outputpath), 'Threaded      = {}'.format(threaded),
+                       'Debugoutput   = {}'.format(self.debug), bar,
+                       '# Throughput channels:         {}'.format(str(self.throughput_channels)),
+                       '# Activity control channels:   {}'.format(str(self.activity_controlled_channels)),
+                       '# Activity detection segments: {}'.format(str(self.activity_detection_segments)), bar):
+                self.log(ln)
         self.channel_params = [get_opt_channelparams(self.blocksize, self.relinvovl, fr, bw)
                                for (fr, bw) in self.throughput_channels]
+        if self.verbose:                                        # :223-224 (dec = blocksize / l)
+            for i, (f, l, lout, pbw, sbw) in enumerate(self.channel_params):
+                self.log('# Throughput Channel {}: dec={}, f={}, l={}, lout={}, bw=({}, {})'.format(
+                    i, self.blocksize / l, f, l, lout, pbw, sbw))
         # activity-controlled channels (:237-251) and detection segments (:261-278) share one spectrum on the device
         self.msgoutput, self.fileoutput, self.outputpath = bool(msgoutput), bool(fileoutput), str(outputpath)
         self.sinks = None
@@ -264,7 +280,8 @@ class FrequencyDomainChannelizer:
                                det_thresh=float(act_det_threshold), det_maxblocks=int(act_det_maxblocks),
                                minchandist=self.get_bw(minchandist) if self.activity_detection_segments else 0.005,
                                det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id,
-                               det_variant=1)      # the hier block instantiates SegmentDetection (:25, :261-278)
+                               det_variant=1,      # the hier block instantiates SegmentDetection (:25, :261-278)
+                               verbose=self.verbose)
         self.pipeline = Pipeline(self.blocksize, self.relinvovl,
                                  [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
                                  windowtype=int(windowtype), max_blocks=max_blocks, device_id=device_id,
@@ -288,6 +305,17 @@ class FrequencyDomainChannelizer:
 
     def get_opt_channelparams(self, freq, bw):
         return get_opt_channelparams(self.blocksize, self.relinvovl, freq, bw)
+
+    def log(self, s):                                           # :359-371
+        if self.verbose == VERBOSEMODE.LOGTOCONSOLE:
+            print(str(s))
+        elif self.verbose == VERBOSEMODE.LOGTOFILE:
+            if not hasattr(self, 'logfile'):
+                self.logfile = 'gr-FDC.FreqDomChan.log'
+                with open(self.logfile, 'w') as fh:
+                    fh.write('\n')
+            with open(self.logfile, 'a') as fh:
+                fh.write(str(s) + '\n')
 
     def get_channel(self, c):                                   # :349-352
         if not isinstance(c, (list, tuple)) or len(c) != 2:

@@ -63,12 +63,14 @@ struct Pac {
     bool active = false;
     float lastpower = FLT_MAX;
     int count = 0, phase = 0, part = 0, finished = 0, id_at_activation = 0;
+    std::string msg_id;                  // create_ID() at activation, :308-312
     std::deque<BlockRef> blocks;
 };
 
 struct DetChan {
     int ID, detect_start, detect_stop, extract_start, extract_stop, extract_width, wclass, ovlskip, outputsamples;
     int count, phase, phaseincrement, inactive, part;
+    std::string msg_id;                  // get_ID_for_msg() at activation, …vcm_impl.cc:526-530
     std::deque<BlockRef> data;
 };
 
@@ -103,9 +105,44 @@ struct fdc_sinks {
     std::vector<fdc::ExtractTask> tasks;
     std::vector<int> task_w, task_skip;
     int64_t ext_used = 0;
+    std::string det_logfile;                 // verbose == 2: …vcm_impl.cc:94 / SegmentDetection_impl.cc:51
 };
 
 namespace {
+
+fdc_log_fn g_log_fn = nullptr;
+void *g_log_user = nullptr;
+
+// get_current_time(), …vcm_impl.cc:56-69 / PowerActivationChannel_impl.cc:435-447 (the reference formats into char p[40]
+// with a stated size of 80; 19 characters are written)
+std::string current_time_string()
+{
+    char buf[40];
+    const time_t t = time(nullptr);
+    struct tm tmv;
+    localtime_r(&t, &tmv);
+    strftime(buf, sizeof buf, "%Y-%m-%d-%H-%M-%S", &tmv);
+    return buf;
+}
+
+// log(), PowerActivationChannel_impl.cc:396-408 / …vcm_impl.cc:578-591: a line to stdout or appended to the log file
+void sink_log(const fdc_sinks *s, const std::string &file, const std::string &line)
+{
+    if (g_log_fn) g_log_fn(line.c_str(), g_log_user);
+    if (s->cfg.verbose == 1) { std::fputs(line.c_str(), stdout); std::fputc('\n', stdout); }
+    else if (s->cfg.verbose == 2) {
+        FILE *f = std::fopen(file.c_str(), "a");
+        if (!f) std::fprintf(stderr, "Outputfile not writable: %s\n", file.c_str());
+        else { std::fputs(line.c_str(), f); std::fputc('\n', f); std::fclose(f); }
+    }
+}
+std::string pac_logfile(const Pac &p) { return "gr-FDC.PowActChan." + std::to_string(p.ID) + ".log"; }
+void start_logfile(const std::string &file)      // constructors: the file is truncated to one empty line
+{
+    FILE *f = std::fopen(file.c_str(), "w");
+    if (!f) std::fprintf(stderr, "Logfile not writable: %s\n", file.c_str());
+    else { std::fputc('\n', f); std::fclose(f); }
+}
 
 int64_t add_task(fdc_sinks *s, int slot, int start, int w, int skip, int win_off)
 {
@@ -136,9 +173,14 @@ void pac_emit(fdc_sinks *s, Pac &p, bool fin)               // emit_data, :212-2
     r.meta.rel_bw = (double)p.extract_width / (double)s->N;
     r.meta.blockstart = s->blockcount - p.count; r.meta.blockend = s->blockcount;
     r.meta.vectorstart = p.extract_start; r.meta.vectorend = p.extract_stop;
+    std::snprintf(r.meta.id, sizeof r.meta.id, "%s", p.msg_id.c_str());
     r.blocklen = p.output_len;
     for (auto &b : p.blocks) r.blocks.push_back(std::move(b));
     p.blocks.clear();
+    if (s->cfg.verbose)                                                    // :246-253
+        sink_log(s, pac_logfile(p), p.msg_id + (fin ? std::string(".fin") : ".parted." + std::to_string(p.part)) + ": start=" +
+                 std::to_string(p.extract_start) + ", stop=" + std::to_string(p.extract_stop) + ", blockstart=" +
+                 std::to_string((long long)r.meta.blockstart) + ", blockend=" + std::to_string((long long)r.meta.blockend));
     s->pdus.push_back(std::move(r));
     p.part++;
 }
@@ -154,6 +196,7 @@ void pac_step(fdc_sinks *s, Pac &p, float pwr, int slot)    // one item of work(
         if (!p.active) {                                                   // activate(), :198-210
             p.part = 0; p.count = 0; p.active = true; p.phase = 0; p.blocks.clear();
             p.id_at_activation = p.finished;
+            p.msg_id = current_time_string() + ".PowActChan." + std::to_string(p.ID) + "." + std::to_string(p.finished);
             pac_process(s, p, slot - 1);                                   // previous block (slot 0 = saved history)
             pac_process(s, p, slot);
         } else {
@@ -191,8 +234,13 @@ void det_emit(fdc_sinks *s, Segment &g, DetChan &c, bool fin, size_t nblk)   // 
     const int64_t bc = s->blockcount - (s->cfg.det_variant == 1 ? 1 : 0);
     r.meta.blockstart = bc - c.count; r.meta.blockend = bc;
     r.meta.vectorstart = c.extract_start; r.meta.vectorend = c.extract_stop;
+    std::snprintf(r.meta.id, sizeof r.meta.id, "%s", c.msg_id.c_str());
     r.blocklen = c.outputsamples;
     for (size_t i = 0; i < nblk; i++) { r.blocks.push_back(std::move(c.data.front())); c.data.pop_front(); }
+    if (s->cfg.verbose)                                                        // …vcm_impl.cc:441-450, :498-508
+        sink_log(s, s->det_logfile, c.msg_id + (fin ? std::string(".fin: ") : ".parted." + std::to_string(c.part) + ": ") + "start=" +
+                 std::to_string(c.extract_start) + ", stop=" + std::to_string(c.extract_stop) + ", blockstart=" +
+                 std::to_string((long long)r.meta.blockstart) + ", blockend=" + std::to_string((long long)r.meta.blockend));
     s->pdus.push_back(std::move(r));
 }
 
@@ -251,6 +299,8 @@ void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, 
         c.extract_width = ew; c.wclass = (int)std::log2((double)ew);
         c.ovlskip = ew / s->R; c.outputsamples = ew - c.ovlskip;
         c.count = 0; c.phase = 0; c.phaseincrement = es % s->R; c.inactive = -1; c.part = 0;
+        const int segname = (s->cfg.det_variant == 1 && s->cfg.det_id >= 0 && s->segs.size() == 1) ? s->cfg.det_id : g.ID;
+        c.msg_id = current_time_string() + ".DETECTED." + std::to_string(segname) + "." + std::to_string(c.ID);
         g.chans.push_back(std::move(c));
     }
 }
@@ -461,6 +511,43 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
     }
 #undef CHKF
+    // ---- logs of the constructors (verbose != 0)
+    if (cfg->verbose) {
+        fdc_sinks *const sp = raw;
+        for (const Pac &pc : sp->pacs) {                                        // PowerActivationChannel_impl.cc:54-62, :113-127
+            if (cfg->verbose == 2) start_logfile(pac_logfile(pc));
+            const std::string bar("############################\n\n");
+            sink_log(sp, pac_logfile(pc), bar + "# gr-FDC.PowActChan." + std::to_string(pc.ID) + "\n\n" + bar +
+                     "# extract_start: " + std::to_string(pc.extract_start) + "\n# extract_stop: " + std::to_string(pc.extract_stop) +
+                     "\n# extract_width: " + std::to_string(pc.extract_width) + "\n# measure_start: " + std::to_string(pc.measure_start) +
+                     "\n# measure_stop: " + std::to_string(pc.measure_stop) + "\n\n# equivalent cfreq: " +
+                     std::to_string((double)(pc.extract_start + pc.extract_width / 2) / (double)N) + "\n# equivalent bw: " +
+                     std::to_string((double)pc.extract_width / (double)N) + "\n\n");
+        }
+        if (!sp->segs.empty()) {
+            if (cfg->det_variant == 1) {                                        // SegmentDetection_impl.cc:49-61, :109-113
+                const int id = cfg->det_id >= 0 && sp->segs.size() == 1 ? cfg->det_id : 0;
+                sp->det_logfile = "gr-FDC.ActDetChan.ID_" + std::to_string(id) + ".log";
+                if (cfg->verbose == 2) start_logfile(sp->det_logfile);
+                for (const Segment &g : sp->segs) {
+                    sink_log(sp, sp->det_logfile, "Threshold               " + std::to_string(sp->det_thr));
+                    sink_log(sp, sp->det_logfile, "decimation factor       " + std::to_string(sp->dec));
+                    sink_log(sp, sp->det_logfile, "start                   " + std::to_string(g.start));
+                    sink_log(sp, sp->det_logfile, "stop                    " + std::to_string(g.stop));
+                    sink_log(sp, sp->det_logfile, "width                   " + std::to_string(g.width));
+                }
+            } else {                                                            // …vcm_impl.cc:89-101, :176-186
+                sp->det_logfile = "gr-FDC.ActDetChan.log";
+                if (cfg->verbose == 2) start_logfile(sp->det_logfile);
+                for (const Segment &g : sp->segs)
+                    sink_log(sp, sp->det_logfile, "# Segment " + std::to_string(g.ID) + ": \n# start: " + std::to_string(g.start) +
+                             " => f_start=" + std::to_string((double)g.start / (double)N) + "\n# stop: " + std::to_string(g.stop) +
+                             " => f_stop=" + std::to_string((double)g.stop / (double)N) + "\n# width: " + std::to_string(g.width) +
+                             " => f_bw=" + std::to_string((double)g.width / (double)N) + "\n# chan_decimation_fact: " +
+                             std::to_string(sp->dec) + "\n");
+            }
+        }
+    }
     *out = raw;
     return FDC_OK;
 }
@@ -630,6 +717,8 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     HIPCHK(hipMemcpyAsync(s->d_spec + s->N, spectrum, sizeof(float2) * (size_t)nitems * s->N, hipMemcpyHostToDevice, s->stream));
     return fdc_sinks_work_device(s, nitems);
 }
+
+void fdc_set_log_callback(fdc_log_fn fn, void *user) { g_log_fn = fn; g_log_user = user; }
 
 int fdc_sinks_pdu_count(const fdc_sinks *s) { return s ? (int)s->pdus.size() : 0; }
 

@@ -18,6 +18,12 @@
 namespace gr {
 namespace FDC {
 
+// What the reference's make() signatures have no room for: the HIP device the blocks made from now on run on, and the
+// largest number of items one device batch takes (sinks: spectrum items per fdc_sinks_work; fdc_pipeline_vcc: its max_items
+// argument when that is 0).  Set before make(); process-wide.
+struct amd_options { int device_id = 0; int max_items = 64; };
+FDC_API amd_options &options();
+
 class FDC_API overlap_save : virtual public gr::sync_block {
 public:
     typedef std::shared_ptr<overlap_save> sptr;

@@ -10,6 +10,7 @@
 #include "FDC/fdc_pipeline_vcc.h"
 
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -80,6 +81,20 @@ int main(int argc, char **argv)
             if (pipe->work(n2, pi2, pv2) != n2) throw std::runtime_error("fdc_pipeline_vcc: second work() failed");
             pipe->unpin_buffers();
             for (size_t c = 0; c < chans.size(); c++) dump(dir + "/pipe" + std::to_string(c) + ".out", po[c]);
+            // a scheduler may offer more items than one device batch (max_items = 2 here): work() cuts the call into pieces
+            {
+                auto small = fdc_pipeline_vcc::make(N, R, chans, 1, 2);
+                std::vector<std::vector<gr_complex>> so(chans.size());
+                gr_vector_void_star sv;
+                for (size_t c = 0; c < chans.size(); c++) { so[c].resize((size_t)nb * small->output_item_len((int)c)); sv.push_back(so[c].data()); }
+                if (small->work(nb, pi, sv) != nb) throw std::runtime_error("fdc_pipeline_vcc: work() beyond max_items failed");
+                for (size_t c = 0; c < chans.size(); c++)
+                    if (std::memcmp(so[c].data(), po[c].data(), so[c].size() * sizeof(gr_complex)) != 0)
+                        throw std::runtime_error("fdc_pipeline_vcc: chunked work() differs from the whole call");
+            }
+            // the device and the batch size of the blocks made from here on (what make() has no argument for)
+            gr::FDC::options().device_id = 0;
+            gr::FDC::options().max_items = 5;
             bool threw2 = false;
             try { fdc_pipeline_vcc::make(N, R, {{0.f, 64.f, 0.9f, 0.5f}}, 1, 4); } catch (const std::invalid_argument &) { threw2 = true; }
             if (!threw2) throw std::runtime_error("fdc_pipeline_vcc: bad channel did not throw");
@@ -103,7 +118,8 @@ int main(int argc, char **argv)
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
             all.insert(all.end(), m.samples.begin(), m.samples.end());
         }
-        auto sd = SegmentDetection::make(2, N, R, 0.5f, 0.9f, 10.0f, 0.01f, 0.2f, -1, 1, true, false, "", false, 0);
+        // verbose = 2: log file gr-FDC.ActDetChan.ID_2.log in the working directory; fileoutput: <dir>/<ID>.fin
+        auto sd = SegmentDetection::make(2, N, R, 0.5f, 0.9f, 10.0f, 0.01f, 0.2f, -1, 1, true, true, dir, false, 2);
         sd->work(ns, si, none);
         for (auto &m : sd->published()) {
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());

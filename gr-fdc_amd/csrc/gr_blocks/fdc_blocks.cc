@@ -6,9 +6,18 @@
 #include <cstdio>
 #include <iostream>
 #include <stdexcept>
+#ifdef FDC_HAVE_GNURADIO
+#include <pmt/pmt.h>
+#endif
 
 namespace gr {
 namespace FDC {
+
+amd_options &options()
+{
+    static amd_options o;
+    return o;
+}
 
 namespace {
 
@@ -18,9 +27,11 @@ void check_create(int rc)
     if (rc != FDC_OK) throw std::runtime_error(fdc_last_error());
 }
 
+// work() never throws.  A failed call cannot be retried with the same arguments by the scheduler (it would be called
+// again at once, for ever): the block reports itself done (WORK_DONE = -1) after printing the reason.
 int report(const char *who, int n)
 {
-    if (n < 0) { std::cerr << who << ": " << fdc_last_error() << std::endl; return 0; }   // work() never throws
+    if (n < 0) { std::cerr << who << ": " << fdc_last_error() << std::endl; return -1; }
     return n;
 }
 
@@ -31,7 +42,7 @@ public:
         : gr::sync_block("overlap_save", gr::io_signature::make(1, 1, itemsize * (outputlen - overlaplen)),
                          gr::io_signature::make(1, 1, itemsize * outputlen))
     {
-        check_create(fdc_overlap_save_create(0, itemsize, outputlen, overlaplen, &d_h));
+        check_create(fdc_overlap_save_create(options().device_id, itemsize, outputlen, overlaplen, &d_h));
     }
     ~overlap_save_impl() override { fdc_overlap_save_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -47,7 +58,7 @@ public:
         : gr::sync_block("vector_cut_vxx", gr::io_signature::make(1, 1, itemsize * veclen),
                          gr::io_signature::make(1, 1, itemsize * blocklen))
     {
-        check_create(fdc_vector_cut_create(0, itemsize, veclen, offset, blocklen, &d_h));
+        check_create(fdc_vector_cut_create(options().device_id, itemsize, veclen, offset, blocklen, &d_h));
     }
     ~vector_cut_vxx_impl() override { fdc_vector_cut_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -63,7 +74,7 @@ public:
         : gr::sync_block("phase_shifting_windowing_vcc", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen))
     {
-        check_create(fdc_phase_window_create(0, blocklen, numphasestates, shifts, passbw, stopbw, windowtype, &d_h));
+        check_create(fdc_phase_window_create(options().device_id, blocklen, numphasestates, shifts, passbw, stopbw, windowtype, &d_h));
     }
     ~phase_shifting_windowing_vcc_impl() override { fdc_phase_window_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -74,6 +85,8 @@ public:
 
 class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc {
     fdc_pipeline *d_p = nullptr;
+    int d_max = 64;
+    size_t d_in_item = 0;
     std::vector<int> d_lout;
     std::vector<void *> d_pinned;
     static std::vector<int> out_sizes(int relinvovl, const std::vector<std::vector<float>> &ch)
@@ -95,14 +108,29 @@ public:
         std::vector<fdc_channel> ch(channels.size());
         for (size_t i = 0; i < channels.size(); i++)
             ch[i] = fdc_channel{(int32_t)channels[i][0], (int32_t)channels[i][1], channels[i][2], channels[i][3]};
-        fdc_pipeline_cfg cfg{0, blocklen, relinvovl, windowtype, (int32_t)ch.size(), ch.data(), max_items, 0, 0};
+        d_max = max_items > 0 ? max_items : options().max_items;
+        fdc_pipeline_cfg cfg{options().device_id, blocklen, relinvovl, windowtype, (int32_t)ch.size(), ch.data(), d_max, 0, 0};
         check_create(fdc_pipeline_create(&cfg, &d_p));
         for (size_t i = 0; i < ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(d_p, (int)i));
+        d_in_item = sizeof(gr_complex) * (size_t)(blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1));
+#ifdef FDC_HAVE_GNURADIO
+        set_max_noutput_items(d_max);                 // the scheduler then never offers more than one device batch
+#endif
     }
     ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
-        return report("fdc_pipeline_vcc", fdc_pipeline_work(d_p, in[0], n, out.data(), nullptr));
+        // noutput_items may exceed the handle's batch size: pieces of at most max_items, every port advanced by its item length
+        std::vector<void *> o(out.size());
+        for (int a = 0; a < n; a += d_max) {
+            const int k = n - a < d_max ? n - a : d_max;
+            for (size_t c = 0; c < out.size(); c++)
+                o[c] = static_cast<char *>(out[c]) + (size_t)a * (size_t)d_lout[c] * sizeof(gr_complex);
+            const int r = report("fdc_pipeline_vcc", fdc_pipeline_work(d_p, static_cast<const char *>(in[0]) + (size_t)a * d_in_item, k,
+                                                                      o.data(), nullptr));
+            if (r != k) return a > 0 ? a : r;
+        }
+        return n;
     }
     bool pin_buffer(void *base, size_t bytes) override
     {
@@ -124,19 +152,38 @@ protected:
     fdc_sinks *d_s = nullptr;
     bool d_msg = false, d_file = false;
     std::string d_path;
-    int d_source_override = -1;      // SegmentDetection: the ID argument names the segment in the message IDs
     void publish(gr::sync_block *blk, bool pac)
     {
         fdc_pdu p;
         for (int i = 0; i < fdc_sinks_pdu_count(d_s); i++) {
             if (fdc_sinks_pdu(d_s, i, &p) != FDC_OK) continue;
-            char id[96];
-            if (pac) std::snprintf(id, sizeof id, "PowActChan.%d.%d", p.source, p.chan_id);
-            else std::snprintf(id, sizeof id, "DETECTED.%d.%d", d_source_override >= 0 ? d_source_override : p.source, p.chan_id);
+            const std::string id(p.id);          // "<time>.PowActChan.<ID>.<n>" / "<time>.DETECTED.<seg>.<n>", fixed at activation
             const gr_complex *d = static_cast<const gr_complex *>(p.samples);
             if (d_msg) {
-                gr::fdc_message m;      // with GNU Radio: pmt::cons(dict, pmt::init_c32vector(n, d)), same keys
-                m.str["ID"] = pac ? std::string(id) + (p.finalized ? ".fin" : ".part") : std::string(id);
+#ifdef FDC_HAVE_GNURADIO
+                // the reference's PDU: pmt::cons(dict, c32vector), keys in its order (PowerActivationChannel_impl.cc:222-232,
+                // activity_detection_channelizer_vcm_impl.cc:415-429)
+                pmt::pmt_t dict = pmt::make_dict();
+                dict = pmt::dict_add(dict, pmt::intern("ID"), pmt::intern(pac ? id + (p.finalized ? ".fin" : ".part") : id));
+                dict = pmt::dict_add(dict, pmt::intern("finalized"), pmt::from_bool(p.finalized != 0));
+                if (p.has_part) dict = pmt::dict_add(dict, pmt::intern("part"), pmt::from_long(p.part));
+                if (pac) {
+                    dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
+                    dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
+                } else {
+                    dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
+                    dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
+                }
+                dict = pmt::dict_add(dict, pmt::intern("blockstart"), pmt::from_long((long)p.blockstart));
+                dict = pmt::dict_add(dict, pmt::intern("blockend"), pmt::from_long((long)p.blockend));
+                if (!pac) {
+                    dict = pmt::dict_add(dict, pmt::intern("vectorstart"), pmt::from_long((long)p.vectorstart));
+                    dict = pmt::dict_add(dict, pmt::intern("vectorend"), pmt::from_long((long)p.vectorend));
+                }
+                blk->message_port_pub(pmt::intern("msgout"), pmt::cons(dict, pmt::init_c32vector((size_t)p.nsamples, d)));
+#else
+                gr::fdc_message m;               // the same PDU without pmt (compat build)
+                m.str["ID"] = pac ? id + (p.finalized ? ".fin" : ".part") : id;
                 m.flag["finalized"] = p.finalized != 0;
                 if (p.has_part) m.num["part"] = p.part;
                 m.real["rel_bw"] = p.rel_bw; m.real["rel_cfreq"] = p.rel_cfreq;
@@ -144,6 +191,7 @@ protected:
                 if (!pac) { m.num["vectorstart"] = (long)p.vectorstart; m.num["vectorend"] = (long)p.vectorend; }
                 m.samples.assign(d, d + p.nsamples);
                 blk->message_port_pub("msgout", m);
+#endif
             }
             if (d_file) {
                 const std::string fn = d_path + "/" + id + (p.finalized ? std::string(".fin") : ".parted." + std::to_string(p.part));
@@ -153,31 +201,42 @@ protected:
             }
         }
     }
+    void register_port(gr::sync_block *blk)
+    {
+#ifdef FDC_HAVE_GNURADIO
+        blk->message_port_register_out(pmt::intern("msgout"));
+#else
+        blk->message_port_register_out("msgout");
+#endif
+    }
+    // items per fdc_sinks_work call (the bank's device batch)
+    int d_batch = 64;
 };
 
 class PowerActivationChannel_impl : public PowerActivationChannel, sink_base {
 public:
     PowerActivationChannel_impl(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
-                                int deactivation_delay, bool msg, bool fileoutput, std::string path, int, int ID)
+                                int deactivation_delay, bool msg, bool fileoutput, std::string path, int verbose, int ID)
         : gr::sync_block("PowerActivationChannel", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
         fdc_pac_cfg pc{cfreq, bw, ID};
         fdc_sinks_cfg c{};
         c.blocklen = blocklen; c.relinvovl = relinvovl; c.npac = 1; c.pac = &pc; c.pac_thresh_db = thresh;
-        c.pac_maxblocks = maxblocks; c.pac_deactivation_delay = deactivation_delay; c.max_blocks = 64;
+        c.pac_maxblocks = maxblocks; c.pac_deactivation_delay = deactivation_delay;
+        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = -1;
         check_create(fdc_sinks_create(&c, &d_s));
         d_msg = msg; d_file = fileoutput; d_path = path;
-        if (msg) message_port_register_out("msgout");
+        if (msg) register_port(this);
     }
     ~PowerActivationChannel_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = sizeof(gr_complex) * (size_t)input_signature()->sizeof_stream_item / sizeof(gr_complex);
-        for (int a = 0; a < n; a += 64) {
-            const int k = n - a < 64 ? n - a : 64;
-            if (report("PowerActivationChannel", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+        for (int a = 0; a < n; a += d_batch) {
+            const int k = n - a < d_batch ? n - a : d_batch;
+            if (report("PowerActivationChannel", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, true);
         }
         return n;
@@ -189,7 +248,7 @@ public:
     activity_detection_channelizer_vcm_impl(int blocklen, std::vector<std::vector<float>> segments, float thresh,
                                             int relinvovl, int maxblocks, bool message, bool fileoutput, std::string path,
                                             bool /*threads: GPU batching replaces the per-channel std::thread fan-out*/,
-                                            float minchandist, int channel_deactivation_delay, double window_flank_puffer, int)
+                                            float minchandist, int channel_deactivation_delay, double window_flank_puffer, int verbose)
         : gr::sync_block("activity_detection_channelizer_vcm", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
@@ -201,19 +260,20 @@ public:
         fdc_sinks_cfg c{};
         c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = (int)sg.size(); c.seg = sg.data(); c.det_thresh_db = thresh;
         c.det_maxblocks = maxblocks; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
-        c.window_flank_puffer = window_flank_puffer; c.max_blocks = 64;
+        c.window_flank_puffer = window_flank_puffer;
+        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = -1;
         check_create(fdc_sinks_create(&c, &d_s));
         d_msg = message; d_file = fileoutput; d_path = path;
-        if (message) message_port_register_out("msgout");
+        if (message) register_port(this);
     }
     ~activity_detection_channelizer_vcm_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
-        for (int a = 0; a < n; a += 64) {
-            const int k = n - a < 64 ? n - a : 64;
-            if (report("activity_detection_channelizer_vcm", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+        for (int a = 0; a < n; a += d_batch) {
+            const int k = n - a < d_batch ? n - a : d_batch;
+            if (report("activity_detection_channelizer_vcm", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }
         return n;
@@ -224,7 +284,7 @@ class SegmentDetection_impl : public SegmentDetection, sink_base {
 public:
     SegmentDetection_impl(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh,
                           float minchandist, float window_flank_puffer, int maxblocks_to_emit,
-                          int channel_deactivation_delay, bool messageoutput, bool fileoutput, std::string path, bool, int)
+                          int channel_deactivation_delay, bool messageoutput, bool fileoutput, std::string path, bool, int verbose)
         : gr::sync_block("SegmentDetection", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
@@ -232,19 +292,20 @@ public:
         fdc_sinks_cfg c{};
         c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = 1; c.seg = &sg; c.det_thresh_db = thresh;
         c.det_maxblocks = maxblocks_to_emit; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
-        c.window_flank_puffer = window_flank_puffer; c.max_blocks = 64; c.det_variant = 1;
+        c.window_flank_puffer = window_flank_puffer; c.det_variant = 1;
+        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = ID;
         check_create(fdc_sinks_create(&c, &d_s));
-        d_msg = messageoutput; d_file = fileoutput; d_path = path; d_source_override = ID;
-        if (messageoutput) message_port_register_out("msgout");
+        d_msg = messageoutput; d_file = fileoutput; d_path = path;
+        if (messageoutput) register_port(this);
     }
     ~SegmentDetection_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
-        for (int a = 0; a < n; a += 64) {
-            const int k = n - a < 64 ? n - a : 64;
-            if (report("SegmentDetection", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a;
+        for (int a = 0; a < n; a += d_batch) {
+            const int k = n - a < d_batch ? n - a : d_batch;
+            if (report("SegmentDetection", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }
         return n;

@@ -8,7 +8,9 @@
 
 work(items) takes normalised-spectrum items and returns the PDUs the reference would publish on "msgout" as
 (dict, complex64 array) pairs with the same keys (…vcm_impl.cc:415-430, PowerActivationChannel_impl.cc:222-233).
-The timestamp prefix of the ID strings is left out: "PowActChan.<ID>.<n>(.fin|.part)", "DETECTED.<seg>.<n>".
+The ID strings are the reference's, timestamp of the activation included: "<Y-m-d-H-M-S>.PowActChan.<ID>.<n>(.fin|.part)",
+"<Y-m-d-H-M-S>.DETECTED.<seg>.<n>" (PowerActivationChannel_impl.cc:308-312, …vcm_impl.cc:526-530); `verbose` selects the
+reference's log lines (1 = stdout, 2 = its log files in the working directory).
 `Sinks` is the shared-spectrum bank both faces (and the hier-block mirror) are built on.
 """
 import ctypes as C
@@ -22,7 +24,7 @@ from . import _lib
 class Sinks:
     def __init__(self, blocklen, relinvovl, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
                  segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
-                 max_blocks=64, device_id=0, det_variant=0):
+                 max_blocks=64, device_id=0, det_variant=0, verbose=0, det_id=-1):
         self._h = C.c_void_p()
         self.N = int(blocklen)
         pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
@@ -33,7 +35,8 @@ class Sinks:
             sg[i].start, sg[i].stop = float(a), float(b)
         cfg = _lib.fdc_sinks_cfg(device_id, self.N, int(relinvovl), len(pac), pa, float(pac_thresh), int(pac_maxblocks),
                                  int(pac_delay), len(segments), sg, float(det_thresh), int(det_maxblocks),
-                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant))
+                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant),
+                                 int(verbose), int(det_id))
         rc = _lib.lib().fdc_sinks_create(C.byref(cfg), C.byref(self._h))
         if rc == -1:
             raise ValueError(_lib.lib().fdc_last_error().decode())
@@ -76,7 +79,7 @@ class Sinks:
             off = 0
             for k in range(i, j + 1):
                 p = arr[k]
-                out.append((dict(kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                out.append((dict(id=p.id.decode(), kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
                                  has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq,
                                  blockstart=p.blockstart, blockend=p.blockend, vectorstart=p.vectorstart,
                                  vectorend=p.vectorend), blob[off:off + p.nsamples]))
@@ -118,7 +121,7 @@ class Sinks:
 
 def _pac_pdu(meta, data):
     """dict keys of PowerActivationChannel_impl.cc:222-230"""
-    d = {"ID": "PowActChan.%d.%d%s" % (meta["source"], meta["chan_id"], ".fin" if meta["finalized"] else ".part"),
+    d = {"ID": meta["id"] + (".fin" if meta["finalized"] else ".part"),
          "finalized": meta["finalized"], "part": meta["part"], "rel_cfreq": meta["rel_cfreq"], "rel_bw": meta["rel_bw"],
          "blockstart": meta["blockstart"], "blockend": meta["blockend"]}
     return d, data
@@ -126,7 +129,7 @@ def _pac_pdu(meta, data):
 
 def _det_pdu(meta, data):
     """dict keys of activity_detection_channelizer_vcm_impl.cc:415-427 / :472-483"""
-    d = {"ID": "DETECTED.%d.%d" % (meta["source"], meta["chan_id"]), "finalized": meta["finalized"]}
+    d = {"ID": meta["id"], "finalized": meta["finalized"]}
     if meta["has_part"]:
         d["part"] = meta["part"]
     d.update(rel_bw=meta["rel_bw"], rel_cfreq=meta["rel_cfreq"], blockstart=meta["blockstart"],
@@ -153,7 +156,7 @@ class PowerActivationChannel:
                  verbose, ID, device_id=0, max_blocks=64):
         self.msg, self.fileoutput, self.path = bool(msg), bool(fileoutput), str(path)
         self.bank = Sinks(blocklen, relinvovl, pac=[(cfreq, bw, ID)], pac_thresh=thresh, pac_maxblocks=maxblocks,
-                          pac_delay=deactivation_delay, max_blocks=max_blocks, device_id=device_id)
+                          pac_delay=deactivation_delay, max_blocks=max_blocks, device_id=device_id, verbose=verbose)
         self.params = self.bank.pac_params(0)
 
     def work(self, spectrum):
@@ -172,7 +175,7 @@ class activity_detection_channelizer_vcm:
                 raise ValueError("Segment is incorrect. must be of size 2")
         self.bank = Sinks(blocklen, relinvovl, segments=[tuple(s) for s in segments], det_thresh=thresh,
                           det_maxblocks=maxblocks, minchandist=minchandist, det_delay=channel_deactivation_delay,
-                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id)
+                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id, verbose=verbose)
         self.segments = [self.bank.segment_params(i) for i in range(len(segments))]
 
     def work(self, spectrum):
@@ -193,14 +196,14 @@ class SegmentDetection:
         self.ID, self.msg, self.fileoutput, self.path = int(ID), bool(messageoutput), bool(fileoutput), str(path)
         self.bank = Sinks(blocklen, relinvovl, segments=[(seg_start, seg_stop)], det_thresh=thresh,
                           det_maxblocks=maxblocks_to_emit, minchandist=minchandist, det_delay=channel_deactivation_delay,
-                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id, det_variant=1)
+                          puffer=window_flank_puffer, max_blocks=max_blocks, device_id=device_id, det_variant=1,
+                          verbose=verbose, det_id=self.ID)
         self.segment = self.bank.segment_params(0)
 
     def work(self, spectrum):
         pdus = []
         for (m, d) in self.bank.work(spectrum):
-            m = dict(m, source=self.ID)
-            pdus.append(_det_pdu(m, d))
+            pdus.append(_det_pdu(dict(m, source=self.ID), d))
         if self.fileoutput:
             _write_files(self.path, pdus, False)
         return pdus

@@ -160,6 +160,13 @@ typedef struct {
                               (include/FDC/SegmentDetection.h:49) per segment, ID = segment index — the twin the hier
                               block instantiates (python/FrequencyDomainChannelizer.py:261-278): its own segment geometry,
                               raw power sums, block counter from 0, partial emission after all channels */
+    int32_t verbose;       /* the blocks' `verbose` argument (lib/PowerActivationChannel_impl.h:46-50): 0 = no log, 1 = to
+                              stdout, 2 = to the reference's log files in the working directory — gr-FDC.PowActChan.<ID>.log
+                              (PowerActivationChannel_impl.cc:54), gr-FDC.ActDetChan.log (…vcm_impl.cc:94),
+                              gr-FDC.ActDetChan.ID_<n>.log (SegmentDetection_impl.cc:51); same lines: the derived geometry at
+                              construction, one line per emitted PDU */
+    int32_t det_id;        /* det_variant 1 with ONE segment: SegmentDetection's ID argument (names the log file and the
+                              segment in the message IDs); < 0 = the segment index */
 } fdc_sinks_cfg;
 typedef struct {
     int32_t kind;        /* 0 = PowerActivationChannel, 1 = detected channel of a segment                       */
@@ -171,7 +178,16 @@ typedef struct {
     int64_t blockstart, blockend, vectorstart, vectorend;   /* vectorstart/end are in the dict for detection only */
     int64_t nsamples;
     const void *samples; /* complex float32, owned by the handle until its next work call                     */
+    char id[72];         /* the message ID the reference builds when the channel is ACTIVATED:
+                            "<YYYY-mm-dd-HH-MM-SS>.PowActChan.<ID>.<n>" (PowerActivationChannel_impl.cc:308-312; the dict and
+                            the file name append ".fin" / ".part" / ".parted.<k>", :224, :237) and
+                            "<YYYY-mm-dd-HH-MM-SS>.DETECTED.<seg>.<n>" (…vcm_impl.cc:526-530); local time, all PDUs of one
+                            activation carry the same string */
 } fdc_pdu;
+
+/* Log lines of the sinks (verbose != 0) additionally go to this callback when one is set (process-wide; NULL = off). */
+typedef void (*fdc_log_fn)(const char *line, void *user);
+void fdc_set_log_callback(fdc_log_fn fn, void *user);
 
 /* Same, for a hier block fed with items that are ALREADY transformed (inpveclen = blocksize: the front end is skipped,
  * python/FrequencyDomainChannelizer.py:201, :284-290): nblocks unnormalised, fftshifted spectrum items in; the 1/N of

@@ -22,7 +22,7 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     spec[3:8, 300:340] += (rng.standard_normal((5, 40)) + 1j * rng.standard_normal((5, 40))).astype(np.complex64)
     spec[5:11, 700:760] += (rng.standard_normal((6, 60)) + 1j * rng.standard_normal((6, 60))).astype(np.complex64)
     x.tofile(tmp_path / "x.c64"); spec.tofile(tmp_path / "spec.c64")
-    subprocess.check_call([DEMO, str(tmp_path)])
+    subprocess.check_call([DEMO, str(tmp_path)], cwd=str(tmp_path))
     rd = lambda n: np.fromfile(tmp_path / n, dtype=np.complex64)   # noqa: E731
     blocks = oracle.OverlapSave(8, N, N // R).work(x)
     assert (rd("overlap_save.out").view(np.uint32) == blocks.view(np.uint32)).all()
@@ -41,7 +41,18 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
         oracle.SegmentDetection(2, N, R, 0.5, 0.9, 10.0, 0.01, 0.2, -1, 1).work(spec)
     lines = open(tmp_path / "pdus.txt").read().split("\n")[:-1]
     assert len(lines) == len(ref) and len(ref) >= 2
-    assert lines[0].split()[0] == "PowActChan.5.0.fin" and lines[-1].split()[0].startswith("DETECTED.2.")
+    import re
+    stamp = r"^\d{4}-\d{2}-\d{2}-\d{2}-\d{2}-\d{2}\."          # ID = <strftime %Y-%m-%d-%H-%M-%S>.<source>... (App. B.5: masked)
+    assert all(re.match(stamp, ln) for ln in lines)
+    assert lines[0].split()[0][20:] == "PowActChan.5.0.fin" and lines[-1].split()[0][20:].startswith("DETECTED.2.")
+    # SegmentDetection was made with fileoutput and verbose = 2 (SegmentDetection_impl.cc:51, :437-539): raw payload file per
+    # finished channel, one log line per emission after the five constructor lines
+    sd_ids = [ln.split()[0] for ln in lines if ".DETECTED.2." in ln]
+    for ident in sd_ids:
+        assert os.path.getsize(tmp_path / (ident + ".fin")) > 0
+    log = open(tmp_path / "gr-FDC.ActDetChan.ID_2.log").read().split("\n")
+    assert log[0] == "" and log[1].startswith("Threshold") and log[2].startswith("decimation factor") and log[5].startswith("width")
+    assert sum(1 for ln in log if ".fin: start=" in ln and ", blockstart=" in ln) == len(sd_ids)
     for ln, r in zip(lines, ref):
         _id, b0, b1, ns = ln.split()
         assert (int(b0), int(b1), int(ns)) == (r["blockstart"], r["blockend"], r["samples"].size)

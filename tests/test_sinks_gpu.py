@@ -14,6 +14,14 @@ TOL = 1e-5
 INTS = ("kind", "source", "chan_id", "finalized", "part", "has_part", "blockstart", "blockend")
 
 
+def unstamp(ident):
+    """ID without its activation timestamp ("YYYY-mm-dd-HH-MM-SS." — non-deterministic); the prefix
+    itself must have the reference's strftime shape."""
+    import re
+    assert re.match(r"^\d{4}-\d{2}-\d{2}-\d{2}-\d{2}-\d{2}\.", ident), ident
+    return ident[20:]
+
+
 def burst_spectrum(N, nb, bursts, seed, floor=1e-3):
     """normalised-spectrum items: white floor plus rectangular bursts (lo_bin, hi_bin, first_block, last_block, amp)"""
     rng = np.random.default_rng(seed)
@@ -84,9 +92,9 @@ def test_pac_face_and_errors(oracle, tmp_path):
     spec = burst_spectrum(N, 10, [(300, 340, 2, 5, 1.0)], 5)
     blk = G.PowerActivationChannel(N, 320 / N, 40 / N, R, 6.0, -1, 0, True, True, str(tmp_path), 0, 3)
     pdus = blk.work(spec)
-    assert len(pdus) == 1 and pdus[0][0]["ID"] == "PowActChan.3.0.fin" and pdus[0][0]["finalized"] is True
+    assert len(pdus) == 1 and unstamp(pdus[0][0]["ID"]) == "PowActChan.3.0.fin" and pdus[0][0]["finalized"] is True
     assert set(pdus[0][0]) == {"ID", "finalized", "part", "rel_cfreq", "rel_bw", "blockstart", "blockend"}
-    f = np.fromfile(os.path.join(str(tmp_path), "PowActChan.3.0.fin"), dtype=np.complex64)
+    f = np.fromfile(os.path.join(str(tmp_path), pdus[0][0]["ID"]), dtype=np.complex64)
     assert (f == pdus[0][1]).all()
     with pytest.raises(ValueError):
         G.PowerActivationChannel(N, 0.01, 0.1, R, 6.0, -1, 0, False, False, "", 0, 0)    # out of band (…cc:318-319)
@@ -130,7 +138,7 @@ def test_vcm_known_answer_and_face(oracle, golden_dir):
     pdus = blk.work(spec)
     assert len(pdus) == 1
     d, data = pdus[0]
-    assert d["ID"] == "DETECTED.0.0" and d["finalized"] is True and "part" not in d
+    assert unstamp(d["ID"]) == "DETECTED.0.0" and d["finalized"] is True and "part" not in d
     assert (abs(d["rel_bw"] - ka["rel_bw"]) < 1e-12 and d["blockstart"] == ka["blockstart"] and d["blockend"] == ka["blockend"]
             and data.size == ka["nsamples"])
     # the survey run's segment geometry is not recorded: the detection grid (dec = 10 bins) may shift the slice
@@ -162,8 +170,8 @@ def test_hier_block_with_sinks_from_device_spectrum(oracle):
     spec = ports[0]
     pac_ref = oracle.PowerActivationChannel(N, (-0.2 + 0.5) % 1.0, 0.04, R, 6.0, -1, 0, 0).work(spec)
     det_ref = oracle.SegmentDetection(0, N, R, 0.75, 0.9, 10.0, 0.005, 0.2, -1, 1).work(spec)
-    got_pac = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("PowActChan")]
-    got_det = [(d, s) for (d, s) in fdc.messages if d["ID"].startswith("DETECTED")]
+    got_pac = [(d, s) for (d, s) in fdc.messages if unstamp(d["ID"]).startswith("PowActChan")]
+    got_det = [(d, s) for (d, s) in fdc.messages if unstamp(d["ID"]).startswith("DETECTED")]
     assert len(pac_ref) >= 1 and len(det_ref) >= 1
     assert len(got_pac) == len(pac_ref) and len(got_det) == len(det_ref)
     for (d, s), r in zip(got_pac + got_det, pac_ref + det_ref):
@@ -191,7 +199,7 @@ def test_segment_detection_face_vs_oracle(oracle, golden_dir, N, R, maxblocks, d
     ref = o.work(spec[:5]) + o.work(spec[5:])
     assert len(ref) >= 3 and len(got) == len(ref)
     for (d, s), r in zip(got, ref):
-        assert d["ID"] == "DETECTED.3.%d" % r["chan_id"]
+        assert unstamp(d["ID"]) == "DETECTED.3.%d" % r["chan_id"]
         assert (d["finalized"], d["blockstart"], d["blockend"], d["vectorstart"], d["vectorend"]) == \
             (r["finalized"], r["blockstart"], r["blockend"], r["vectorstart"], r["vectorend"])
         assert ("part" in d) == r["has_part"] and s.size == r["samples"].size
@@ -234,3 +242,39 @@ def test_pipeline_refuses_sinks_of_other_size():
         with pytest.raises(G.FdcError):
             p.work(x, sinks=bank)
     p.work(x[:4 * H], sinks=small)          # within capacity: fine
+
+
+def test_message_ids_log_files_and_output_files(oracle, tmp_path, monkeypatch):
+    """f2: ID = <activation time>.PowActChan.<ID>.<n> / <activation time>.DETECTED.<seg>.<n> (PowerActivationChannel_impl.cc:
+    308-312, …vcm_impl.cc:526-530), the same string on every part of one activation; files <path>/<ID>.fin and
+    <path>/<ID>.parted.<k> (:235-244, …vcm_impl.cc:431-439, :488-496); verbose = 2 writes the reference's log files
+    (PowerActivationChannel_impl.cc:54, …vcm_impl.cc:94) with its lines."""
+    monkeypatch.chdir(tmp_path)
+    N, R, nb = 1024, 4, 16
+    spec = burst_spectrum(N, nb, [(300, 340, 3, 12, 1.0)], 5)
+    pac = G.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, 3, 0, True, True, str(tmp_path), 2, 7)
+    pdus = pac.work(spec)
+    assert len(pdus) >= 3
+    ids = [d["ID"] for d, _s in pdus]
+    base = ids[0].rsplit(".", 1)[0]
+    assert unstamp(base) == "PowActChan.7.0" and all(i.rsplit(".", 1)[0] == base for i in ids)      # one activation, one timestamp
+    assert [i.rsplit(".", 1)[1] for i in ids[:-1]] == ["part"] * (len(ids) - 1) and ids[-1].endswith(".fin")
+    for k, (d, s) in enumerate(pdus):
+        fn = base + (".fin" if d["finalized"] else ".parted.%d" % d["part"])
+        assert np.array_equal(np.fromfile(tmp_path / fn, dtype=np.complex64), s) and d["part"] == k
+    log = open(tmp_path / "gr-FDC.PowActChan.7.log").read()
+    assert log.startswith("\n############################") and "# extract_start: " in log and "# equivalent bw: " in log
+    lines = [ln for ln in log.split("\n") if ln.startswith(base)]
+    assert len(lines) == len(pdus) and lines[-1].startswith(base + ".fin: start=") and ", blockend=" in lines[-1]
+    assert lines[0].startswith(base + ".parted.0: start=")
+    # vcm face: one log file for the block, segment lines at construction, one line per emitted channel
+    det = G.activity_detection_channelizer_vcm(N, [[0.2, 0.6]], 10.0, R, -1, True, True, str(tmp_path), False, 0.01, 1, 0.2, 2)
+    dp = det.work(spec)
+    assert len(dp) == 1 and unstamp(dp[0][0]["ID"]) == "DETECTED.0.0"
+    assert np.array_equal(np.fromfile(tmp_path / (dp[0][0]["ID"] + ".fin"), dtype=np.complex64), dp[0][1])
+    dlog = open(tmp_path / "gr-FDC.ActDetChan.log").read()
+    assert "# Segment 0: \n# start: " in dlog and "# chan_decimation_fact: " in dlog and dp[0][0]["ID"] + ".fin: start=" in dlog
+    # verbose = 1 prints, verbose = 0 stays silent and writes no log
+    os.remove(tmp_path / "gr-FDC.PowActChan.7.log")
+    G.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, 3, 0, True, False, "", 0, 7).work(spec)
+    assert not os.path.exists(tmp_path / "gr-FDC.PowActChan.7.log")
