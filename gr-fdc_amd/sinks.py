@@ -92,7 +92,7 @@ class Sinks:
         return self._collect()
 
     def work(self, spectrum):
-        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64).reshape(-1)     # items one behind the other
         if spectrum.size % self.N:
             raise ValueError("input is not a whole number of spectrum items")
         n = spectrum.size // self.N
