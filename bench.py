@@ -10,6 +10,8 @@ slice/window/IFFT/discard) over one batch of device-resident synthetic multicarr
   python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|5]
 
 --config picks the BASELINE.json workload (numbered as SURVEY.md §8d does, cfgK = configs[K-1]):
+  1            configs[0]: the example flowgraph's plan (4096-pt FFT, 4 channels of l = 256/512/1024/512), a mixed plan on
+               the generic kernels; 16384 blocks per step (the same sample count as the headline)
   2 (default)  configs[1]: 65536-pt FFT, 256 fixed channels                        <- the headline line
   3            configs[2]: the same 256 channels as PowerActivationChannel sinks, bursty carriers
   4            configs[3]'s per-GPU shape: 262144-pt FFT, 1024 fixed channels, 256 blocks per step
@@ -40,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE workload, see the module text")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4, 5), help="BASELINE workload, see the module text")
     ap.add_argument("--blocks", type=int, default=0, help="input blocks per step per GPU (0 = the workload's default)")
     ap.add_argument("--blocklen", type=int, default=0)
     ap.add_argument("--channels", type=int, default=0)
@@ -54,8 +56,12 @@ def parse():
     ap.add_argument("--cpu-blocks", type=int, default=0, help="blocks in the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the whole cpu_baseline object")
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
+    ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
+                                                             "dropped): a tiling that does not start at bin 0")
     a = ap.parse_args()
-    if a.config == 4:
+    if a.config == 1:      # the reference's own example flowgraph (plumbing case): 4096-pt FFT, its 4 channels of mixed width
+        a.blocklen, a.channels, a.blocks = a.blocklen or 4096, 4, a.blocks or 16384
+    elif a.config == 4:
         a.blocklen, a.channels, a.blocks = a.blocklen or 262144, a.channels or 1024, a.blocks or 256
     else:
         a.blocklen, a.channels, a.blocks = a.blocklen or 65536, a.channels or 256, a.blocks or 1024
@@ -319,17 +325,24 @@ def main():
     first_block, _n = G.span_for_rank(world * nb, rank, world)   # contiguous span per rank (§8e); weak scaling
     sinks, segments = None, None
     extracted = [0, 0]                                 # cfg3 / cfg5: samples and PDUs emitted in the timed region
-    if a.config in (2, 4):
+    if a.config in (1, 2, 4):
         # channel plan through the reference's own parameter derivation (py:322-345): tiles the spectrum
-        params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, 0.8 / C) for c in range(C)]
+        if a.config == 1:    # examples/FDC_example.grc: [[0.12,0.05],[0.22,0.1],[-0.14,0.12],[0,0.081]]
+            params = [G.get_opt_channelparams(N, R, (u + 0.5) % 1.0, bw) for (u, bw) in
+                      ((0.12, 0.05), (0.22, 0.1), (-0.14, 0.12), (0.0, 0.081))]
+        else:
+            params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, 0.8 / C) for c in range(C)]
+        if a.offset:
+            params = [(f + a.offset, l, lo, p, s) for (f, l, lo, p, s) in params[:-1]]
         plan = [(f, l, p, s) for (f, l, _lo, p, s) in params]
         sum_lout = sum(lo for (_f, _l, lo, _p, _s) in params)
         pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk)
         x = synth_input(torch, dev, N, R, C, nb, first_block, 2025 + rank)
         out = torch.empty(pipe.output_samples(nb), dtype=torch.complex64, device=dev)
         wl = "%s: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), %d blocks/step/GPU" % (
+            "configs[0] (example flowgraph plan)" if a.config == 1 else
             "configs[1]" if (N, R, C) == (65536, 2, 256) else "configs[3] per-GPU shape" if (N, R, C) == (262144, 2, 1024)
-            else "non-default shape", N, R, C, params[0][1], params[0][2], nb)
+            else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "")
     else:
         # the stateful sinks run on a spectrum in device memory: forward transform into the bank's buffer, then the bank
         plan, params, sum_lout = [], [], 0

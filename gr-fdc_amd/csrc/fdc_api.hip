@@ -124,6 +124,7 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
     bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
@@ -295,16 +296,21 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     {
         const char *np = getenv("FDC_NO_POLY");
         bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
+        // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
+        // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
         std::vector<char> used(N / 256 + 1, 0);
+        const int r0 = p->C > 0 ? (cfg->channels[0].f & 255) : 0;
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != 256 || (ch.f & 255) || used[ch.f >> 8] || ch.passbw != cfg->channels[0].passbw ||
+            if (ch.l != 256 || (ch.f & 255) != r0 || used[ch.f >> 8] || ch.passbw != cfg->channels[0].passbw ||
                 ch.stopbw != cfg->channels[0].stopbw) ok = false;
             else used[ch.f >> 8] = 1;
         }
-        p->poly_ok = ok;
         const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
         p->poly_block = ok && N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
+        p->poly_r = ok ? r0 : 0;
+        p->poly_ok = ok && (r0 == 0 || p->poly_block);
+        if (!p->poly_ok) { p->poly_block = false; p->poly_r = 0; }
         if (bh) p->block_hints = atoi(bh) & 255;
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
@@ -368,7 +374,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         for (int n1 = 0; n1 < N1; n1++)
             for (int j = 0; j < 16; j++) {
                 const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
-                const double ab = -2.0 * M_PI * double(n1 * j) / double(N);
+                const double ab = -2.0 * M_PI * double(((long long)n1 * (j + p->poly_r)) % N) / double(N);   // offset plans: W_N^(r n1) folded in
                 const double sg = (n1 & 1) ? -1.0 : 1.0;
                 tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
                 cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
@@ -536,7 +542,8 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg));
+                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
+                                          p->poly_r, first_block + m0));
             if (tg) {
                 HIPCHK(hipEventRecord(p->events[span[1]], s));
                 span[2] = span[3] = span[1];

@@ -55,23 +55,29 @@ constexpr int kBlkOffB = kBlkOffWrow + 16 * 18 * 8;               // 139264
 constexpr int kBlkOffSA = kBlkOffB + 32 * 18 * 8;                 // 143872
 constexpr int kBlkOffSoff = kBlkOffSA + 128 * 18 * 8;             // 162304
 constexpr int kBlkLds = kBlkOffSoff + 256 * 4;                    // 163328 <= 163840
+constexpr int kBlkOffSoffOff = kBlkOffSA + 128 * 16 * 8;          // offset plans: unpadded SA rows, then soff, then wrowF
+constexpr int kBlkOffWrowF = kBlkOffSoffOff + 256 * 4;
+constexpr int kBlkLdsOff = kBlkOffWrowF + 16 * 18 * 8;           // 163584 <= 163840
+static_assert(kBlkLdsOff <= 160 * 1024, "LDS budget of the offset-plan variant");
 static_assert(kBlkLds <= 160 * 1024, "LDS budget");
 static_assert(kBlkOffX >= 32 * kBlkGbufLd * 8, "G chunk must fit the scratch region");
 
-template <bool NT>
+template <bool NT, bool OFF>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
                                                 const long long *__restrict__ slot_off, long long out_base,
                                                 long long nb_call, unsigned out_bytes, int nb, int hints,
-                                                unsigned long long *__restrict__ dbg)
+                                                unsigned long long *__restrict__ dbg, int roff, long long first_block)
 {
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: G chunk
     float2 *xbuf = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffX);
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrow);      // [b][p] = W256^(b p), rows of 18
     float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffB);           // [c5][q] = W_N^(16 c5 q)
     float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffSA);          // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
-    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + kBlkOffSoff);
+    // offset plans need a second twiddle table: the SA rows give up their padding for it (2-way conflicts on 8 reads per pass)
+    constexpr int kSaLd = OFF ? 16 : 18;
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (OFF ? kBlkOffSoffOff : kBlkOffSoff));
     const int tid = threadIdx.x;
     // stage-1 roles
     const int w = tid >> 6, lane = tid & 63, col = lane & 3, b = lane >> 2, c5 = 4 * w + col;
@@ -81,8 +87,16 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     const int r2 = tid & 31, p2 = tid >> 5;
 
     // ---- tables (once per workgroup; the workgroup is persistent)
+    // Offset plans (every channel at f = 256*slot + r, OFF): the block is modulated by exp(-2 pi i r n / N), n = n1 + 256 (16a + b),
+    // without a single extra multiplication.  W_16^(r a) rotates the outputs of the first DFT-16 (index p reads Z[(p + r) mod 16]:
+    // the exchange slot of register Z[p] becomes (p - r) mod 16), W_256^(r b) joins the forward twiddle (table wrowF), W_N^(r n1)
+    // sits in cbt (host), and for odd r the window phase (-1)^block (phase_shifting_windowing_vcc_impl.cc:82, R = 2) in cb.
+    float2 *wrowF = OFF ? reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrowF) : wrow;
+    const int r16 = roff & 15;
     for (int i = tid; i < 256; i += 512) {
         wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
+        if (OFF)     // entry [b][p]: the twiddle of register Z[p], whose true index is pt = (p - r) mod 16: W_256^(b (pt + r))
+            wrowF[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * ((((i & 15) - r16) & 15) + roff)) & 255];
         const long long o = slot_off[i];                                      // slot i = p2 + 16 q is entry [p2][q]
         soff[(i & 15) * 16 + (i >> 4)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
@@ -91,7 +105,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15;
         const float2 t = twq[(size_t)(32 * ps) * 16 + q];                        // W_N^(16 * 32 ps * q)
         const float s = shn[bb + 16 * q];
-        SA[(ps * 16 + bb) * 18 + q] = make_float2(t.x * s, t.y * s);
+        SA[(ps * 16 + bb) * kSaLd + q] = make_float2(t.x * s, t.y * s);
     }
     __syncthreads();
 
@@ -107,6 +121,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     float2 *const scrw = scr + w * kBlkScrPts + lane;             // exchange write base: element p at + 68 p
     const float2 *const scrr = scr + w * kBlkScrPts + col + 68 * b;   // exchange read base: element bb at + 4 bb
     const float2 *const wr = wrow + b * 18;
+    const float2 *const wrf = wrowF + b * 18;
     const float2 *const btr = Bt + c5 * 18;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
 
@@ -130,6 +145,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 #define FDC_STAMP(i) do { if (dbg && blockIdx.x == 0 && lane == 0 && dbgk < 4) dbg[(w * 4 + dbgk) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
+        const float sgn = (OFF && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
         FDC_STAMP(0);
         f16v G[8];                                                // G[j][2 pass .. 2 pass + 1]: row t' = b + 16 j, column 32 pass + c5
 #define FDC_GGET(j, ps) mk(G[j][2 * (ps)], G[j][2 * (ps) + 1])
@@ -140,7 +156,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 #pragma nounroll
         for (int ps = 0; ps < 8; ps++) {
             if (hints & 8) { if (((w >> 2) ^ ps) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
-            const cf cb = cbn;
+            const cf cb = OFF ? cbn * sgn : cbn;
             cf cur[16];
 #pragma unroll
             for (int a = 0; a < 16; a++) cur[a] = L[a];
@@ -163,12 +179,17 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             cf tw[16];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float4 t = ld4(&wr[2 * i]);
+                const float4 t = ld4(&wrf[2 * i]);
                 tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
             }
-            st2(&scrw[0], cur[rev16(0)]);                         // W256^0 = 1
+            if (OFF) {
 #pragma unroll
-            for (int p = 1; p < 16; p++) st2(&scrw[68 * p], cmul(cur[rev16(p)], tw[p]));
+                for (int p = 0; p < 16; p++) st2(&scrw[68 * ((p - r16) & 15)], cmul(cur[rev16(p)], tw[p]));
+            } else {
+                st2(&scrw[0], cur[rev16(0)]);                     // W256^0 = 1
+#pragma unroll
+                for (int p = 1; p < 16; p++) st2(&scrw[68 * p], cmul(cur[rev16(p)], tw[p]));
+            }
             __builtin_amdgcn_wave_barrier();                      // same wave, in-order LDS queue: no s_barrier
             cf v[16];
 #pragma unroll
@@ -176,7 +197,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             dft16<false>(v);                                      // A[k2 = b + 16 q] in v[rev16(q)]
             cf u[16];
             {
-                const float2 *sar = SA + (ps * 16 + b) * 18;
+                const float2 *sar = SA + (ps * 16 + b) * kSaLd;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
@@ -276,25 +297,30 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 
 hipError_t init_block_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
+    hipError_t e;
+#define FDC_SETB(A, B) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kBlkLdsOff : kBlkLds); \
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
+    FDC_SETB(true, false) FDC_SETB(false, false) FDC_SETB(true, true) FDC_SETB(false, true)
+#undef FDC_SETB
+    return hipSuccess;
 }
 
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                             unsigned long long *dbg)
+                             unsigned long long *dbg, int r, long long first_block)
 {
     if (nb_chunk <= 0) return hipSuccess;
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: 159.5 KiB each)
     if (grid > nb_chunk) grid = nb_chunk;
-    if (hints & 1)          // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms
-        hipLaunchKernelGGL(k_blk256<true>, dim3((unsigned)grid), dim3(512), kBlkLds, s, in, in_stride, out, tw256, twq, cbt, shn,
-                           slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg);
-    else
-        hipLaunchKernelGGL(k_blk256<false>, dim3((unsigned)grid), dim3(512), kBlkLds, s, in, in_stride, out, tw256, twq, cbt, shn,
-                           slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg);
+    // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)
+#define FDC_LB(A, B) \
+    hipLaunchKernelGGL((k_blk256<A, B>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, in, in_stride, out, tw256, twq, cbt, shn, \
+                       slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block)
+    if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
+    else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
+#undef FDC_LB
     return hipGetLastError();
 }
 

@@ -96,7 +96,9 @@ hipError_t init_block_kernels();
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                             unsigned long long *dbg = nullptr /* diagnostics: 8 x 4 x 24 cycle stamps of workgroup 0 */);
+                             unsigned long long *dbg = nullptr /* diagnostics: 8 x 4 x 32 cycle stamps of workgroup 0 */,
+                             int r = 0 /* common offset f mod 256 of the channels; cbt must then hold (-1)^n1 W_N^(n1 (b + r)) */,
+                             long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */);
 
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
 

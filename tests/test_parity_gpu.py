@@ -272,6 +272,47 @@ def test_uniform_plan_one_kernel_path(oracle, nslots, nb, chunk):
         assert_close(outs[c], outs2[c], "slot %d vs two-launch path" % slots[c])
 
 
+@pytest.mark.parametrize("r,nslots", [(1, 255), (16, 40), (37, 255), (128, 7), (255, 255), (200, 1)])
+def test_offset_uniform_plan_one_kernel_path(oracle, r, nslots):
+    """A tiling that does not start at bin 0 — every channel at f = 256*slot + r, one window — runs on the one-kernel path too
+    (the block modulated by exp(-2 pi i r n / N) inside the kernel; for odd r the window phase alternates per block,
+    lib/phase_shifting_windowing_vcc_impl.cc:57-58,82).  Against the oracle, against the spectrum-in-memory path, and in
+    ragged calls (the phase depends on the GLOBAL block index)."""
+    N, R, nb = 65536, 2, 7
+    H = N - N // R
+    rng = np.random.default_rng(r * 31 + nslots)
+    slots = [int(v) for v in rng.permutation(255)[:nslots]]          # slot 255 would leave the spectrum for r > 0
+    chans = [(256 * c + r, 256, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 11 + r)
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3
+    outs = p.work(x)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
+    for c in range(0, len(chans), max(1, len(chans) // 16)):
+        assert_close(outs[c], ref[c], "slot %d offset %d" % (slots[c], r))
+    os.environ["FDC_NO_POLY"] = "1"
+    try:
+        q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+        assert q.path() == 1
+        outs3 = q.work(x)
+    finally:
+        del os.environ["FDC_NO_POLY"]
+    for a, b in zip(outs, outs3):
+        assert_close(a, b)
+    p.reset()
+    parts = [p.work(x[a * H:b * H]) for a, b in [(0, 1), (1, 4), (4, 7)]]     # calls starting at odd and even block indices
+    for c in range(len(chans)):
+        assert_close(np.concatenate([q_[c] for q_ in parts]), outs[c])
+    # without the one-kernel form an offset plan is not a uniform plan
+    os.environ["FDC_NO_BLOCK"] = "1"
+    try:
+        assert G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb).path() == 1
+    finally:
+        del os.environ["FDC_NO_BLOCK"]
+
+
 def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
     """BASELINE configs[3] at a size the oracle finishes in seconds: N=262144, R=2, 1024 channels (l=256), processed as
     two independent block spans (halo + global first-block index) exactly as the 8-GPU sharding does, through the
