@@ -67,6 +67,7 @@ SYMBOLS = {
     "fdc_pipeline_channel_offset": (C.c_int64, [_vp, C.c_int, C.c_int]),
     "fdc_pipeline_channel_lout": (C.c_int32, [_vp, C.c_int]),
     "fdc_pipeline_work": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_work_real": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
     "fdc_host_register": (C.c_int, [_vp, C.c_size_t]),
     "fdc_host_unregister": (C.c_int, [_vp]),
     "fdc_pipeline_reset": (None, [_vp]),

@@ -142,6 +142,19 @@ class Pipeline:
                                                    spec.ctypes.data if spec is not None else None))
         return (outs, spec) if want_spectrum else outs
 
+    def work_real(self, x, want_spectrum=False):
+        """Real input stream (float32 items; fdc_pipeline_work_real): the block's imaginary part is zero."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.size % self.H:
+            raise ValueError("input must be a whole number of (N - N/R)-sample items")
+        nb = x.size // self.H
+        outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
+        spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
+        _lib.check(_lib.lib().fdc_pipeline_work_real(self._h, x.ctypes.data, nb, ptrs,
+                                                    spec.ctypes.data if spec is not None else None))
+        return (outs, spec) if want_spectrum else outs
+
     def work_raw(self, in_ptr, nblocks, out_ptrs):
         """fdc_pipeline_work on raw addresses (out_ptrs: ctypes array of c_void_p, one per channel) — for callers that
         keep their buffers and want no per-call Python work, e.g. timing the C entry itself."""
@@ -227,8 +240,10 @@ class FrequencyDomainChannelizer:
         self.verbose = int(verbose)
         self.itemsize = inptype
         self.debug = bool(debug)
-        if self.itemsize != 8:
-            raise ValueError('Unknown input type. ')            # only gr_complex is reachable (:205-210)
+        if self.itemsize not in (8, 4):
+            raise ValueError('Unknown input type. ')            # :205-210 (there only gr_complex is reachable; the Float
+        #                                                         input type of the GRC block, itemsize 4, is served here
+        #                                                         by the fft_vfc front end the reference meant at :207-208)
 
         # frequency conventions (:70-91): everything is stored normalised to [0, 1) with DC at 0.5
         self.freqmode, self.get_freq, self.set_freq, self.get_bw, self.set_bw = freq_converters(freqmode, fs, centerfrequency)
@@ -331,7 +346,11 @@ class FrequencyDomainChannelizer:
         """Returns the hier block's stream ports; PDUs of the sink blocks ("msgout", :166-168) are left in
         self.messages as (dict, complex64 array) pairs.  Detection segments run as SegmentDetection instances, like in
         the reference hier block (:261-278)."""
-        if self.inpveclen == 1:
+        if self.inpveclen == 1 and self.itemsize == 4:
+            if self.sinks is not None:
+                raise ValueError("real input with sink blocks is not supported")
+            res = self.pipeline.work_real(samples, want_spectrum=self.debug)
+        elif self.inpveclen == 1:
             res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
         else:       # the front end (stream_to_vector, overlap_save, fft_vcc) is the caller's: :201, :284-290
             res = self.pipeline.work_spectrum(samples, want_spectrum=self.debug, sinks=self.sinks)

@@ -141,6 +141,7 @@ struct fdc_pipeline {
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
     float2 *d_spec = nullptr;    // spectrum, chunk*N (or max_blocks*N with keep_spectrum)
     float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
+    float *d_real = nullptr;     // work_real(): max_blocks*H real samples
     float2 *d_out = nullptr;     // work(): max_blocks*sum_lout
     int64_t blockcount = 0;      // work(): blocks consumed so far
     // work(): transfers and kernels of consecutive sub-batches overlap (H2D on s_in, kernels on stream, D2H on s_out)
@@ -222,7 +223,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
-    (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out);
+    (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -792,6 +793,40 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
 int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
 {
     return pipeline_work_impl(p, in, nblocks, outs, spectrum, nullptr);
+}
+
+// Real input: the float items are copied to the device and widened there into the complex ring (imaginary part 0); the
+// rest of the call is the one-stream form of the complex entry.
+int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (nblocks == 0) return 0;
+    if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
+    if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    if (spectrum && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    int rc = work_io_setup(p);
+    if (rc != FDC_OK) return rc;
+    hipStream_t s = p->stream;
+    const size_t nin = (size_t)nblocks * p->H;
+    if (!p->d_real) HIPCHK(hipMalloc(&p->d_real, sizeof(float) * (size_t)p->cfg.max_blocks * p->H));
+    float2 *d_specfull = nullptr;
+    if (spectrum) HIPCHK(hipMalloc(&d_specfull, sizeof(float2) * (size_t)nblocks * p->N));
+    struct Guard { float2 *p; ~Guard() { if (p) (void)hipFree(p); } } guard{d_specfull};
+    HIPCHK(hipMemcpyAsync(p->d_real, in, sizeof(float) * nin, hipMemcpyHostToDevice, s));
+    HIPCHK(fdc::launch_real_to_complex(p->d_real, p->d_ring + p->ovl, nin, s));
+    rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
+    if (rc != FDC_OK) return rc;
+    for (int c = 0; c < p->C; c++)
+        if (outs[c])
+            HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
+                                  sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, s));
+    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_specfull, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    p->blockcount += nblocks;
+    return nblocks;
 }
 
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,

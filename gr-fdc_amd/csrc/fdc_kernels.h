@@ -100,6 +100,9 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              int r = 0 /* common offset f mod 256 of the channels; cbt must then hold (-1)^n1 W_N^(n1 (b + r)) */,
                              long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */);
 
+// real samples -> complex samples with zero imaginary part (the real-input front end)
+hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s);
+
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s);
 
 // sinks

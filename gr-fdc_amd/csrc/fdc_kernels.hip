@@ -666,6 +666,19 @@ hipError_t launch_scatter_out(const float2 *src, const ScatterEnt *tab, int ncha
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_real_to_complex(const float *__restrict__ in, float2 *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = make_float2(in[i], 0.f);
+}
+
+hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    size_t g = (n + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)g), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStream_t s)
 {
     if (!n) return hipSuccess;

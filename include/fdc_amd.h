@@ -86,6 +86,12 @@ int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int channel);
  *   spectrum    NULL, or nblocks*N samples of the normalised spectrum (needs keep_spectrum)
  * Returns nblocks (items consumed, sync 1:1) or a negative fdc_status. */
 int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum);
+/* The same for a REAL input stream (float32 items, the hier block's "Float" input type: stream_to_vector(4, ...),
+ * overlap_save(4, ...) and the fft_vfc the reference meant to put at python/FrequencyDomainChannelizer.py:207-208 — the branch
+ * is unreachable there, :205-210): in = nblocks*(N-N/R) float32 samples, taken as the real part of the block; everything
+ * behind the load is the complex path unchanged (fftshift, 1/N, channels).  History and block counter are shared with
+ * fdc_pipeline_work; do not mix the two on one handle. */
+int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum);
 
 /* Optional: pin a host range that will be handed to fdc_pipeline_work() again and again (GNU Radio's circular buffers
  * live as long as the flowgraph: register them in start(), unregister in stop()).  A call whose `in` lies in a

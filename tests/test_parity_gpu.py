@@ -501,3 +501,28 @@ def test_distinct_handles_from_concurrent_threads(oracle):
         assert got[i] is not None
         for a, b in zip(got[i], want[i]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "plan %d differs under concurrency" % i
+
+
+@pytest.mark.parametrize("N,R", [(4096, 4), (65536, 2)])
+def test_real_input_front_end(oracle, N, R):
+    """f4: float32 input items (the hier block's Float input type, python/FrequencyDomainChannelizer.py:207-208): the chain on
+    x + 0j.  State carries across calls; through the hier-block mirror with inptype = 4 as well."""
+    H = N - N // R
+    nb = 5
+    chans = [(256 * c, 256, 0.88, 1.0) for c in (3, 9, N // 256 - 1)] if N == 65536 else [(100, 256, 0.88, 1.0), (2001, 512, 0.7, 0.95)]
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal(nb * H).astype(np.float32)
+    ref, rspec = oracle.channelizer(N, R, 1, chans, x.astype(np.complex64), want_spectrum=True, nthreads=4)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, keep_spectrum=True)
+    a, spec = p.work_real(x[:2 * H], want_spectrum=True)
+    b = p.work_real(x[2 * H:])
+    for c in range(len(chans)):
+        assert_close(np.concatenate([a[c], b[c]]), ref[c], "ch%d" % c)
+    assert_close(spec, rspec[:2 * N])
+    # a real signal has a Hermitian spectrum: bin k and bin N - k of the UNSHIFTED transform are conjugates (shifted: N/2 +- d)
+    s0 = spec[:N]
+    assert np.abs(s0[N // 2 + 5] - np.conj(s0[N // 2 - 5])) <= 1e-5 * np.abs(s0).max()
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)            # without a spectrum consumer: the fast paths
+    c2 = q.work_real(x)
+    for c in range(len(chans)):
+        assert_close(c2[c], ref[c], "fast path ch%d" % c)
