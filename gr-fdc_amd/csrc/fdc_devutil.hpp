@@ -58,5 +58,20 @@ __device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 __device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
 
+// 16-byte buffer store of two complex values (NT: streamed, aux bit 1)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, cf a, cf b)
+{
+    u32x4 t;
+    t.x = __float_as_uint(a.x); t.y = __float_as_uint(a.y); t.z = __float_as_uint(b.x); t.w = __float_as_uint(b.y);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, 0, NT ? 2 : 0);
+}
+// the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float swap_pair(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
 
 }  // namespace fdc
