@@ -111,6 +111,13 @@ hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, 
 hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip,
                           const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 
+// extractions wider than kMaxLdsFft, a whole width class at once: gather (slice * window) into [ntasks][w], batched two-pass
+// inverse transform (launch_fft), scatter of [skip, w) to the tasks' landing offsets
+hipError_t launch_extract_gather(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, const float2 *wins,
+                                 float2 *dst, hipStream_t s);
+hipError_t launch_extract_scatter(const float2 *src, const ExtractTask *tasks, int ntasks, int w, int skip, float2 *out,
+                                  hipStream_t s);
+
 // single-block faces
 hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,
                                size_t out_item_bytes, int nitems, hipStream_t s);

@@ -523,6 +523,24 @@ __global__ void k_phase_window(const float2 *__restrict__ in, float2 *__restrict
         out[(size_t)m * l + i] = cmulf(in[(size_t)m * l + i], w[i]);
 }
 
+__global__ __launch_bounds__(256) void k_extract_gather(const float2 *__restrict__ spec, int N, const ExtractTask *__restrict__ tasks,
+                                                        int w, const float2 *__restrict__ wins, float2 *__restrict__ dst)
+{
+    const ExtractTask tk = tasks[blockIdx.y];
+    const float2 *src = spec + (size_t)tk.slot * N + tk.start, *win = wins + tk.win_off;
+    float2 *d = dst + (size_t)blockIdx.y * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w; i += gridDim.x * 256) d[i] = cmulf(src[i], win[i]);
+}
+
+__global__ __launch_bounds__(256) void k_extract_scatter(const float2 *__restrict__ src, const ExtractTask *__restrict__ tasks, int w,
+                                                         int skip, float2 *__restrict__ out)
+{
+    const ExtractTask tk = tasks[blockIdx.y];
+    const float2 *sp = src + (size_t)blockIdx.y * w;
+    float2 *d = out + tk.out_off - skip;
+    for (int i = skip + blockIdx.x * 256 + threadIdx.x; i < w; i += gridDim.x * 256) d[i] = sp[i];
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 
@@ -752,6 +770,21 @@ hipError_t launch_phase_window(const float2 *in, float2 *out, const float2 *win,
         hipLaunchKernelGGL(k_phase_window, dim3(gx, nb), dim3(256), 0, s, in + (size_t)m0 * l, out + (size_t)m0 * l, win,
                            l, R, shift, c0);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_gather(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, const float2 *wins,
+                                 float2 *dst, hipStream_t s)
+{
+    if (ntasks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_extract_gather, dim3((unsigned)((w + 1023) / 1024), (unsigned)ntasks), dim3(256), 0, s, spec, N, tasks, w, wins, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_scatter(const float2 *src, const ExtractTask *tasks, int ntasks, int w, int skip, float2 *out, hipStream_t s)
+{
+    if (ntasks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_extract_scatter, dim3((unsigned)((w + 1023) / 1024), (unsigned)ntasks), dim3(256), 0, s, src, tasks, w, skip, out);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 #include <deque>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" const char *fdc_last_error(void);
@@ -51,6 +52,7 @@ struct BlockRef {
 };
 
 struct PduRec {
+    int64_t key = 0;                // emission order inside a call: block, then PowerActivationChannels in order, then detections
     fdc_pdu meta{};
     std::vector<BlockRef> blocks;
     int blocklen = 0;               // samples per block
@@ -97,7 +99,8 @@ struct fdc_sinks {
     float *d_power = nullptr;
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
     float2 *d_ext = nullptr; size_t cap_ext = 0;
-    float2 *d_wide = nullptr;                       // scratch of extractions wider than kMaxLdsFft: 3 x N
+    float2 *d_wide = nullptr; size_t wide_cap = 0;  // scratch of extractions wider than kMaxLdsFft: 3 x wide_cap points
+    std::vector<fdc::ExtractTask> sorted;          // tasks grouped by width class
     cfl *h_ext = nullptr; size_t cap_hext = 0;      // pinned landing buffer of the extractions
     std::vector<float> h_power;
     std::vector<PduRec> pdus;
@@ -115,14 +118,21 @@ void *g_log_user = nullptr;
 
 // get_current_time(), …vcm_impl.cc:56-69 / PowerActivationChannel_impl.cc:435-447 (the reference formats into char p[40]
 // with a stated size of 80; 19 characters are written)
-std::string current_time_string()
+// One second of resolution: the string is formatted once per second and thread (localtime_r takes the C library's time-zone
+// lock; a bank of 256 channels activates thousands of times per batch).
+const std::string &current_time_string()
 {
-    char buf[40];
+    thread_local time_t last = (time_t)-1;
+    thread_local std::string text;
     const time_t t = time(nullptr);
-    struct tm tmv;
-    localtime_r(&t, &tmv);
-    strftime(buf, sizeof buf, "%Y-%m-%d-%H-%M-%S", &tmv);
-    return buf;
+    if (t != last) {
+        char buf[40];
+        struct tm tmv;
+        localtime_r(&t, &tmv);
+        strftime(buf, sizeof buf, "%Y-%m-%d-%H-%M-%S", &tmv);
+        text = buf; last = t;
+    }
+    return text;
 }
 
 // log(), PowerActivationChannel_impl.cc:396-408 / …vcm_impl.cc:578-591: a line to stdout or appended to the log file
@@ -144,34 +154,46 @@ void start_logfile(const std::string &file)      // constructors: the file is tr
     else { std::fputc('\n', f); std::fclose(f); }
 }
 
-int64_t add_task(fdc_sinks *s, int slot, int start, int w, int skip, int win_off)
+// Where the decisions of one batch are collected: the handle's own lists, or the private lists of a worker thread that
+// runs a range of PowerActivationChannels on its own (they do not interact; the lists are merged afterwards).
+struct Emit {
+    std::vector<fdc::ExtractTask> *tasks;
+    std::vector<int> *task_w, *task_skip;
+    int64_t *ext_used;
+    std::vector<PduRec> *pdus;
+    int64_t blockcount;             // the block counter while the current block is processed
+    int64_t key;                    // order key of a PDU emitted now
+};
+
+int64_t add_task(Emit &e, int slot, int start, int w, int skip, int win_off)
 {
     fdc::ExtractTask t{};
-    t.slot = slot; t.start = start; t.win_off = win_off; t.out_off = s->ext_used;
-    s->ext_used += w - skip;
-    s->tasks.push_back(t);
-    s->task_w.push_back(w); s->task_skip.push_back(skip);
-    return (int64_t)s->tasks.size() - 1;
+    t.slot = slot; t.start = start; t.win_off = win_off; t.out_off = *e.ext_used;
+    *e.ext_used += w - skip;
+    e.tasks->push_back(t);
+    e.task_w->push_back(w); e.task_skip->push_back(skip);
+    return (int64_t)e.tasks->size() - 1;
 }
 
 // ---------------------------------------------------------------- PowerActivationChannel
-void pac_process(fdc_sinks *s, Pac &p, int slot)            // process_channel, …_impl.cc:260-284
+void pac_process(const fdc_sinks *s, Emit &e, Pac &p, int slot)            // process_channel, …_impl.cc:260-284
 {
     BlockRef b;
-    b.task = add_task(s, slot, p.extract_start, p.extract_width, p.ovl_offset, p.win_off + p.phase * p.extract_width);
+    b.task = add_task(e, slot, p.extract_start, p.extract_width, p.ovl_offset, p.win_off + p.phase * p.extract_width);
     p.blocks.push_back(std::move(b));
     p.count++;
     p.phase = (p.phase + p.deltaphase) % s->R;
 }
 
-void pac_emit(fdc_sinks *s, Pac &p, bool fin)               // emit_data, :212-258
+void pac_emit(const fdc_sinks *s, Emit &e, Pac &p, bool fin)               // emit_data, :212-258
 {
     PduRec r;
+    r.key = e.key;
     r.meta.kind = 0; r.meta.source = p.ID; r.meta.chan_id = p.id_at_activation;
     r.meta.finalized = fin; r.meta.part = p.part; r.meta.has_part = 1;
     r.meta.rel_cfreq = (double)(p.extract_start + p.extract_stop) / 2.0 / (double)s->N;
     r.meta.rel_bw = (double)p.extract_width / (double)s->N;
-    r.meta.blockstart = s->blockcount - p.count; r.meta.blockend = s->blockcount;
+    r.meta.blockstart = e.blockcount - p.count; r.meta.blockend = e.blockcount;
     r.meta.vectorstart = p.extract_start; r.meta.vectorend = p.extract_stop;
     std::snprintf(r.meta.id, sizeof r.meta.id, "%s", p.msg_id.c_str());
     r.blocklen = p.output_len;
@@ -181,11 +203,11 @@ void pac_emit(fdc_sinks *s, Pac &p, bool fin)               // emit_data, :212-2
         sink_log(s, pac_logfile(p), p.msg_id + (fin ? std::string(".fin") : ".parted." + std::to_string(p.part)) + ": start=" +
                  std::to_string(p.extract_start) + ", stop=" + std::to_string(p.extract_stop) + ", blockstart=" +
                  std::to_string((long long)r.meta.blockstart) + ", blockend=" + std::to_string((long long)r.meta.blockend));
-    s->pdus.push_back(std::move(r));
+    e.pdus->push_back(std::move(r));
     p.part++;
 }
 
-void pac_step(fdc_sinks *s, Pac &p, float pwr, int slot)    // one item of work(), :146-170
+void pac_step(const fdc_sinks *s, Emit &e, Pac &p, float pwr, int slot)    // one item of work(), :146-170
 {
     if (pwr == 0.0f) pwr = FLT_MIN;                                        // :293-294
     bool changed = false;
@@ -197,41 +219,42 @@ void pac_step(fdc_sinks *s, Pac &p, float pwr, int slot)    // one item of work(
             p.part = 0; p.count = 0; p.active = true; p.phase = 0; p.blocks.clear();
             p.id_at_activation = p.finished;
             p.msg_id = current_time_string() + ".PowActChan." + std::to_string(p.ID) + "." + std::to_string(p.finished);
-            pac_process(s, p, slot - 1);                                   // previous block (slot 0 = saved history)
-            pac_process(s, p, slot);
+            pac_process(s, e, p, slot - 1);                                // previous block (slot 0 = saved history)
+            pac_process(s, e, p, slot);
         } else {
-            pac_process(s, p, slot);
+            pac_process(s, e, p, slot);
             p.active = false;                                              // deactivate(), :189-196
-            pac_emit(s, p, true);
+            pac_emit(s, e, p, true);
             p.finished++;
         }
     } else if (p.active) {
-        pac_process(s, p, slot);
+        pac_process(s, e, p, slot);
         const int mb = s->cfg.pac_maxblocks;
-        if (mb == 0 || (mb > 0 && p.count % mb == 0)) pac_emit(s, p, false);
+        if (mb == 0 || (mb > 0 && p.count % mb == 0)) pac_emit(s, e, p, false);
     }
 }
 
 // ---------------------------------------------------------------- activity_detection_channelizer_vcm
-void det_process(fdc_sinks *s, DetChan &c, int slot)        // process_channel, …vcm_impl.cc:373-397
+void det_process(fdc_sinks *s, Emit &e, DetChan &c, int slot)        // process_channel, …vcm_impl.cc:373-397
 {
     BlockRef b;
-    b.task = add_task(s, slot, c.extract_start, c.extract_width, c.ovlskip,
+    b.task = add_task(e, slot, c.extract_start, c.extract_width, c.ovlskip,
                       s->det_win_off[c.wclass] + c.phase * c.extract_width);
     c.data.push_back(std::move(b));
     c.count++;
     c.phase = (c.phase + c.phaseincrement) % s->R;
 }
 
-void det_emit(fdc_sinks *s, Segment &g, DetChan &c, bool fin, size_t nblk)   // :406-452 / :454-510
+void det_emit(fdc_sinks *s, Emit &e, Segment &g, DetChan &c, bool fin, size_t nblk)   // :406-452 / :454-510
 {
     PduRec r;
+    r.key = e.key++;
     r.meta.kind = 1; r.meta.source = g.ID; r.meta.chan_id = c.ID;
     r.meta.finalized = fin; r.meta.part = c.part; r.meta.has_part = fin ? (c.part > 0) : 1;
     r.meta.rel_bw = (double)c.extract_width / (double)s->N;
     r.meta.rel_cfreq = (double)(c.extract_start + c.extract_stop) / 2.0 / (double)s->N;
     // the vcm block counts from 1 (…vcm_impl.cc:188), SegmentDetection from 0 (SegmentDetection_impl.cc:118)
-    const int64_t bc = s->blockcount - (s->cfg.det_variant == 1 ? 1 : 0);
+    const int64_t bc = e.blockcount - (s->cfg.det_variant == 1 ? 1 : 0);
     r.meta.blockstart = bc - c.count; r.meta.blockend = bc;
     r.meta.vectorstart = c.extract_start; r.meta.vectorend = c.extract_stop;
     std::snprintf(r.meta.id, sizeof r.meta.id, "%s", c.msg_id.c_str());
@@ -241,7 +264,7 @@ void det_emit(fdc_sinks *s, Segment &g, DetChan &c, bool fin, size_t nblk)   // 
         sink_log(s, s->det_logfile, c.msg_id + (fin ? std::string(".fin: ") : ".parted." + std::to_string(c.part) + ": ") + "start=" +
                  std::to_string(c.extract_start) + ", stop=" + std::to_string(c.extract_stop) + ", blockstart=" +
                  std::to_string((long long)r.meta.blockstart) + ", blockend=" + std::to_string((long long)r.meta.blockend));
-    s->pdus.push_back(std::move(r));
+    e.pdus->push_back(std::move(r));
 }
 
 void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, :617-628
@@ -305,23 +328,23 @@ void seg_detect(fdc_sinks *s, Segment &g, const float *P)   // detect_channels, 
     }
 }
 
-void seg_extract(fdc_sinks *s, Segment &g, int slot)        // extract_channels_in_segments_singlethread, :306-337
+void seg_extract(fdc_sinks *s, Emit &e, Segment &g, int slot)        // extract_channels_in_segments_singlethread, :306-337
 {
     const int mb = s->cfg.det_maxblocks, delay = s->cfg.det_deactivation_delay;
     for (auto &c : g.chans) {
-        if (c.inactive < 0) { det_process(s, c, slot - 1); det_process(s, c, slot); c.inactive = 0; }   // :399-403
-        else if (c.inactive > delay) det_emit(s, g, c, true, c.data.size());
-        else det_process(s, c, slot);
+        if (c.inactive < 0) { det_process(s, e, c, slot - 1); det_process(s, e, c, slot); c.inactive = 0; }   // :399-403
+        else if (c.inactive > delay) det_emit(s, e, g, c, true, c.data.size());
+        else det_process(s, e, c, slot);
         if (s->cfg.det_variant == 0 && mb >= 0 && (int)c.data.size() >= mb) {  // :317-318, :454-470
             const size_t ntx = mb == 0 ? c.data.size() : (size_t)mb;
-            if (ntx > 0) { det_emit(s, g, c, false, ntx); c.part++; }
+            if (ntx > 0) { det_emit(s, e, g, c, false, ntx); c.part++; }
         }
     }
     if (s->cfg.det_variant == 1 && mb >= 0)                                     // SegmentDetection: separate pass, :359-362
         for (auto &c : g.chans)
             if ((int)c.data.size() >= mb) {
                 const size_t ntx = mb == 0 ? c.data.size() : (size_t)mb;
-                if (ntx > 0) { det_emit(s, g, c, false, ntx); c.part++; }
+                if (ntx > 0) { det_emit(s, e, g, c, false, ntx); c.part++; }
             }
     for (size_t i = 0; i < g.chans.size();)                                     // clear_inactive_channels, :512-524
         if (g.chans[i].inactive > delay) g.chans.erase(g.chans.begin() + i); else i++;
@@ -599,16 +622,74 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         HIPCHK(hipStreamSynchronize(s->stream));
     }
     lap("cell power + D2H");
-    // phase 2: decisions, one block after the other (work() loops of both reference blocks)
+    // phase 2: decisions (work() loops of both reference blocks).  Every block: the PowerActivationChannels in order, then the
+    // detection segments.  PowerActivationChannel instances do not interact, so a large bank is cut into ranges that worker
+    // threads run over the whole batch on their own; the PDUs carry an order key (block, then instance) and are put back
+    // into the order the sequential loop emits them in.
     s->tasks.clear(); s->task_w.clear(); s->task_skip.clear(); s->ext_used = 0;
-    for (int m = 0; m < nblocks; m++) {
-        const float *P = s->h_power.data() + (size_t)m * ncells;
-        const int slot = m + 1;
-        for (auto &p : s->pacs) pac_step(s, p, P[p.cell], slot);
-        for (auto &g : s->segs) seg_detect(s, g, P + g.cell0);                  // …vcm_impl.cc:558
-        for (auto &g : s->segs) seg_extract(s, g, slot);                        // :562
-        s->blockcount++;
+    const int64_t bc0 = s->blockcount;
+    const int npac = (int)s->pacs.size();
+    int nthr = 1;
+    if (npac >= 32 && (int64_t)npac * nblocks >= 16384 && s->cfg.verbose == 0) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        nthr = (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
+        if (const char *t = getenv("FDC_SINKS_THREADS")) if (atoi(t) >= 1) nthr = std::min(atoi(t), 32);
+        nthr = std::min(nthr, npac / 8);
     }
+    auto run_pacs = [&](int a, int b, Emit e) {
+        for (int m = 0; m < nblocks; m++) {
+            const float *P = s->h_power.data() + (size_t)m * ncells;
+            e.blockcount = bc0 + m;
+            for (int i = a; i < b; i++) {
+                e.key = ((int64_t)m << 24) | i;
+                pac_step(s, e, s->pacs[(size_t)i], P[s->pacs[(size_t)i].cell], m + 1);
+            }
+        }
+    };
+    Emit em{&s->tasks, &s->task_w, &s->task_skip, &s->ext_used, &s->pdus, bc0, 0};
+    if (nthr > 1) {
+        // one cache-line-aligned set of lists per worker (the vector headers are written on every push_back)
+        struct alignas(256) Local { std::vector<fdc::ExtractTask> tasks; std::vector<int> w, skip; int64_t used = 0; std::vector<PduRec> pdus; };
+        std::vector<Local> loc((size_t)nthr);
+        std::vector<std::thread> pool;
+        std::vector<int> lo((size_t)nthr + 1);
+        for (int t = 0; t <= nthr; t++) lo[(size_t)t] = (int)((int64_t)npac * t / nthr);
+        for (int t = 0; t < nthr; t++) {
+            Local &L = loc[(size_t)t];
+            pool.emplace_back(run_pacs, lo[(size_t)t], lo[(size_t)t + 1], Emit{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0});
+        }
+        for (auto &th : pool) th.join();
+        lap("  PAC state machines (threads)");
+        // merge: task indices of a worker move up by the number of tasks in front of them (live channels and PDUs alike)
+        for (int t = 0; t < nthr; t++) {
+            Local &L = loc[(size_t)t];
+            const int64_t base = (int64_t)s->tasks.size();
+            s->tasks.insert(s->tasks.end(), L.tasks.begin(), L.tasks.end());
+            s->task_w.insert(s->task_w.end(), L.w.begin(), L.w.end());
+            s->task_skip.insert(s->task_skip.end(), L.skip.begin(), L.skip.end());
+            s->ext_used += L.used;
+            if (base) {
+                for (auto &r : L.pdus) for (auto &bk : r.blocks) if (bk.task >= 0) bk.task += base;
+                for (int i = lo[(size_t)t]; i < lo[(size_t)t + 1]; i++)
+                    for (auto &bk : s->pacs[(size_t)i].blocks) if (bk.task >= 0) bk.task += base;
+            }
+            for (auto &r : L.pdus) s->pdus.push_back(std::move(r));
+        }
+    } else if (npac) {
+        run_pacs(0, npac, em);
+    }
+    lap("  PAC total incl. merge");
+    if (!s->segs.empty())
+        for (int m = 0; m < nblocks; m++) {
+            const float *P = s->h_power.data() + (size_t)m * ncells;
+            em.blockcount = bc0 + m;
+            em.key = ((int64_t)m << 24) | (1 << 23);
+            for (auto &g : s->segs) seg_detect(s, g, P + g.cell0);                  // …vcm_impl.cc:558
+            for (auto &g : s->segs) seg_extract(s, em, g, m + 1);                   // :562
+        }
+    s->blockcount = bc0 + nblocks;
+    if (npac && (nthr > 1 || !s->segs.empty()))
+        std::stable_sort(s->pdus.begin(), s->pdus.end(), [](const PduRec &a, const PduRec &b) { return a.key < b.key; });
     lap("decisions (host)");
     // Landing layout: the blocks of every PDU emitted in this call sit one behind the other (PDU order, block order),
     // so a PDU whose blocks all come from this call needs no assembly — its payload IS a run of the landing buffer;
@@ -626,11 +707,21 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     // phase 3: extractions, one launch per width class
     const size_t nt = s->tasks.size();
     if (nt) {
-        std::vector<size_t> order(nt);
-        for (size_t i = 0; i < nt; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return s->task_w[a] < s->task_w[b]; });
-        std::vector<fdc::ExtractTask> sorted(nt);
-        for (size_t i = 0; i < nt; i++) sorted[i] = s->tasks[order[i]];
+        // tasks grouped by width: a counting sort over the (at most 25) power-of-two classes, order inside a class kept;
+        // nothing to do when every task has the same width (a PowerActivationChannel bank of equal channels)
+        size_t cnt[32] = {0}, first[32];
+        for (size_t i = 0; i < nt; i++) cnt[31 - __builtin_clz((unsigned)s->task_w[i])]++;
+        size_t acc = 0;
+        int nclasses = 0;
+        for (int k = 0; k < 32; k++) { first[k] = acc; acc += cnt[k]; nclasses += cnt[k] != 0; }
+        const fdc::ExtractTask *upload = s->tasks.data();
+        if (nclasses > 1) {
+            s->sorted.resize(nt);
+            size_t pos[32];
+            std::copy(first, first + 32, pos);
+            for (size_t i = 0; i < nt; i++) s->sorted[pos[31 - __builtin_clz((unsigned)s->task_w[i])]++] = s->tasks[i];
+            upload = s->sorted.data();
+        }
         if (nt > s->cap_tasks) {
             (void)hipFree(s->d_tasks); s->d_tasks = nullptr; s->cap_tasks = 0;
             HIPCHK(hipMalloc(&s->d_tasks, sizeof(fdc::ExtractTask) * nt * 2));
@@ -647,28 +738,35 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             HIPCHK(hipMalloc(&s->d_ext, sizeof(float2) * (size_t)s->ext_used * 2));
             s->cap_ext = (size_t)s->ext_used * 2;
         }
-        HIPCHK(hipMemcpyAsync(s->d_tasks, sorted.data(), sizeof(fdc::ExtractTask) * nt, hipMemcpyHostToDevice, s->stream));
-        for (size_t i = 0; i < nt;) {
-            const int w = s->task_w[order[i]], skip = s->task_skip[order[i]];
-            size_t j = i;
-            while (j < nt && s->task_w[order[j]] == w) j++;
+        lap("  task grouping + buffers");
+        HIPCHK(hipMemcpyAsync(s->d_tasks, upload, sizeof(fdc::ExtractTask) * nt, hipMemcpyHostToDevice, s->stream));
+        for (int k = 0; k < 32; k++) {
+            if (!cnt[k]) continue;
+            const int w = 1 << k, skip = w / s->R;
+            const size_t i = first[k], j = first[k] + cnt[k];
+            if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
             if (w <= fdc::kMaxLdsFft) {
                 HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
             } else {
-                // wider than one workgroup's transform (rare: a carrier over 1/8 of a 65536-bin band): task by task on
-                // scratch — slice, window, two-pass inverse transform with the half swap as input rotation, discard
-                if (!s->d_wide) HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * (size_t)N));
-                float2 *A = s->d_wide, *B = A + N, *T = B + N;
-                for (size_t k = i; k < j; k++) {
-                    const fdc::ExtractTask &tk = sorted[k];
-                    HIPCHK(hipMemcpyAsync(A, s->d_spec + (size_t)tk.slot * N + tk.start, sizeof(float2) * (size_t)w, hipMemcpyDeviceToDevice, s->stream));
-                    HIPCHK(fdc::launch_phase_window(A, A, s->d_wins + tk.win_off, w, 1, 0, 0, 1, s->stream));
-                    HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, 1, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
-                    HIPCHK(hipMemcpyAsync(s->d_ext + tk.out_off, B + skip, sizeof(float2) * (size_t)(w - skip), hipMemcpyDeviceToDevice, s->stream));
+                // wider than one workgroup's transform (a carrier, or a run of merged carriers, over 1/8 of a 65536-bin band):
+                // the whole class in batches of up to 64 Mi points — gather (slice * window), batched two-pass inverse transform
+                // with the half swap as input rotation, scatter of [skip, w) to the landing offsets
+                const size_t per = std::max<size_t>(1, ((size_t)64 << 20) / (size_t)w);
+                if (s->wide_cap < per * (size_t)w) {
+                    (void)hipFree(s->d_wide); s->d_wide = nullptr; s->wide_cap = 0;
+                    HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * per * (size_t)w));
+                    s->wide_cap = per * (size_t)w;
+                }
+                float2 *A = s->d_wide, *B = A + s->wide_cap, *T = B + s->wide_cap;
+                for (size_t k0 = i; k0 < j; k0 += per) {
+                    const int n = (int)std::min(per, j - k0);
+                    HIPCHK(fdc::launch_extract_gather(s->d_spec, N, s->d_tasks + k0, n, w, s->d_wins, A, s->stream));
+                    HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, n, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
+                    HIPCHK(fdc::launch_extract_scatter(B, s->d_tasks + k0, n, w, skip, s->d_ext, s->stream));
                 }
             }
-            i = j;
         }
+        if (trace) { HIPCHK(hipStreamSynchronize(s->stream)); lap("  task upload + extraction kernels"); }
         HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
     }
     // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
