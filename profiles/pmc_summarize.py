@@ -33,7 +33,7 @@ for k in acc:
     if base in names and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024
         w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
-        out[names[base]] = {"kernel": k, "fetch_size_raw_bytes": f, "write_size_bytes": w,
+        out[names[base]] = {"kernel": k, "config": int(os.environ.get("PMC_CONFIG", "2")), "fetch_size_raw_bytes": f, "write_size_bytes": w,
                             "hbm_bytes_per_launch": 2 * f + w, "blocks_per_launch": float(os.environ.get("PMC_BLOCKS", "1024")),
                             "blocklen": int(os.environ.get("PMC_BLOCKLEN", "65536"))}
 with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
