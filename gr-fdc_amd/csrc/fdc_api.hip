@@ -540,13 +540,13 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
         if (use_poly && p->poly_block) {
             // one launch: nothing but the input rows and the output samples crosses the memory interface
-            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            // timing: the two events take the dispatch's own begin / end stamps, no packets around the kernel
             HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
                                           (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
-                                          p->poly_r, first_block + m0));
+                                          p->poly_r, first_block + m0, tg ? p->events[span[0]] : nullptr,
+                                          tg ? p->events[span[1]] : nullptr));
             if (tg) {
-                HIPCHK(hipEventRecord(p->events[span[1]], s));
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);
             }

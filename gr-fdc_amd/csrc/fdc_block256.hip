@@ -14,9 +14,10 @@
 //       wave's LDS phases overlap the other waves' DFT-16 arithmetic.  The next pass's rows are loaded into
 //       registers before the current pass is computed.  The 8 kept outputs t = b + 16q, q >= 8, of every pass go
 //       into the G registers (indexed by the pass: s_set_gpr_idx).
-//   stage 2, 4 chunks of 32 rows t': G registers -> LDS [row][n1] -> DFT-16 over a (n1 = 16a + b2) -> twiddle ->
-//       LDS [p2][b2][row] -> DFT-16 over b2 -> the 256 slot outputs of 32 consecutive rows: 256-byte runs per channel.
-//       Two LDS buffers, two s_barriers per chunk.
+//   stage 2, 2 chunks of 64 rows t': the FFT-256 over n1 = 32 pass + c5 starts with a DFT-8 over the pass index, which
+//       is the register index of G (no exchange), then W_256^(c5 klo), then ONE trip through LDS ([row][klo][c5]) to the
+//       lane that owns (row, klo) and transforms the remaining 32 points over c5 in registers.  Slot klo + 8 khi of 64
+//       consecutive rows: every wave store is a 512-byte run of one channel.  Two s_barriers per chunk.
 // Every LDS access is base register + immediate offset; all layouts are padded (not XOR-swizzled) so that no
 // per-element address arithmetic is left, and conflict-free for the lane groups of ds_write_b64 (16 lanes) and
 // ds_read_b64 (32 lanes) (MI355X_MICROARCH.md, LDS table).
@@ -28,6 +29,7 @@
 //
 // The arithmetic is the uniform-plan commutation of fdc_fast256.hip (same tables, same rounding points), so the
 // result matches k_p1 + k_p2 to the last few ulps; parity against the oracle: tests/test_parity_gpu.py.
+#include <hip/hip_ext.h>
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
 #include "fdc_devutil.hpp"
@@ -49,8 +51,9 @@ __device__ __forceinline__ cf unpack_cf(unsigned long long u) { return mk(__uint
 
 // LDS map (bytes).  Stage-1 scratch: per wave 68*15 + 64 = 1084 points (element (p; lane) at lane + 68 p).
 constexpr int kBlkScrPts = 1084;
-constexpr int kBlkGbufLd = 260;                                   // stage-2 G chunk: [32 rows][260]
-constexpr int kBlkXbufPts = 8448;                                 // stage-2 exchange: r + 33 b2 + 528 p2
+constexpr int kBlkGbufLd = 260;                                   // stage-2 G chunk: [64 rows][260] (8 klo x 32 c5 + pad)
+constexpr int kBlkOffCt = 64 * kBlkGbufLd * 8;                    // 133120: stage-2 twiddles [32][8]
+constexpr int kBlkXbufPts = 8448;                                 // upper part of the stage-2 chunk (free during stage 1)
 constexpr int kBlkOffX = 8 * kBlkScrPts * 8;                      // 69376 (>= 32*260*8 = 66560)
 constexpr int kBlkOffWrow = kBlkOffX + kBlkXbufPts * 8;           // 136960
 constexpr int kBlkOffB = kBlkOffWrow + 16 * 18 * 8;               // 139264
@@ -62,7 +65,7 @@ constexpr int kBlkOffWrowF = kBlkOffSoffOff + 256 * 4;
 constexpr int kBlkLdsOff = kBlkOffWrowF + 16 * 18 * 8;           // 163584 <= 163840
 static_assert(kBlkLdsOff <= 160 * 1024, "LDS budget of the offset-plan variant");
 static_assert(kBlkLds <= 160 * 1024, "LDS budget");
-static_assert(kBlkOffX >= 32 * kBlkGbufLd * 8, "G chunk must fit the scratch region");
+static_assert(kBlkOffCt >= kBlkOffX && kBlkOffCt + 32 * 8 * 8 <= kBlkOffWrow, "stage-2 chunk and twiddles below the tables");
 
 template <bool NT, bool OFF>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
@@ -73,21 +76,37 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                                                 unsigned long long *__restrict__ dbg, int roff, long long first_block)
 {
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: G chunk
-    float2 *xbuf = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffX);
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrow);      // [b][p] = W256^(b p), rows of 18
     float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffB);           // [c5][q] = W_N^(16 c5 q)
     float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffSA);          // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
     // offset plans need a second twiddle table: the SA rows give up their padding for it (2-way conflicts on 8 reads per pass)
     constexpr int kSaLd = OFF ? 16 : 18;
     unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (OFF ? kBlkOffSoffOff : kBlkOffSoff));
+    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffCt);      // [c5][klo] = W_256^(c5 klo): stage 2, after the DFT-8
     const int tid = threadIdx.x;
     // stage-1 roles
     const int w = tid >> 6, lane = tid & 63, col = lane & 3, b = lane >> 2, c5 = 4 * w + col;
-    // stage-2 roles.  Layer 1: row r (the two rows of a 32-lane read group are 4 apart: their 16-point runs then sit on
-    // opposite halves of the 64 banks), points n1 = 16a + b2.  Layer 2: row r2 (fast: stores are 256-B runs), outputs p2 + 16q.
-    const int rr = tid >> 4, b2 = tid & 15, r1 = (rr >> 3) * 8 + ((rr >> 1) & 3) + 4 * (rr & 1);
-    const int r2 = tid & 31, p2 = tid >> 5;
+    // stage-2 roles: writer = the stage-1 role (column c5, rows b + 16 j); reader: row = lane, klo = wave
 
+    // block order: round rho, XCD x = workgroup mod 8 (round-robin dispatch), slot = workgroup / 8:
+    // block = rho*grid + x*(grid/8) + slot, i.e. one XCD works on grid/8 consecutive blocks at a time
+    const int grid = gridDim.x, per = grid >> 3;
+    const bool xmap = (grid & 7) == 0;
+    const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (first >= nb) return;
+
+    const unsigned inbytes = 65536u * 8u;
+    const unsigned voff = (unsigned)(b * 256 + c5) * 8u;          // row b, column c5 of pass 0; pass adds 256 B, row group a 32 KiB
+    // the first block's rows are requested before the tables are built: their latency hides behind the table set-up
+    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 256u * 16u * 8u);      // cbt[n1][b], n1 = 32 pass + c5
+    const unsigned voffc = (unsigned)(c5 * 16 + b) * 8u;
+    cf L[16], cbn;
+    {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
+#pragma unroll
+        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+        cbn = bld2(rcb, voffc, 0);
+    }
     // ---- tables (once per workgroup; the workgroup is persistent)
     // Offset plans (every channel at f = 256*slot + r, OFF): the block is modulated by exp(-2 pi i r n / N), n = n1 + 256 (16a + b),
     // without a single extra multiplication.  W_16^(r a) rotates the outputs of the first DFT-16 (index p reads Z[(p + r) mod 16]:
@@ -99,8 +118,9 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
         if (OFF)     // entry [b][p]: the twiddle of register Z[p], whose true index is pt = (p - r) mod 16: W_256^(b (pt + r))
             wrowF[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * ((((i & 15) - r16) & 15) + roff)) & 255];
-        const long long o = slot_off[i];                  // slot i = p2 + 16 q, q = 2k + odd, is entry [p2][odd][k]
-        soff[(i & 15) * 16 + ((i >> 4) & 1) * 8 + (i >> 5)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+        const long long o = slot_off[i];                  // slot i = klo + 8 khi, khi = k0 + 2 k1, is entry [klo][16 k0 + rev16(k1)]
+        soff[(i & 7) * 32 + ((i >> 3) & 1) * 16 + rev16(i >> 4)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+        ctab[i] = tw256[((i >> 3) * (i & 7)) & 255];      // [c5][klo] = W_256^(c5 klo)
     }
     Bt[(tid >> 4) * 18 + (tid & 15)] = twq[tid];                                // c5 = tid >> 4 < 32, q = tid & 15
     for (int i = tid; i < 2048; i += 512) {
@@ -111,15 +131,6 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     }
     __syncthreads();
 
-    // block order: round rho, XCD x = workgroup mod 8 (round-robin dispatch), slot = workgroup / 8:
-    // block = rho*grid + x*(grid/8) + slot, i.e. one XCD works on grid/8 consecutive blocks at a time
-    const int grid = gridDim.x, per = grid >> 3;
-    const bool xmap = (grid & 7) == 0;
-    const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (first >= nb) return;
-
-    const unsigned inbytes = 65536u * 8u;
-    const unsigned voff = (unsigned)(b * 256 + c5) * 8u;          // row b, column c5 of pass 0; pass adds 256 B, row group a 32 KiB
     float2 *const scrw = scr + w * kBlkScrPts + lane;             // exchange write base: element p at + 68 p
     const float2 *const scrr = scr + w * kBlkScrPts + col + 68 * b;   // exchange read base: element bb at + 4 bb
     const float2 *const wr = wrow + b * 18;
@@ -133,20 +144,20 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     // hints bit 2: static (waves 0-3 favoured); bit 3: the favoured half alternates every pass.
     if (hints & 4) { if (w < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
 
-    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 256u * 16u * 8u);      // cbt[n1][b], n1 = 32 pass + c5
-    const unsigned voffc = (unsigned)(c5 * 16 + b) * 8u;
-    cf L[16], cbn;
-    {
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
-#pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
-        cbn = bld2(rcb, voffc, 0);
-    }
     // diagnostics (FDC_BLOCK_DEBUG=1): cycle stamps of workgroup 0, per wave: [wave][block round][24]
-    int dbgk = 0;
-#define FDC_STAMP(i) do { if (dbg && blockIdx.x == 0 && lane == 0 && dbgk < 4) dbg[(w * 4 + dbgk) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+    [[maybe_unused]] int dbgk = 0;
+    // (only in the -DFDC_BLK_STAMPS build, tools/block_probe.py: the stamps cost half a dozen registers the kernel does not have)
+#ifdef FDC_BLK_STAMPS
+    // the stamps are taken into scalar registers (s_memtime) and written out once per block: no vector register is held
+#define FDC_STAMP(i) do { st[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FDC_STAMP(i) do { } while (0)
+#endif
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
+#ifdef FDC_BLK_STAMPS
+        unsigned long long st[32] = {};
+#endif
         const float sgn = (OFF && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
         FDC_STAMP(0);
         // G[j][pass]: row t' = b + 16 j, column 32 pass + c5.  One complex value = one 64-bit vector element: the element index
@@ -237,78 +248,85 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             FDC_STAMP(1 + ps);
         }
         // ---------------- stage 2 ----------------
+        // FFT-256 over n1 = 32 pass + c5 of every row t' = b + 16 j.  The 8 passes of a column sit in ONE lane: a DFT-8 over
+        // the pass index needs no exchange at all (k1 = klo + 8 khi: W_256^(n1 k1) = W_8^(pass klo) W_256^(c5 klo) W_32^(c5 khi)).
+        // What is left is a DFT-32 over c5 = 4 wave + col, i.e. across the whole workgroup: ONE trip through LDS per value
+        // (two chunks of 64 rows: [row][klo][c5], rows 260 apart), read back as whole 32-point runs by lane = row, wave = klo,
+        // transformed in registers.  A wave's store is 64 consecutive samples of one channel (512 B).
         __syncthreads();                                          // every wave is done with its stage-1 scratch
         FDC_STAMP(9);
-        float2 *const gw = scr + b * kBlkGbufLd + c5;             // G chunk write base: (row b + 16 jj, column 32 pass + c5)
-        const float2 *const gr = scr + r1 * kBlkGbufLd + b2;      // layer-1 read base: point n1 = 16 a + b2
-        float2 *const xw = xbuf + r1 + 33 * b2;                   // exchange write base: element p at + 528 p
-        const float2 *const xr = xbuf + r2 + 528 * p2;            // exchange read base: element bb at + 33 bb
-        const float2 *const wr2 = wrow + b2 * 18;
-        const unsigned rowb = (unsigned)(m * 128 + r2) * 8u;
+        // the stage-2 roles are worked out here, from a thread index the compiler cannot trace back: loop-invariant address
+        // registers would otherwise stay live across stage 1, which has none to spare
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6), b_2 = lane2 >> 2, c5_2 = 4 * w2 + (lane2 & 3);
+        float2 *const gw0 = scr + b_2 * kBlkGbufLd + c5_2;        // element (row b + 16 jj, klo) at + 16 jj * 260 + 32 klo
+        // rows 32.. are out of reach of the 16-bit ds offset from gw0: a second base, opaque to the constant folder (it would
+        // otherwise materialise one address register per write)
+        int row32 = 32 * kBlkGbufLd;
+        asm volatile("" : "+v"(row32));
+        float2 *const gw1 = gw0 + row32;
+        const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
+        const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
+        cf ct[8];                                                 // W_256^(c5 klo)
+        {
+            const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-            for (int ps = 0; ps < 8; ps++) st2(&gw[jj * 16 * kBlkGbufLd + 32 * ps], FDC_GGET(jj, ps));
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            __syncthreads();                                      // chunk c of G is in LDS; every read of xbuf (chunk c-1) is done
-            FDC_STAMP(10 + 5 * c);
-            cf v[16];
-#pragma unroll
-            for (int a = 0; a < 16; a++) v[a] = ld2(&gr[16 * a]);
-            dft16<false>(v);
-            {
-                cf tw[16];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 t = ld4(&wr2[2 * i]);
-                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
-                }
-#pragma unroll
-                for (int p = 0; p < 16; p++) st2(&xw[528 * p], cmul(v[rev16(p)], tw[p]));
-            }
-            FDC_STAMP(11 + 5 * c);
-            __syncthreads();                                      // exchange written; every read of the G chunk is done
-            FDC_STAMP(12 + 5 * c);
-            if (c < 3) {
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                    for (int ps = 0; ps < 8; ps++)
-                        st2(&gw[jj * 16 * kBlkGbufLd + 32 * ps], FDC_GGET(2 * c + 2 + jj, ps));
-            }
-            FDC_STAMP(13 + 5 * c);
-#pragma unroll
-            for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&xr[33 * bb]);
-            dft16<false>(v);                                      // slot k1 = p2 + 16 q in v[rev16(q)], row t' = 32 c + r2
-            FDC_STAMP(14 + 5 * c);
-            // Stores.  A lane holds the 16 slot outputs p2 + 16 q of ONE row; neighbouring lanes hold neighbouring rows.  The pair
-            // trades halves (lane ^ 1, DPP): the even lane ends up with both rows of the even q, the odd lane with both rows of
-            // the odd q, and every store is 16 bytes — half as many store instructions (their issue, 16 per wave and chunk at
-            // one per ~100 cycles, was the longest part of this phase).  Unused slots: the byte offset is pushed beyond the
-            // buffer's extent and the store is dropped by the range check of the descriptor (no branch per store).
-            const bool oddrow = (tid & 1) != 0;
-            const unsigned rb = rowb + (unsigned)c * 256u - (oddrow ? 8u : 0u);        // the even row of the pair
-            // this lane's 8 stream offsets: slots p2 + 16 (2k + odd), one b128 pair (table laid out [p2][odd][k])
-            unsigned so[8];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const uint4 t = *reinterpret_cast<const uint4 *>(&soff[p2 * 16 + (oddrow ? 8 : 0) + 4 * i]);
-                so[4 * i] = t.x; so[4 * i + 1] = t.y; so[4 * i + 2] = t.z; so[4 * i + 3] = t.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const cf A = v[rev16(2 * k)], B = v[rev16(2 * k + 1)];
-                const cf send = oddrow ? A : B;
-                const cf recv = mk(swap_pair(send.x), swap_pair(send.y));
-                const cf lo = oddrow ? recv : A, hi = oddrow ? B : recv;
-                bst4<NT>(rout, so[k] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[k] + rb, lo, hi);
+            for (int i = 0; i < 4; i++) {
+                const float4 t = ld4(&ctr[2 * i]);
+                ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
             }
         }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                cf a[8];
+#pragma unroll
+                for (int ps = 0; ps < 8; ps++) a[ps] = FDC_GGET(4 * ch + jj, ps);
+                dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
+                float2 *const gw = (jj < 2 ? gw0 : gw1) + (jj & 1) * 16 * kBlkGbufLd;
+                st2(&gw[0], a[0]);
+#pragma unroll
+                for (int k = 1; k < 8; k++) st2(&gw[32 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+            }
+            FDC_STAMP(10 + 5 * ch);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the next phase's arithmetic (and its registers) behind
+            __syncthreads();                                      // the chunk is in LDS
+            FDC_STAMP(11 + 5 * ch);
+            cf v[32];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float4 t = ld4(&gr[2 * i]);
+                v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+            }
+            __syncthreads();                                      // every read of the chunk is done: the region may be rewritten
+            __builtin_amdgcn_sched_barrier(0);
+            FDC_STAMP(12 + 5 * ch);
+            dft32<false>(v);                                      // khi = k0 + 2 k1 in v[16 k0 + rev16(k1)]
+            FDC_STAMP(13 + 5 * ch);
+            // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
+            // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
+            // dropped by the range check of the descriptor (no branch per store).
+            const unsigned rb = (unsigned)(m * 128 + 64 * ch + lane2) * 8u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint4 t = sow[q];
+                const unsigned so[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+            }
+            FDC_STAMP(14 + 5 * ch);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         FDC_STAMP(30);
+#ifdef FDC_BLK_STAMPS
+        if (dbg && blockIdx.x == 0 && lane == 0 && dbgk < 4)
+            for (int i = 0; i < 32; i++) dbg[(w * 4 + dbgk) * 32 + i] = st[i];
+#endif
         dbgk++;
-        // the last chunk's xbuf reads may still be in flight in other waves: xbuf is not touched by stage 1, and the G chunk
-        // region (= stage-1 scratch) was last read before the barrier above, so the next block starts without a barrier
+        // the chunk region (= stage-1 scratch) was last read before the barrier above: the next block starts without one
     }
 }
 
@@ -326,15 +344,17 @@ hipError_t init_block_kernels()
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                             unsigned long long *dbg, int r, long long first_block)
+                             unsigned long long *dbg, int r, long long first_block, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (nb_chunk <= 0) return hipSuccess;
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: 159.5 KiB each)
     if (grid > nb_chunk) grid = nb_chunk;
     // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)
+    // ev_start / ev_stop (timing): the dispatch packet's own begin / end time stamps (hipExtLaunchKernel) — no barrier packet
+    // in front of or behind the kernel, unlike hipEventRecord (measured 7-17 us per bracketed launch)
 #define FDC_LB(A, B) \
-    hipLaunchKernelGGL((k_blk256<A, B>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, in, in_stride, out, tw256, twq, cbt, shn, \
-                       slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block)
+    hipExtLaunchKernelGGL((k_blk256<A, B>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
+                          tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block)
     if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
     else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
 #undef FDC_LB

@@ -56,6 +56,13 @@ __device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff,
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 2);
 }
+template <bool NT>
+__device__ __forceinline__ void bst2t(__amdgpu_buffer_rsrc_t r, unsigned voff, cf v)
+{
+    u32x2 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, NT ? 2 : 0);
+}
 __device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
 
 // 16-byte buffer store of two complex values (NT: streamed, aux bit 1)

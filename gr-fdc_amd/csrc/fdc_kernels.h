@@ -98,7 +98,8 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
                              unsigned long long *dbg = nullptr /* diagnostics: 8 x 4 x 32 cycle stamps of workgroup 0 */,
                              int r = 0 /* common offset f mod 256 of the channels; cbt must then hold (-1)^n1 W_N^(n1 (b + r)) */,
-                             long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */);
+                             long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */,
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* timing: stamped by the dispatch itself */);
 
 // real samples -> complex samples with zero imaginary part (the real-input front end)
 hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s);

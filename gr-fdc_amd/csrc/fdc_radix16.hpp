@@ -105,4 +105,57 @@ __device__ __forceinline__ void dft16(cf (&v)[16])
     for (int p = 0; p < 4; p++) dft4<INV>(v[4 * p], v[4 * p + 1], v[4 * p + 2], v[4 * p + 3]);
 }
 
+// In-register DFT-8: v[n], n = 4 n1 + n0, becomes X[k], k = k0 + 2 k1, left in v[4 k0 + k1].
+template <bool INV>
+__device__ __forceinline__ void dft8(cf (&v)[8])
+{
+#pragma unroll
+    for (int n0 = 0; n0 < 4; n0++) {
+        const cf a = v[n0] + v[n0 + 4], d = v[n0] - v[n0 + 4];
+        v[n0] = a; v[n0 + 4] = d;
+    }
+    v[5] = mul_w16<INV, 2>(v[5]);          // W8^(n0 k0), k0 = 1
+    v[6] = mul_w16<INV, 4>(v[6]);
+    v[7] = mul_w16<INV, 6>(v[7]);
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+    dft4<INV>(v[4], v[5], v[6], v[7]);
+}
+
+// multiply by exp(-/+ j*2*pi*E/32), 0 <= E < 16 compile-time
+template <bool INV, int E>
+__device__ __forceinline__ cf mul_w32(cf v)
+{
+    static_assert(E >= 0 && E < 16, "first half of the circle only");
+    if constexpr (E == 0) return v;
+    else if constexpr (E == 8) return mulj<INV>(v);
+    else {
+        constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f,
+                                 0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508978178f,
+                                 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508978178f,
+                                 -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                                 -0.92387953251128673848f, -0.98078528040323044913f};
+        constexpr float c = C[E], s0 = C[(E + 24) & 15] * ((E + 24) & 16 ? -1.0f : 1.0f);   // sin(x) = cos(x - pi/2)
+        constexpr float s = INV ? s0 : -s0;
+        return __builtin_elementwise_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
+    }
+}
+
+// In-register DFT-32: v[n], n = 16 n1 + n0, becomes X[k], k = k0 + 2 k1, left in v[16 k0 + rev16(k1)].
+template <bool INV, int N0 = 0>
+__device__ __forceinline__ void dft32_layer1(cf (&v)[32])
+{
+    if constexpr (N0 < 16) {
+        const cf a = v[N0] + v[N0 + 16], d = v[N0] - v[N0 + 16];
+        v[N0] = a; v[N0 + 16] = mul_w32<INV, N0>(d);
+        dft32_layer1<INV, N0 + 1>(v);
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void dft32(cf (&v)[32])
+{
+    dft32_layer1<INV>(v);
+    dft16<INV>(reinterpret_cast<cf (&)[16]>(v[0]));
+    dft16<INV>(reinterpret_cast<cf (&)[16]>(v[16]));
+}
+
 }  // namespace fdc

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-blocks", "32",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-blocks", "32",
                           "--cpu-budget", "6"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -22,7 +22,7 @@ def test_bench_json_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["kernel_path"] == 3
     r = d["roofline"]
@@ -32,7 +32,8 @@ def test_bench_json_line():
     assert abs(r["achieved"] - r["alg_bytes_per_block"] * r["blocks_per_launch"] / (r["kernel_avg_launch_ms"] * 1e-3) / 1e9) < 1.0
     assert d["value"] > 1e4 and abs(d["value"] - 1024 * 32768 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
     # one kernel: the dominant kernel is the step, so the contract's frac and the whole-step fraction agree to the launch gaps
-    assert 0.8 < r["pipeline_frac"] / r["frac"] <= 1.05
+    # (the driver's own arguments; a region of 20 launches still carries ~10 us of fixed cost)
+    assert 0.75 < r["pipeline_frac"] / r["frac"] <= 1.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["one_thread"]["cores"] == 1 and 0 < c["one_thread"]["value"] <= c["value"] * 1.5

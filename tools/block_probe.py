@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """GPU box helper: one launch of the one-block-per-CU kernel with FDC_BLOCK_DEBUG=1; the library prints the
-cycle stamps of workgroup 0 (per wave: end of each stage-1 pass, stage-2 barriers) on stderr at synchronize."""
+cycle stamps of workgroup 0 (per wave: end of each stage-1 pass, stage-2 phases) on stderr at synchronize.
+The stamps are compiled in only with -DFDC_BLK_STAMPS (they cost registers the kernel does not have):
+  tools/build_variant.sh stamps -DFDC_BLK_STAMPS && FDC_AMD_LIB=gr-fdc_amd/libfdc_amd_stamps.so python tools/block_probe.py"""
 import os
 import sys
 os.environ["FDC_BLOCK_DEBUG"] = "1"
