@@ -440,6 +440,7 @@ def main():
     path = pipe.path()
     names = ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 and sinks is None else \
             ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 and sinks is None else \
+            ["block_fft(forward, one kernel)", "unused", "channels"] if path == 1 and N == 65536 and os.environ.get("FDC_NO_BLOCK") != "1" else \
             ["fft_pass_a", "fft_pass_b", "channels"]
     if sinks is not None:
         b_alg += 8.0 * extracted[0] / max(1, a.steps * nb)     # the data-dependent part, counted by the harness

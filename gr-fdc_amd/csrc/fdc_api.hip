@@ -134,6 +134,11 @@ struct fdc_pipeline {
     float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
     float *d_shn = nullptr;                      // uniform path: shape[k2] / N
     long long *d_slot_off = nullptr;
+    // N = 65536 spectrum path: forward transform by the block kernel (fdc_block256.hip, FWD), own r = 0 tables
+    bool fwd_block = false;
+    float2 *d_ftwq = nullptr, *d_fcbt = nullptr;
+    float *d_fshn = nullptr;
+    long long *d_fslot = nullptr;
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
     float2 *d_big = nullptr;     // channels wider than one workgroup's transform: 3 x chunk x (widest l) scratch
@@ -222,6 +227,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     }
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
+    (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -402,6 +408,34 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         }
     }
     {
+        const char *nbk = getenv("FDC_NO_BLOCK");
+        p->fwd_block = N == 65536 && !p->cfg_generic && !(nbk && nbk[0] == '1');
+    }
+    if (p->fwd_block) {
+        // the block kernel as a forward transform: twq / cbt as on the uniform path with r = 0, a flat "window" 1/N, and the
+        // slots of stage 2 mapped to the bins 256 c (+ k2) of the shifted spectrum
+        std::vector<float2> tq(256 * 16), cb(256 * 16);
+        for (int n1 = 0; n1 < 256; n1++)
+            for (int j = 0; j < 16; j++) {
+                const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
+                const double ab = -2.0 * M_PI * double(((long long)n1 * j) % N) / double(N);
+                const double sg = (n1 & 1) ? -1.0 : 1.0;
+                tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
+                cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
+            }
+        std::vector<float> sn(256, float(1.0 / double(N)));
+        std::vector<long long> so(256);
+        for (int c = 0; c < 256; c++) so[c] = 256ll * c;
+        CHK_OR_FREE(hipMalloc(&p->d_ftwq, sizeof(float2) * tq.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_ftwq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_fcbt, sizeof(float2) * cb.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_fcbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_fshn, sizeof(float) * 256));
+        CHK_OR_FREE(hipMemcpy(p->d_fshn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_fslot, sizeof(long long) * 256));
+        CHK_OR_FREE(hipMemcpy(p->d_fslot, so.data(), sizeof(long long) * 256, hipMemcpyHostToDevice));
+    }
+    {
         hipDeviceProp_t prop;
         CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -416,7 +450,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
     for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
     if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
-    if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));
+    if (N > fdc::kMaxLdsFft && !p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));   // the block kernel needs no scratch
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
     *out = p;
@@ -571,7 +605,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        if (p->N == 65536 && !p->cfg_generic)
+        if (p->fwd_block)
+            HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
+                                              p->d_fshn, p->d_fslot, p->ncu, p->block_hints, s, evp));
+        else if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
         else

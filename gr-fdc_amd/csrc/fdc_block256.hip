@@ -67,7 +67,14 @@ static_assert(kBlkLdsOff <= 160 * 1024, "LDS budget of the offset-plan variant")
 static_assert(kBlkLds <= 160 * 1024, "LDS budget");
 static_assert(kBlkOffCt >= kBlkOffX && kBlkOffCt + 32 * 8 * 8 <= kBlkOffWrow, "stage-2 chunk and twiddles below the tables");
 
-template <bool NT, bool OFF>
+// FWD = false: the channelizer (above).  FWD = true: the same machinery as a plain forward transform of the block (no window,
+// no inverse transform).  A block is done in two halves, one after the other in the same workgroup: stage 1 keeps the k2 half
+// [128 h, 128 h + 128) of every column's FFT-256, times W_N^(n1 k2) / N, in the G registers (the rows are read again for the
+// second half: they were in this XCD's L2 / the memory-side cache a few microseconds ago); stage 2 is unchanged and its "slots"
+// are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 = fftshift), 64
+// consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans, the sinks, the
+// debug port) use instead of two passes through a scratch buffer.
+template <bool NT, bool OFF, bool FWD>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -159,10 +166,9 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         unsigned long long st[32] = {};
 #endif
         const float sgn = (OFF && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
+#pragma nounroll
+        for (int h = 0; h < (FWD ? 2 : 1); h++) {                 // FWD: the two halves of k2
         FDC_STAMP(0);
-        // G[j][pass]: row t' = b + 16 j, column 32 pass + c5.  One complex value = one 64-bit vector element: the element index
-        // is the pass number at run time, and with 64-bit elements the compiler brackets all sixteen moves of a pass with
-        // one s_set_gpr_idx_on / off pair (with 32-bit elements it emits a pair per dword).
         // G[j][pass]: row t' = b + 16 j, column 32 pass + c5.  One complex value = one 64-bit vector element (two floats packed
         // into an integer): the element index is the pass number at run time, and with 64-bit elements the compiler brackets
         // all sixteen moves of a pass with ONE s_set_gpr_idx_on / off pair (a pair per dword with 32-bit elements).  Integer,
@@ -183,7 +189,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             for (int a = 0; a < 16; a++) cur[a] = L[a];
             {
                 const int pn = ps < 7 ? ps + 1 : 0;
-                const int mb = ps < 7 ? m : mnext;
+                const int mb = (ps < 7 || (FWD && h == 0)) ? m : mnext;
                 // the pass offset (32 columns) sits in the descriptor's base: every pass uses the same per-lane offset and the
                 // same 16 scalar row offsets
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 32 * pn, inbytes);
@@ -216,35 +222,47 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 #pragma unroll
             for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&scrr[4 * bb]);
             dft16<false>(v);                                      // A[k2 = b + 16 q] in v[rev16(q)]
-            cf u[16];
-            {
-                const float2 *sar = SA + (ps * 16 + b) * kSaLd;
+            if constexpr (FWD) {
+                // forward only: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N for the 8 q of this half (q = 8 h + j)
+                const float2 *sar = SA + (ps * 16 + b) * kSaLd + 8 * h, *bth = btr + 8 * h;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 t0 = ld4(&bth[2 * i]), t1 = ld4(&sar[2 * i]);
+                    const cf x0 = h ? v[rev16(8 + 2 * i)] : v[rev16(2 * i)], x1 = h ? v[rev16(9 + 2 * i)] : v[rev16(2 * i + 1)];
+                    FDC_GPUT(2 * i, ps, cmul(cmul(cmul(x0, mk(t0.x, t0.y)), mk(t1.x, t1.y)), cb));
+                    FDC_GPUT(2 * i + 1, ps, cmul(cmul(cmul(x1, mk(t0.z, t0.w)), mk(t1.z, t1.w)), cb));
+                }
+            } else {
+                cf u[16];
+                {
+                    const float2 *sar = SA + (ps * 16 + b) * kSaLd;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
+                        // window * inter-pass twiddle, placed at the ifftshifted position (k2 ^ 128 <=> q ^ 8)
+                        u[(2 * i) ^ 8] = cmul(cmul(v[rev16(2 * i)], mk(t0.x, t0.y)), mk(t1.x, t1.y));
+                        u[(2 * i + 1) ^ 8] = cmul(cmul(v[rev16(2 * i + 1)], mk(t0.z, t0.w)), mk(t1.z, t1.w));
+                    }
+                }
+                dft16<true>(u);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
-                    // window * inter-pass twiddle, placed at the ifftshifted position (k2 ^ 128 <=> q ^ 8)
-                    u[(2 * i) ^ 8] = cmul(cmul(v[rev16(2 * i)], mk(t0.x, t0.y)), mk(t1.x, t1.y));
-                    u[(2 * i + 1) ^ 8] = cmul(cmul(v[rev16(2 * i + 1)], mk(t0.z, t0.w)), mk(t1.z, t1.w));
+                    const float4 t = ld4(&wr[2 * i]);
+                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
                 }
+                u[rev16(0)] = cmul(u[rev16(0)], cb);
+#pragma unroll
+                for (int p = 1; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], tw[p]), cb);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int p = 0; p < 16; p++) st2(&scrw[68 * p], u[rev16(p)]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&scrr[4 * bb]);
+                dft16<true>(u);                                       // y[t = b + 16 q] in u[rev16(q)]; keep q >= 8 (R = 2)
+#pragma unroll
+                for (int j = 0; j < 8; j++) FDC_GPUT(j, ps, u[rev16(8 + j)]);
             }
-            dft16<true>(u);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float4 t = ld4(&wr[2 * i]);
-                tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
-            }
-            u[rev16(0)] = cmul(u[rev16(0)], cb);
-#pragma unroll
-            for (int p = 1; p < 16; p++) u[rev16(p)] = cmul(cmulc(u[rev16(p)], tw[p]), cb);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int p = 0; p < 16; p++) st2(&scrw[68 * p], u[rev16(p)]);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&scrr[4 * bb]);
-            dft16<true>(u);                                       // y[t = b + 16 q] in u[rev16(q)]; keep q >= 8 (R = 2)
-#pragma unroll
-            for (int j = 0; j < 8; j++) FDC_GPUT(j, ps, u[rev16(8 + j)]);
             FDC_STAMP(1 + ps);
         }
         // ---------------- stage 2 ----------------
@@ -308,7 +326,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
             // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
             // dropped by the range check of the descriptor (no branch per store).
-            const unsigned rb = (unsigned)(m * 128 + 64 * ch + lane2) * 8u;
+            const unsigned rb = (unsigned)(m * (FWD ? 65536 : 128) + (FWD ? 128 * h : 0) + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint4 t = sow[q];
@@ -321,6 +339,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             __builtin_amdgcn_sched_barrier(0);
         }
         FDC_STAMP(30);
+        }                                                         // halves
 #ifdef FDC_BLK_STAMPS
         if (dbg && blockIdx.x == 0 && lane == 0 && dbgk < 4)
             for (int i = 0; i < 32; i++) dbg[(w * 4 + dbgk) * 32 + i] = st[i];
@@ -333,10 +352,11 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 hipError_t init_block_kernels()
 {
     hipError_t e;
-#define FDC_SETB(A, B) \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kBlkLdsOff : kBlkLds); \
+#define FDC_SETB(A, B, F) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<A, B, F>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kBlkLdsOff : kBlkLds); \
     if (e != hipSuccess) return e;
-    FDC_SETB(true, false) FDC_SETB(false, false) FDC_SETB(true, true) FDC_SETB(false, true)
+    FDC_SETB(true, false, false) FDC_SETB(false, false, false) FDC_SETB(true, true, false) FDC_SETB(false, true, false)
+    FDC_SETB(true, false, true) FDC_SETB(false, false, true)
 #undef FDC_SETB
     return hipSuccess;
 }
@@ -353,11 +373,35 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
     // ev_start / ev_stop (timing): the dispatch packet's own begin / end time stamps (hipExtLaunchKernel) — no barrier packet
     // in front of or behind the kernel, unlike hipEventRecord (measured 7-17 us per bracketed launch)
 #define FDC_LB(A, B) \
-    hipExtLaunchKernelGGL((k_blk256<A, B>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
+    hipExtLaunchKernelGGL((k_blk256<A, B, false>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
                           tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block)
     if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
     else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
 #undef FDC_LB
+    return hipGetLastError();
+}
+
+// Forward transform of nitems blocks of 65536 samples (item m at in + m*in_stride) into the shifted, 1/N-scaled spectrum
+// out[m][65536] with the block kernel.  slot_off[c] = 256 c; shn1[k2] = 1/N; cbt0 = the r = 0 table.
+// ev: null or 3 events: start and end of the kernel (dispatch stamps), and an event recorded behind it (the 3-event protocol
+// of the two-pass transform: its second interval is empty here).
+hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
+                                 const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
+                                 int ncu, int hints, hipStream_t s, hipEvent_t *ev)
+{
+    for (int m0 = 0; m0 < nitems; m0 += 4096) {            // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum
+        const int nb = nitems - m0 < 4096 ? nitems - m0 : 4096;
+        int grid = ncu > 0 ? ncu : 256;
+        if (grid > nb) grid = nb;
+        hipEvent_t e0 = ev && m0 == 0 ? ev[0] : nullptr, e2 = ev && m0 + nb >= nitems ? ev[1] : nullptr;
+#define FDC_LF(A) \
+        hipExtLaunchKernelGGL((k_blk256<A, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
+                              in_stride, out + (size_t)m0 * 65536, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
+                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll)
+        if (hints & 1) FDC_LF(true); else FDC_LF(false);
+#undef FDC_LF
+    }
+    if (ev) { hipError_t e = hipEventRecord(ev[2], s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
 

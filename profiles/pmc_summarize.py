@@ -30,6 +30,9 @@ names = {"fdc::k_blk256": "block_kernel(colFFT+window+IFFT+slotFFT)", "fdc::k_p1
 out = {}
 for k in acc:
     base = k.split("<")[0]
+    if base == "fdc::k_blk256" and k.rstrip(">").endswith("true") and k.count(",") == 2:      # <NT, OFF, FWD = true>
+        names[base + "_fwd"] = "block_fft(forward, one kernel)"
+        base += "_fwd"
     if base in names and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024
         w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024

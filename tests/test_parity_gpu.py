@@ -526,3 +526,32 @@ def test_real_input_front_end(oracle, N, R):
     c2 = q.work_real(x)
     for c in range(len(chans)):
         assert_close(c2[c], ref[c], "fast path ch%d" % c)
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_spectrum_path_block_forward_kernel_vs_two_pass(oracle, R):
+    """N = 65536 with a mixed channel plan (spectrum in memory): the forward transform runs on the block kernel (both halves of
+    k2 in one launch, fdc_block256.hip FWD); the two-pass kernels k_a256/k_b256 (FDC_NO_BLOCK=1) must give the same spectrum
+    and the same channel outputs, and both must match the oracle.  R = 4: nothing in the forward kernel depends on R."""
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, nb = 65536, 5
+    chans = [(37, 256, 0.88, 1.0), (300, 512, 0.9, 1.0), (4096, 1024, 0.88, 1.0), (65536 - 256, 256, 0.8, 0.95), (32768 - 64, 128, 0.88, 1.0)]
+    x = noise(nb * (N - N // R), 77 + R)
+    ref, sref = oracle.channelizer(N, R, 1, chans, x, want_spectrum=True, nthreads=4)
+    res = {}
+    for force in (None, "FDC_NO_BLOCK"):
+        if force:
+            os.environ[force] = "1"
+        try:
+            p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, keep_spectrum=True)
+            assert p.path() == 1
+            res[force] = p.work(x, want_spectrum=True)
+        finally:
+            if force:
+                del os.environ[force]
+    for force, (outs, spec) in res.items():
+        assert_close(spec.reshape(-1), sref.reshape(-1), "spectrum (%s)" % force)
+        for c in range(len(chans)):
+            assert_close(outs[c], ref[c], "channel %d (%s)" % (c, force))
+    assert_close(res[None][1].reshape(-1), res["FDC_NO_BLOCK"][1].reshape(-1), "block kernel vs two-pass spectrum")
