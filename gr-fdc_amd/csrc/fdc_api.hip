@@ -126,6 +126,11 @@ struct fdc_pipeline {
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
     bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
+    // One-kernel form only: a plan may be the union of up to kMaxPolyClasses tilings (classes), each with its own offset r,
+    // window and slot table — e.g. two banks of 256-bin channels 128 bins apart (a 2x oversampled bank), or the same bank with
+    // two window shapes.  One launch per class; class 0 is what poly_r / d_cbt / d_shn / d_slot_off name.
+    struct PolyClass { int r = 0; float passbw = 0, stopbw = 0; std::vector<int> chan; float2 *d_cbt = nullptr; float *d_shn = nullptr; long long *d_slot_off = nullptr; };
+    std::vector<PolyClass> classes;
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
     float2 *d_g = nullptr;                       // uniform path (two launches): stage-1 output G, chunk*lout*N/256 samples
@@ -226,7 +231,8 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
         if (p->pin_out[i]) (void)hipHostFree(p->pin_out[i]);
     }
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
-    (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq); (void)hipFree(p->d_cbt); (void)hipFree(p->d_shn); (void)hipFree(p->d_slot_off);
+    (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
+    for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
@@ -305,19 +311,38 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
         // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
         // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
-        std::vector<char> used(N / 256 + 1, 0);
-        const int r0 = p->C > 0 ? (cfg->channels[0].f & 255) : 0;
+        // classes: same offset r = f mod 256, same window, every slot at most once
+        const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
+        const bool block_form = N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
+        constexpr size_t kMaxPolyClasses = 3;
+        std::vector<std::vector<char>> used;
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != 256 || (ch.f & 255) != r0 || used[ch.f >> 8] || ch.passbw != cfg->channels[0].passbw ||
-                ch.stopbw != cfg->channels[0].stopbw) ok = false;
-            else used[ch.f >> 8] = 1;
+            if (ch.l != 256) { ok = false; break; }
+            size_t k = 0;
+            for (; k < p->classes.size(); k++) {
+                const auto &pc = p->classes[k];
+                if (pc.r == (ch.f & 255) && pc.passbw == ch.passbw && pc.stopbw == ch.stopbw && !used[k][ch.f >> 8]) break;
+            }
+            if (k == p->classes.size()) {
+                if (k == (block_form ? kMaxPolyClasses : 1)) { ok = false; break; }
+                fdc_pipeline::PolyClass pc;
+                pc.r = ch.f & 255; pc.passbw = ch.passbw; pc.stopbw = ch.stopbw;
+                p->classes.push_back(pc);
+                used.emplace_back(N / 256 + 1, 0);
+            }
+            used[k][ch.f >> 8] = 1;
+            p->classes[k].chan.push_back(c);
         }
-        const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
-        p->poly_block = ok && N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
-        p->poly_r = ok ? r0 : 0;
-        p->poly_ok = ok && (r0 == 0 || p->poly_block);
-        if (!p->poly_ok) { p->poly_block = false; p->poly_r = 0; }
+        // the two-launch form knows one class on the grid (r = 0) only
+        if (ok && !block_form && p->classes[0].r != 0) ok = false;
+        // one launch per class (0.165 ms per 1024 blocks each, measured) against the spectrum path (0.27 ms forward transform +
+        // 0.163 ms per 256 channels): several classes only where that is the faster of the two
+        if (ok && p->classes.size() > 1 && 0.165 * (double)p->classes.size() >= 0.27 + 0.163 * (double)p->C / 256.0) ok = false;
+        p->poly_block = ok && block_form;
+        p->poly_ok = ok;
+        p->poly_r = ok ? p->classes[0].r : 0;
+        if (!ok) p->classes.clear();
         if (bh) p->block_hints = atoi(bh) & 255;
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
@@ -373,30 +398,37 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
     }
     if (p->poly_ok) {
-        std::vector<std::complex<float>> shape(256);
-        fdc::window_table(cfg->windowtype, 256, cfg->channels[0].passbw, cfg->channels[0].stopbw, 1, 0, true, shape.data());
         const int N1 = N / 256;
-        std::vector<float2> tq((size_t)N1 * 16), cb((size_t)N1 * 16);
-        std::vector<float> sn(256);
+        std::vector<float2> tq((size_t)N1 * 16);
         for (int n1 = 0; n1 < N1; n1++)
             for (int j = 0; j < 16; j++) {
                 const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
-                const double ab = -2.0 * M_PI * double(((long long)n1 * (j + p->poly_r)) % N) / double(N);   // offset plans: W_N^(r n1) folded in
-                const double sg = (n1 & 1) ? -1.0 : 1.0;
                 tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
-                cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
             }
-        for (int k2 = 0; k2 < 256; k2++) sn[k2] = float(double(shape[k2].real()) / double(N));
         CHK_OR_FREE(hipMalloc(&p->d_twq, sizeof(float2) * tq.size()));
         CHK_OR_FREE(hipMemcpy(p->d_twq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_cbt, sizeof(float2) * cb.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_shn, sizeof(float) * 256));
-        CHK_OR_FREE(hipMemcpy(p->d_shn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
-        std::vector<long long> so(N1, -1);
-        for (int c = 0; c < p->C; c++) so[p->chans[c].f >> 8] = p->chans[c].out_off;
-        CHK_OR_FREE(hipMalloc(&p->d_slot_off, sizeof(long long) * N1));
-        CHK_OR_FREE(hipMemcpy(p->d_slot_off, so.data(), sizeof(long long) * N1, hipMemcpyHostToDevice));
+        for (auto &pc : p->classes) {
+            std::vector<std::complex<float>> shape(256);
+            fdc::window_table(cfg->windowtype, 256, pc.passbw, pc.stopbw, 1, 0, true, shape.data());
+            std::vector<float2> cb((size_t)N1 * 16);
+            std::vector<float> sn(256);
+            for (int n1 = 0; n1 < N1; n1++)
+                for (int j = 0; j < 16; j++) {
+                    const double ab = -2.0 * M_PI * double(((long long)n1 * (j + pc.r)) % N) / double(N);   // offset plans: W_N^(r n1) folded in
+                    const double sg = (n1 & 1) ? -1.0 : 1.0;
+                    cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
+                }
+            for (int k2 = 0; k2 < 256; k2++) sn[k2] = float(double(shape[k2].real()) / double(N));
+            CHK_OR_FREE(hipMalloc(&pc.d_cbt, sizeof(float2) * cb.size()));
+            CHK_OR_FREE(hipMemcpy(pc.d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&pc.d_shn, sizeof(float) * 256));
+            CHK_OR_FREE(hipMemcpy(pc.d_shn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
+            std::vector<long long> so(N1, -1);
+            for (int c : pc.chan) so[p->chans[c].f >> 8] = p->chans[c].out_off;
+            CHK_OR_FREE(hipMalloc(&pc.d_slot_off, sizeof(long long) * N1));
+            CHK_OR_FREE(hipMemcpy(pc.d_slot_off, so.data(), sizeof(long long) * N1, hipMemcpyHostToDevice));
+        }
+        p->d_cbt = p->classes[0].d_cbt; p->d_shn = p->classes[0].d_shn; p->d_slot_off = p->classes[0].d_slot_off;   // class 0 (two-launch form)
         if (N1 == 1024) {
             std::vector<float2> t1k(1024);
             for (int j = 0; j < 1024; j++) {
@@ -575,11 +607,14 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         if (use_poly && p->poly_block) {
             // one launch: nothing but the input rows and the output samples crosses the memory interface
             // timing: the two events take the dispatch's own begin / end stamps, no packets around the kernel
-            HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
-                                          p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->d_slot_off,
-                                          (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
-                                          p->poly_r, first_block + m0, tg ? p->events[span[0]] : nullptr,
-                                          tg ? p->events[span[1]] : nullptr));
+            for (size_t k = 0; k < p->classes.size(); k++) {         // one launch per class of the plan (normally one)
+                const auto &pc = p->classes[k];
+                HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
+                                              p->d_tw256, p->d_twq, pc.d_cbt, pc.d_shn, pc.d_slot_off,
+                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
+                                              pc.r, first_block + m0, tg && k == 0 ? p->events[span[0]] : nullptr,
+                                              tg && k + 1 == p->classes.size() ? p->events[span[1]] : nullptr));
+            }
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

@@ -286,17 +286,17 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         float2 *const gw1 = gw0 + row32;
         const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
         const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
-        cf ct[8];                                                 // W_256^(c5 klo)
-        {
-            const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float4 t = ld4(&ctr[2 * i]);
-                ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
-            }
-        }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
+            cf ct[8];                                             // W_256^(c5 klo): read per chunk, not held across the DFT-32 phase
+            {
+                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 t = ld4(&ctr[2 * i]);
+                    ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
+                }
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 cf a[8];

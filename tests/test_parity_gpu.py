@@ -555,3 +555,45 @@ def test_spectrum_path_block_forward_kernel_vs_two_pass(oracle, R):
         for c in range(len(chans)):
             assert_close(outs[c], ref[c], "channel %d (%s)" % (c, force))
     assert_close(res[None][1].reshape(-1), res["FDC_NO_BLOCK"][1].reshape(-1), "block kernel vs two-pass spectrum")
+
+
+def test_plan_classes_one_kernel_path(oracle):
+    """A plan that is the union of a few 256-bin tilings stays on the one-kernel path, one launch per class (fdc_api.hip,
+    PolyClass): (a) a 2x oversampled bank (tilings at offsets 0 and 128, 200 + 200 channels, interleaved in plan order),
+    (b) the same slots with two different windows, (c) the same slot twice with the same window (two classes).  Plans whose
+    classes would cost more than the spectrum path (few channels in several classes, or more than three classes) fall back.
+    Every output is checked against the oracle and against the spectrum path."""
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 2, 5
+    H = N - N // R
+    x = noise(nb * H, 4242)
+    rng = np.random.default_rng(5)
+    s0 = [int(v) for v in rng.permutation(255)[:200]]
+    s1 = [int(v) for v in rng.permutation(255)[:200]]
+    plan_a = [ch for pair in zip([(256 * c, 256, 0.88, 1.0) for c in s0], [(256 * c + 128, 256, 0.88, 1.0) for c in s1]) for ch in pair]
+    win = [(0.7, 0.9), (0.88, 1.0)]
+    plan_b = [(256 * c + 37, 256) + win[i % 2] for i, c in enumerate(s0)] + [(256 * c + 37, 256) + win[(i + 1) % 2] for i, c in enumerate(s0)]
+    plan_c = [(256 * c, 256, 0.88, 1.0) for c in s0] + [(256 * c, 256, 0.88, 1.0) for c in s0[:150]]
+    for name, plan in (("oversampled", plan_a), ("two windows", plan_b), ("slots twice", plan_c)):
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+        assert p.path() == 3, name
+        outs = p.work(x)
+        ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+        for c in list(range(0, len(plan), 23)) + [len(plan) - 1]:
+            assert_close(outs[c], ref[c], "%s: channel %d" % (name, c))
+        os.environ["FDC_NO_POLY"] = "1"
+        try:
+            outs3 = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb).work(x)
+        finally:
+            del os.environ["FDC_NO_POLY"]
+        for a, b in zip(outs, outs3):
+            assert_close(a, b, name)
+        p.reset()                                       # ragged calls: the odd offset's sign follows the global block index
+        parts = [p.work(x[a * H:b * H]) for a, b in [(0, 2), (2, 5)]]
+        for c in range(0, len(plan), 41):
+            assert_close(np.concatenate([q_[c] for q_ in parts]), outs[c], name)
+    # too few channels for two launches to pay, and four classes: spectrum path
+    assert G.Pipeline(N, R, plan_a[:40], windowtype=1, max_blocks=nb).path() == 1
+    four = [(256 * c + r, 256, 0.88, 1.0) for r in (0, 64, 128, 192) for c in range(200)]
+    assert G.Pipeline(N, R, four, windowtype=1, max_blocks=nb).path() == 1
