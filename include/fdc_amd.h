@@ -115,11 +115,13 @@ int fdc_pipeline_synchronize(fdc_pipeline *p);
 void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per internal launch group */
 /* Which kernels a process call without spectrum output runs: 0 = generic LDS Stockham kernels (any size),
- * 1 = radix-16 register kernels with the spectrum in memory (N = 65536), 2 = uniform-plan path (all channels
+ * 1 = spectrum in memory at N = 65536 (forward transform by the block kernel in one launch, ms[0]; channel kernels
+ * ms[2]), 2 = uniform-plan path (all channels
  * l = 256 on the 256-bin grid: stage 1 = column FFT + window + IFFT, stage 2 = FFT across slots; timing
  * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0), 3 = the uniform plan at N = 65536, R = 2 as ONE
  * kernel (one block per compute unit, nothing between the input rows and the output samples touches memory;
- * ms[0] = that kernel, ms[1] = ms[2] = 0). */
+ * ms[0] = that kernel, ms[1] = ms[2] = 0).  Path 3 also takes tilings that start at any bin (f = 256*slot + r) and
+ * unions of up to three tilings (different r, different windows, a slot used twice): one launch per tiling. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 
 /* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's
