@@ -405,7 +405,7 @@ def main():
                 if n > 0:
                     arr = (_lib.fdc_pdu * n)()
                     _lib.lib().fdc_sinks_pdus(sinks._h, arr, n)
-                    extracted[0] += sum(arr[i].nsamples for i in range(n))
+                    extracted[0] += int(np.frombuffer(arr, dtype=np.dtype(_lib.fdc_pdu))["nsamples"].sum())
                     extracted[1] += n
 
     def fence():

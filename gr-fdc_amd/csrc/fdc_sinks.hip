@@ -19,6 +19,9 @@
 #include <chrono>
 #include <cmath>
 #include <complex>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -66,7 +69,7 @@ struct Pac {
     float lastpower = FLT_MAX;
     int count = 0, phase = 0, part = 0, finished = 0, id_at_activation = 0;
     std::string msg_id;                  // create_ID() at activation, :308-312
-    std::deque<BlockRef> blocks;
+    std::vector<BlockRef> blocks;        // handed to the PDU as a whole when it is emitted
 };
 
 struct DetChan {
@@ -79,6 +82,76 @@ struct DetChan {
 struct Segment {
     int ID = 0, start = 0, stop = 0, width = 0, ncell = 0, cell0 = 0, counter = 0;
     std::deque<DetChan> chans;
+};
+
+
+// What a worker thread collects while it runs its range of PowerActivationChannels over a batch.  Kept from call to call:
+// the lists keep their capacity (no page faults on fresh heap memory in every call).
+struct WorkerLists {
+    std::vector<fdc::ExtractTask> tasks;
+    std::vector<int> w, skip;
+    int64_t used = 0;
+    std::vector<PduRec> pdus;
+    void clear() { tasks.clear(); w.clear(); skip.clear(); used = 0; pdus.clear(); }
+};
+
+// Fork-join pool of the handle (threads are made once; a batch costs two condition-variable round trips instead of a
+// thread creation per worker).
+class WorkerPool {
+public:
+    ~WorkerPool() { stop(); }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if ((int)th_.size() < n) grow(n);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &fn; njob_ = n; pending_ = n; gen_++;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+        th_.clear();
+    }
+private:
+    void grow(int n)
+    {
+        for (int i = (int)th_.size(); i < n; i++)
+            th_.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void(int)> *fn = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lk(m_);
+                        cv_.wait(lk, [&] { return quit_ || (gen_ != seen && i < njob_); });
+                        if (quit_) return;
+                        seen = gen_; fn = job_;
+                    }
+                    (*fn)(i);
+                    {
+                        std::lock_guard<std::mutex> g(m_);
+                        pending_--;
+                    }
+                    done_.notify_one();
+                }
+            });
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int njob_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
 };
 
 }  // namespace
@@ -108,6 +181,8 @@ struct fdc_sinks {
     std::vector<fdc::ExtractTask> tasks;
     std::vector<int> task_w, task_skip;
     int64_t ext_used = 0;
+    std::vector<std::unique_ptr<WorkerLists>> wl;    // one per worker thread (separate heap objects: no shared cache lines)
+    WorkerPool pool;
     std::string det_logfile;                 // verbose == 2: …vcm_impl.cc:94 / SegmentDetection_impl.cc:51
 };
 
@@ -197,8 +272,9 @@ void pac_emit(const fdc_sinks *s, Emit &e, Pac &p, bool fin)               // em
     r.meta.vectorstart = p.extract_start; r.meta.vectorend = p.extract_stop;
     std::snprintf(r.meta.id, sizeof r.meta.id, "%s", p.msg_id.c_str());
     r.blocklen = p.output_len;
-    for (auto &b : p.blocks) r.blocks.push_back(std::move(b));
+    r.blocks = std::move(p.blocks);                                        // the whole list changes hands: no per-block move
     p.blocks.clear();
+    p.blocks.reserve(r.blocks.size() + 2);
     if (s->cfg.verbose)                                                    // :246-253
         sink_log(s, pac_logfile(p), p.msg_id + (fin ? std::string(".fin") : ".parted." + std::to_string(p.part)) + ": start=" +
                  std::to_string(p.extract_start) + ", stop=" + std::to_string(p.extract_stop) + ", blockstart=" +
@@ -648,33 +724,37 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     };
     Emit em{&s->tasks, &s->task_w, &s->task_skip, &s->ext_used, &s->pdus, bc0, 0};
     if (nthr > 1) {
-        // one cache-line-aligned set of lists per worker (the vector headers are written on every push_back)
-        struct alignas(256) Local { std::vector<fdc::ExtractTask> tasks; std::vector<int> w, skip; int64_t used = 0; std::vector<PduRec> pdus; };
-        std::vector<Local> loc((size_t)nthr);
-        std::vector<std::thread> pool;
+        while ((int)s->wl.size() < nthr) s->wl.emplace_back(new WorkerLists());
         std::vector<int> lo((size_t)nthr + 1);
         for (int t = 0; t <= nthr; t++) lo[(size_t)t] = (int)((int64_t)npac * t / nthr);
-        for (int t = 0; t < nthr; t++) {
-            Local &L = loc[(size_t)t];
-            pool.emplace_back(run_pacs, lo[(size_t)t], lo[(size_t)t + 1], Emit{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0});
-        }
-        for (auto &th : pool) th.join();
+        s->pool.run(nthr, [&](int t) {
+            WorkerLists &L = *s->wl[(size_t)t];
+            L.clear();
+            run_pacs(lo[(size_t)t], lo[(size_t)t + 1], Emit{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0});
+        });
         lap("  PAC state machines (threads)");
-        // merge: task indices of a worker move up by the number of tasks in front of them (live channels and PDUs alike)
+        // merge: task indices of a worker move up by the number of tasks in front of them (live channels and PDUs alike);
+        // every worker moves its own lists into place
+        std::vector<int64_t> base((size_t)nthr + 1, (int64_t)s->tasks.size());
         for (int t = 0; t < nthr; t++) {
-            Local &L = loc[(size_t)t];
-            const int64_t base = (int64_t)s->tasks.size();
-            s->tasks.insert(s->tasks.end(), L.tasks.begin(), L.tasks.end());
-            s->task_w.insert(s->task_w.end(), L.w.begin(), L.w.end());
-            s->task_skip.insert(s->task_skip.end(), L.skip.begin(), L.skip.end());
-            s->ext_used += L.used;
-            if (base) {
-                for (auto &r : L.pdus) for (auto &bk : r.blocks) if (bk.task >= 0) bk.task += base;
-                for (int i = lo[(size_t)t]; i < lo[(size_t)t + 1]; i++)
-                    for (auto &bk : s->pacs[(size_t)i].blocks) if (bk.task >= 0) bk.task += base;
-            }
-            for (auto &r : L.pdus) s->pdus.push_back(std::move(r));
+            base[(size_t)t + 1] = base[(size_t)t] + (int64_t)s->wl[(size_t)t]->tasks.size();
+            s->ext_used += s->wl[(size_t)t]->used;
         }
+        s->tasks.resize((size_t)base[(size_t)nthr]); s->task_w.resize((size_t)base[(size_t)nthr]); s->task_skip.resize((size_t)base[(size_t)nthr]);
+        s->pool.run(nthr, [&](int t) {
+            WorkerLists &L = *s->wl[(size_t)t];
+            const int64_t b0 = base[(size_t)t];
+            std::copy(L.tasks.begin(), L.tasks.end(), s->tasks.begin() + b0);
+            std::copy(L.w.begin(), L.w.end(), s->task_w.begin() + b0);
+            std::copy(L.skip.begin(), L.skip.end(), s->task_skip.begin() + b0);
+            if (b0) {
+                for (auto &r : L.pdus) for (auto &bk : r.blocks) if (bk.task >= 0) bk.task += b0;
+                for (int i = lo[(size_t)t]; i < lo[(size_t)t + 1]; i++)
+                    for (auto &bk : s->pacs[(size_t)i].blocks) if (bk.task >= 0) bk.task += b0;
+            }
+        });
+        for (int t = 0; t < nthr; t++)
+            for (auto &r : s->wl[(size_t)t]->pdus) s->pdus.push_back(std::move(r));
     } else if (npac) {
         run_pacs(0, npac, em);
     }
@@ -781,7 +861,7 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             b.task = -1;
         }
     };
-    for (auto &r : s->pdus) {
+    auto finish_pdu = [&](PduRec &r) {
         bool all_here = !r.blocks.empty();
         for (auto &b : r.blocks) if (b.task < 0) { all_here = false; break; }
         if (all_here) {                     // contiguous in the landing buffer by construction (layout above)
@@ -797,8 +877,19 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             r.meta.samples = r.payload.data();
         }
         r.blocks.clear();
+    };
+    // PDUs and live channels are independent of each other: a large bank is finished by the worker threads
+    const int npdu = (int)s->pdus.size();
+    if (nthr > 1 && (npdu >= 64 || npac >= 64)) {
+        s->pool.run(nthr, [&](int t) {
+            for (int i = (int)((int64_t)npdu * t / nthr), e = (int)((int64_t)npdu * (t + 1) / nthr); i < e; i++) finish_pdu(s->pdus[(size_t)i]);
+            for (int i = (int)((int64_t)npac * t / nthr), e = (int)((int64_t)npac * (t + 1) / nthr); i < e; i++)
+                for (auto &b : s->pacs[(size_t)i].blocks) resolve(b, s->pacs[(size_t)i].output_len);
+        });
+    } else {
+        for (auto &r : s->pdus) finish_pdu(r);
+        for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
     }
-    for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
     for (auto &g : s->segs) for (auto &c : g.chans) for (auto &b : c.data) resolve(b, c.outputsamples);
     lap("payload assembly");
     if (trace) std::fprintf(stderr, "[fdc_sinks] %zu tasks, %lld samples extracted, %zu PDUs\n", nt, (long long)s->ext_used, s->pdus.size());
