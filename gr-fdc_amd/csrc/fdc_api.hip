@@ -107,6 +107,9 @@ int set_error(int code, const char *fmt, ...)
 int pick_device(int device_id) { return select_device(device_id); }
 }  // namespace fdc
 
+// launch groups below this many blocks do not go to the one-block-per-CU kernels (see fdc_pipeline_process_device)
+constexpr int kBlockMinBlocks = 96;
+
 struct fdc_pipeline {
     fdc_pipeline_cfg cfg{};
     int N = 0, R = 0, ovl = 0, H = 0, C = 0;
@@ -133,6 +136,7 @@ struct fdc_pipeline {
     std::vector<PolyClass> classes;
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
+    int block_min = kBlockMinBlocks;   // FDC_BLOCK_MIN_BLOCKS (tests: 1 = the block kernels at any size)
     float2 *d_g = nullptr;                       // uniform path (two launches): stage-1 output G, chunk*lout*N/256 samples
     bool last_was_poly = false;
     int ncu = 0;                                 // compute units of the handle's device
@@ -344,6 +348,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->poly_r = ok ? p->classes[0].r : 0;
         if (!ok) p->classes.clear();
         if (bh) p->block_hints = atoi(bh) & 255;
+        if (const char *bm = getenv("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
@@ -482,7 +487,8 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
     for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
     if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
-    if (N > fdc::kMaxLdsFft && !p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)chunk * N));   // the block kernel needs no scratch
+    // two-pass scratch; with the block kernel only launch groups shorter than kBlockMinBlocks take the two-pass kernels
+    if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)(p->fwd_block ? std::min(chunk, p->block_min) : chunk) * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
     *out = p;
@@ -604,7 +610,11 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             evp = ev;
         }
         // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        if (use_poly && p->poly_block) {
+        // The block kernel gives a whole block to one compute unit: a launch group of fewer blocks than the device has compute
+        // units leaves the rest idle (one block takes ~42 us there, however few there are).  Short calls — a scheduler handing
+        // over a few items — take the tiled kernels, which spread every block over the device.
+        const bool few = nb < p->block_min;
+        if (use_poly && p->poly_block && !(few && p->classes.size() == 1 && p->classes[0].r == 0)) {
             // one launch: nothing but the input rows and the output samples crosses the memory interface
             // timing: the two events take the dispatch's own begin / end stamps, no packets around the kernel
             for (size_t k = 0; k < p->classes.size(); k++) {         // one launch per class of the plan (normally one)
@@ -640,7 +650,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        if (p->fwd_block)
+        if (p->fwd_block && !few)
             HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
                                               p->d_fshn, p->d_fslot, p->ncu, p->block_hints, s, evp));
         else if (p->N == 65536 && !p->cfg_generic)

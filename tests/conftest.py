@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))   # tests may use the oracle (checker only)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# The library sends launch groups of fewer than 96 blocks to the tiled kernels (a block kernel gives one compute unit a whole
+# block; fdc_api.hip, kBlockMinBlocks).  The parity tests use a handful of blocks and are about the block kernels too:
+# they run with the threshold at 1; test_short_calls_take_the_tiled_kernels checks the default.
+os.environ.setdefault("FDC_BLOCK_MIN_BLOCKS", "1")
 
 
 def pytest_configure(config):

@@ -597,3 +597,36 @@ def test_plan_classes_one_kernel_path(oracle):
     assert G.Pipeline(N, R, plan_a[:40], windowtype=1, max_blocks=nb).path() == 1
     four = [(256 * c + r, 256, 0.88, 1.0) for r in (0, 64, 128, 192) for c in range(200)]
     assert G.Pipeline(N, R, four, windowtype=1, max_blocks=nb).path() == 1
+
+
+def test_short_calls_take_the_tiled_kernels(oracle):
+    """Default dispatch (no FDC_BLOCK_MIN_BLOCKS): a launch group of fewer than 96 blocks runs on the tiled kernels (two-launch
+    uniform path, two-pass forward transform), 96 and more on the block kernels; a call of 100 blocks cut into groups of
+    96 + 4 uses both.  All of them must agree with the oracle — and the path id stays what the plan qualifies for."""
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 2, 100
+    H = N - N // R
+    chans = [(256 * c, 256, 0.88, 1.0) for c in (0, 5, 128, 200, 255)]
+    mixed = [(37, 256, 0.88, 1.0), (4096, 512, 0.9, 1.0)]
+    x = noise(nb * H, 99)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
+    refm, _ = oracle.channelizer(N, R, 1, mixed, x, nthreads=8)
+    saved = os.environ.pop("FDC_BLOCK_MIN_BLOCKS", None)
+    try:
+        for chunk in (0, 96):
+            p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+            assert p.path() == 3
+            for calls in ([(0, 100)], [(0, 7), (7, 100)]):           # 7 blocks: tiled kernels; 93: tiled; 100: block kernel (+4 tiled)
+                p.reset()
+                parts = [p.work(x[a * H:b * H]) for a, b in calls]
+                for c in range(len(chans)):
+                    assert_close(np.concatenate([q_[c] for q_ in parts]), ref[c], "chunk %d calls %s channel %d" % (chunk, calls, c))
+            q = G.Pipeline(N, R, mixed, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+            assert q.path() == 1
+            parts = [q.work(x[a * H:b * H]) for a, b in [(0, 3), (3, 100)]]
+            for c in range(len(mixed)):
+                assert_close(np.concatenate([q_[c] for q_ in parts]), refm[c], "mixed plan channel %d" % c)
+    finally:
+        if saved is not None:
+            os.environ["FDC_BLOCK_MIN_BLOCKS"] = saved
