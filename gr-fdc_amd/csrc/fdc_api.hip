@@ -148,6 +148,7 @@ struct fdc_pipeline {
     float2 *d_ftwq = nullptr, *d_fcbt = nullptr;
     float *d_fshn = nullptr;
     long long *d_fslot = nullptr;
+    float2 *d_fscr = nullptr;    // 256 KiB per compute unit: the half of T the block kernel puts aside between its two stage-2 runs
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
     float2 *d_big = nullptr;     // channels wider than one workgroup's transform: 3 x chunk x (widest l) scratch
@@ -237,7 +238,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
     for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
-    (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot);
+    (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
     (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -477,6 +478,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->poly_block) {
         if (const char *dg = getenv("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
             CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
@@ -652,7 +654,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
         if (p->fwd_block && !few)
             HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
-                                              p->d_fshn, p->d_fslot, p->ncu, p->block_hints, s, evp));
+                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, evp));
         else if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));

@@ -71,19 +71,20 @@ static_assert(kBlkLds <= 160 * 1024, "LDS budget");
 static_assert(kBlkOffCt >= kBlkOffX && kBlkOffCt + 32 * 8 * 8 <= kBlkOffWrow, "stage-2 chunk and twiddles below the tables");
 
 // FWD = false: the channelizer (above).  FWD = true: the same machinery as a plain forward transform of the block (no window,
-// no inverse transform).  A block is done in two halves, one after the other in the same workgroup: stage 1 keeps the k2 half
-// [128 h, 128 h + 128) of every column's FFT-256, times W_N^(n1 k2) / N, in the G registers (the rows are read again for the
-// second half: they were in this XCD's L2 / the memory-side cache a few microseconds ago); stage 2 is unchanged and its "slots"
-// are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 = fftshift), 64
-// consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans, the sinks, the
-// debug port) use instead of two passes through a scratch buffer.
+// no inverse transform).  Stage 1 stops after the forward FFT-256 of a column: T[k2][n1] = A[k2] W_N^(n1 k2) / N.  The half
+// k2 < 128 stays in the G registers, the other half goes to 256 KiB of per-workgroup scratch (it stays in the L2 / the
+// memory-side cache) and is read back into the G registers after the first run of stage 2; stage 2 is unchanged and runs
+// twice, its "slots" are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 =
+// fftshift), 64 consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans,
+// the sinks, the debug port) use instead of two passes through a scratch buffer of the whole batch.
 template <bool NT, bool OFF, bool FWD>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
                                                 const long long *__restrict__ slot_off, long long out_base,
                                                 long long nb_call, unsigned out_bytes, int nb, int hints,
-                                                unsigned long long *__restrict__ dbg, int roff, long long first_block)
+                                                unsigned long long *__restrict__ dbg, int roff, long long first_block,
+                                                float2 *__restrict__ fwd_scratch)
 {
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: G chunk
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrow);      // [b][p] = W256^(b p), rows of 18
@@ -147,6 +148,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     const float2 *const wrf = wrowF + b * 18;
     const float2 *const btr = Bt + c5 * 18;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    // FWD: this workgroup's scratch for the second half of k2, [pass][j][thread]
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(FWD ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, FWD ? 32768u * 8u : 0u);
 
     // Two waves share a SIMD (waves w and w + 4).  With equal priority they convoy: both do their DFT-16 arithmetic at
     // half speed together and then wait for their LDS exchanges together.  Unequal priority breaks the tie: the
@@ -169,8 +172,6 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         unsigned long long st[32] = {};
 #endif
         const float sgn = (OFF && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
-#pragma nounroll
-        for (int h = 0; h < (FWD ? 2 : 1); h++) {                 // FWD: the two halves of k2
         FDC_STAMP(0);
         // G[j][pass]: row t' = b + 16 j, column 32 pass + c5.  One complex value = one 64-bit vector element (two floats packed
         // into an integer): the element index is the pass number at run time, and with 64-bit elements the compiler brackets
@@ -192,7 +193,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             for (int a = 0; a < 16; a++) cur[a] = L[a];
             {
                 const int pn = ps < 7 ? ps + 1 : 0;
-                const int mb = (ps < 7 || (FWD && h == 0)) ? m : mnext;
+                const int mb = ps < 7 ? m : mnext;
                 // the pass offset (32 columns) sits in the descriptor's base: every pass uses the same per-lane offset and the
                 // same 16 scalar row offsets
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 32 * pn, inbytes);
@@ -226,14 +227,20 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&scrr[4 * bb]);
             dft16<false>(v);                                      // A[k2 = b + 16 q] in v[rev16(q)]
             if constexpr (FWD) {
-                // forward only: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N for the 8 q of this half (q = 8 h + j)
-                const float2 *sar = SA + (ps * 16 + b) * kSaLd + 8 * h, *bth = btr + 8 * h;
+                // forward only: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N.  The half q < 8 stays in the G registers, the
+                // half q >= 8 goes to this workgroup's 256 KiB of scratch ([pass][j][thread]: every wave store is 512
+                // contiguous bytes) and comes back into the G registers for the second run of stage 2.
+                const float2 *sar = SA + (ps * 16 + b) * kSaLd;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float4 t0 = ld4(&bth[2 * i]), t1 = ld4(&sar[2 * i]);
-                    const cf x0 = h ? v[rev16(8 + 2 * i)] : v[rev16(2 * i)], x1 = h ? v[rev16(9 + 2 * i)] : v[rev16(2 * i + 1)];
-                    FDC_GPUT(2 * i, ps, cmul(cmul(cmul(x0, mk(t0.x, t0.y)), mk(t1.x, t1.y)), cb));
-                    FDC_GPUT(2 * i + 1, ps, cmul(cmul(cmul(x1, mk(t0.z, t0.w)), mk(t1.z, t1.w)), cb));
+                for (int i = 0; i < 8; i++) {
+                    const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
+                    const cf y0 = cmul(cmul(cmul(v[rev16(2 * i)], mk(t0.x, t0.y)), mk(t1.x, t1.y)), cb);
+                    const cf y1 = cmul(cmul(cmul(v[rev16(2 * i + 1)], mk(t0.z, t0.w)), mk(t1.z, t1.w)), cb);
+                    if (i < 4) { FDC_GPUT(2 * i, ps, y0); FDC_GPUT(2 * i + 1, ps, y1); }
+                    else {
+                        bst2(rscr, (unsigned)tid * 8u + (unsigned)(2 * i - 8) * 4096u, (unsigned)ps * 32768u, y0);
+                        bst2(rscr, (unsigned)tid * 8u + (unsigned)(2 * i - 7) * 4096u, (unsigned)ps * 32768u, y1);
+                    }
                 }
             } else {
                 cf u[16];
@@ -274,75 +281,88 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // What is left is a DFT-32 over c5 = 4 wave + col, i.e. across the whole workgroup: ONE trip through LDS per value
         // (two chunks of 64 rows: [row][klo][c5], rows 262 apart), read back as whole 32-point runs by lane = row, wave = klo,
         // transformed in registers.  A wave's store is 64 consecutive samples of one channel (512 B).
-        __syncthreads();                                          // every wave is done with its stage-1 scratch
-        FDC_STAMP(9);
-        // the stage-2 roles are worked out here, from a thread index the compiler cannot trace back: loop-invariant address
-        // registers would otherwise stay live across stage 1, which has none to spare
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6), b_2 = lane2 >> 2, c5_2 = 4 * w2 + (lane2 & 3);
-        float2 *const gw0 = scr + b_2 * kBlkGbufLd + c5_2;        // element (row b + 16 jj, klo) at + 16 jj * 262 + 32 klo
-        // rows 32.. are out of reach of the 16-bit ds offset from gw0: a second base, opaque to the constant folder (it would
-        // otherwise materialise one address register per write)
-        int row32 = 32 * kBlkGbufLd;
-        asm volatile("" : "+v"(row32));
-        float2 *const gw1 = gw0 + row32;
-        const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
-        const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
+        auto stage2 = [&](auto get, const int h) __attribute__((always_inline)) {
+            __syncthreads();                                          // every wave is done with its stage-1 scratch
+            FDC_STAMP(9);
+            // the stage-2 roles are worked out here, from a thread index the compiler cannot trace back: loop-invariant address
+            // registers would otherwise stay live across stage 1, which has none to spare
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6), b_2 = lane2 >> 2, c5_2 = 4 * w2 + (lane2 & 3);
+            float2 *const gw0 = scr + b_2 * kBlkGbufLd + c5_2;        // element (row b + 16 jj, klo) at + 16 jj * 262 + 32 klo
+            // rows 32.. are out of reach of the 16-bit ds offset from gw0: a second base, opaque to the constant folder (it would
+            // otherwise materialise one address register per write)
+            int row32 = 32 * kBlkGbufLd;
+            asm volatile("" : "+v"(row32));
+            float2 *const gw1 = gw0 + row32;
+            const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
+            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            cf ct[8];                                             // W_256^(c5 klo): read per chunk, not held across the DFT-32 phase
-            {
-                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
+            for (int ch = 0; ch < 2; ch++) {
+                cf ct[8];                                             // W_256^(c5 klo): read per chunk, not held across the DFT-32 phase
+                {
+                    const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float4 t = ld4(&ctr[2 * i]);
-                    ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
+                    for (int i = 0; i < 4; i++) {
+                        const float4 t = ld4(&ctr[2 * i]);
+                        ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
+                    }
                 }
+                // the 32 values of this chunk: register reads, or (second half of a forward transform) 32 loads in flight at once
+                cf src[4][8];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(4 * ch + jj, ps);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    cf a[8];
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
+                    dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
+                    float2 *const gw = (jj < 2 ? gw0 : gw1) + (jj & 1) * 16 * kBlkGbufLd;
+                    st2(&gw[0], a[0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) st2(&gw[32 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+                }
+                FDC_STAMP(10 + 5 * ch);
+                __builtin_amdgcn_sched_barrier(0);                    // keep the next phase's arithmetic (and its registers) behind
+                __syncthreads();                                      // the chunk is in LDS
+                FDC_STAMP(11 + 5 * ch);
+                cf v[32];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float4 t = ld4(&gr[2 * i]);
+                    v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                }
+                __syncthreads();                                      // every read of the chunk is done: the region may be rewritten
+                __builtin_amdgcn_sched_barrier(0);
+                FDC_STAMP(12 + 5 * ch);
+                dft32<false>(v);                                      // khi = k0 + 2 k1 in v[16 k0 + rev16(k1)]
+                FDC_STAMP(13 + 5 * ch);
+                // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
+                // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
+                // dropped by the range check of the descriptor (no branch per store).
+                const unsigned rb = (unsigned)(m * (FWD ? 65536 : 128) + (FWD ? 128 * h : 0) + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint4 t = sow[q];
+                    const unsigned so[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+                }
+                FDC_STAMP(14 + 5 * ch);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                cf a[8];
-#pragma unroll
-                for (int ps = 0; ps < 8; ps++) a[ps] = FDC_GGET(4 * ch + jj, ps);
-                dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
-                float2 *const gw = (jj < 2 ? gw0 : gw1) + (jj & 1) * 16 * kBlkGbufLd;
-                st2(&gw[0], a[0]);
-#pragma unroll
-                for (int k = 1; k < 8; k++) st2(&gw[32 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
-            }
-            FDC_STAMP(10 + 5 * ch);
-            __builtin_amdgcn_sched_barrier(0);                    // keep the next phase's arithmetic (and its registers) behind
-            __syncthreads();                                      // the chunk is in LDS
-            FDC_STAMP(11 + 5 * ch);
-            cf v[32];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float4 t = ld4(&gr[2 * i]);
-                v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
-            }
-            __syncthreads();                                      // every read of the chunk is done: the region may be rewritten
-            __builtin_amdgcn_sched_barrier(0);
-            FDC_STAMP(12 + 5 * ch);
-            dft32<false>(v);                                      // khi = k0 + 2 k1 in v[16 k0 + rev16(k1)]
-            FDC_STAMP(13 + 5 * ch);
-            // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
-            // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
-            // dropped by the range check of the descriptor (no branch per store).
-            const unsigned rb = (unsigned)(m * (FWD ? 65536 : 128) + (FWD ? 128 * h : 0) + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint4 t = sow[q];
-                const unsigned so[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
-            }
-            FDC_STAMP(14 + 5 * ch);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, 0);
+        if constexpr (FWD) {
+            // second half of k2: the values stage 1 put aside are this lane's own stores; sc1 loads are served by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 32768), 0u); }, 1);
         }
         FDC_STAMP(30);
-        }                                                         // halves
 #ifdef FDC_BLK_STAMPS
         if (dbg && blockIdx.x == 0 && lane == 0 && dbgk < 4)
             for (int i = 0; i < 32; i++) dbg[(w * 4 + dbgk) * 32 + i] = st[i];
@@ -377,7 +397,8 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
     // in front of or behind the kernel, unlike hipEventRecord (measured 7-17 us per bracketed launch)
 #define FDC_LB(A, B) \
     hipExtLaunchKernelGGL((k_blk256<A, B, false>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
-                          tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block)
+                          tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block, \
+                          (float2 *)nullptr)
     if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
     else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
 #undef FDC_LB
@@ -390,7 +411,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 // of the two-pass transform: its second interval is empty here).
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
                                  const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
-                                 int ncu, int hints, hipStream_t s, hipEvent_t *ev)
+                                 float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev)
 {
     for (int m0 = 0; m0 < nitems; m0 += 4096) {            // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum
         const int nb = nitems - m0 < 4096 ? nitems - m0 : 4096;
@@ -400,7 +421,7 @@ hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out
 #define FDC_LF(A) \
         hipExtLaunchKernelGGL((k_blk256<A, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
                               in_stride, out + (size_t)m0 * 65536, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
-                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll)
+                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch)
         if (hints & 1) FDC_LF(true); else FDC_LF(false);
 #undef FDC_LF
     }

@@ -104,7 +104,8 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 // forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
                                  const float2 *twq, const float2 *cbt0 /* r = 0 */, const float *shn1 /* 256 x 1/N */,
-                                 const long long *slot_off /* [256]: 256 c */, int ncu, int hints, hipStream_t s,
+                                 const long long *slot_off /* [256]: 256 c */, float2 *scratch /* ncu x 32768 points */,
+                                 int ncu, int hints, hipStream_t s,
                                  hipEvent_t *ev /* null or 3: start, end, end */);
 
 // real samples -> complex samples with zero imaginary part (the real-input front end)
