@@ -348,7 +348,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
         if (!ok) p->classes.clear();
-        if (bh) p->block_hints = atoi(bh) & 255;
+        if (bh) p->block_hints = atoi(bh) & 3;
         if (const char *bm = getenv("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per

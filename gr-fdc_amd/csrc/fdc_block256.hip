@@ -151,11 +151,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     // FWD: this workgroup's scratch for the second half of k2, [pass][j][thread]
     const __amdgpu_buffer_rsrc_t rscr = make_rsrc(FWD ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, FWD ? 32768u * 8u : 0u);
 
-    // Two waves share a SIMD (waves w and w + 4).  With equal priority they convoy: both do their DFT-16 arithmetic at
-    // half speed together and then wait for their LDS exchanges together.  Unequal priority breaks the tie: the
-    // favoured wave runs its arithmetic at full rate, and the other one fills the gaps its waits leave.
-    // hints bit 2: static (waves 0-3 favoured); bit 3: the favoured half alternates every pass.
-    if (hints & 4) { if (w < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+    // Two waves share a SIMD (waves w and w + 4).  The older one wins the issue arbitration and finishes stage 1 ~10 k cycles
+    // earlier; s_setprio (either half favoured, or alternating per pass) changes nothing about that (profiles/r02/NOTES.md).
 
     // diagnostics (FDC_BLOCK_DEBUG=1): cycle stamps of workgroup 0, per wave: [wave][block round][24]
     [[maybe_unused]] int dbgk = 0;
@@ -186,7 +183,6 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // are requested first, unconditionally (a conditional request costs a second set of register copies).
 #pragma nounroll
         for (int ps = 0; ps < 8; ps++) {
-            if (hints & 8) { if (((w >> 2) ^ ps) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
             const cf cb = OFF ? cbn * sgn : cbn;
             cf cur[16];
 #pragma unroll
