@@ -341,9 +341,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         }
         // the two-launch form knows one class on the grid (r = 0) only
         if (ok && !block_form && p->classes[0].r != 0) ok = false;
-        // one launch per class (0.165 ms per 1024 blocks each, measured) against the spectrum path (0.27 ms forward transform +
-        // 0.163 ms per 256 channels): several classes only where that is the faster of the two
-        if (ok && p->classes.size() > 1 && 0.165 * (double)p->classes.size() >= 0.27 + 0.163 * (double)p->C / 256.0) ok = false;
+        // one launch per class (0.16 ms per 1024 blocks each, measured) against the spectrum path (0.25 ms forward transform +
+        // 0.16 ms per 256 channels): several classes only where that is the faster of the two
+        if (ok && p->classes.size() > 1 && 0.16 * (double)p->classes.size() >= 0.25 + 0.16 * (double)p->C / 256.0) ok = false;
         p->poly_block = ok && block_form;
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
