@@ -486,7 +486,14 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         }
     }
     if (p->poly_ok)
-        CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)chunk * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
+    {
+        // G scratch of the two-launch form.  With the one-kernel form only launch groups shorter than block_min take the two
+        // launches, and only plans of one on-grid class can (see fdc_pipeline_process_device)
+        const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
+        const int gblocks = p->poly_block ? std::min(chunk, p->block_min) : chunk;
+        if (two_launch)
+            CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
+    }
     for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
     if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
     // two-pass scratch; with the block kernel only launch groups shorter than kBlockMinBlocks take the two-pass kernels
