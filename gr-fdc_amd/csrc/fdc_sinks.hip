@@ -722,16 +722,34 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             }
         }
     };
+    // the workers' form: one channel at a time over the whole batch (its state stays in registers, its tasks are appended in
+    // one run); the PDUs find their place through the order key, the tasks through the landing layout
+    auto run_pacs_by_channel = [&](int a, int b, Emit e) {
+        const float *P0 = s->h_power.data();
+        for (int i = a; i < b; i++) {
+            Pac &p = s->pacs[(size_t)i];
+            const float *P = P0 + p.cell;
+            for (int m = 0; m < nblocks; m++) {
+                e.blockcount = bc0 + m;
+                e.key = ((int64_t)m << 24) | i;
+                pac_step(s, e, p, P[(size_t)m * ncells], m + 1);
+            }
+        }
+    };
     Emit em{&s->tasks, &s->task_w, &s->task_skip, &s->ext_used, &s->pdus, bc0, 0};
     if (nthr > 1) {
         while ((int)s->wl.size() < nthr) s->wl.emplace_back(new WorkerLists());
         std::vector<int> lo((size_t)nthr + 1);
         for (int t = 0; t <= nthr; t++) lo[(size_t)t] = (int)((int64_t)npac * t / nthr);
+        std::vector<double> tms((size_t)nthr, 0.0);
         s->pool.run(nthr, [&](int t) {
+            const auto a0 = now();
             WorkerLists &L = *s->wl[(size_t)t];
             L.clear();
-            run_pacs(lo[(size_t)t], lo[(size_t)t + 1], Emit{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0});
+            run_pacs_by_channel(lo[(size_t)t], lo[(size_t)t + 1], Emit{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0});
+            tms[(size_t)t] = std::chrono::duration<double, std::milli>(now() - a0).count();
         });
+        if (trace) { std::fprintf(stderr, "[fdc_sinks]     worker ms:"); for (double v : tms) std::fprintf(stderr, " %.3f", v); std::fprintf(stderr, "\n"); }
         lap("  PAC state machines (threads)");
         // merge: task indices of a worker move up by the number of tasks in front of them (live channels and PDUs alike);
         // every worker moves its own lists into place
