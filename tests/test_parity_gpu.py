@@ -211,7 +211,7 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
     forced = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
-    assert forced or p.path() == (3 if (N, R) == (65536, 2) else 2)      # N = 65536, R = 2: the one-kernel form
+    assert forced or p.path() == (3 if (N, R) == (65536, 2) and not os.environ.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
