@@ -630,3 +630,22 @@ def test_short_calls_take_the_tiled_kernels(oracle):
     finally:
         if saved is not None:
             os.environ["FDC_BLOCK_MIN_BLOCKS"] = saved
+
+
+def test_every_offset_of_the_one_kernel_path(oracle):
+    """All 255 non-zero offsets r (f = 256*slot + r): the rotation of the exchange slots by r mod 16, the second twiddle row
+    table, the cbt table with (b + r) and the per-block sign of odd r, each against the oracle on three blocks."""
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 2, 3
+    x = noise(nb * (N - N // R), 2718)
+    rng = np.random.default_rng(31)
+    for r in range(1, 256):
+        slots = [int(v) for v in rng.permutation(255)[:2]]
+        chans = [(256 * c + r, 256, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=4)
+        for c in range(2):
+            assert_close(outs[c], ref[c], "offset %d slot %d" % (r, slots[c]))
