@@ -677,10 +677,6 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
 {
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
-    s->pdus.clear();
-    if (nblocks == 0) return 0;
-    HIPCHK(hipSetDevice(s->cfg.device_id));
-    const int N = s->N, ncells = (int)s->cells.size();
     static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;      // phase times on stderr (diagnostics)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
@@ -690,6 +686,11 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         std::fprintf(stderr, "[fdc_sinks] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
+    s->pdus.clear();
+    lap("previous PDUs released");
+    if (nblocks == 0) return 0;
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    const int N = s->N, ncells = (int)s->cells.size();
     // phase 1: power of every cell of every block
     if (ncells) {
         HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
