@@ -16,6 +16,8 @@ for c in 1 3 4 5; do
 done
 python3 bench.py --offset 37 --no-cpu-baseline > $OUT/bench_offset37.json 2> $OUT/bench_offset.err || echo "bench offset failed"
 FDC_NO_BLOCK=1 python3 bench.py --no-cpu-baseline > $OUT/bench_two_launch.json 2> /dev/null || echo "bench two-launch failed"
+# steps of 4096 blocks: nothing of the 1 GiB of input is left in the 256 MiB memory-side cache from the step before
+python3 bench.py --blocks 4096 --chunk 4096 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_blocks4096.json 2> /dev/null || echo "bench 4096 failed"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $ROOT/bench.py --steps 20 --no-cpu-baseline > $OUT/stats_default.log 2>&1 || echo "rocprof default failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg4 -- python3 $ROOT/bench.py --steps 20 --no-cpu-baseline --config 4 > $OUT/stats_cfg4.log 2>&1 || echo "rocprof cfg4 failed"
