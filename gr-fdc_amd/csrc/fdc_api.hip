@@ -678,6 +678,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                                (int)p->groups[g].second.size(), p->g_aligned[g] != 0,
                                                p->g_out_aligned[g] != 0, p->N, p->R, nb, m0, nblocks, first_block,
                                                p->d_wins, p->d_tw256, s));
+            else if ((l == 512 || l == 1024) && l <= p->N && !p->cfg_generic)
+                HIPCHK(fdc::launch_channels_wide(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
+                                                 (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks, first_block,
+                                                 p->d_wins, p->d_tw, p->ntab, s));
             else
                 HIPCHK(fdc::launch_channels(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
                                             (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks,

@@ -1,0 +1,183 @@
+// Fused channel kernels for l = 512 and l = 1024 on gfx950 — the register form of k_c256 (fdc_fast256.hip) for the two
+// wider channel classes that mixed plans use most (the reference's example flowgraph has one of each): slice
+// (vector_cut_vxx) + phase/window (phase_shifting_windowing_vcc) + ifftshift + IFFT-l + overlap discard + *l in one pass,
+// one (block, channel) pair per row of lanes, every lane holding 32 points.
+//
+//   l = 1024 = 32 x 32: a row is 32 lanes; DFT-32 over a (points 32a + b), twiddle W_1024^(-b p), 32 x 32 exchange inside
+//       the row (LDS, element (b, p) at p*32 + (b ^ p): conflict-free for the 16-lane store groups and the 32-lane read
+//       groups), DFT-32 over b; 8 rows per workgroup.
+//   l =  512 = 32 x 16: a row is 16 lanes; DFT-32 over a (points 16a + b), twiddle W_512^(-b p), exchange, then every lane
+//       does the DFT-16 over b for p = lane and p = lane + 16; 16 rows per workgroup.
+// The generic LDS kernel (k_channels, fdc_kernels.hip) stays for every other width and for odd discard lengths.
+#include "fdc_kernels.h"
+#include "fdc_radix16.hpp"
+#include "fdc_devutil.hpp"
+
+namespace fdc {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_wide[];
+
+namespace {
+struct RowInfoW { long long src; long long dst; int win; int valid; };
+// dft32 leaves X[k0 + 2 k1] in v[16 k0 + rev16(k1)]
+__device__ __forceinline__ constexpr int pos32(int k) { return 16 * (k & 1) + rev16(k >> 1); }
+
+template <int L, int ROWS>
+__device__ __forceinline__ void row_setup(RowInfoW *rows, const ChanDev *__restrict__ chans, const int32_t *__restrict__ group,
+                                          int ngroup, int N, int R, long long ntrans, int mbase, int nb_call, long long first_block)
+{
+    const int tid = threadIdx.x;
+    if (tid < ROWS) {
+        const long long t = (long long)blockIdx.x * ROWS + tid;
+        RowInfoW ri{0, 0, 0, 0};
+        if (t < ntrans) {
+            const int m = (int)(t / ngroup);
+            const ChanDev ch = chans[group[(int)(t - (long long)m * ngroup)]];
+            const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);     // phase counter in closed form
+            const int lout = L - L / R;
+            ri.src = (long long)m * N + ch.f;
+            ri.win = ch.win_off + cnt * L;
+            ri.dst = (long long)nb_call * ch.out_off + (long long)(mbase + m) * lout - (L - lout);
+            ri.valid = 1;
+        }
+        rows[tid] = ri;
+    }
+}
+}  // namespace
+
+constexpr int kW1024RowPts = 1024 + 32;          // rows of one half-wave pair on different bank halves
+constexpr int kW1024Tile = 8 * kW1024RowPts * 8;
+constexpr int kW512RowPts = 512 + 1;             // two rows of a 32-lane read group on complementary banks
+constexpr int kW512Tile = 16 * kW512RowPts * 8;
+
+__global__ __launch_bounds__(256, 2) void k_c1024(const float2 *__restrict__ spec, float2 *__restrict__ out,
+                                                  const ChanDev *__restrict__ chans, const int32_t *__restrict__ group,
+                                                  int ngroup, int N, int R, int nb_chunk, int mbase, int nb_call,
+                                                  long long first_block, const float2 *__restrict__ wins,
+                                                  const float2 *__restrict__ tw, int twstride /* ntab / 1024 */)
+{
+    __shared__ RowInfoW rows[8];
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_wide);
+    float2 *wt = reinterpret_cast<float2 *>(fdc_smem_wide + kW1024Tile);                 // [b][p] = W_1024^(b p), 32 x 34
+    const int tid = threadIdx.x, r = tid >> 5, b = tid & 31;
+    const int skip = 1024 / R;
+    row_setup<1024, 8>(rows, chans, group, ngroup, N, R, (long long)nb_chunk * ngroup, mbase, nb_call, first_block);
+    for (int i = tid; i < 1024; i += 256) wt[(i >> 5) * 34 + (i & 31)] = tw[(((i >> 5) * (i & 31)) & 1023) * twstride];
+    __syncthreads();
+    const RowInfoW ri = rows[r];
+    cf v[32];
+    {   // all 64 loads of the lane (spectrum slice, window row) in flight before the first is used
+        cf x[32];
+#pragma unroll
+        for (int a = 0; a < 32; a++) x[a] = ri.valid ? ld2(spec + ri.src + 32 * a + b) : mk(0.f, 0.f);
+        cf w[32];
+#pragma unroll
+        for (int a = 0; a < 32; a++) w[a] = ri.valid ? ld2(wins + ri.win + 32 * a + b) : mk(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 32; a++) v[a ^ 16] = cmul(x[a], w[a]);       // ifftshift of the IFFT input: i -> i + l/2
+    }
+    dft32<true>(v);                                              // index p in v[pos32(p)]
+    float2 *row = tile + r * kW1024RowPts;
+    {
+        const float2 *wr = wt + b * 34;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float4 t = ld4(&wr[2 * i]);
+            st2(&row[(2 * i) * 32 + (b ^ (2 * i))], cmulc(v[pos32(2 * i)], mk(t.x, t.y)));          // inverse: conjugate twiddles
+            st2(&row[(2 * i + 1) * 32 + (b ^ (2 * i + 1))], cmulc(v[pos32(2 * i + 1)], mk(t.z, t.w)));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 32; bb++) v[bb] = ld2(&row[b * 32 + (bb ^ b)]);   // this lane now plays p = b
+    dft32<true>(v);                                              // y[t = b + 32 q] in v[pos32(q)]
+    if (ri.valid) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int tt = b + 32 * q;
+            if (tt >= skip) st2(out + ri.dst + tt, v[pos32(q)] * 1024.f);       // overlap discard, multiply_const(l)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_c512(const float2 *__restrict__ spec, float2 *__restrict__ out,
+                                                 const ChanDev *__restrict__ chans, const int32_t *__restrict__ group,
+                                                 int ngroup, int N, int R, int nb_chunk, int mbase, int nb_call,
+                                                 long long first_block, const float2 *__restrict__ wins,
+                                                 const float2 *__restrict__ tw, int twstride /* ntab / 512 */)
+{
+    __shared__ RowInfoW rows[16];
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_wide);
+    float2 *wt = reinterpret_cast<float2 *>(fdc_smem_wide + kW512Tile);                  // [b][p] = W_512^(b p), 16 x 34
+    const int tid = threadIdx.x, r = tid >> 4, b = tid & 15;
+    const int skip = 512 / R;
+    row_setup<512, 16>(rows, chans, group, ngroup, N, R, (long long)nb_chunk * ngroup, mbase, nb_call, first_block);
+    for (int i = tid; i < 512; i += 256) wt[(i >> 5) * 34 + (i & 31)] = tw[(((i >> 5) * (i & 31)) & 511) * twstride];
+    __syncthreads();
+    const RowInfoW ri = rows[r];
+    cf v[32];
+    {   // all 64 loads of the lane (spectrum slice, window row) in flight before the first is used
+        cf x[32];
+#pragma unroll
+        for (int a = 0; a < 32; a++) x[a] = ri.valid ? ld2(spec + ri.src + 16 * a + b) : mk(0.f, 0.f);
+        cf w[32];
+#pragma unroll
+        for (int a = 0; a < 32; a++) w[a] = ri.valid ? ld2(wins + ri.win + 16 * a + b) : mk(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 32; a++) v[a ^ 16] = cmul(x[a], w[a]);       // i = 16 a + b -> i + 256
+    }
+    dft32<true>(v);                                              // over a: index p (0..31) in v[pos32(p)]
+    float2 *row = tile + r * kW512RowPts;
+    {
+        const float2 *wr = wt + b * 34;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float4 t = ld4(&wr[2 * i]);
+            st2(&row[(2 * i) * 16 + (b ^ ((2 * i) & 15))], cmulc(v[pos32(2 * i)], mk(t.x, t.y)));
+            st2(&row[(2 * i + 1) * 16 + (b ^ ((2 * i + 1) & 15))], cmulc(v[pos32(2 * i + 1)], mk(t.z, t.w)));
+        }
+    }
+    __syncthreads();
+    // second layer: DFT-16 over b for p = lane and p = lane + 16; y[t = p + 32 q], q < 16
+    cf u0[16], u1[16];
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) {
+        u0[bb] = ld2(&row[b * 16 + (bb ^ b)]);
+        u1[bb] = ld2(&row[(b + 16) * 16 + (bb ^ b)]);
+    }
+    dft16<true>(u0); dft16<true>(u1);
+    if (ri.valid) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int t0 = b + 32 * q, t1 = t0 + 16;
+            if (t0 >= skip) st2(out + ri.dst + t0, u0[rev16(q)] * 512.f);
+            if (t1 >= skip) st2(out + ri.dst + t1, u1[rev16(q)] * 512.f);
+        }
+    }
+}
+
+hipError_t init_wide_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c1024), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kW1024Tile + 32 * 34 * 8);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_c512), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kW512Tile + 16 * 34 * 8);
+}
+
+hipError_t launch_channels_wide(const float2 *spec, float2 *out, const ChanDev *chans, const int32_t *group, int ngroup, int l,
+                                int N, int R, int nb_chunk, int mbase, int nb_call, int64_t first_block, const float2 *wins,
+                                const float2 *tw, int ntab, hipStream_t s)
+{
+    const long long ntrans = (long long)nb_chunk * ngroup;
+    if (ntrans <= 0) return hipSuccess;
+    if (l == 1024)
+        hipLaunchKernelGGL(k_c1024, dim3((unsigned)((ntrans + 7) / 8)), dim3(256), kW1024Tile + 32 * 34 * 8, s, spec, out, chans, group,
+                           ngroup, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / 1024);
+    else
+        hipLaunchKernelGGL(k_c512, dim3((unsigned)((ntrans + 15) / 16)), dim3(256), kW512Tile + 16 * 34 * 8, s, spec, out, chans, group,
+                           ngroup, N, R, nb_chunk, mbase, nb_call, (long long)first_block, wins, tw, ntab / 512);
+    return hipGetLastError();
+}
+
+}  // namespace fdc

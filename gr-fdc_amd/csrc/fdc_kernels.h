@@ -69,6 +69,12 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
                               int nb_call, int64_t first_block, const float2 *wins, const float2 *tw256,
                               hipStream_t s);
 
+// the same for l = 512 and l = 1024 (fdc_chanwide.hip: 32 points per lane, DFT-32 layers); needs an even discard length l/R
+hipError_t init_wide_kernels();
+hipError_t launch_channels_wide(const float2 *spec, float2 *out, const ChanDev *chans, const int32_t *group, int ngroup, int l,
+                                int N, int R, int nb_chunk, int mbase, int nb_call, int64_t first_block, const float2 *wins,
+                                const float2 *tw, int ntab, hipStream_t s);
+
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
 //   slot_off[c] = per-block sample offset of the channel sitting in slot c, or -1;  g: nb_chunk*lout*N1 scratch
