@@ -156,6 +156,88 @@ __global__ __launch_bounds__(256, 2) void k_c512(const float2 *__restrict__ spec
     }
 }
 
+// ---- 4096-point transform, one block per workgroup, in registers ------------------------------------------------------------
+// N = 4096 = 16 x 16 x 16, n = a + 16 b + 256 c, k = k0 + 16 k1 + 256 k2.  256 threads, 16 points each, three DFT-16 layers:
+//   layer 1 over c (thread = a + 16 b; the loads are 2 KiB runs), times W_256^(b k0);
+//   exchange [k0][b][a] (rows 272 apart) -> thread = a + 16 k0, layer 2 over b, times W_4096^(a k0) W_256^(a k1);
+//   exchange [k1][k0][a ^ k0] (rows 257 apart) -> thread = k0 + 16 k1, layer 3 over a: bins k0 + 16 k1 + 256 k2, 2 KiB runs.
+// Both exchanges are conflict-free for the 16-lane store groups and the 32-lane read groups.  The twiddles are two 16 x 16
+// tables in LDS (the generic core of fdc_kernels.hip reads six table entries per butterfly and pass from global memory).
+// Same interface as k_fft_small (input rotation, output rotation = fftshift, scale, item stride = overlap-save gather).
+constexpr int kF4096Tile = 16 * 272 * 8;                       // 34816 >= 16 * 257 * 8
+template <bool INV>
+__global__ __launch_bounds__(256, 4) void k_fft4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
+                                                    int nitems, int in_rot, int out_rot, float scale,
+                                                    const float2 *__restrict__ tw, int twstride /* ntab / 4096 */)
+{
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_wide);
+    float2 *t256 = reinterpret_cast<float2 *>(fdc_smem_wide + kF4096Tile);               // [x][y] = W_256^(x y), 16 x 18
+    float2 *t4k = t256 + 16 * 18;                                                         // [x][y] = W_4096^(x y), 16 x 18
+    const int tid = threadIdx.x, lo = tid & 15, hi = tid >> 4;
+    const size_t m = blockIdx.x;
+    t256[hi * 18 + lo] = tw[((16 * hi * lo) & 4095) * twstride];
+    t4k[hi * 18 + lo] = tw[(hi * lo) * twstride];
+    cf v[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) v[c] = ld2(in + m * in_stride + ((tid + 256 * c + in_rot) & 4095));
+    __syncthreads();
+    dft16<INV>(v);                                               // layer 1 over c: k0 in v[rev16(k0)]; thread = (a = lo, b = hi)
+    {
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&t256[hi * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0++)
+            st2(&tile[k0 * 272 + tid], k0 == 0 ? v[rev16(0)] : (INV ? cmulc(v[rev16(k0)], w[k0]) : cmul(v[rev16(k0)], w[k0])));
+    }
+    __syncthreads();
+    // thread = (a = lo, k0 = hi): points over b
+#pragma unroll
+    for (int b = 0; b < 16; b++) v[b] = ld2(&tile[hi * 272 + b * 16 + lo]);
+    dft16<INV>(v);                                               // layer 2 over b: k1 in v[rev16(k1)]
+    __syncthreads();                                             // every read of exchange 1 is done
+    {
+        const cf s = ld2(&t4k[lo * 18 + hi]);                    // W_4096^(a k0)
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&t256[lo * 18 + 2 * i]);        // W_256^(a k1)
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) {
+            const cf t = k1 == 0 ? s : cmul(s, w[k1]);
+            st2(&tile[k1 * 257 + hi * 16 + (lo ^ hi)], INV ? cmulc(v[rev16(k1)], t) : cmul(v[rev16(k1)], t));
+        }
+    }
+    __syncthreads();
+    // thread = (k0 = lo, k1 = hi): points over a
+#pragma unroll
+    for (int a = 0; a < 16; a++) v[a] = ld2(&tile[hi * 257 + lo * 16 + (a ^ lo)]);
+    dft16<INV>(v);                                               // layer 3 over a: k2 in v[rev16(k2)]
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++)
+        st2(out + m * 4096 + ((tid + 256 * k2 + out_rot) & 4095), v[rev16(k2)] * scale);
+    (void)nitems;
+}
+
+hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int nitems, bool inverse, int in_rot, int out_rot,
+                          float scale, const float2 *tw, int ntab, hipStream_t s)
+{
+    if (nitems <= 0) return hipSuccess;
+    const int lds = kF4096Tile + 2 * 16 * 18 * 8;
+    if (inverse)
+        hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)nitems), dim3(256), lds, s, in, in_stride, out, nitems, in_rot, out_rot,
+                           scale, tw, ntab / 4096);
+    else
+        hipLaunchKernelGGL(k_fft4096<false>, dim3((unsigned)nitems), dim3(256), lds, s, in, in_stride, out, nitems, in_rot, out_rot,
+                           scale, tw, ntab / 4096);
+    return hipGetLastError();
+}
+
 hipError_t init_wide_kernels()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c1024), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -75,6 +75,10 @@ hipError_t launch_channels_wide(const float2 *spec, float2 *out, const ChanDev *
                                 int N, int R, int nb_chunk, int mbase, int nb_call, int64_t first_block, const float2 *wins,
                                 const float2 *tw, int ntab, hipStream_t s);
 
+// 4096-point transforms in registers (fdc_chanwide.hip), same meaning of the arguments as launch_fft
+hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int nitems, bool inverse, int in_rot, int out_rot,
+                          float scale, const float2 *tw, int ntab, hipStream_t s);
+
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
 //   slot_off[c] = per-block sample offset of the channel sitting in slot c, or -1;  g: nb_chunk*lout*N1 scratch

@@ -15,6 +15,7 @@
 //   fft_vcc(l, inv, shift)  python/FrequencyDomainChannelizer.py:228 (ifftshift fused into the LDS index)
 //   cut + *l                python/FrequencyDomainChannelizer.py:229-231
 #include "fdc_kernels.h"
+#include <cstdlib>
 #include "fdc_radix16.hpp"
 
 namespace fdc {
@@ -586,7 +587,11 @@ hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *t
     if (nitems <= 0) return hipSuccess;
     hipError_t e;
     if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
-    if (N <= kMaxLdsFft) {
+    static const bool generic_only = [] { const char *g = getenv("FDC_FORCE_GENERIC"); return g && g[0] == '1'; }();
+    if (N == 4096 && ntab % 4096 == 0 && !generic_only) {
+        if ((e = launch_fft4096(in, in_stride, out, nitems, inverse, in_rot, out_rot, scale, tw, ntab, s)) != hipSuccess) return e;
+        if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
+    } else if (N <= kMaxLdsFft) {
         const TileGeom g = tile_geom(N);
         dim3 grid((nitems + g.TC - 1) / g.TC);
 #define FDC_LS(I, B) \
