@@ -778,7 +778,47 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         run_pacs(0, npac, em);
     }
     lap("  PAC total incl. merge");
-    if (!s->segs.empty())
+    const int nseg = (int)s->segs.size();
+    const int nthr_s = (nseg >= 2 && (int64_t)nseg * nblocks >= 256 && s->cfg.verbose == 0) ? std::min(nseg, 8) : 1;
+    if (nthr_s > 1) {
+        // The segments of a detection block do not interact either (…vcm_impl.cc:558-562 loops over them per item): a worker
+        // takes whole segments through the batch; the order key (block, then segment, then emission) restores the reference's order.
+        while ((int)s->wl.size() < nthr_s) s->wl.emplace_back(new WorkerLists());
+        s->pool.run(nthr_s, [&](int t) {
+            WorkerLists &L = *s->wl[(size_t)t];
+            L.clear();
+            Emit e{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0};
+            for (int gi = t; gi < nseg; gi += nthr_s) {
+                Segment &g = s->segs[(size_t)gi];
+                for (int m = 0; m < nblocks; m++) {
+                    e.blockcount = bc0 + m;
+                    e.key = ((int64_t)m << 24) | (1 << 23) | ((int64_t)gi << 12);
+                    seg_detect(s, g, s->h_power.data() + (size_t)m * ncells + g.cell0);
+                    seg_extract(s, e, g, m + 1);
+                }
+            }
+        });
+        std::vector<int64_t> base((size_t)nthr_s + 1, (int64_t)s->tasks.size());
+        for (int t = 0; t < nthr_s; t++) {
+            base[(size_t)t + 1] = base[(size_t)t] + (int64_t)s->wl[(size_t)t]->tasks.size();
+            s->ext_used += s->wl[(size_t)t]->used;
+        }
+        s->tasks.resize((size_t)base[(size_t)nthr_s]); s->task_w.resize((size_t)base[(size_t)nthr_s]); s->task_skip.resize((size_t)base[(size_t)nthr_s]);
+        s->pool.run(nthr_s, [&](int t) {
+            WorkerLists &L = *s->wl[(size_t)t];
+            const int64_t b0 = base[(size_t)t];
+            std::copy(L.tasks.begin(), L.tasks.end(), s->tasks.begin() + b0);
+            std::copy(L.w.begin(), L.w.end(), s->task_w.begin() + b0);
+            std::copy(L.skip.begin(), L.skip.end(), s->task_skip.begin() + b0);
+            if (b0) {
+                for (auto &r : L.pdus) for (auto &bk : r.blocks) if (bk.task >= 0) bk.task += b0;
+                for (int gi = t; gi < nseg; gi += nthr_s)
+                    for (auto &c : s->segs[(size_t)gi].chans) for (auto &bk : c.data) if (bk.task >= 0) bk.task += b0;
+            }
+        });
+        for (int t = 0; t < nthr_s; t++)
+            for (auto &r : s->wl[(size_t)t]->pdus) s->pdus.push_back(std::move(r));
+    } else if (nseg)
         for (int m = 0; m < nblocks; m++) {
             const float *P = s->h_power.data() + (size_t)m * ncells;
             em.blockcount = bc0 + m;
@@ -787,7 +827,7 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
             for (auto &g : s->segs) seg_extract(s, em, g, m + 1);                   // :562
         }
     s->blockcount = bc0 + nblocks;
-    if (npac && (nthr > 1 || !s->segs.empty()))
+    if ((npac && (nthr > 1 || nseg)) || nthr_s > 1)
         std::stable_sort(s->pdus.begin(), s->pdus.end(), [](const PduRec &a, const PduRec &b) { return a.key < b.key; });
     lap("decisions (host)");
     // Landing layout: the blocks of every PDU emitted in this call sit one behind the other (PDU order, block order),
@@ -899,10 +939,11 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     };
     // PDUs and live channels are independent of each other: a large bank is finished by the worker threads
     const int npdu = (int)s->pdus.size();
-    if (nthr > 1 && (npdu >= 64 || npac >= 64)) {
-        s->pool.run(nthr, [&](int t) {
-            for (int i = (int)((int64_t)npdu * t / nthr), e = (int)((int64_t)npdu * (t + 1) / nthr); i < e; i++) finish_pdu(s->pdus[(size_t)i]);
-            for (int i = (int)((int64_t)npac * t / nthr), e = (int)((int64_t)npac * (t + 1) / nthr); i < e; i++)
+    const int nasm = std::max(nthr, nthr_s);
+    if (nasm > 1 && (npdu >= 64 || npac >= 64)) {
+        s->pool.run(nasm, [&](int t) {
+            for (int i = (int)((int64_t)npdu * t / nasm), e = (int)((int64_t)npdu * (t + 1) / nasm); i < e; i++) finish_pdu(s->pdus[(size_t)i]);
+            for (int i = (int)((int64_t)npac * t / nasm), e = (int)((int64_t)npac * (t + 1) / nasm); i < e; i++)
                 for (auto &b : s->pacs[(size_t)i].blocks) resolve(b, s->pacs[(size_t)i].output_len);
         });
     } else {
