@@ -649,3 +649,18 @@ def test_every_offset_of_the_one_kernel_path(oracle):
         ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=4)
         for c in range(2):
             assert_close(outs[c], ref[c], "offset %d slot %d" % (r, slots[c]))
+
+
+def test_randomized_plans_and_call_patterns():
+    """tools/fuzz_paths.py, 24 seeded cases: random plans (on-grid, offset, classes, mixed widths, few channels), block counts
+    on both sides of the dispatch threshold, chunk sizes and ragged call patterns; the default dispatch against the
+    spectrum-in-memory path on every sample, mixed plans and every fifth case against the oracle."""
+    import subprocess
+    import sys
+    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paths.py"), "24", "7"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "all 24 cases within" in out.stdout

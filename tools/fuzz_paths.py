@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2.  Every case draws a plan (on-grid,
+offset, two or three classes, or mixed widths), a block count, a chunk size and a call pattern, runs it on the default
+dispatch and on the spectrum-in-memory path (FDC_NO_POLY=1) and compares every output sample; every fifth case is also
+compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import gr_fdc_amd as G  # noqa: E402
+import oracle as O      # noqa: E402  (checker)
+
+N, R = 65536, 2
+H = N - N // R
+TOL = 1e-5
+
+
+def rel(a, b):
+    d = np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max()
+    return float(d / max(np.abs(b).max(), 1e-30))
+
+
+def draw_plan(rng):
+    kind = rng.integers(0, 5)
+    if kind == 0:                                     # on-grid subset
+        slots = rng.permutation(256)[:rng.integers(1, 257)]
+        return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "grid"
+    if kind == 1:                                     # one offset
+        r = int(rng.integers(1, 256))
+        slots = rng.permutation(255)[:rng.integers(1, 256)]
+        return [(256 * int(c) + r, 256, 0.88, 1.0) for c in slots], "offset %d" % r
+    if kind == 2:                                     # two or three classes, enough channels for the launches to pay
+        ncl = int(rng.integers(2, 4))
+        plan = []
+        for k in range(ncl):
+            r = int(rng.integers(0, 256))
+            win = [(0.88, 1.0), (0.7, 0.9), (0.8, 0.95)][int(rng.integers(0, 3))]
+            slots = rng.permutation(255)[:rng.integers(150, 256)]
+            plan += [(256 * int(c) + r, 256) + win for c in slots]
+        order = rng.permutation(len(plan))
+        return [plan[int(i)] for i in order], "%d classes" % ncl
+    if kind == 3:                                     # mixed widths: spectrum path either way, register channel kernels
+        plan = []
+        for _ in range(int(rng.integers(1, 12))):
+            l = int(2 ** rng.integers(6, 12))
+            plan.append((int(rng.integers(0, N - l + 1)), l, 0.88, 1.0))
+        return plan, "mixed"
+    slots = rng.permutation(256)[:rng.integers(1, 40)]   # few channels
+    return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "few"
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(cases):
+        plan, what = draw_plan(rng)
+        nb = int(rng.choice([1, 2, 3, 7, 40, 95, 96, 97, 130, 256, 300]))
+        chunk = int(rng.choice([0, 0, 64, 96, 128]))
+        x = (rng.standard_normal(nb * H) + 1j * rng.standard_normal(nb * H)).astype(np.complex64)
+        cuts = sorted(set([0, nb] + [int(v) for v in rng.integers(0, nb + 1, size=int(rng.integers(0, 3)))]))
+        if rng.integers(0, 2):
+            os.environ["FDC_BLOCK_MIN_BLOCKS"] = "1"
+        else:
+            os.environ.pop("FDC_BLOCK_MIN_BLOCKS", None)
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+        path = p.path()
+        parts = [p.work(x[a * H:b * H]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        outs = [np.concatenate([q[c] for q in parts]) for c in range(len(plan))]
+        os.environ["FDC_NO_POLY"] = "1"
+        try:
+            ref = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb).work(x)
+        finally:
+            del os.environ["FDC_NO_POLY"]
+        e = max(rel(a, b) for a, b in zip(outs, ref))
+        eo = 0.0
+        if case % 5 == 0 or path == 1:                # the comparison above is vacuous when both runs take the spectrum path
+            oref, _ = O.channelizer(N, R, 1, plan, x, nthreads=8)
+            eo = max(rel(a, b) for a, b in zip(outs, oref))
+        worst = max(worst, e, eo)
+        flag = "" if max(e, eo) <= TOL else "   <-- FAIL"
+        print("case %3d  %-10s path %d  %3d ch  %3d blocks  chunk %3d  cuts %-14s vs spectrum path %.2e  vs oracle %.2e%s"
+              % (case, what, path, len(plan), nb, chunk, cuts, e, eo, flag), flush=True)
+        if flag:
+            sys.exit(1)
+    print("all %d cases within %.0e (worst %.2e)" % (cases, TOL, worst))
+
+
+if __name__ == "__main__":
+    main()
