@@ -198,3 +198,40 @@ def test_cfg5_full_size_activity_detection(oracle):
     ref = oracle.ActivityDetectionVcm(N, segs, 10.0, R, 128, 0.005, 1, 0.2).work(spec.reshape(nb, N))
     assert len(ref) > 50
     compare(got, ref)
+
+
+def test_combined_bank_both_threaded_phases_two_calls(oracle):
+    """One bank with 64 PowerActivationChannels AND two detection segments, fed in two calls of 256 blocks: both decision
+    phases run on the worker threads (PowerActivationChannels by channel, segments by segment), their lists are merged twice
+    per call, PDUs that span the call boundary carry blocks over, and the emission order is restored from the order keys.
+    Every PDU against the oracle; the order inside a call: block-major, PowerActivationChannels before detections."""
+    N, R, nb = 65536, 2, 512
+    C = 64
+    pac = [(((4 * c + 0.5) / 256) % 1.0, 0.8 / 256, c) for c in range(C)]
+    carriers = []
+    for c in range(C):
+        k = (256 * 4 * c + 128 - N // 2) % N
+        carriers.append((k - 20, k + 20))
+    x, _ = bursty_stream(N, R, nb, carriers, 77, tone_amp=8.7e-3)
+    segs = [[0.05, 0.45], [0.55, 0.95]]
+    p = G.Pipeline(N, R, [], windowtype=1, max_blocks=256, keep_spectrum=True)
+    bank = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, segments=[tuple(s) for s in segs],
+                   det_thresh=10.0, det_maxblocks=128, minchandist=0.005, det_delay=1, puffer=0.2, max_blocks=256)
+    H = N - N // R
+    got = []
+    for a in (0, 256):
+        p.work(x[a * H:(a + 256) * H], sinks=bank)
+        pdus = bank.pdus()
+        keys = [(int(m["blockend"]), 0 if m["kind"] == 0 else 1) for m, _ in pdus]
+        assert keys == sorted(keys), "emission order inside a call"
+        got += pdus
+    _, spec = oracle.channelizer(N, R, 1, [], x, want_spectrum=True, nthreads=min(16, os.cpu_count() or 1))
+    spec = spec.reshape(nb, N)
+    npac = 0
+    for c in range(C):
+        ref = oracle.PowerActivationChannel(N, pac[c][0], pac[c][1], R, 6.0, 128, 1, c).work(spec)
+        compare([g for g in got if g[0]["kind"] == 0 and g[0]["source"] == c], ref, vec=False)
+        npac += len(ref)
+    ref = oracle.ActivityDetectionVcm(N, segs, 10.0, R, 128, 0.005, 1, 0.2).work(spec)
+    compare([g for g in got if g[0]["kind"] == 1], ref)
+    assert npac > C and len(ref) > 10 and npac + len(ref) == len(got)
