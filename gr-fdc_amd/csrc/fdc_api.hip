@@ -667,7 +667,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
         else
             HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
-                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf));
+                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic));
         for (size_t g = 0; g < p->groups.size(); g++) {
             const int l = p->groups[g].first;
             if (l > fdc::kMaxLdsFft) {

@@ -50,7 +50,8 @@ hipError_t init_kernels();   // raises the dynamic-LDS limits once per process
 hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,
                       bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
                       hipStream_t s, hipEvent_t *ev /* null or 3 events: start, after pass A, end */,
-                      const float2 *twf = nullptr /* two-pass sizes: [k2][n1] = exp(-2 pi i n1*k2/N), N entries, optional */);
+                      const float2 *twf = nullptr /* two-pass sizes: [k2][n1] = exp(-2 pi i n1*k2/N), N entries, optional */,
+                      bool generic_only = false /* no size-specific register kernels (FDC_FORCE_GENERIC handles) */);
 
 // Fused slice + phase + window + ifftshift + IFFT(l) + overlap discard + *l for one group of channels of
 // equal l (<= kMaxLdsFft).  spec holds nb_chunk spectra; block m of the chunk is block mbase+m of the call.
