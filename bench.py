@@ -58,7 +58,13 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
                                                              "dropped): a tiling that does not start at bin 0")
+    ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
+                                                         "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
     a = ap.parse_args()
+    if a.offset and a.config not in (2, 4):
+        ap.error("--offset applies to --config 2 and 4 only")
+    if a.mixed and a.config != 2:
+        ap.error("--mixed applies to --config 2 only")
     if a.config == 1:      # the reference's own example flowgraph (plumbing case): 4096-pt FFT, its 4 channels of mixed width
         a.blocklen, a.channels, a.blocks = a.blocklen or 4096, 4, a.blocks or 16384
     elif a.config == 4:
@@ -331,7 +337,8 @@ def main():
             params = [G.get_opt_channelparams(N, R, (u + 0.5) % 1.0, bw) for (u, bw) in
                       ((0.12, 0.05), (0.22, 0.1), (-0.14, 0.12), (0.0, 0.081))]
         else:
-            params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, 0.8 / C) for c in range(C)]
+            bws = (0.8, 0.4, 0.8, 1.6) if a.mixed else (0.8,)
+            params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
         if a.offset:
             params = [(f + a.offset, l, lo, p, s) for (f, l, lo, p, s) in params[:-1]]
         plan = [(f, l, p, s) for (f, l, _lo, p, s) in params]
@@ -342,7 +349,8 @@ def main():
         wl = "%s: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), %d blocks/step/GPU" % (
             "configs[0] (example flowgraph plan)" if a.config == 1 else
             "configs[1]" if (N, R, C) == (65536, 2, 256) else "configs[3] per-GPU shape" if (N, R, C) == (262144, 2, 1024)
-            else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "")
+            else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "") + \
+            (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "")
     else:
         # the stateful sinks run on a spectrum in device memory: forward transform into the bank's buffer, then the bank
         plan, params, sum_lout = [], [], 0
@@ -450,13 +458,15 @@ def main():
     achieved = b_alg * blocks_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
-        ent = pt.get(names[dom])
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and ent.get("config", 2) == a.config:
+        ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
+            traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
+                             "not counters of this process"
     except (OSError, ValueError):
         pass
     pipe_gbs = b_alg * nb * a.steps / dt / 1e9
@@ -472,8 +482,8 @@ def main():
         # pipeline_frac: SURVEY.md §8d's headline, algorithmic bytes over the WHOLE step.  With the one-kernel path (3) the
         # dominant kernel IS the step, and the two coincide up to the launch gaps.
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel_ms_per_step": {n: round(v / ngroups * nlaunch, 4) for n, v in zip(names, last)},
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_ms_per_step": {n: round(v / ngroups * nlaunch, 4) for n, v in zip(names, last) if not n.startswith("unused")},
                      "kernel_avg_launch_ms": round(dom_avg_ms, 5), "blocks_per_launch": blocks_per_launch,
                      "launches_per_step": nlaunch, "timed_launches": ngroups, "timing_stride": max(1, a.timing_stride),
                      "alg_bytes_per_block": b_alg,

@@ -44,7 +44,12 @@ class fdc_sinks_cfg(C.Structure):
                 ("nseg", C.c_int32), ("seg", C.POINTER(fdc_segment_cfg)),
                 ("det_thresh_db", C.c_float), ("det_maxblocks", C.c_int32), ("minchandist", C.c_float),
                 ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32),
-                ("det_variant", C.c_int32), ("verbose", C.c_int32), ("det_id", C.c_int32)]
+                ("det_variant", C.c_int32), ("verbose", C.c_int32), ("det_id", C.c_int32), ("flags", C.c_int32),
+                ("threads", C.c_int32)]
+
+
+FDC_SINKS_HOST_DECISIONS = 1
+FDC_SINKS_DEVICE_PAYLOAD = 2
 
 
 class fdc_pdu(C.Structure):
@@ -88,6 +93,9 @@ SYMBOLS = {
     "fdc_sinks_blocklen": (C.c_int32, [_vp]),
     "fdc_sinks_max_blocks": (C.c_int32, [_vp]),
     "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),
+    "fdc_sinks_submit_device": (C.c_int, [_vp, C.c_int]),
+    "fdc_sinks_flush": (C.c_int, [_vp]),
+    "fdc_sinks_engine": (C.c_int32, [_vp]),
     "fdc_set_log_callback": (None, [_vp, _vp]),
     "fdc_sinks_pdu_count": (C.c_int, [_vp]),
     "fdc_sinks_pdu": (C.c_int, [_vp, C.c_int, C.POINTER(fdc_pdu)]),

@@ -20,6 +20,8 @@
 
 namespace fdc {
 
+hipError_t init_sink_kernels();   // fdc_sinks_dev.hip
+
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem[];
 
 // A tile holds 4096*NB complex points (NB = 1: 32 KiB, four workgroups per CU; NB = 2 only for L = 8192), every
@@ -577,6 +579,7 @@ hipError_t init_kernels()
     FDC_SETLDS((k_fft_small<false, 2>)) FDC_SETLDS((k_fft_small<true, 2>))
     FDC_SETLDS(k_channels<2>) FDC_SETLDS(k_extract<2>)
 #undef FDC_SETLDS
+    if ((e = init_sink_kernels()) != hipSuccess) return e;
     return init_fast_kernels();
 }
 

@@ -13,6 +13,7 @@
 // replaces the per-channel std::thread fan-out).
 #include "../../include/fdc_amd.h"
 #include "fdc_kernels.h"
+#include "fdc_sinks_dev.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -184,6 +185,34 @@ struct fdc_sinks {
     std::vector<std::unique_ptr<WorkerLists>> wl;    // one per worker thread (separate heap objects: no shared cache lines)
     WorkerPool pool;
     std::string det_logfile;                 // verbose == 2: …vcm_impl.cc:94 / SegmentDetection_impl.cc:51
+    int host_threads = 0;                    // cfg.threads (host engine), 0 = from the bank's size
+    // ---- device engine (fdc_sinks_dev.hip): decisions, layout and buffered blocks stay on the device
+    struct Dev {
+        bool on = false;
+        int nlist = 0, npw = 0;
+        long long max_list = 0;              // longest task list (grid of the scatter kernel)
+        std::vector<int64_t> task_base, pdu_base, owner_base, cand_base;
+        int64_t *d_task_base = nullptr, *d_pdu_base = nullptr, *d_owner_base = nullptr, *d_cand_base = nullptr;
+        int32_t *d_ntask = nullptr, *d_npdu = nullptr, *d_nowner = nullptr, *d_error = nullptr, *d_class_fill = nullptr;
+        int32_t *d_ncand = nullptr, *d_winoff = nullptr, *d_live = nullptr;
+        int64_t *d_live_off = nullptr;
+        int2 *d_cand = nullptr;
+        fdc::PacGeom *d_pgeom = nullptr; fdc::PacState *d_pstate = nullptr;
+        fdc::DetGeom *d_dgeom = nullptr; fdc::DetSegState *d_sst = nullptr;
+        fdc::SinkTask *d_tasks = nullptr; fdc::SinkPdu *d_pdus = nullptr, *d_pdus_out = nullptr; fdc::SinkOwner *d_owners = nullptr;
+        fdc::ExtractTask *d_sorted = nullptr;
+        fdc::SinkSummary *d_sum = nullptr, *h_sum = nullptr;
+        fdc::SinkPdu *h_pdus = nullptr;      // pinned: the first kEagerPdus records travel with the summary
+        float2 *d_land[2] = {nullptr, nullptr}; size_t cap_land[2] = {0, 0};      // landing buffers (emitted runs, then buffered rests)
+        cfl *h_land[2] = {nullptr, nullptr}; size_t cap_hland[2] = {0, 0};        // pinned copies of the emitted runs
+        hipStream_t s_copy = nullptr;
+        hipEvent_t ev_decide = nullptr, ev_extract[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+        std::vector<fdc::SinkPdu> recs[2];
+        fdc::SinkSummary sum[2];
+        int cur = 1;                          // landing buffer of the newest batch
+        bool inflight = false; int inflight_nb = 0;
+        bool any = false;                     // a batch has run: d_land[cur] holds buffered blocks
+    } dev;
 };
 
 namespace {
@@ -426,6 +455,97 @@ void seg_extract(fdc_sinks *s, Emit &e, Segment &g, int slot)        // extract_
         if (g.chans[i].inactive > delay) g.chans.erase(g.chans.begin() + i); else i++;
 }
 
+// ---------------------------------------------------------------- device engine: set-up
+// Which engine a bank gets, and the device-side tables and lists of the device engine.  Every list is allocated for its
+// worst case (a channel toggling in every block, a segment full of one-cell carriers), so no call can overflow one; a bank
+// whose worst case does not fit a 2 GiB budget takes the host engine.
+constexpr int kEagerPdus = 4096;
+
+int dev_setup(fdc_sinks *s)
+{
+    auto &d = s->dev;
+    const fdc_sinks_cfg &cfg = s->cfg;
+    if ((cfg.flags & FDC_SINKS_HOST_DECISIONS) || cfg.verbose != 0) return FDC_OK;
+    const int npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
+    if (npac + nseg == 0) return FDC_OK;
+    for (const Segment &g : s->segs) if (g.ncell > fdc::kDetMaxCells) return FDC_OK;
+    const int64_t nbmax = cfg.max_blocks;
+    d.npw = (npac + 63) / 64;
+    d.nlist = d.npw + nseg;
+    d.task_base.assign((size_t)d.nlist + 1, 0); d.pdu_base.assign((size_t)d.nlist + 1, 0);
+    d.owner_base.assign((size_t)nseg + 1, npac); d.cand_base.assign((size_t)nseg + 1, 0);
+    for (int l = 0; l < d.nlist; l++) {
+        int64_t tc, pc;
+        if (l < d.npw) { tc = 64 * 2 * nbmax; pc = 64 * nbmax; }             // per block: at most two extractions, one emission
+        else {
+            const int64_t nc = s->segs[(size_t)(l - d.npw)].ncell;
+            tc = nbmax * nc + nbmax * (nc / 2 + 1);                            // every live channel once, every activation twice
+            pc = nbmax * nc;
+        }
+        d.task_base[(size_t)l + 1] = d.task_base[(size_t)l] + tc; d.pdu_base[(size_t)l + 1] = d.pdu_base[(size_t)l] + pc;
+        d.max_list = std::max<long long>(d.max_list, tc);
+    }
+    for (int g = 0; g < nseg; g++) {
+        const int64_t nc = s->segs[(size_t)g].ncell;
+        d.owner_base[(size_t)g + 1] = d.owner_base[(size_t)g] + nc + nbmax * (nc / 2 + 1);
+        d.cand_base[(size_t)g + 1] = d.cand_base[(size_t)g] + nbmax * (nc / 2 + 1);
+    }
+    const int64_t ntask = d.task_base.back(), npdu = d.pdu_base.back(), nown = d.owner_base.back(), ncand = d.cand_base.back();
+    const int64_t bytes = ntask * (int64_t)(sizeof(fdc::SinkTask) + sizeof(fdc::ExtractTask)) + npdu * 2 * (int64_t)sizeof(fdc::SinkPdu) +
+                          nown * (int64_t)sizeof(fdc::SinkOwner) + ncand * (int64_t)sizeof(int2);
+    if (bytes > (2ll << 30)) return FDC_OK;
+#define DALLOC(ptr, n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&(ptr)), std::max<size_t>(16, sizeof(*(ptr)) * (size_t)(n))))
+#define DUP(ptr, vec) do { DALLOC(ptr, (vec).size()); HIPCHK(hipMemcpy(ptr, (vec).data(), sizeof(*(ptr)) * (vec).size(), hipMemcpyHostToDevice)); } while (0)
+    DUP(d.d_task_base, d.task_base); DUP(d.d_pdu_base, d.pdu_base); DUP(d.d_owner_base, d.owner_base); DUP(d.d_cand_base, d.cand_base);
+    DALLOC(d.d_ntask, d.nlist); DALLOC(d.d_npdu, d.nlist); DALLOC(d.d_nowner, nseg + 1); DALLOC(d.d_error, 1); DALLOC(d.d_class_fill, 32);
+    HIPCHK(hipMemset(d.d_error, 0, sizeof(int32_t)));
+    HIPCHK(hipMemset(d.d_nowner, 0, sizeof(int32_t) * (size_t)(nseg + 1)));
+    DALLOC(d.d_tasks, ntask); DALLOC(d.d_sorted, ntask); DALLOC(d.d_pdus, npdu); DALLOC(d.d_pdus_out, std::max<int64_t>(npdu, kEagerPdus)); DALLOC(d.d_owners, nown);
+    DALLOC(d.d_sum, 1);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d.h_sum), sizeof(fdc::SinkSummary), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d.h_pdus), sizeof(fdc::SinkPdu) * kEagerPdus, hipHostMallocDefault));
+    if (npac) {
+        std::vector<fdc::PacGeom> pg((size_t)npac);
+        std::vector<fdc::PacState> ps((size_t)npac);
+        for (int i = 0; i < npac; i++) {
+            const Pac &p = s->pacs[(size_t)i];
+            pg[(size_t)i] = fdc::PacGeom{p.cell, p.extract_start, p.extract_width, 31 - __builtin_clz((unsigned)p.extract_width), p.ovl_offset,
+                                         p.output_len, p.deltaphase, p.win_off, p.ID, 0};
+            fdc::PacState st{};
+            st.lastpower = FLT_MAX;                                            // PowerActivationChannel_impl.cc:92
+            ps[(size_t)i] = st;
+        }
+        DUP(d.d_pgeom, pg); DUP(d.d_pstate, ps);
+    }
+    if (nseg) {
+        std::vector<fdc::DetGeom> dg((size_t)nseg);
+        for (int g = 0; g < nseg; g++) {
+            const Segment &sg = s->segs[(size_t)g];
+            dg[(size_t)g] = fdc::DetGeom{sg.ID, sg.start, sg.ncell, sg.cell0, sg.ncell / 2 + 1, 0};
+        }
+        DUP(d.d_dgeom, dg);
+        std::vector<fdc::DetSegState> st((size_t)nseg, fdc::DetSegState{0, 0});
+        DUP(d.d_sst, st);
+        DALLOC(d.d_live, (size_t)nseg * fdc::kDetFields * fdc::kDetMaxCells);
+        DALLOC(d.d_live_off, (size_t)nseg * fdc::kDetMaxCells);
+        DALLOC(d.d_cand, ncand);
+        DALLOC(d.d_ncand, (size_t)nseg * nbmax);
+        std::vector<int32_t> wo(32, -1);
+        for (size_t k = 0; k < s->det_win_off.size() && k < 32; k++) wo[k] = s->det_win_off[k];
+        DUP(d.d_winoff, wo);
+    }
+#undef DUP
+#undef DALLOC
+    HIPCHK(hipStreamCreateWithFlags(&d.s_copy, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&d.ev_decide, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&d.ev_extract[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d.ev_copied[i], hipEventDisableTiming));
+    }
+    d.on = true;
+    return FDC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -437,6 +557,19 @@ void fdc_sinks_destroy(fdc_sinks *s)
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
+    {
+        auto &d = s->dev;
+        if (d.s_copy) { (void)hipStreamSynchronize(d.s_copy); (void)hipStreamDestroy(d.s_copy); }
+        for (hipEvent_t e : {d.ev_decide, d.ev_extract[0], d.ev_extract[1], d.ev_copied[0], d.ev_copied[1]}) if (e) (void)hipEventDestroy(e);
+        for (void *q : {(void *)d.d_task_base, (void *)d.d_pdu_base, (void *)d.d_owner_base, (void *)d.d_cand_base, (void *)d.d_ntask,
+                        (void *)d.d_npdu, (void *)d.d_nowner, (void *)d.d_error, (void *)d.d_class_fill, (void *)d.d_ncand,
+                        (void *)d.d_winoff, (void *)d.d_live, (void *)d.d_live_off, (void *)d.d_cand, (void *)d.d_pgeom,
+                        (void *)d.d_pstate, (void *)d.d_dgeom, (void *)d.d_sst, (void *)d.d_tasks, (void *)d.d_pdus,
+                        (void *)d.d_pdus_out, (void *)d.d_owners, (void *)d.d_sorted, (void *)d.d_sum, (void *)d.d_land[0],
+                        (void *)d.d_land[1]})
+            (void)hipFree(q);
+        for (void *q : {(void *)d.h_sum, (void *)d.h_pdus, (void *)d.h_land[0], (void *)d.h_land[1]}) if (q) (void)hipHostFree(q);
+    }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -609,6 +742,13 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipMemcpy(raw->d_cells, raw->cells.data(), sizeof(fdc::PowerCell) * raw->cells.size(), hipMemcpyHostToDevice));
         CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
     }
+    raw->host_threads = cfg->threads > 0 ? std::min(cfg->threads, 32) : 0;
+    if (const char *dbg = getenv("FDC_DEBUG_ENV")) if (dbg[0] == '1')       // debugging override only (the knob is cfg.threads)
+        if (const char *t = getenv("FDC_SINKS_THREADS")) if (atoi(t) >= 1) raw->host_threads = std::min(atoi(t), 32);
+    {
+        const int rcd = dev_setup(raw);
+        if (rcd != FDC_OK) { fdc_sinks_destroy(raw); return rcd; }
+    }
 #undef CHKF
     // ---- logs of the constructors (verbose != 0)
     if (cfg->verbose) {
@@ -673,10 +813,45 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
     return FDC_OK;
 }
 
-int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
+// Extractions of one call, one launch (or one gather / batched transform / scatter sequence) per width class.
+// tasks: grouped by class, class k (width 2^k) = [first[k], first[k] + cnt[k])
+static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const size_t *first, const size_t *cnt, float2 *d_out, bool trace)
 {
-    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
-    if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
+    const int N = s->N;
+    for (int k = 0; k < 32; k++) {
+        if (!cnt[k]) continue;
+        const int w = 1 << k, skip = w / s->R;
+        const size_t i = first[k], j = first[k] + cnt[k];
+        if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
+        if (w <= fdc::kMaxLdsFft) {
+            HIPCHK(fdc::launch_extract(s->d_spec, N, d_tasks + i, (int)(j - i), w, skip, s->d_wins, d_out, s->d_tw, N, s->stream));
+        } else {
+            // wider than one workgroup's transform (a carrier, or a run of merged carriers, over 1/8 of a 65536-bin band):
+            // the whole class in batches of up to 64 Mi points — gather (slice * window), batched two-pass inverse transform
+            // with the half swap as input rotation, scatter of [skip, w) to the landing offsets.  The scratch follows the
+            // demand (3 x batch x w points, grown geometrically), not the 64 Mi ceiling.
+            const size_t per = std::min(std::max<size_t>(1, ((size_t)64 << 20) / (size_t)w), j - i);
+            if (s->wide_cap < per * (size_t)w) {
+                const size_t want = std::min(std::max(per * (size_t)w, s->wide_cap * 2), std::max<size_t>((size_t)64 << 20, (size_t)w));
+                (void)hipFree(s->d_wide); s->d_wide = nullptr; s->wide_cap = 0;
+                HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * want));
+                s->wide_cap = want;
+            }
+            const size_t fit = std::max<size_t>(1, s->wide_cap / (size_t)w);
+            float2 *A = s->d_wide, *B = A + s->wide_cap, *T = B + s->wide_cap;
+            for (size_t k0 = i; k0 < j; k0 += fit) {
+                const int n = (int)std::min(fit, j - k0);
+                HIPCHK(fdc::launch_extract_gather(s->d_spec, N, d_tasks + k0, n, w, s->d_wins, A, s->stream));
+                HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, n, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
+                HIPCHK(fdc::launch_extract_scatter(B, d_tasks + k0, n, w, skip, d_out, s->stream));
+            }
+        }
+    }
+    return FDC_OK;
+}
+
+static int host_work_device(fdc_sinks *s, int nblocks)
+{
     static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;      // phase times on stderr (diagnostics)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
@@ -688,8 +863,6 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     };
     s->pdus.clear();
     lap("previous PDUs released");
-    if (nblocks == 0) return 0;
-    HIPCHK(hipSetDevice(s->cfg.device_id));
     const int N = s->N, ncells = (int)s->cells.size();
     // phase 1: power of every cell of every block
     if (ncells) {
@@ -710,7 +883,7 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     if (npac >= 32 && (int64_t)npac * nblocks >= 16384 && s->cfg.verbose == 0) {
         const unsigned hc = std::thread::hardware_concurrency();
         nthr = (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
-        if (const char *t = getenv("FDC_SINKS_THREADS")) if (atoi(t) >= 1) nthr = std::min(atoi(t), 32);
+        if (s->host_threads > 0) nthr = s->host_threads;
         nthr = std::min(nthr, npac / 8);
     }
     auto run_pacs = [&](int a, int b, Emit e) {
@@ -879,31 +1052,9 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
         }
         lap("  task grouping + buffers");
         HIPCHK(hipMemcpyAsync(s->d_tasks, upload, sizeof(fdc::ExtractTask) * nt, hipMemcpyHostToDevice, s->stream));
-        for (int k = 0; k < 32; k++) {
-            if (!cnt[k]) continue;
-            const int w = 1 << k, skip = w / s->R;
-            const size_t i = first[k], j = first[k] + cnt[k];
-            if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
-            if (w <= fdc::kMaxLdsFft) {
-                HIPCHK(fdc::launch_extract(s->d_spec, N, s->d_tasks + i, (int)(j - i), w, skip, s->d_wins, s->d_ext, s->d_tw, N, s->stream));
-            } else {
-                // wider than one workgroup's transform (a carrier, or a run of merged carriers, over 1/8 of a 65536-bin band):
-                // the whole class in batches of up to 64 Mi points — gather (slice * window), batched two-pass inverse transform
-                // with the half swap as input rotation, scatter of [skip, w) to the landing offsets
-                const size_t per = std::max<size_t>(1, ((size_t)64 << 20) / (size_t)w);
-                if (s->wide_cap < per * (size_t)w) {
-                    (void)hipFree(s->d_wide); s->d_wide = nullptr; s->wide_cap = 0;
-                    HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * per * (size_t)w));
-                    s->wide_cap = per * (size_t)w;
-                }
-                float2 *A = s->d_wide, *B = A + s->wide_cap, *T = B + s->wide_cap;
-                for (size_t k0 = i; k0 < j; k0 += per) {
-                    const int n = (int)std::min(per, j - k0);
-                    HIPCHK(fdc::launch_extract_gather(s->d_spec, N, s->d_tasks + k0, n, w, s->d_wins, A, s->stream));
-                    HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, n, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
-                    HIPCHK(fdc::launch_extract_scatter(B, s->d_tasks + k0, n, w, skip, s->d_ext, s->stream));
-                }
-            }
+        {
+            const int rce = run_extractions(s, s->d_tasks, first, cnt, s->d_ext, trace);
+            if (rce != FDC_OK) return rce;
         }
         if (trace) { HIPCHK(hipStreamSynchronize(s->stream)); lap("  task upload + extraction kernels"); }
         HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
@@ -956,10 +1107,199 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     return nblocks;
 }
 
+// ---------------------------------------------------------------- device engine: a call
+// dev_enqueue(): power cells, decision kernels, layout — nothing here waits for the device.  dev_launch_extractions(): needs
+// the summary of the layout kernel (buffer sizes, tasks per width class) on the host, then enqueues the rest: placement of the
+// tasks, blocks buffered from the call before, extraction kernels, history block, and the copy of the emitted runs to the host
+// on a stream of its own.  dev_complete(): waits for that copy and turns the emission records into fdc_pdu.
+static int dev_enqueue(fdc_sinks *s, int nblocks)
+{
+    auto &d = s->dev;
+    const int N = s->N, ncells = (int)s->cells.size(), npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
+    const long long now = (long long)time(nullptr), bc0 = s->blockcount;
+    if (ncells) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
+    HIPCHK(fdc::launch_pac_decide(s->d_power, ncells, nblocks, d.d_pgeom, d.d_pstate, npac, s->pac_thr, s->cfg.pac_maxblocks, s->R, bc0, now,
+                                  d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners, s->stream));
+    if (nseg) {
+        const int sd = s->cfg.det_variant == 1;
+        HIPCHK(fdc::launch_det_cands(s->d_power, ncells, nblocks, d.d_dgeom, nseg, s->dec, s->det_thr, sd, d.d_cand, d.d_cand_base,
+                                     d.d_ncand, s->cfg.max_blocks, s->stream));
+        fdc::DetParams dp{};
+        dp.N = N; dp.R = s->R; dp.dec = s->dec; dp.variant = sd; dp.maxblocks = s->cfg.det_maxblocks; dp.delay = s->cfg.det_deactivation_delay;
+        dp.nseg = nseg; dp.npac = npac; dp.nbmax = s->cfg.max_blocks; dp.puffer = s->cfg.window_flank_puffer;
+        dp.segname0 = s->cfg.det_id;
+        HIPCHK(fdc::launch_det_track(dp, nblocks, d.d_dgeom, d.d_sst, d.d_live, d.d_live_off, d.d_cand, d.d_cand_base, d.d_ncand, d.d_winoff,
+                                     bc0, now, d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners,
+                                     d.d_owner_base, d.d_nowner, d.d_error, s->stream));
+    }
+    HIPCHK(fdc::launch_sink_layout(d.nlist, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_tasks, d.d_pdus, d.d_pdus_out, d.d_owners,
+                                   npac, nseg, d.d_owner_base, d.d_nowner, d.d_pstate, d.d_sst, d.d_live, d.d_live_off, d.d_sum,
+                                   d.d_class_fill, d.d_error, s->stream));
+    HIPCHK(hipMemcpyAsync(d.h_sum, d.d_sum, sizeof(fdc::SinkSummary), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(d.h_pdus, d.d_pdus_out, sizeof(fdc::SinkPdu) * kEagerPdus, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipEventRecord(d.ev_decide, s->stream));
+    s->blockcount = bc0 + nblocks;
+    return FDC_OK;
+}
+
+static int dev_launch_extractions(fdc_sinks *s, int nblocks)
+{
+    auto &d = s->dev;
+    static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;
+    const int N = s->N, npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
+    HIPCHK(hipEventSynchronize(d.ev_decide));
+    const int b = d.cur ^ 1;                                   // this call's landing buffer; d.cur still names the previous call's
+    const fdc::SinkSummary sum = *d.h_sum;
+    if (sum.error) {
+        HIPCHK(hipMemsetAsync(d.d_error, 0, sizeof(int32_t), s->stream));
+        return fdc::set_error(FDC_ERR_UNSUPPORTED, "detection: more than %d live channels in one segment", fdc::kDetMaxCells);
+    }
+    d.sum[b] = sum;
+    d.recs[b].assign(d.h_pdus, d.h_pdus + std::min(sum.npdu, kEagerPdus));
+    if (sum.npdu > kEagerPdus) {
+        d.recs[b].resize((size_t)sum.npdu);
+        HIPCHK(hipMemcpyAsync(d.recs[b].data() + kEagerPdus, d.d_pdus_out + kEagerPdus, sizeof(fdc::SinkPdu) * (size_t)(sum.npdu - kEagerPdus),
+                              hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    const bool devpay = (s->cfg.flags & FDC_SINKS_DEVICE_PAYLOAD) != 0;
+    // the buffer last held call k-2: its copy to the host was waited for when that call was completed, its buffered blocks were
+    // moved on by call k-1 (enqueued; hipFree waits for the device)
+    if ((size_t)sum.used_total > d.cap_land[b]) {
+        const size_t want = std::max<size_t>((size_t)sum.used_total * 3 / 2, (size_t)1 << 16);
+        (void)hipFree(d.d_land[b]); d.d_land[b] = nullptr; d.cap_land[b] = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d.d_land[b]), sizeof(float2) * want));
+        d.cap_land[b] = want;
+    }
+    if (!devpay && (size_t)sum.used_a > d.cap_hland[b]) {
+        const size_t want = std::max<size_t>((size_t)sum.used_a * 3 / 2, (size_t)1 << 16);
+        if (d.h_land[b]) (void)hipHostFree(d.h_land[b]);
+        d.h_land[b] = nullptr; d.cap_hland[b] = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d.h_land[b]), sizeof(cfl) * want, hipHostMallocDefault));
+        d.cap_hland[b] = want;
+    }
+    if (sum.ntask)
+        HIPCHK(fdc::launch_task_scatter(d.nlist, d.d_task_base, d.d_ntask, d.max_list, d.d_tasks, d.d_owners, d.d_sum, d.d_class_fill,
+                                        d.d_sorted, s->stream));
+    if (d.any)
+        HIPCHK(fdc::launch_carry_copy(d.d_owners, std::max(npac, fdc::kDetMaxCells), d.d_owner_base, d.d_nowner, npac, nseg, d.d_sum,
+                                      d.d_land[d.cur], d.d_land[b], s->stream));
+    if (sum.ntask) {
+        size_t first[32], cnt[32];
+        for (int k = 0; k < 32; k++) { first[k] = (size_t)sum.class_base[k]; cnt[k] = (size_t)sum.class_cnt[k]; }
+        const int rce = run_extractions(s, d.d_sorted, first, cnt, d.d_land[b], trace);
+        if (rce != FDC_OK) return rce;
+    }
+    // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
+    HIPCHK(hipMemcpyAsync(s->d_spec, s->d_spec + (size_t)nblocks * N, sizeof(float2) * (size_t)N, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipEventRecord(d.ev_extract[b], s->stream));
+    if (!devpay && sum.used_a) {
+        HIPCHK(hipStreamWaitEvent(d.s_copy, d.ev_extract[b], 0));
+        HIPCHK(hipMemcpyAsync(d.h_land[b], d.d_land[b], sizeof(float2) * (size_t)sum.used_a, hipMemcpyDeviceToHost, d.s_copy));
+        HIPCHK(hipEventRecord(d.ev_copied[b], d.s_copy));
+    }
+    d.cur = b; d.any = true; d.inflight = true; d.inflight_nb = nblocks;
+    if (trace) std::fprintf(stderr, "[fdc_sinks dev] %d tasks, %d PDUs, %lld samples emitted, %lld buffered\n", sum.ntask, sum.npdu,
+                            (long long)sum.used_a, (long long)(sum.used_total - sum.b_start));
+    return FDC_OK;
+}
+
+// the PDUs of the batch in flight become the handle's current PDUs
+static int dev_complete(fdc_sinks *s)
+{
+    auto &d = s->dev;
+    if (!d.inflight) return 0;
+    const int b = d.cur;
+    const bool devpay = (s->cfg.flags & FDC_SINKS_DEVICE_PAYLOAD) != 0;
+    if (devpay) HIPCHK(hipEventSynchronize(d.ev_extract[b]));
+    else if (d.sum[b].used_a) HIPCHK(hipEventSynchronize(d.ev_copied[b]));
+    else HIPCHK(hipEventSynchronize(d.ev_extract[b]));
+    std::vector<fdc::SinkPdu> &recs = d.recs[b];
+    std::sort(recs.begin(), recs.end(), [](const fdc::SinkPdu &a, const fdc::SinkPdu &c) { return a.key < c.key; });
+    const char *base = devpay ? reinterpret_cast<const char *>(d.d_land[b]) : reinterpret_cast<const char *>(d.h_land[b]);
+    s->pdus.resize(recs.size());
+    time_t last_t = (time_t)-1;
+    char tbuf[40] = "";
+    for (size_t i = 0; i < recs.size(); i++) {
+        const fdc::SinkPdu &r = recs[i];
+        PduRec &o = s->pdus[i];
+        o.blocks.clear(); o.payload.clear(); o.key = r.key; o.blocklen = r.len;
+        fdc_pdu &m = o.meta;
+        m = fdc_pdu{};
+        m.kind = r.kind; m.source = r.source; m.chan_id = r.chan_id; m.finalized = r.fin; m.part = r.part; m.has_part = r.has_part;
+        m.rel_bw = (double)r.width / (double)s->N;
+        m.rel_cfreq = (double)(r.vstart + r.vend) / 2.0 / (double)s->N;
+        m.blockstart = r.blockstart; m.blockend = r.blockend; m.vectorstart = r.vstart; m.vectorend = r.vend;
+        m.nsamples = (int64_t)(r.q1 - r.q0) * r.len;
+        m.samples = m.nsamples ? base + sizeof(float2) * (size_t)r.off : nullptr;
+        if ((time_t)r.act_time != last_t) {                    // create_ID() / get_ID_for_msg(): local time of the activation
+            last_t = (time_t)r.act_time;
+            struct tm tmv;
+            localtime_r(&last_t, &tmv);
+            strftime(tbuf, sizeof tbuf, "%Y-%m-%d-%H-%M-%S", &tmv);
+        }
+        if (r.kind == 0) std::snprintf(m.id, sizeof m.id, "%s.PowActChan.%d.%d", tbuf, r.source, r.chan_id);
+        else std::snprintf(m.id, sizeof m.id, "%s.DETECTED.%d.%d", tbuf, r.source, r.chan_id);
+    }
+    d.inflight = false;
+    return d.inflight_nb;
+}
+
+int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
+    if (!s->dev.on) {                                          // host engine: the batch is done when the call returns
+        if (nblocks == 0) { s->pdus.clear(); return 0; }
+        HIPCHK(hipSetDevice(s->cfg.device_id));
+        return host_work_device(s, nblocks);
+    }
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    if (nblocks == 0) {
+        const int done = dev_complete(s);
+        if (done == 0) s->pdus.clear();
+        return done;
+    }
+    int rc = dev_enqueue(s, nblocks);
+    if (rc != FDC_OK) return rc;
+    const bool had = s->dev.inflight;
+    const int done = dev_complete(s);                          // while the device works on the new batch
+    if (done < 0) return done;
+    if (!had) s->pdus.clear();
+    rc = dev_launch_extractions(s, nblocks);
+    if (rc != FDC_OK) return rc;
+    return done;
+}
+
+int fdc_sinks_flush(fdc_sinks *s)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!s->dev.on || !s->dev.inflight) return 0;
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    return dev_complete(s);
+}
+
+int32_t fdc_sinks_engine(const fdc_sinks *s) { return s ? (s->dev.on ? 1 : 0) : -1; }
+
+int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
+    if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
+    if (nblocks == 0) { s->pdus.clear(); return 0; }
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    if (!s->dev.on) return host_work_device(s, nblocks);
+    int rc = fdc_sinks_submit_device(s, nblocks);
+    if (rc < 0) return rc;
+    rc = dev_complete(s);
+    return rc < 0 ? rc : nblocks;
+}
+
 int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
 {
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
+    if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
     if (nitems == 0) { s->pdus.clear(); return 0; }
     if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     HIPCHK(hipSetDevice(s->cfg.device_id));

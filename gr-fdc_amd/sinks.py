@@ -24,7 +24,8 @@ from . import _lib
 class Sinks:
     def __init__(self, blocklen, relinvovl, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
                  segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
-                 max_blocks=64, device_id=0, det_variant=0, verbose=0, det_id=-1):
+                 max_blocks=64, device_id=0, det_variant=0, verbose=0, det_id=-1, host_decisions=False, device_payload=False,
+                 threads=0):
         self._h = C.c_void_p()
         self.N = int(blocklen)
         pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
@@ -36,7 +37,10 @@ class Sinks:
         cfg = _lib.fdc_sinks_cfg(device_id, self.N, int(relinvovl), len(pac), pa, float(pac_thresh), int(pac_maxblocks),
                                  int(pac_delay), len(segments), sg, float(det_thresh), int(det_maxblocks),
                                  float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant),
-                                 int(verbose), int(det_id))
+                                 int(verbose), int(det_id),
+                                 (_lib.FDC_SINKS_HOST_DECISIONS if host_decisions else 0) |
+                                 (_lib.FDC_SINKS_DEVICE_PAYLOAD if device_payload else 0), int(threads))
+        self.device_payload = bool(device_payload)
         rc = _lib.lib().fdc_sinks_create(C.byref(cfg), C.byref(self._h))
         if rc == -1:
             raise ValueError(_lib.lib().fdc_last_error().decode())
@@ -58,12 +62,21 @@ class Sinks:
     def spectrum_ptr(self):
         return _lib.lib().fdc_sinks_spectrum(self._h)
 
+    def engine(self):
+        """1 = decisions on the device (default), 0 = on host threads (verbose != 0, host_decisions, very fine segments)"""
+        return int(_lib.lib().fdc_sinks_engine(self._h))
+
     def _collect(self):
         n = _lib.lib().fdc_sinks_pdu_count(self._h)
         if n <= 0:
             return []
         arr = (_lib.fdc_pdu * n)()
         _lib.check(_lib.lib().fdc_sinks_pdus(self._h, arr, n))
+        if self.device_payload and self.engine() == 1:      # payloads stay on the device: (address, sample count) instead of arrays
+            return [(dict(id=p.id.decode(), kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                          has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq, blockstart=p.blockstart,
+                          blockend=p.blockend, vectorstart=p.vectorstart, vectorend=p.vectorend), (p.samples or 0, p.nsamples))
+                    for p in arr]
         # payloads that sit one behind the other in the handle's buffer are copied out as ONE array and sliced
         out, i = [], 0
         while i < n:
@@ -106,6 +119,16 @@ class Sinks:
     def work_device(self, nblocks):
         _lib.check(_lib.lib().fdc_sinks_work_device(self._h, int(nblocks)))
         return self._collect()
+
+    def submit_device(self, nblocks):
+        """Two-deep form (fdc_sinks_submit_device): enqueue the batch in the spectrum buffer; returns the PDUs of the batch
+        submitted BEFORE it (empty list for the first one)."""
+        done = _lib.check(_lib.lib().fdc_sinks_submit_device(self._h, int(nblocks)))
+        return self._collect() if done > 0 else []
+
+    def flush(self):
+        done = _lib.check(_lib.lib().fdc_sinks_flush(self._h))
+        return self._collect() if done > 0 else []
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -175,7 +175,20 @@ typedef struct {
                               construction, one line per emitted PDU */
     int32_t det_id;        /* det_variant 1 with ONE segment: SegmentDetection's ID argument (names the log file and the
                               segment in the message IDs); < 0 = the segment index */
+    int32_t flags;         /* FDC_SINKS_* bits, 0 = defaults */
+    int32_t threads;       /* host engine only: worker threads of the decision phase (0 = chosen from the bank's size) */
 } fdc_sinks_cfg;
+/* fdc_sinks_cfg.flags.  A bank runs on one of two engines.  DEVICE (default): the work() loops of the blocks
+ * (lib/PowerActivationChannel_impl.cc:146-170, lib/activity_detection_channelizer_vcm_impl.cc:551-568) are device kernels —
+ * per-channel state machines, edge detection and matching, the layout of the emitted payloads — so a batch is enqueued without a
+ * host round trip and only finished PDUs cross PCIe.  HOST: the same decisions on host threads between two GPU phases (round 1/2
+ * form); taken for verbose != 0 (the log lines are written while the decisions are made), for detection segments of more than
+ * 1024 power cells, and on request.  Both engines emit the same PDUs in the same order (tests/test_sinks_gpu.py). */
+enum {
+    FDC_SINKS_HOST_DECISIONS = 1,   /* use the host engine */
+    FDC_SINKS_DEVICE_PAYLOAD = 2    /* device engine: fdc_pdu.samples are DEVICE pointers (no payload copy to the host); valid like
+                                       the host pointers, until the next-but-one batch is submitted */
+};
 typedef struct {
     int32_t kind;        /* 0 = PowerActivationChannel, 1 = detected channel of a segment                       */
     int32_t source;      /* PAC: its ID argument; detection: segment index                                      */
@@ -218,11 +231,21 @@ void *fdc_sinks_stream(fdc_sinks *s);
 int32_t fdc_sinks_blocklen(const fdc_sinks *s);     /* N the bank was created for                                  */
 int32_t fdc_sinks_max_blocks(const fdc_sinks *s);   /* capacity of its device-resident spectrum buffer, in blocks   */
 int fdc_sinks_work_device(fdc_sinks *s, int nblocks);
+/* Two-deep form of fdc_sinks_work_device for a producer that keeps the device busy: submit() enqueues the batch that sits in
+ * the spectrum buffer and, if an earlier batch is still in flight, finishes that one first (waits for its payload copy, builds its
+ * PDUs) while the device works on the new one.  Returns the number of blocks of the batch whose PDUs are readable now through
+ * fdc_sinks_pdu*() (0 = none yet), or a negative fdc_status.  flush() finishes the batch in flight (returns its block count, 0 if
+ * there was none).  The spectrum buffer may be overwritten by work enqueued on fdc_sinks_stream() as soon as submit() returns.
+ * fdc_sinks_work_device(s, n) == submit(s, n) + flush(s); it refuses to run while a submitted batch is in flight.
+ * PDUs (and their payload pointers) stay valid until the next submit / flush / work call on the handle. */
+int fdc_sinks_submit_device(fdc_sinks *s, int nblocks);
+int fdc_sinks_flush(fdc_sinks *s);
+int32_t fdc_sinks_engine(const fdc_sinks *s);       /* 0 = host decisions, 1 = device decisions */
 /* PDUs emitted by the last work call, in emission order */
 int fdc_sinks_pdu_count(const fdc_sinks *s);
 int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);
-/* all of them at once: fills out[0 .. min(count, cap)) and returns the count.  PDUs whose blocks all come from the last call
- * have their payloads one behind the other in one pinned buffer, in this order. */
+/* all of them at once: fills out[0 .. min(count, cap)) and returns the count.  Every payload is one contiguous run of a pinned
+ * buffer of the handle (device engine: always; host engine: when all blocks of the PDU come from the last call). */
 int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap);
 /* derived geometry (for logs and tests): v[8] = extract_start, extract_stop, extract_width, measure_start,
  * measure_stop, output_len, output_ovl_offset, deltaphase;  v[5] = start, stop, width, decimation, power cells */

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Lines the default collection does not cover: the reference's default overlap (R = 4) at configs[1], a mixed-width
+# 256-channel plan, and PMC traffic for configs other than the headline.  Usage: profiles/collect_extra.sh <tag> [what...]
+#   what: r4 mixed pmc1 pmc3 pmc4 pmc5   (default: all)
+set -u
+TAG=${1:-r03}; shift || true
+WHAT=${*:-r4 mixed pmc1 pmc3 pmc4 pmc5}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/extra_$TAG
+mkdir -p $OUT
+cd $ROOT
+stats() {   # name, bench args...
+  local name=$1; shift
+  python3 bench.py --steps 50 --warmup 5 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed"
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $OUT/stats_$name.log 2>&1 ) || echo "rocprof $name failed"
+  local f=$(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then head -1 "$f" > $OUT/rocprof_kernel_stats_$name.csv; grep "fdc::" "$f" >> $OUT/rocprof_kernel_stats_$name.csv; fi
+  rm -rf $OUT/stats_$name
+}
+pmc() {     # config, blocks, blocklen
+  PMC_CONFIG=$1 PMC_BLOCKS=$2 PMC_BLOCKLEN=$3 bash profiles/pmc_run.sh ${TAG}_cfg$1 --config $1 > $OUT/pmc_cfg$1.log 2>&1
+  cp gpurun_out/pmc_${TAG}_cfg$1/summary.txt $OUT/pmc_summary_cfg$1.txt 2>/dev/null
+  cp gpurun_out/pmc_${TAG}_cfg$1/pmc_traffic.json $OUT/pmc_traffic_cfg$1.json 2>/dev/null
+  rm -rf gpurun_out/pmc_${TAG}_cfg$1/pass*/
+}
+for w in $WHAT; do
+  case $w in
+    r4) stats r4 --relinvovl 4 --no-cpu-baseline ;;
+    mixed) stats mixed --mixed --no-cpu-baseline ;;
+    pmc1) pmc 1 16384 4096 ;;
+    pmc3) pmc 3 1024 65536 ;;
+    pmc4) pmc 4 256 262144 ;;
+    pmc5) pmc 5 1024 65536 ;;
+  esac
+  echo "$w done"
+done
+ls -la $OUT

@@ -24,20 +24,29 @@ for k in sorted(acc):
 
 # HBM traffic per dispatch for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
 # FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md §HBM) -> doubled.
+# One entry per (config, kernel label); `kernels` lists every fdc:: kernel of the run with its own bytes, so that the
+# traffic of a multi-kernel step (configs 3-5) can be added up.  PMC_CONFIG / PMC_BLOCKS / PMC_BLOCKLEN describe the run.
 import json
 names = {"fdc::k_blk256": "block_kernel(colFFT+window+IFFT+slotFFT)", "fdc::k_p1": "poly_stage1(colFFT+window+IFFT)", "fdc::k_p2": "poly_stage2(slotFFT)",
-         "fdc::k_a256": "fft_pass_a", "fdc::k_b256": "fft_pass_b", "fdc::k_c256": "channels"}
-out = {}
+         "fdc::k_p2k": "poly_stage2(slotFFT)", "fdc::k_a256": "fft_pass_a", "fdc::k_b256": "fft_pass_b", "fdc::k_c256": "channels",
+         "fdc::k_fft4096": "fft_pass_b", "fdc::k_channels": "channels"}
+cfg = int(os.environ.get("PMC_CONFIG", "2"))
+tag = os.environ.get("PMC_TAG", "")
+out, allk = {}, {}
 for k in acc:
+    if "FETCH_SIZE" not in acc[k] or "WRITE_SIZE" not in acc[k]:
+        continue
+    f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024
+    w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
+    allk[k] = {"fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w, "dispatches": len(acc[k]["FETCH_SIZE"])}
     base = k.split("<")[0]
     if base == "fdc::k_blk256" and k.rstrip(">").endswith("true") and k.count(",") == 2:      # <NT, OFF, FWD = true>
         names[base + "_fwd"] = "block_fft(forward, one kernel)"
         base += "_fwd"
-    if base in names and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
-        f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024
-        w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
-        out[names[base]] = {"kernel": k, "config": int(os.environ.get("PMC_CONFIG", "2")), "fetch_size_raw_bytes": f, "write_size_bytes": w,
-                            "hbm_bytes_per_launch": 2 * f + w, "blocks_per_launch": float(os.environ.get("PMC_BLOCKS", "1024")),
-                            "blocklen": int(os.environ.get("PMC_BLOCKLEN", "65536"))}
+    if base in names:
+        out["cfg%d%s/%s" % (cfg, tag, names[base])] = {
+            "kernel": k, "config": cfg, "fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
+            "blocks_per_launch": float(os.environ.get("PMC_BLOCKS", "1024")), "blocklen": int(os.environ.get("PMC_BLOCKLEN", "65536"))}
+out["cfg%d%s/all_kernels" % (cfg, tag)] = allk
 with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
