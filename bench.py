@@ -58,6 +58,13 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
                                                              "dropped): a tiling that does not start at bin 0")
+    ap.add_argument("--payload", choices=("host", "device"), default="host",
+                    help="configs 3/5: PDU payloads copied to pinned host memory (default; PCIe-bound) or left in HBM (fdc_pdu.samples "
+                         "are device pointers)")
+    ap.add_argument("--sink-engine", choices=("device", "host"), default="device",
+                    help="configs 3/5: where the blocks' work() loops run (FDC_SINKS_HOST_DECISIONS = the round-2 form)")
+    ap.add_argument("--sync-sinks", action="store_true", help="configs 3/5: fdc_sinks_work_device per step instead of the two-deep "
+                                                               "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
     a = ap.parse_args()
@@ -330,7 +337,7 @@ def main():
     H = N - N // R
     first_block, _n = G.span_for_rank(world * nb, rank, world)   # contiguous span per rank (§8e); weak scaling
     sinks, segments = None, None
-    extracted = [0, 0]                                 # cfg3 / cfg5: samples and PDUs emitted in the timed region
+    extracted = [0, 0, 0]                              # cfg3 / cfg5: samples, PDUs and batches handed out in the timed region
     if a.config in (1, 2, 4):
         # channel plan through the reference's own parameter derivation (py:322-345): tiles the spectrum
         if a.config == 1:    # examples/FDC_example.grc: [[0.12,0.05],[0.22,0.1],[-0.14,0.12],[0,0.081]]
@@ -357,14 +364,16 @@ def main():
         pipe = G.Pipeline(N, R, [], windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk, keep_spectrum=True)
         if a.config == 3:
             pac = [(((c + 0.5) / C) % 1.0, 0.8 / C, c) for c in range(C)]
-            sinks = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=nb, device_id=local)
+            sinks = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=nb, device_id=local,
+                            host_decisions=a.sink_engine == "host", device_payload=a.payload == "device")
             carriers = [((c + 0.5) / C - 0.5, 1.0 / C) for c in range(C)]
             wl = "configs[2]: %d-pt FFT, 1/%d overlap-save, %d PowerActivationChannel sinks (6 dB, maxblocks 128), bursty " \
                  "carriers (8-64 blocks, 50 %% duty, 30 dB), %d blocks/step" % (N, R, C, nb)
         else:
             segments = [((0.05 + 0.5) % 1.0, (0.45 + 0.5) % 1.0), ((-0.45 + 0.5) % 1.0, (-0.05 + 0.5) % 1.0)]
             sinks = G.Sinks(N, R, segments=segments, det_thresh=10.0, det_maxblocks=128, minchandist=0.005, det_delay=1,
-                            puffer=0.2, max_blocks=nb, device_id=local)
+                            puffer=0.2, max_blocks=nb, device_id=local, host_decisions=a.sink_engine == "host",
+                            device_payload=a.payload == "device")
             rng = np.random.default_rng(2028)
             carriers, used = [], []
             while len(carriers) < 24:                  # 24 carriers of width 0.002-0.03 at non-overlapping centres inside the segments
@@ -403,18 +412,26 @@ def main():
         sstream = _lib.lib().fdc_sinks_stream(sinks._h)
         count = [False]
 
+        def tally():
+            n = _lib.lib().fdc_sinks_pdu_count(sinks._h)
+            if n > 0:
+                arr = (_lib.fdc_pdu * n)()
+                _lib.lib().fdc_sinks_pdus(sinks._h, arr, n)
+                extracted[0] += int(np.frombuffer(arr, dtype=np.dtype(_lib.fdc_pdu))["nsamples"].sum())
+                extracted[1] += n
+
         def step():
             # forward transform of the batch straight into the bank's spectrum buffer (the bank's stream), then the bank:
-            # power cells -> decisions -> extraction of the active (block, channel) pairs -> PDUs
+            # power cells -> decisions -> extraction of the active (block, channel) pairs -> PDUs.  Two deep: the PDUs handed
+            # out by a step are those of the batch before, whose payload copy ran beside this batch's kernels.
             pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=sstream)
-            _lib.check(_lib.lib().fdc_sinks_work_device(sinks._h, nb))
-            if count[0]:
-                n = _lib.lib().fdc_sinks_pdu_count(sinks._h)
-                if n > 0:
-                    arr = (_lib.fdc_pdu * n)()
-                    _lib.lib().fdc_sinks_pdus(sinks._h, arr, n)
-                    extracted[0] += int(np.frombuffer(arr, dtype=np.dtype(_lib.fdc_pdu))["nsamples"].sum())
-                    extracted[1] += n
+            if a.sync_sinks:
+                done = _lib.check(_lib.lib().fdc_sinks_work_device(sinks._h, nb))
+            else:
+                done = _lib.check(_lib.lib().fdc_sinks_submit_device(sinks._h, nb))
+            if count[0] and done > 0:
+                tally()
+                extracted[2] += 1
 
     def fence():
         if dist is not None:
@@ -423,6 +440,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if sinks is not None:
+        _lib.check(_lib.lib().fdc_sinks_flush(sinks._h))
     fence()
     if sinks is not None:
         count[0] = True
@@ -430,6 +449,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    if sinks is not None and _lib.check(_lib.lib().fdc_sinks_flush(sinks._h)) > 0:     # the batch still in flight belongs to the region
+        tally()
+        extracted[2] += 1
     fence()
     dt = time.perf_counter() - t0
     # per-kernel HIP-event durations, summed over every launch of the timed region (the events sit on the
@@ -451,7 +473,7 @@ def main():
             ["block_fft(forward, one kernel)", "unused", "channels"] if path == 1 and N == 65536 and os.environ.get("FDC_NO_BLOCK") != "1" else \
             ["fft_pass_a", "fft_pass_b", "channels"]
     if sinks is not None:
-        b_alg += 8.0 * extracted[0] / max(1, a.steps * nb)     # the data-dependent part, counted by the harness
+        b_alg += 8.0 * extracted[0] / max(1, extracted[2] * nb)     # the data-dependent part, counted by the harness
     dom = max(range(3), key=lambda i: last[i])
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel
     blocks_per_launch = nb / nlaunch            # units one launch processes
@@ -494,8 +516,12 @@ def main():
                      "pipeline_frac_of_achievable_6300": round(pipe_gbs / 6300.0, 4)},
     }
     if sinks is not None:
-        res["config"]["pdus_per_step"] = round(extracted[1] / max(1, a.steps), 1)
-        res["config"]["extracted_samples_per_step"] = round(extracted[0] / max(1, a.steps), 1)
+        res["config"]["pdus_per_step"] = round(extracted[1] / max(1, extracted[2]), 1)
+        res["config"]["extracted_samples_per_step"] = round(extracted[0] / max(1, extracted[2]), 1)
+        res["config"]["batches_with_pdus_read"] = extracted[2]
+        res["config"]["sink_engine"] = "device" if sinks.engine() == 1 else "host"
+        res["config"]["payload"] = a.payload if sinks.engine() == 1 else "host"
+        res["config"]["submission"] = "synchronous" if a.sync_sinks else "two deep (fdc_sinks_submit_device)"
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if sinks is None:
             _model, _nproc, share = host_info()

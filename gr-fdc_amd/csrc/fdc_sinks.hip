@@ -209,8 +209,11 @@ struct fdc_sinks {
         hipEvent_t ev_decide = nullptr, ev_extract[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
         std::vector<fdc::SinkPdu> recs[2];
         fdc::SinkSummary sum[2];
+        int64_t bc0[2] = {0, 0};              // block counter at the start of the batch in landing buffer b
+        int nb_of[2] = {0, 0};
+        bool pend[2] = {false, false};        // batch in landing buffer b is enqueued and not yet handed out
         int cur = 1;                          // landing buffer of the newest batch
-        bool inflight = false; int inflight_nb = 0;
+        bool inflight = false;                // some batch is pending
         bool any = false;                     // a batch has run: d_land[cur] holds buffered blocks
     } dev;
 };
@@ -470,13 +473,13 @@ int dev_setup(fdc_sinks *s)
     if (npac + nseg == 0) return FDC_OK;
     for (const Segment &g : s->segs) if (g.ncell > fdc::kDetMaxCells) return FDC_OK;
     const int64_t nbmax = cfg.max_blocks;
-    d.npw = (npac + 63) / 64;
+    d.npw = npac;                                                              // one list per PowerActivationChannel (one wave each)
     d.nlist = d.npw + nseg;
     d.task_base.assign((size_t)d.nlist + 1, 0); d.pdu_base.assign((size_t)d.nlist + 1, 0);
     d.owner_base.assign((size_t)nseg + 1, npac); d.cand_base.assign((size_t)nseg + 1, 0);
     for (int l = 0; l < d.nlist; l++) {
         int64_t tc, pc;
-        if (l < d.npw) { tc = 64 * 2 * nbmax; pc = 64 * nbmax; }             // per block: at most two extractions, one emission
+        if (l < d.npw) { tc = 2 * nbmax; pc = nbmax; }                         // per block: at most two extractions, one emission
         else {
             const int64_t nc = s->segs[(size_t)(l - d.npw)].ncell;
             tc = nbmax * nc + nbmax * (nc / 2 + 1);                            // every live channel once, every activation twice
@@ -1198,18 +1201,17 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         HIPCHK(hipMemcpyAsync(d.h_land[b], d.d_land[b], sizeof(float2) * (size_t)sum.used_a, hipMemcpyDeviceToHost, d.s_copy));
         HIPCHK(hipEventRecord(d.ev_copied[b], d.s_copy));
     }
-    d.cur = b; d.any = true; d.inflight = true; d.inflight_nb = nblocks;
+    d.cur = b; d.any = true; d.inflight = true; d.pend[b] = true; d.nb_of[b] = nblocks; d.bc0[b] = s->blockcount - nblocks;
     if (trace) std::fprintf(stderr, "[fdc_sinks dev] %d tasks, %d PDUs, %lld samples emitted, %lld buffered\n", sum.ntask, sum.npdu,
                             (long long)sum.used_a, (long long)(sum.used_total - sum.b_start));
     return FDC_OK;
 }
 
-// the PDUs of the batch in flight become the handle's current PDUs
-static int dev_complete(fdc_sinks *s)
+// the PDUs of the batch in landing buffer b become the handle's current PDUs
+static int dev_complete(fdc_sinks *s, int b)
 {
     auto &d = s->dev;
-    if (!d.inflight) return 0;
-    const int b = d.cur;
+    if (!d.pend[b]) return 0;
     const bool devpay = (s->cfg.flags & FDC_SINKS_DEVICE_PAYLOAD) != 0;
     if (devpay) HIPCHK(hipEventSynchronize(d.ev_extract[b]));
     else if (d.sum[b].used_a) HIPCHK(hipEventSynchronize(d.ev_copied[b]));
@@ -1220,17 +1222,36 @@ static int dev_complete(fdc_sinks *s)
     s->pdus.resize(recs.size());
     time_t last_t = (time_t)-1;
     char tbuf[40] = "";
+    const bool sd = s->cfg.det_variant == 1;
     for (size_t i = 0; i < recs.size(); i++) {
         const fdc::SinkPdu &r = recs[i];
         PduRec &o = s->pdus[i];
-        o.blocks.clear(); o.payload.clear(); o.key = r.key; o.blocklen = r.len;
+        o.blocks.clear(); o.payload.clear(); o.key = r.key;
         fdc_pdu &m = o.meta;
         m = fdc_pdu{};
-        m.kind = r.kind; m.source = r.source; m.chan_id = r.chan_id; m.finalized = r.fin; m.part = r.part; m.has_part = r.has_part;
-        m.rel_bw = (double)r.width / (double)s->N;
-        m.rel_cfreq = (double)(r.vstart + r.vend) / 2.0 / (double)s->N;
-        m.blockstart = r.blockstart; m.blockend = r.blockend; m.vectorstart = r.vstart; m.vectorend = r.vend;
-        m.nsamples = (int64_t)(r.q1 - r.q0) * r.len;
+        const bool det = (r.flags >> 16) & 1;
+        const int64_t blk = r.key >> 24;                       // block index inside the batch
+        int width, vstart;
+        if (!det) {
+            const Pac &p = s->pacs[(size_t)r.owner];
+            width = p.extract_width; vstart = p.extract_start;
+            m.kind = 0; m.source = p.ID; m.has_part = 1;
+            m.blockend = d.bc0[b] + blk;                       // blockcount while the item is processed (:226-227)
+        } else {
+            const int sgi = (int)((r.key >> 12) & 0x7FF);
+            width = 1 << ((r.flags >> 8) & 0xFF); vstart = r.vstart;
+            m.kind = 1;
+            m.source = (sd && s->cfg.det_id >= 0 && s->segs.size() == 1) ? s->cfg.det_id : s->segs[(size_t)sgi].ID;
+            m.has_part = (r.flags & 1) ? (r.part > 0) : 1;     // …vcm_impl.cc:419-420
+            // the vcm block counts from 1 (…vcm_impl.cc:188), SegmentDetection from 0 (SegmentDetection_impl.cc:118)
+            m.blockend = d.bc0[b] + blk - (sd ? 1 : 0);
+        }
+        o.blocklen = width - width / s->R;
+        m.chan_id = r.chan_id; m.finalized = r.flags & 1; m.part = r.part;
+        m.rel_bw = (double)width / (double)s->N;
+        m.rel_cfreq = (double)(vstart + vstart + width) / 2.0 / (double)s->N;
+        m.blockstart = m.blockend - r.count; m.vectorstart = vstart; m.vectorend = vstart + width;
+        m.nsamples = (int64_t)(r.q1 - r.q0) * o.blocklen;
         m.samples = m.nsamples ? base + sizeof(float2) * (size_t)r.off : nullptr;
         if ((time_t)r.act_time != last_t) {                    // create_ID() / get_ID_for_msg(): local time of the activation
             last_t = (time_t)r.act_time;
@@ -1238,11 +1259,12 @@ static int dev_complete(fdc_sinks *s)
             localtime_r(&last_t, &tmv);
             strftime(tbuf, sizeof tbuf, "%Y-%m-%d-%H-%M-%S", &tmv);
         }
-        if (r.kind == 0) std::snprintf(m.id, sizeof m.id, "%s.PowActChan.%d.%d", tbuf, r.source, r.chan_id);
-        else std::snprintf(m.id, sizeof m.id, "%s.DETECTED.%d.%d", tbuf, r.source, r.chan_id);
+        if (!det) std::snprintf(m.id, sizeof m.id, "%s.PowActChan.%d.%d", tbuf, m.source, r.chan_id);
+        else std::snprintf(m.id, sizeof m.id, "%s.DETECTED.%d.%d", tbuf, m.source, r.chan_id);
     }
-    d.inflight = false;
-    return d.inflight_nb;
+    d.pend[b] = false;
+    d.inflight = d.pend[0] || d.pend[1];
+    return d.nb_of[b];
 }
 
 int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
@@ -1255,19 +1277,23 @@ int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
         return host_work_device(s, nblocks);
     }
     HIPCHK(hipSetDevice(s->cfg.device_id));
+    auto &d = s->dev;
     if (nblocks == 0) {
-        const int done = dev_complete(s);
+        const int done = dev_complete(s, d.cur);
         if (done == 0) s->pdus.clear();
         return done;
     }
+    // this batch: everything enqueued (the one wait is for the layout summary, ~ the forward transform + decision kernels);
+    // then the batch before it: its payload copy has been running beside all of that
     int rc = dev_enqueue(s, nblocks);
     if (rc != FDC_OK) return rc;
-    const bool had = s->dev.inflight;
-    const int done = dev_complete(s);                          // while the device works on the new batch
-    if (done < 0) return done;
-    if (!had) s->pdus.clear();
+    const int before = d.cur;
     rc = dev_launch_extractions(s, nblocks);
     if (rc != FDC_OK) return rc;
+    const bool had = d.pend[before];
+    const int done = dev_complete(s, before);
+    if (done < 0) return done;
+    if (!had) s->pdus.clear();
     return done;
 }
 
@@ -1276,7 +1302,7 @@ int fdc_sinks_flush(fdc_sinks *s)
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (!s->dev.on || !s->dev.inflight) return 0;
     HIPCHK(hipSetDevice(s->cfg.device_id));
-    return dev_complete(s);
+    return dev_complete(s, s->dev.cur);
 }
 
 int32_t fdc_sinks_engine(const fdc_sinks *s) { return s ? (s->dev.on ? 1 : 0) : -1; }
@@ -1291,7 +1317,7 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     if (!s->dev.on) return host_work_device(s, nblocks);
     int rc = fdc_sinks_submit_device(s, nblocks);
     if (rc < 0) return rc;
-    rc = dev_complete(s);
+    rc = dev_complete(s, s->dev.cur);
     return rc < 0 ? rc : nblocks;
 }
 

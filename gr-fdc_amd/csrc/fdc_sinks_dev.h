@@ -16,7 +16,8 @@ constexpr int kDetMaxCells = 1024;      // power cells per detection segment the
 // a call the first `emitted` blocks of the stream have gone out in PDUs and the rest stays buffered.
 struct SinkOwner {
     int32_t len;                 // samples per block (output_len / outputsamples)
-    int32_t carried, emitted, total;
+    int32_t cls;                 // log2 of the extraction width
+    int32_t carried, emitted, total, pad;
     int64_t prev_off;            // samples, in the previous call's landing buffer
     int64_t a_off, b_off;        // layout of this call (k_sink_layout): emitted prefix / buffered rest, samples in the landing buffer
 };
@@ -24,13 +25,17 @@ struct SinkOwner {
 // Extraction decided by a state machine: block `q` of stream `owner`
 struct SinkTask { int32_t owner, q, slot, start, win_off, cls; };
 
-// Emission record: blocks [q0, q1) of stream `owner`
+// Emission record: blocks [q0, q1) of stream `owner`.  Kept small (the state machines write one per emission): what the
+// host can work out itself — the dictionary's block numbers from the block index in `key` and `count`, the geometry of a
+// PowerActivationChannel from `owner` — is not in it.
 struct SinkPdu {
-    int64_t key;                 // emission order inside a call (see fdc_sinks.hip)
-    int64_t blockstart, blockend, act_time;
+    int64_t key;                 // emission order inside a call: block << 24 | (PowerActivationChannel index, or 1 << 23 | segment << 12 | n)
+    int64_t act_time;            // time() of the call that activated the channel (create_ID / get_ID_for_msg)
     int64_t off;                 // k_sink_layout: samples into the landing buffer
-    int32_t owner, q0, q1, len;
-    int32_t kind, source, chan_id, fin, part, has_part, vstart, vend, width, pad;
+    int32_t owner, q0, q1, count;
+    int32_t chan_id, part;
+    int32_t flags;               // bit 0 finalized, bits 8-15 log2 width (detection), bit 16 kind (1 = detection)
+    int32_t vstart;              // detection: first bin of the extraction
 };
 
 // PowerActivationChannel: geometry (constant) and state (lives on the device between calls)

@@ -22,10 +22,26 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 }
 
 // ---------------------------------------------------------------- PowerActivationChannel
-// One lane per channel, one wave per 64 channels.  Per super-chunk of 2048 blocks: (1) the two comparisons of measure_power()
-// (PowerActivationChannel_impl.cc:286-306) for every block — they need the previous block's power only, not the state — as bit
-// masks in LDS, loads of consecutive blocks independent of each other; (2) the work() loop (:146-170) over those bits.
-constexpr int kPacSuper = 2048;
+// One wave per channel, lanes = 64 consecutive blocks.  The work() loop (PowerActivationChannel_impl.cc:146-170) is a
+// two-state machine: block m toggles the state if (inactive and P[m] / P[m-1] >= thr) or (active and P[m-1] / P[m] >= thr)
+// (measure_power(), :286-306; lastpower follows every block).  Both comparisons need the neighbouring powers only, so they
+// are taken for 64 blocks at once (two ballots); the toggles are then found by walking the set bits of the mask the current
+// state listens to (a scalar loop over the state CHANGES, not over the blocks), and everything else about a block follows in
+// closed form from the toggle mask: whether it is extracted, its place in the channel's block stream, count and phase, the
+// emissions (count % maxblocks, :163-165) and their part numbers.
+__device__ __forceinline__ unsigned long long mask_lt(int m) { return m <= 0 ? 0ull : (m >= 64 ? ~0ull : ((1ull << m) - 1ull)); }
+__device__ __forceinline__ int last_bit_below(unsigned long long msk, int m)      // highest set bit of msk below position m, or -1
+{
+    const unsigned long long x = msk & mask_lt(m);
+    return x ? 63 - __clzll((long long)x) : -1;
+}
+// emissions of a run before its count reaches c (they happen at counts >= 3 that the maxblocks rule selects, :163-165)
+__device__ __forceinline__ int emissions_before(int c, int mb)
+{
+    if (mb < 0 || c <= 3) return 0;
+    if (mb == 0) return c - 3;
+    return (c - 1) / mb - 2 / mb;                                           // multiples of mb in [3, c - 1]
+}
 
 __global__ __launch_bounds__(64) void k_pac_decide(const float *__restrict__ power, int ncells, int nb, const PacGeom *__restrict__ geom,
                                                    PacState *__restrict__ st, int npac, float thr, int mb, int R, long long bc0,
@@ -33,87 +49,100 @@ __global__ __launch_bounds__(64) void k_pac_decide(const float *__restrict__ pow
                                                    const int64_t *__restrict__ task_base, const int64_t *__restrict__ pdu_base,
                                                    int32_t *__restrict__ ntask, int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners)
 {
-    __shared__ unsigned upw[kPacSuper / 32][64], dnw[kPacSuper / 32][64];
-    const int lane = threadIdx.x, wv = blockIdx.x, i = wv * 64 + lane;
-    const bool valid = i < npac;
-    const PacGeom g = geom[valid ? i : 0];
-    PacState s = st[valid ? i : 0];
-    SinkTask *const tl = tasks + task_base[wv];
-    SinkPdu *const pl = pdus + pdu_base[wv];
-    int tcur = 0, pcur = 0;                            // wave-uniform cursors of this wave's lists
-    const int carried = s.tail;
-    int q = carried, E = 0;                            // stream length so far, emitted prefix
-    const unsigned long long lt = lanemask_lt();
-    float prev = s.lastpower;
-    for (int m0 = 0; m0 < nb; m0 += kPacSuper) {
-        const int mc = nb - m0 < kPacSuper ? nb - m0 : kPacSuper;
-        // (1) ratios
-        for (int w0 = 0; w0 < mc; w0 += 32) {
-            unsigned u = 0, d = 0;
-            const int wn = mc - w0 < 32 ? mc - w0 : 32;
-            float p[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) p[k] = (k < wn && valid) ? power[(size_t)(m0 + w0 + k) * ncells + g.cell] : 1.0f;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                float pw = p[k];
-                if (pw == 0.0f) pw = FLT_MIN;                               // :293-294
-                if (k < wn) {
-                    if (pw / prev >= thr) u |= 1u << k;                     // :296
-                    if (prev / pw >= thr) d |= 1u << k;                     // :299
-                    prev = pw;                                              // lastpower follows every block (:297, :300, :304)
-                }
+    const int lane = threadIdx.x, i = blockIdx.x;
+    const PacGeom g = geom[i];
+    const PacState s0 = st[i];
+    SinkTask *const tl = tasks + task_base[i];
+    SinkPdu *const pl = pdus + pdu_base[i];
+    const int rm = R - 1, dph = g.deltaphase & rm;
+    const float *const pcol = power + g.cell;
+    // wave-uniform running state
+    int active = s0.active, count = s0.count, finished = s0.finished, id_at = s0.id_at_act;
+    long long act_time = s0.act_time;
+    int q = s0.tail, E = 0, tcur = 0, pcur = 0;                              // stream length, emitted prefix, list cursors
+    float last = s0.lastpower;
+    for (int m0 = 0; m0 < nb; m0 += 64) {
+        const int m = m0 + lane;
+        const bool in = m < nb;
+        float pw = in ? pcol[(size_t)m * ncells] : 1.0f;
+        if (pw == 0.0f) pw = FLT_MIN;                                       // :293-294
+        float pv = __shfl_up(pw, 1, 64);
+        if (lane == 0) pv = last;
+        const unsigned long long U = __ballot(in && pw / pv >= thr), D = __ballot(in && pv / pw >= thr);   // :296, :299
+        const int nin = nb - m0 < 64 ? nb - m0 : 64;
+        last = __shfl(pw, nin - 1, 64);
+        // toggles: walk the changes
+        unsigned long long T = 0;
+        {
+            int sa = active, pos = 0;
+            while (pos < 64) {
+                const unsigned long long c = (sa ? D : U) & ~mask_lt(pos);
+                if (!c) break;
+                const int t = __builtin_ctzll(c);
+                T |= 1ull << t; sa ^= 1; pos = t + 1;
             }
-            upw[w0 >> 5][lane] = u; dnw[w0 >> 5][lane] = d;
         }
-        // (2) work() loop
-        for (int mm = 0; mm < mc; mm++) {
-            const int m = m0 + mm;
-            const unsigned u = (upw[mm >> 5][lane] >> (mm & 31)) & 1u, d = (dnw[mm >> 5][lane] >> (mm & 31)) & 1u;
-            const bool rise = valid && !s.active && u, fall = valid && s.active && d;
-            const bool proc = valid && (s.active || rise);                  // this block is extracted
-            const unsigned long long b1 = __ballot(proc), b2 = __ballot(rise);
-            if (b1) {
-                const int pos = tcur + __popcll(b1 & lt) + __popcll(b2 & lt);
-                if (rise) {                                                 // activate(), :198-210: previous and current block
-                    s.part = 0; s.count = 0; s.active = 1; s.phase = 0; s.id_at_act = s.finished; s.act_time = now;
-                    tl[pos] = SinkTask{i, q, m, g.extract_start, g.win_off, g.cls};                      // slot m = the block before
-                    const int ph1 = g.deltaphase % R;
-                    tl[pos + 1] = SinkTask{i, q + 1, m + 1, g.extract_start, g.win_off + ph1 * g.width, g.cls};
-                    q += 2; s.count = 2; s.phase = (ph1 + g.deltaphase) % R;
-                } else if (proc) {                                          // process_channel(), :260-284
-                    tl[pos] = SinkTask{i, q, m + 1, g.extract_start, g.win_off + s.phase * g.width, g.cls};
-                    q += 1; s.count += 1; s.phase = (s.phase + g.deltaphase) % R;
-                }
-                tcur += __popcll(b1) + __popcll(b2);
+        const unsigned long long lt = mask_lt(lane);
+        const bool before = (active ^ (__popcll(T & lt) & 1)) != 0;          // state when block m arrives
+        const bool tog = (T >> lane) & 1ull;
+        const bool rise = in && tog && !before, fall = in && tog && before, proc = in && (before || rise);
+        const unsigned long long RISE = __ballot(rise), FALL = __ballot(fall), PROC = __ballot(proc);
+        // the run this block belongs to: activated at block a of this chunk (rises and falls alternate, so that is the case
+        // when the last rise at or below m is later than the last fall below m), or alive since before the chunk — then
+        // nothing has toggled below m, and every block of the chunk so far was processed
+        const int a = last_bit_below(RISE, lane + 1), lf = last_bit_below(FALL, lane);
+        const bool mine = a >= 0 && a > lf;
+        const int cnt = mine ? lane - a + 2 : count + lane + 1;             // count after this block is processed
+        const int qpos = q + __popcll(PROC & lt) + __popcll(RISE & lt);      // stream position of this block's (first) extraction
+        if (proc) {
+            const int pos = tcur + __popcll(PROC & lt) + __popcll(RISE & lt);
+            if (rise) {                                                      // activate(), :198-210: previous and current block
+                tl[pos] = SinkTask{i, qpos, m, g.extract_start, g.win_off, g.cls};
+                tl[pos + 1] = SinkTask{i, qpos + 1, m + 1, g.extract_start, g.win_off + dph * g.width, g.cls};
+            } else {                                                         // process_channel(), :260-284: phase = (count - 1) deltaphase
+                tl[pos] = SinkTask{i, qpos, m + 1, g.extract_start, g.win_off + (((cnt - 1) * dph) & rm) * g.width, g.cls};
             }
-            const bool part = proc && !rise && !fall && (mb == 0 || (mb > 0 && s.count % mb == 0));      // :163-165
-            const bool emit = fall || part;
-            const unsigned long long be = __ballot(emit);
-            if (be) {
-                if (emit) {                                                 // emit_data(), :212-258
-                    SinkPdu r{};
-                    r.key = ((long long)m << 24) | i;
-                    r.blockstart = bc0 + m - s.count; r.blockend = bc0 + m; r.act_time = s.act_time;
-                    r.owner = i; r.q0 = E; r.q1 = q; r.len = g.out_len;
-                    r.kind = 0; r.source = g.id; r.chan_id = s.id_at_act; r.fin = fall ? 1 : 0; r.part = s.part; r.has_part = 1;
-                    r.vstart = g.extract_start; r.vend = g.extract_start + g.width; r.width = g.width;
-                    pl[pcur + __popcll(be & lt)] = r;
-                    E = q; s.part += 1;
-                    if (fall) { s.active = 0; s.finished += 1; }            // deactivate(), :189-196
-                }
-                pcur += __popcll(be);
+        }
+        const bool part = proc && !rise && !fall && (mb == 0 || (mb > 0 && cnt % mb == 0));
+        const bool emit = fall || part;
+        const unsigned long long EM = __ballot(emit);
+        if (emit) {                                                          // emit_data(), :212-258
+            const int pe = last_bit_below(EM, lane);                         // the emission before this one flushed everything up to there
+            const int q0 = pe >= 0 ? q + __popcll(PROC & mask_lt(pe + 1)) + __popcll(RISE & mask_lt(pe + 1)) : E;
+            SinkPdu r;
+            r.key = ((long long)m << 24) | i; r.act_time = mine ? now : act_time; r.off = 0;
+            r.owner = i; r.q0 = q0; r.q1 = qpos + 1; r.count = cnt;
+            r.chan_id = mine ? finished + __popcll(FALL & mask_lt(a)) : id_at;
+            r.part = emissions_before(cnt, mb);
+            r.flags = fall ? 1 : 0; r.vstart = g.extract_start;
+            pl[pcur + __popcll(EM & lt)] = r;
+        }
+        // carry the chunk's end state on
+        {
+            const int nproc = __popcll(PROC) + __popcll(RISE);
+            const int le_ = EM ? 63 - __clzll((long long)EM) : -1;            // last emission of the chunk
+            if (le_ >= 0) E = q + __popcll(PROC & mask_lt(le_ + 1)) + __popcll(RISE & mask_lt(le_ + 1));
+            q += nproc; tcur += nproc; pcur += __popcll(EM);
+            const int lr = RISE ? 63 - __clzll((long long)RISE) : -1;
+            const int act_end = active ^ (__popcll(T) & 1);
+            if (act_end) {                                                   // (count / id of a finished run do not matter any more)
+                if (lr >= 0) { count = nin - 1 - lr + 2; id_at = finished + __popcll(FALL & mask_lt(lr)); act_time = now; }
+                else count += nin;
             }
+            finished += __popcll(FALL);
+            active = act_end;
         }
     }
-    if (valid) {
-        s.lastpower = prev;
+    if (lane == 0) {
+        PacState s = s0;
+        s.lastpower = last; s.active = active; s.count = count; s.finished = finished; s.id_at_act = id_at; s.act_time = act_time;
+        s.phase = (count * dph) & rm; s.part = 0;
         SinkOwner o{};
-        o.len = g.out_len; o.carried = carried; o.emitted = E; o.total = q; o.prev_off = s.tail_off;
+        o.len = g.out_len; o.cls = g.cls; o.carried = s0.tail; o.emitted = E; o.total = q; o.prev_off = s0.tail_off;
         owners[i] = o;
         st[i] = s;                                     // tail / tail_off follow in k_sink_layout
+        ntask[i] = tcur; npdu[i] = pcur;
     }
-    if (lane == 0) { ntask[wv] = tcur; npdu[wv] = pcur; }
 }
 
 hipError_t launch_pac_decide(const float *power, int ncells, int nb, const PacGeom *geom, PacState *st, int npac, float thr,
@@ -122,7 +151,7 @@ hipError_t launch_pac_decide(const float *power, int ncells, int nb, const PacGe
                              SinkOwner *owners, hipStream_t s)
 {
     if (npac <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pac_decide, dim3((unsigned)((npac + 63) / 64)), dim3(64), 0, s, power, ncells, nb, geom, st, npac, thr,
+    hipLaunchKernelGGL(k_pac_decide, dim3((unsigned)npac), dim3(64), 0, s, power, ncells, nb, geom, st, npac, thr,
                        maxblocks, R, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners);
     return hipGetLastError();
 }
@@ -204,8 +233,10 @@ hipError_t launch_det_cands(const float *power, int ncells, int nb, const DetGeo
 // ---------------------------------------------------------------- detection, phase 2
 // match_active_channels() + activation (…vcm_impl.cc:741-841), extract_channels_in_segments_singlethread() (:306-337) and
 // clear_inactive_channels() (:512-524) for one segment: a loop over the blocks, lanes = live channels (chunks of 64).
+constexpr int kDetStage = 32;        // blocks whose candidate lists are staged in LDS at a time (first 64 candidates of each)
 constexpr int kDetLds = (int)(sizeof(int) * kDetFields * kDetMaxCells + sizeof(long long) * kDetMaxCells + sizeof(int) * 4 * kDetMaxCells +
-                              sizeof(int) * (kDetMaxCells / 2 + 2) + sizeof(int2) * (kDetMaxCells / 2 + 2));
+                              sizeof(int) * (kDetMaxCells / 2 + 2) + sizeof(int2) * (kDetMaxCells / 2 + 2) +
+                              sizeof(int2) * kDetStage * 64 + sizeof(int) * (kDetStage + 32));
 static_assert(kDetLds <= 160 * 1024, "LDS budget of the detection tracker");
 __device__ __forceinline__ int pow2ceil_dev(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 
@@ -226,9 +257,12 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
     int *oE = reinterpret_cast<int *>(oP + kDetMaxCells), *oQ = oE + kDetMaxCells, *oC = oQ + kDetMaxCells;  // emitted, total, carried
     int *hit = oC + kDetMaxCells, *claimed = hit + kDetMaxCells;
     int2 *cd = reinterpret_cast<int2 *>(claimed + kDetMaxCells / 2 + 2);
+    int2 *stc = cd + kDetMaxCells / 2 + 2;                                   // [kDetStage][64]: staged candidates
+    int *stk = reinterpret_cast<int *>(stc + kDetStage * 64);                // [kDetStage]: staged candidate counts
+    int *wofs = stk + kDetStage;                                             // [32]: window table offsets per width class
     const int lane = threadIdx.x, sg = blockIdx.x;
     const DetGeom g = geom[sg];
-    const int lst = dp.npac ? (dp.npac + 63) / 64 + sg : sg;               // list index of this segment
+    const int lst = dp.npac + sg;                                           // list index of this segment
     SinkTask *const tl = tasks + task_base[lst];
     SinkPdu *const pl = pdus + pdu_base[lst];
     SinkOwner *const ow = owners + owner_base[sg];
@@ -236,21 +270,194 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
     int32_t *const Lg = live_g + (size_t)sg * kDetFields * kDetMaxCells;
     int64_t *const Og = live_off_g + (size_t)sg * kDetMaxCells;
     const unsigned long long lt = lanemask_lt();
+    const int rm = dp.R - 1;
     int nlive = sst[sg].nlive, counter = sst[sg].counter;
     for (int c = lane; c < nlive; c += 64) {
         for (int f = 0; f < kDetFields; f++) L[f][c] = Lg[f * kDetMaxCells + c];
         oE[c] = 0; oQ[c] = oC[c] = L[DC_TAIL][c]; oP[c] = Og[c];
         L[DC_OWNER][c] = c;                                                 // owners of the channels alive at the start: 0 .. nlive-1
     }
+    if (lane < 32) wofs[lane] = win_off[lane];
     int nown = nlive, tcur = 0, pcur = 0, err = 0;
     __syncthreads();
-    const int segname = (dp.variant == 1 && dp.segname0 >= 0 && dp.nseg == 1) ? dp.segname0 : g.id;
+    // Up to 64 live channels and 64 candidates — the normal case — a block is worked on from registers: lane c holds live
+    // channel c, lane j candidate j.  The list in LDS stays the master copy of what never changes about a channel (it is where
+    // channels are appended and compacted); count, phase, inactivity, part and the stream counters live in the registers until a
+    // compaction or the general code (more than 64 of either) needs them back.
+    const int32_t *const kc = ncand + (size_t)sg * dp.nbmax;
+    const int2 *const cbase = cand + cand_base[sg];
+    int rDS = 0, rDE = 0, rES = 0, rCLS = 0, rCNT = 0, rPH = 0, rPI = 0, rIN = 0, rPART = 0, rOWN = 0, rE = 0, rQ = 0, rID = 0, rTL = 0, rTH = 0,
+        rWO = 0;
+    bool regs = false;
+    auto load_static = [&]() {
+        rDS = L[DC_DSTART][lane]; rDE = L[DC_DSTOP][lane]; rES = L[DC_ESTART][lane]; rCLS = L[DC_CLS][lane]; rPI = L[DC_PINC][lane];
+        rOWN = L[DC_OWNER][lane]; rID = L[DC_ID][lane]; rTL = L[DC_TIME_LO][lane]; rTH = L[DC_TIME_HI][lane]; rWO = wofs[rCLS];
+    };
+    auto load_regs = [&]() {
+        if (lane < nlive) {
+            load_static();
+            rCNT = L[DC_COUNT][lane]; rPH = L[DC_PHASE][lane]; rIN = L[DC_INACT][lane]; rPART = L[DC_PART][lane]; rE = oE[lane]; rQ = oQ[lane];
+        }
+        regs = true;
+    };
+    auto spill_regs = [&]() {
+        if (regs && lane < nlive) {
+            L[DC_COUNT][lane] = rCNT; L[DC_PHASE][lane] = rPH; L[DC_INACT][lane] = rIN; L[DC_PART][lane] = rPART; oE[lane] = rE; oQ[lane] = rQ;
+        }
+        regs = false;
+    };
+    auto mkpdu = [&](int m, int idx, int own, int q0, int q1, int cnt, int id, int part, bool fin, int cls, int es, int tlo, int thi) {
+        SinkPdu r;
+        r.key = ((long long)m << 24) | (1ll << 23) | ((long long)sg << 12) | idx;
+        r.act_time = ((long long)thi << 32) | (unsigned)tlo; r.off = 0;
+        r.owner = ow0 + own; r.q0 = q0; r.q1 = q1; r.count = cnt; r.chan_id = id; r.part = part;
+        r.flags = (fin ? 1 : 0) | (cls << 8) | (1 << 16); r.vstart = es;
+        return r;
+    };
+    // geometry of a new channel from a candidate (:785-841); false = skipped (wider than the block, or no window table)
+    auto new_geom = [&](int2 pc, int &es, int &cls) {
+        const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
+        const int ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
+        if (ew > dp.N) return false;
+        cls = 31 - __clz(ew);
+        if (wofs[cls] < 0) return false;
+        es = mid - ew / 2;
+        int ee = mid + ew / 2;
+        if (es < 0) { es = 0; ee = ew; }
+        if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
+        return true;
+    };
+    auto append = [&](int c, int id, int2 pc, int es, int cls, int own) {       // a new entry of the list in LDS
+        L[DC_ID][c] = id; L[DC_DSTART][c] = pc.x; L[DC_DSTOP][c] = pc.y; L[DC_ESTART][c] = es; L[DC_CLS][c] = cls;
+        L[DC_COUNT][c] = 0; L[DC_PHASE][c] = 0; L[DC_PINC][c] = es & rm; L[DC_INACT][c] = -1; L[DC_PART][c] = 0;
+        L[DC_OWNER][c] = own; L[DC_TAIL][c] = 0;
+        L[DC_TIME_LO][c] = (int)(unsigned)(now & 0xFFFFFFFFll); L[DC_TIME_HI][c] = (int)(now >> 32);
+        oE[c] = 0; oQ[c] = 0; oC[c] = 0; oP[c] = 0;
+    };
+    // One channel's share of extract_channels_in_segments_singlethread() (:306-337) in pass `pass` (SegmentDetection emits the
+    // partial PDUs in a pass of its own, :359-362); every lane of the wave calls it.  Returns the lanes that finalised.
+    auto step = [&](int m, int pass, int c, bool in, int &cnt, int &ph, int &inact, int &part, int &E, int &Q, int cls, int es, int own,
+                    int pinc, int id, int tlo, int thi, int wo) -> unsigned long long {
+        const int ew = 1 << cls;
+        bool isnew = false, fin = false, proc = false;
+        if (pass == 0) { isnew = in && inact < 0; fin = in && !isnew && inact > dp.delay; proc = in && !isnew && !fin; }
+        const unsigned long long b1 = __ballot(isnew || proc), b2 = __ballot(isnew);
+        if (b1) {
+            const int pos = tcur + __popcll(b1 & lt) + __popcll(b2 & lt);
+            if (isnew) {                                                    // process_channel_hist(), :399-403
+                tl[pos] = SinkTask{ow0 + own, Q, m, es, wo, cls};
+                tl[pos + 1] = SinkTask{ow0 + own, Q + 1, m + 1, es, wo + pinc * ew, cls};
+                Q += 2; cnt = 2; ph = (2 * pinc) & rm; inact = 0;
+            } else if (proc) {                                              // process_channel(), :373-397
+                tl[pos] = SinkTask{ow0 + own, Q, m + 1, es, wo + ph * ew, cls};
+                Q += 1; cnt += 1; ph = (ph + pinc) & rm;
+            }
+            tcur += __popcll(b1) + __popcll(b2);
+        }
+        // partial emission: inline behind the channel in the vcm block (:317-318), a pass of its own in SegmentDetection
+        const bool pcheck = in && dp.maxblocks >= 0 && (dp.variant == 1 ? pass == 1 : true) && !fin;
+        int ntx = 0;
+        if (pcheck && Q - E >= dp.maxblocks) ntx = dp.maxblocks == 0 ? Q - E : dp.maxblocks;
+        const bool prt = ntx > 0;
+        const unsigned long long bf = __ballot(fin), bp = __ballot(prt);
+        if (bf | bp) {
+            if (fin || prt) {
+                const int idx = dp.variant == 1 ? (pass == 0 ? c : nlive + c) : 2 * c + (prt ? 1 : 0);
+                const int q1 = fin ? Q : E + ntx;
+                pl[pcur + __popcll(bf & lt) + __popcll(bp & lt)] =           // a lane emits at most one of the two in a pass
+                    mkpdu(m, idx, own, E, q1, cnt, id, part, fin, cls, es, tlo, thi);
+                E = q1;
+                if (prt) part += 1;
+            }
+            pcur += __popcll(bf) + __popcll(bp);
+        }
+        return bf;
+    };
+    // clear_inactive_channels(), :512-524, on the list in LDS (everything spilled): finalised channels leave their stream record
+    auto compact = [&]() {
+        int keep = 0;
+        for (int c0 = 0; c0 < nlive; c0 += 64) {
+            const int c = c0 + lane;
+            const bool in = c < nlive;
+            const bool gone = in && L[DC_INACT][c] > dp.delay;
+            int v[kDetFields], e = 0, qq = 0, cc = 0;
+            long long pp = 0;
+            if (in) {
+#pragma unroll
+                for (int f = 0; f < kDetFields; f++) v[f] = L[f][c];
+                e = oE[c]; qq = oQ[c]; cc = oC[c]; pp = oP[c];
+            }
+            if (gone) {
+                SinkOwner o{};
+                o.len = (1 << v[DC_CLS]) - (1 << v[DC_CLS]) / dp.R; o.cls = v[DC_CLS]; o.carried = cc; o.emitted = e; o.total = qq; o.prev_off = pp;
+                ow[v[DC_OWNER]] = o;
+            }
+            const unsigned long long bk = __ballot(in && !gone);
+            __syncthreads();
+            if (in && !gone) {
+                const int d = keep + __popcll(bk & lt);
+#pragma unroll
+                for (int f = 0; f < kDetFields; f++) L[f][d] = v[f];
+                oE[d] = e; oQ[d] = qq; oC[d] = cc; oP[d] = pp;
+            }
+            keep += __popcll(bk);
+            __syncthreads();
+        }
+        nlive = keep;
+    };
     for (int m = 0; m < nb; m++) {
-        const int k = ncand[(size_t)sg * dp.nbmax + m];
+        if ((m & (kDetStage - 1)) == 0) {                                   // candidate lists of the next kDetStage blocks -> LDS
+            const int nst = nb - m < kDetStage ? nb - m : kDetStage;
+            __syncthreads();
+            if (lane < nst) stk[lane] = kc[m + lane];
+            const int cc = g.cand_cap < 64 ? g.cand_cap : 64;
+            for (int t = 0; t < nst; t++) if (lane < cc) stc[t * 64 + lane] = cbase[(size_t)(m + t) * g.cand_cap + lane];
+            __syncthreads();
+        }
+        const int k = stk[m & (kDetStage - 1)];
+        if (nlive <= 64 && k <= 64) {
+            const int2 cme = stc[(m & (kDetStage - 1)) * 64 + lane];
+            if (!regs) load_regs();
+            bool clm = false;
+            unsigned long long hitm = 0;
+            if (k) {
+                for (int c = 0; c < nlive; c++) {                           // channel c takes every candidate it overlaps (:757-766)
+                    const int ds = __builtin_amdgcn_readlane(rDS, c), de = __builtin_amdgcn_readlane(rDE, c);
+                    const bool ov = lane < k && !clm && cme.x < de && cme.y >= ds;
+                    if (__ballot(ov)) { hitm |= 1ull << c; clm = clm || ov; }
+                }
+            }
+            int nes = 0, ncls = 0;
+            const bool ok = lane < k && !clm && new_geom(cme, nes, ncls);   // what is left becomes new channels, in candidate order
+            const unsigned long long bo = __ballot(ok);
+            const int nnew = __popcll(bo);
+            if (nlive + nnew <= 64) {
+                if (lane < nlive) rIN = (k != 0 && ((hitm >> lane) & 1ull)) ? 0 : rIN + 1;      // :748-752, :768-771
+                if (nnew) {
+                    const int r = __popcll(bo & lt);
+                    if (ok) append(nlive + r, counter + r, cme, nes, ncls, nown + r);
+                    __syncthreads();
+                    if (lane >= nlive && lane < nlive + nnew) { load_static(); rCNT = 0; rPH = 0; rIN = -1; rPART = 0; rE = 0; rQ = 0; }
+                    nlive += nnew; counter += nnew; nown += nnew;
+                }
+                unsigned long long anyfin = 0;
+                for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
+                    anyfin |= step(m, pass, lane, lane < nlive, rCNT, rPH, rIN, rPART, rE, rQ, rCLS, rES, rOWN, rPI, rID, rTL, rTH, rWO);
+                if (anyfin) {
+                    spill_regs();
+                    __syncthreads();
+                    compact();
+                }
+                continue;
+            }
+        }
+        // ---- general form: any number of channels and candidates, the list in LDS
+        spill_regs();
+        __syncthreads();
         if (k == 0) {                                                       // :748-752
             for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] += 1;
         } else {
-            const int2 *cs = cand + cand_base[sg] + (size_t)m * g.cand_cap;
+            const int2 *cs = cbase + (size_t)m * g.cand_cap;
             for (int j = lane; j < k; j += 64) { cd[j] = cs[j]; claimed[j] = 0; }
             for (int c = lane; c < nlive; c += 64) hit[c] = 0;
             __syncthreads();
@@ -268,138 +475,38 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
             }
             __syncthreads();
             for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] = hit[c] ? 0 : L[DC_INACT][c] + 1;
-            // what is left becomes new channels, in candidate order (:785-841)
-            for (int j0 = 0; j0 < k; j0 += 64) {
+            for (int j0 = 0; j0 < k; j0 += 64) {                            // new channels, in candidate order (:785-841)
                 const int j = j0 + lane;
-                bool ok = false;
-                int ew = 0, es = 0, cls = 0;
+                int es = 0, cls = 0;
                 int2 pc = make_int2(0, 0);
-                if (j < k && !claimed[j]) {
-                    pc = cd[j];
-                    const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
-                    ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
-                    if (ew <= dp.N) {
-                        cls = 31 - __clz(ew);
-                        if (win_off[cls] >= 0) {
-                            ok = true;
-                            es = mid - ew / 2;
-                            int ee = mid + ew / 2;
-                            if (es < 0) { es = 0; ee = ew; }
-                            if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
-                        }
-                    }
-                }
+                bool ok = false;
+                if (j < k && !claimed[j]) { pc = cd[j]; ok = new_geom(pc, es, cls); }
                 const unsigned long long bo = __ballot(ok);
                 const int nnew = __popcll(bo);
                 if (nlive + nnew > kDetMaxCells) { err = 1; break; }
-                if (ok) {
-                    const int r = __popcll(bo & lt), c = nlive + r;
-                    L[DC_ID][c] = counter + r; L[DC_DSTART][c] = pc.x; L[DC_DSTOP][c] = pc.y; L[DC_ESTART][c] = es; L[DC_CLS][c] = cls;
-                    L[DC_COUNT][c] = 0; L[DC_PHASE][c] = 0; L[DC_PINC][c] = es % dp.R; L[DC_INACT][c] = -1; L[DC_PART][c] = 0;
-                    L[DC_OWNER][c] = nown + r; L[DC_TAIL][c] = 0;
-                    L[DC_TIME_LO][c] = (int)(unsigned)(now & 0xFFFFFFFFll); L[DC_TIME_HI][c] = (int)(now >> 32);
-                    oE[c] = 0; oQ[c] = 0; oC[c] = 0; oP[c] = 0;
-                }
+                if (ok) { const int r = __popcll(bo & lt); append(nlive + r, counter + r, pc, es, cls, nown + r); }
                 nlive += nnew; counter += nnew; nown += nnew;
             }
             if (err) break;
             __syncthreads();
         }
-        // extract_channels_in_segments_singlethread(), :306-337.  The block counter of the dictionaries: vcm counts from 1
-        // (…vcm_impl.cc:188), SegmentDetection from 0 (SegmentDetection_impl.cc:118)
-        const long long bc = bc0 + m - (dp.variant == 1 ? 1 : 0);
-        bool anyfin = false;
+        unsigned long long anyfin = 0;
         for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
             for (int c0 = 0; c0 < nlive; c0 += 64) {
-                const int c = c0 + lane;
-                const bool in = c < nlive;
-                int inact = in ? L[DC_INACT][c] : 0;
-                bool isnew = false, fin = false, proc = false;
-                if (pass == 0) { isnew = in && inact < 0; fin = in && !isnew && inact > dp.delay; proc = in && !isnew && !fin; }
-                const unsigned long long b1 = __ballot(isnew || proc), b2 = __ballot(isnew);
-                int E = in ? oE[c] : 0, Q = in ? oQ[c] : 0;
-                const int cls = in ? L[DC_CLS][c] : 0, ew = 1 << cls, es = in ? L[DC_ESTART][c] : 0;
-                const int own = in ? L[DC_OWNER][c] : 0;
-                if (b1) {
-                    const int pos = tcur + __popcll(b1 & lt) + __popcll(b2 & lt);
-                    const int wo = win_off[cls];
-                    if (isnew) {                                            // process_channel_hist(), :399-403
-                        const int pinc = L[DC_PINC][c];
-                        tl[pos] = SinkTask{ow0 + own, Q, m, es, wo, cls};
-                        tl[pos + 1] = SinkTask{ow0 + own, Q + 1, m + 1, es, wo + (pinc % dp.R) * ew, cls};
-                        Q += 2; L[DC_COUNT][c] = 2; L[DC_PHASE][c] = (2 * pinc) % dp.R; L[DC_INACT][c] = 0; inact = 0;
-                    } else if (proc) {                                      // process_channel(), :373-397
-                        const int ph = L[DC_PHASE][c];
-                        tl[pos] = SinkTask{ow0 + own, Q, m + 1, es, wo + ph * ew, cls};
-                        Q += 1; L[DC_COUNT][c] += 1; L[DC_PHASE][c] = (ph + L[DC_PINC][c]) % dp.R;
-                    }
-                    tcur += __popcll(b1) + __popcll(b2);
-                }
-                // partial emission: inline behind the channel in the vcm block (:317-318), a pass of its own in SegmentDetection (:359-362)
-                const bool pcheck = in && dp.maxblocks >= 0 && (dp.variant == 1 ? pass == 1 : true) && !fin;
-                int ntx = 0;
-                if (pcheck && Q - E >= dp.maxblocks) ntx = dp.maxblocks == 0 ? Q - E : dp.maxblocks;
-                const bool part = ntx > 0;
-                const unsigned long long bf = __ballot(fin), bp = __ballot(part);
-                if (bf | bp) {
-                    if (fin || part) {
-                        SinkPdu r{};
-                        const int idx = dp.variant == 1 ? (pass == 0 ? c : nlive + c) : 2 * c + (part ? 1 : 0);
-                        r.key = ((long long)m << 24) | (1ll << 23) | ((long long)sg << 12) | idx;
-                        const int cnt = L[DC_COUNT][c];
-                        r.blockstart = bc - cnt; r.blockend = bc;
-                        r.act_time = ((long long)L[DC_TIME_HI][c] << 32) | (unsigned)L[DC_TIME_LO][c];
-                        r.owner = ow0 + own; r.q0 = E; r.q1 = fin ? Q : E + ntx; r.len = ew - ew / dp.R;
-                        r.kind = 1; r.source = segname; r.chan_id = L[DC_ID][c]; r.fin = fin ? 1 : 0; r.part = L[DC_PART][c];
-                        r.has_part = fin ? (r.part > 0) : 1;
-                        r.vstart = es; r.vend = es + ew; r.width = ew;
-                        pl[pcur + __popcll(bf & lt) + __popcll(bp & lt)] = r;    // a lane emits at most one of the two in a pass
-                        E = r.q1;
-                        if (part) L[DC_PART][c] += 1;
-                    }
-                    pcur += __popcll(bf) + __popcll(bp);
-                    anyfin = anyfin || bf != 0;
-                }
-                if (in) { oE[c] = E; oQ[c] = Q; }
+                const int c = c0 + lane, cc = c < kDetMaxCells ? c : kDetMaxCells - 1;
+                const int cls = L[DC_CLS][cc] & 31;
+                anyfin |= step(m, pass, c, c < nlive, L[DC_COUNT][cc], L[DC_PHASE][cc], L[DC_INACT][cc], L[DC_PART][cc], oE[cc], oQ[cc], cls,
+                               L[DC_ESTART][cc], L[DC_OWNER][cc], L[DC_PINC][cc], L[DC_ID][cc], L[DC_TIME_LO][cc], L[DC_TIME_HI][cc], wofs[cls]);
             }
         __syncthreads();
-        if (anyfin) {                                                       // clear_inactive_channels(), :512-524
-            int keep = 0;
-            for (int c0 = 0; c0 < nlive; c0 += 64) {
-                const int c = c0 + lane;
-                const bool in = c < nlive;
-                const bool gone = in && L[DC_INACT][c] > dp.delay;
-                int v[kDetFields], e = 0, qq = 0, cc = 0;
-                long long pp = 0;
-                if (in) {
-#pragma unroll
-                    for (int f = 0; f < kDetFields; f++) v[f] = L[f][c];
-                    e = oE[c]; qq = oQ[c]; cc = oC[c]; pp = oP[c];
-                }
-                if (gone) {
-                    SinkOwner o{};
-                    o.len = (1 << v[DC_CLS]) - (1 << v[DC_CLS]) / dp.R; o.carried = cc; o.emitted = e; o.total = qq; o.prev_off = pp;
-                    ow[v[DC_OWNER]] = o;
-                }
-                const unsigned long long bk = __ballot(in && !gone);
-                __syncthreads();
-                if (in && !gone) {
-                    const int d = keep + __popcll(bk & lt);
-#pragma unroll
-                    for (int f = 0; f < kDetFields; f++) L[f][d] = v[f];
-                    oE[d] = e; oQ[d] = qq; oC[d] = cc; oP[d] = pp;
-                }
-                keep += __popcll(bk);
-                __syncthreads();
-            }
-            nlive = keep;
-        }
+        if (anyfin) compact();
     }
+    spill_regs();
     __syncthreads();
     for (int c = lane; c < nlive; c += 64) {
         SinkOwner o{};
         const int cls = L[DC_CLS][c];
-        o.len = (1 << cls) - (1 << cls) / dp.R; o.carried = oC[c]; o.emitted = oE[c]; o.total = oQ[c]; o.prev_off = oP[c];
+        o.len = (1 << cls) - (1 << cls) / dp.R; o.cls = cls; o.carried = oC[c]; o.emitted = oE[c]; o.total = oQ[c]; o.prev_off = oP[c];
         ow[L[DC_OWNER][c]] = o;
         for (int f = 0; f < kDetFields; f++) Lg[f * kDetMaxCells + c] = L[f][c];
     }
@@ -455,6 +562,7 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
     __shared__ int hist[32];
     const int tid = threadIdx.x;
     if (tid < 32) hist[tid] = 0;
+    __syncthreads();
     long long accA = 0, accB = 0;
     int total_owner = 0;
     for (int rg = 0; rg <= nseg; rg++) {
@@ -464,7 +572,11 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
         for (int c0 = 0; c0 < cnt; c0 += 1024) {
             const int c = c0 + tid;
             long long a = 0, b = 0;
-            if (c < cnt) { const SinkOwner o = owners[o0 + c]; a = (long long)o.emitted * o.len; b = (long long)(o.total - o.emitted) * o.len; }
+            if (c < cnt) {
+                const SinkOwner o = owners[o0 + c];
+                a = (long long)o.emitted * o.len; b = (long long)(o.total - o.emitted) * o.len;
+                if (o.total > o.carried) atomicAdd(&hist[o.cls & 31], o.total - o.carried);     // extractions of the call, per width class
+            }
             long long ta, tb;
             const long long ea = block_exscan(a, &ta, sh);
             const long long eb = block_exscan(b, &tb, sh);
@@ -493,25 +605,32 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
             live_off[(size_t)sg * kDetMaxCells + c] = o.b_off;
         }
     }
-    // tasks per width class
-    int nt = 0;
-    for (int l = 0; l < nlist; l++) {
-        const int n = ntask[l];
-        nt += n;
-        const SinkTask *t = tasks + task_base[l];
-        for (int k = tid; k < n; k += 1024) atomicAdd(&hist[t[k].cls], 1);
-    }
-    // emission records, compacted; payload offsets
-    int np = 0;
-    for (int l = 0; l < nlist; l++) {
-        const int n = npdu[l];
-        const SinkPdu *p = pdus + pdu_base[l];
-        for (int k = tid; k < n; k += 1024) {
-            SinkPdu r = p[k];
-            r.off = owners[r.owner].a_off + (long long)r.q0 * r.len;
-            pdus_out[np + k] = r;
+    // emission records, compacted (list after list; the waves of the workgroup take lists in turn); payload offsets
+    __shared__ int lbase[1024];
+    int nt = 0, np = 0;
+    for (int l0 = 0; l0 < nlist; l0 += 1024) {
+        const int l = l0 + tid;
+        const int n = l < nlist ? npdu[l] : 0;
+        long long tot;
+        const long long ex = block_exscan((long long)n, &tot, sh);
+        lbase[tid] = np + (int)ex;
+        long long tt;
+        (void)block_exscan((long long)(l < nlist ? ntask[l] : 0), &tt, sh);
+        nt += (int)tt;
+        __syncthreads();
+        const int wv = tid >> 6, ln = tid & 63, lim = nlist - l0 < 1024 ? nlist - l0 : 1024;
+        for (int ll = wv; ll < lim; ll += 16) {
+            const int nn = npdu[l0 + ll], b0 = lbase[ll];
+            const SinkPdu *p = pdus + pdu_base[l0 + ll];
+            for (int k = ln; k < nn; k += 64) {
+                SinkPdu r = p[k];
+                const SinkOwner o = owners[r.owner];
+                r.off = o.a_off + (long long)r.q0 * o.len;
+                pdus_out[b0 + k] = r;
+            }
         }
-        np += n;
+        np += (int)tot;
+        __syncthreads();
     }
     __syncthreads();
     if (tid < 32) { sum->class_cnt[tid] = hist[tid]; class_fill[tid] = 0; }
@@ -540,13 +659,28 @@ __global__ __launch_bounds__(256) void k_task_scatter(const int64_t *__restrict_
 {
     const int l = blockIdx.y;
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= ntask[l]) return;
-    const SinkTask t = tasks[task_base[l] + k];
+    const bool have = k < ntask[l];
+    SinkTask t{};
+    if (have) t = tasks[task_base[l] + k];
+    // one atomic per wave and width class (a bank of equal channels has one class: a counter per task would serialise)
+    int pos = 0;
+    unsigned long long todo = __ballot(have);
+    const unsigned long long lt = lanemask_lt();
+    while (todo) {
+        const int c0 = __builtin_amdgcn_readlane(t.cls, __builtin_ctzll(todo));
+        const unsigned long long peers = __ballot(have && t.cls == c0) & todo;
+        int base = 0;
+        if ((threadIdx.x & 63) == __builtin_ctzll(peers)) base = atomicAdd(&class_fill[c0], __popcll(peers));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(peers));
+        if (have && t.cls == c0) pos = sum->class_base[c0] + base + __popcll(peers & lt);
+        todo &= ~peers;
+    }
+    if (!have) return;
     const SinkOwner o = owners[t.owner];
     ExtractTask e{};
     e.slot = t.slot; e.start = t.start; e.win_off = t.win_off;
     e.out_off = t.q < o.emitted ? o.a_off + (long long)t.q * o.len : o.b_off + (long long)(t.q - o.emitted) * o.len;
-    sorted[sum->class_base[t.cls] + atomicAdd(&class_fill[t.cls], 1)] = e;
+    sorted[pos] = e;
 }
 
 hipError_t launch_task_scatter(int nlist, const int64_t *task_base, const int32_t *ntask, long long max_list, const SinkTask *tasks,
@@ -560,6 +694,7 @@ hipError_t launch_task_scatter(int nlist, const int64_t *task_base, const int32_
 }
 
 // blocks buffered across the call boundary: from the previous landing buffer to their place in this one
+constexpr int kCarrySplit = 16;     // workgroups per stream (a wide carrier buffers megabytes)
 __global__ __launch_bounds__(256) void k_carry_copy(const SinkOwner *__restrict__ owners, const int64_t *__restrict__ owner_base,
                                                     const int32_t *__restrict__ nowner, int npac, const float2 *__restrict__ prev,
                                                     float2 *__restrict__ cur)
@@ -573,7 +708,7 @@ __global__ __launch_bounds__(256) void k_carry_copy(const SinkOwner *__restrict_
     const float2 *src = prev + o.prev_off;
     float2 *da = cur + o.a_off, *db = cur + o.b_off - (long long)ne * o.len;
     const long long nA = (long long)ne * o.len, n = (long long)o.carried * o.len;
-    for (long long i = threadIdx.x; i < n; i += 256) (i < nA ? da : db)[i] = src[i];
+    for (long long i = (long long)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * kCarrySplit) (i < nA ? da : db)[i] = src[i];
 }
 
 hipError_t launch_carry_copy(const SinkOwner *owners, int nowner_cap, const int64_t *owner_base, const int32_t *nowner, int npac, int nseg,
@@ -581,8 +716,8 @@ hipError_t launch_carry_copy(const SinkOwner *owners, int nowner_cap, const int6
 {
     (void)sum;
     if (nowner_cap <= 0 || !prev) return hipSuccess;
-    hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)nowner_cap, (unsigned)(nseg + 1)), dim3(256), 0, s, owners, owner_base, nowner, npac,
-                       prev, cur);
+    hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)nowner_cap, (unsigned)(nseg + 1), kCarrySplit), dim3(256), 0, s, owners, owner_base,
+                       nowner, npac, prev, cur);
     return hipGetLastError();
 }
 
