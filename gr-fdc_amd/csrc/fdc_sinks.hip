@@ -1134,6 +1134,7 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
         HIPCHK(fdc::launch_det_track(dp, nblocks, d.d_dgeom, d.d_sst, d.d_live, d.d_live_off, d.d_cand, d.d_cand_base, d.d_ncand, d.d_winoff,
                                      bc0, now, d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners,
                                      d.d_owner_base, d.d_nowner, d.d_error, s->stream));
+        HIPCHK(fdc::launch_det_expand(nseg, npac, s->R, d.d_owners, d.d_owner_base, d.d_nowner, d.d_tasks, d.d_task_base, d.d_ntask, s->stream));
     }
     HIPCHK(fdc::launch_sink_layout(d.nlist, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_tasks, d.d_pdus, d.d_pdus_out, d.d_owners,
                                    npac, nseg, d.d_owner_base, d.d_nowner, d.d_pstate, d.d_sst, d.d_live, d.d_live_off, d.d_sum,

@@ -17,7 +17,11 @@ constexpr int kDetMaxCells = 1024;      // power cells per detection segment the
 struct SinkOwner {
     int32_t len;                 // samples per block (output_len / outputsamples)
     int32_t cls;                 // log2 of the extraction width
-    int32_t carried, emitted, total, pad;
+    int32_t carried, emitted, total;
+    // detected channels only: a channel is extracted from every block between its activation and its end, so the
+    // extractions of a call are one run — blocks total - carried of them, the first from spectrum slot `slot0` with window
+    // phase `phase0`, the phase advancing by `pinc` per block; k_det_expand writes the tasks out
+    int32_t slot0, phase0, pinc, estart, win0, pad;
     int64_t prev_off;            // samples, in the previous call's landing buffer
     int64_t a_off, b_off;        // layout of this call (k_sink_layout): emitted prefix / buffered rest, samples in the landing buffer
 };
@@ -90,6 +94,10 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
                             SinkTask *tasks, SinkPdu *pdus, const int64_t *task_base, const int64_t *pdu_base, int32_t *ntask,
                             int32_t *npdu, SinkOwner *owners, const int64_t *owner_base /* [nseg + 1], first = npac */,
                             int32_t *nowner /* [nseg] */, int32_t *error, hipStream_t s);
+
+// extraction tasks of the detected channels of a call, from their stream records (one workgroup per segment)
+hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const int64_t *owner_base, const int32_t *nowner, SinkTask *tasks,
+                             const int64_t *task_base, int32_t *ntask, hipStream_t s);
 
 // layout of the landing buffer, class counts, emission records compacted to `pdus_out`, persistent tail offsets
 hipError_t launch_sink_layout(int nlist, const int64_t *task_base, const int64_t *pdu_base, const int32_t *ntask, const int32_t *npdu,

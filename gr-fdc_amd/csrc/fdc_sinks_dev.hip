@@ -12,6 +12,7 @@
 // kernel places the streams in the landing buffer so that every PDU is one contiguous run and only emitted runs cross PCIe.
 #include "fdc_sinks_dev.h"
 #include <cfloat>
+#include <cstdio>
 
 namespace fdc {
 
@@ -19,6 +20,16 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     return lane ? (~0ull >> (64 - lane)) : 0ull;
+}
+
+// A workgroup of the detection kernels is ONE wave: its LDS operations execute in program order, so making one lane's write
+// visible to another lane needs no s_barrier — and above all not the wait for outstanding global stores that __syncthreads()
+// implies (the task and record stores of a block would be waited for, ~1 us, at every list operation).  What is needed is that
+// the compiler neither reorders nor caches LDS accesses across the point.
+__device__ __forceinline__ void lds_sync()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---------------------------------------------------------------- PowerActivationChannel
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(64) void k_det_cands(const float *__restrict__ powe
         if (isf) fpos[nf + __popcll(bf & lt)] = i * dec + g.start;
         nr += __popcll(br); nf += __popcll(bf);
     }
-    __syncthreads();
+    lds_sync();
     // std::sort by descending ratio (:713); equal ratios keep their order here (rank = elements in front in a stable sort)
     for (int a = lane; a < nr; a += 64) {
         const float ra = rr[a];
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(64) void k_det_cands(const float *__restrict__ powe
         for (int b = 0; b < nr; b++) { const float rb = rr[b]; rank += (rb > ra || (rb == ra && b < a)) ? 1 : 0; }
         spos[rank] = rpos[a];
     }
-    __syncthreads();
+    lds_sync();
     int nc = 0;
     for (int e = 0; e < nr; e++) {
         const int pos = spos[e];
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(64) void k_det_cands(const float *__restrict__ powe
         if (!clash) {
             if (lane == 0) acc[nc] = make_int2(pos, ne);
             nc++;
-            __syncthreads();
+            lds_sync();
         }
     }
     int2 *out = cand + cand_base[sg] + (size_t)m * g.cand_cap;
@@ -230,11 +241,36 @@ hipError_t launch_det_cands(const float *power, int ncells, int nb, const DetGeo
     return hipGetLastError();
 }
 
+__device__ long long block_exscan(long long v, long long *tot, long long *sh /* [1024 / 64] */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __syncthreads();
+    if (lane == 63) sh[wv] = x;
+    __syncthreads();
+    long long base = 0, all = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { if (w < wv) base += sh[w]; all += sh[w]; }
+    *tot = all;
+    return base + x - v;
+}
+
 // ---------------------------------------------------------------- detection, phase 2
 // match_active_channels() + activation (…vcm_impl.cc:741-841), extract_channels_in_segments_singlethread() (:306-337) and
-// clear_inactive_channels() (:512-524) for one segment: a loop over the blocks, lanes = live channels (chunks of 64).
+// clear_inactive_channels() (:512-524) for one segment: a loop over the blocks of the call.
+//
+// This loop is a dependence chain (the list of live channels of block m decides what block m + 1 sees) run by ONE wave, so what
+// counts is the number of instructions per block.  Three things keep it short:
+//  * a live channel is extracted from EVERY block between its activation and its end, so no per-block extraction record is
+//    written here: the channel's stream record says where its run starts, k_det_expand writes the tasks afterwards, in parallel;
+//  * up to 64 live channels and 64 candidates (the normal case) a block is worked on from registers: lane c holds live channel c,
+//    lane j candidate j; candidates x channels are compared as pairs in one step when they fit the wave;
+//  * a workgroup is one wave: LDS needs no barrier (lds_sync), and nothing waits for stores.
+// The list in LDS is the master copy (channels are appended and compacted there); count, inactivity, part and the stream
+// counters live in registers until a compaction or the general form (more than 64 channels or candidates) needs them back.
 constexpr int kDetStage = 32;        // blocks whose candidate lists are staged in LDS at a time (first 64 candidates of each)
-constexpr int kDetLds = (int)(sizeof(int) * kDetFields * kDetMaxCells + sizeof(long long) * kDetMaxCells + sizeof(int) * 4 * kDetMaxCells +
+constexpr int kDetLds = (int)(sizeof(int) * kDetFields * kDetMaxCells + sizeof(long long) * kDetMaxCells + sizeof(int) * 6 * kDetMaxCells +
                               sizeof(int) * (kDetMaxCells / 2 + 2) + sizeof(int2) * (kDetMaxCells / 2 + 2) +
                               sizeof(int2) * kDetStage * 64 + sizeof(int) * (kDetStage + 32));
 static_assert(kDetLds <= 160 * 1024, "LDS budget of the detection tracker");
@@ -248,22 +284,31 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
                                                   const int64_t *__restrict__ task_base, const int64_t *__restrict__ pdu_base,
                                                   int32_t *__restrict__ ntask, int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners,
                                                   const int64_t *__restrict__ owner_base, int32_t *__restrict__ nowner,
-                                                  int32_t *__restrict__ error)
+                                                  int32_t *__restrict__ error, long long *__restrict__ dbg)
 {
+#ifdef FDC_DET_STAMPS
+    long long tS = 0, tM = 0, tX = 0, tC = 0, nG = 0, nC = 0, sK = 0, sL = 0;
+    const long long t00 = __builtin_readcyclecounter();
+#define DSTAMP(v) do { const long long _t = __builtin_readcyclecounter(); v += _t - tlast; tlast = _t; } while (0)
+    long long tlast = t00;
+#else
+#define DSTAMP(v) do { } while (0)
+#endif
     // LDS (dynamic, kDetLds bytes): the live list (DetCol columns), the stream bookkeeping of each live channel, the candidates
     extern __shared__ __attribute__((aligned(16))) unsigned char fdc_det_smem[];
     int (*L)[kDetMaxCells] = reinterpret_cast<int (*)[kDetMaxCells]>(fdc_det_smem);                 // [kDetFields][cap]
     long long *oP = reinterpret_cast<long long *>(fdc_det_smem + sizeof(int) * kDetFields * kDetMaxCells);   // where its carried blocks lie
     int *oE = reinterpret_cast<int *>(oP + kDetMaxCells), *oQ = oE + kDetMaxCells, *oC = oQ + kDetMaxCells;  // emitted, total, carried
-    int *hit = oC + kDetMaxCells, *claimed = hit + kDetMaxCells;
+    int *oS = oC + kDetMaxCells, *oH = oS + kDetMaxCells;                    // first spectrum slot of the call's run, its window phase
+    int *hit = oH + kDetMaxCells, *claimed = hit + kDetMaxCells;
     int2 *cd = reinterpret_cast<int2 *>(claimed + kDetMaxCells / 2 + 2);
     int2 *stc = cd + kDetMaxCells / 2 + 2;                                   // [kDetStage][64]: staged candidates
     int *stk = reinterpret_cast<int *>(stc + kDetStage * 64);                // [kDetStage]: staged candidate counts
     int *wofs = stk + kDetStage;                                             // [32]: window table offsets per width class
+    (void)tasks; (void)task_base; (void)ntask; (void)bc0;
     const int lane = threadIdx.x, sg = blockIdx.x;
     const DetGeom g = geom[sg];
     const int lst = dp.npac + sg;                                           // list index of this segment
-    SinkTask *const tl = tasks + task_base[lst];
     SinkPdu *const pl = pdus + pdu_base[lst];
     SinkOwner *const ow = owners + owner_base[sg];
     const int ow0 = (int)owner_base[sg];
@@ -275,35 +320,31 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
     for (int c = lane; c < nlive; c += 64) {
         for (int f = 0; f < kDetFields; f++) L[f][c] = Lg[f * kDetMaxCells + c];
         oE[c] = 0; oQ[c] = oC[c] = L[DC_TAIL][c]; oP[c] = Og[c];
+        oS[c] = 1; oH[c] = L[DC_PHASE][c];                                  // goes on with the first block of the call (slot 1)
         L[DC_OWNER][c] = c;                                                 // owners of the channels alive at the start: 0 .. nlive-1
     }
     if (lane < 32) wofs[lane] = win_off[lane];
-    int nown = nlive, tcur = 0, pcur = 0, err = 0;
-    __syncthreads();
-    // Up to 64 live channels and 64 candidates — the normal case — a block is worked on from registers: lane c holds live
-    // channel c, lane j candidate j.  The list in LDS stays the master copy of what never changes about a channel (it is where
-    // channels are appended and compacted); count, phase, inactivity, part and the stream counters live in the registers until a
-    // compaction or the general code (more than 64 of either) needs them back.
+    int nown = nlive, pcur = 0, err = 0;
+    lds_sync();
     const int32_t *const kc = ncand + (size_t)sg * dp.nbmax;
     const int2 *const cbase = cand + cand_base[sg];
-    int rDS = 0, rDE = 0, rES = 0, rCLS = 0, rCNT = 0, rPH = 0, rPI = 0, rIN = 0, rPART = 0, rOWN = 0, rE = 0, rQ = 0, rID = 0, rTL = 0, rTH = 0,
-        rWO = 0;
-    bool regs = false;
+    int rDS = 0, rDE = 0, rES = 0, rCLS = 0, rCNT = 0, rIN = 0, rPART = 0, rOWN = 0, rE = 0, rQ = 0, rID = 0, rTL = 0, rTH = 0;
+    bool regs = false, pairs = false;
+    int plw = 0, pc_ = 0, pj_ = 0, pDS = 0, pDE = 0;
+    unsigned long long pstr = 0;
     auto load_static = [&]() {
-        rDS = L[DC_DSTART][lane]; rDE = L[DC_DSTOP][lane]; rES = L[DC_ESTART][lane]; rCLS = L[DC_CLS][lane]; rPI = L[DC_PINC][lane];
-        rOWN = L[DC_OWNER][lane]; rID = L[DC_ID][lane]; rTL = L[DC_TIME_LO][lane]; rTH = L[DC_TIME_HI][lane]; rWO = wofs[rCLS];
+        rDS = L[DC_DSTART][lane]; rDE = L[DC_DSTOP][lane]; rES = L[DC_ESTART][lane]; rCLS = L[DC_CLS][lane];
+        rOWN = L[DC_OWNER][lane]; rID = L[DC_ID][lane]; rTL = L[DC_TIME_LO][lane]; rTH = L[DC_TIME_HI][lane];
     };
     auto load_regs = [&]() {
         if (lane < nlive) {
             load_static();
-            rCNT = L[DC_COUNT][lane]; rPH = L[DC_PHASE][lane]; rIN = L[DC_INACT][lane]; rPART = L[DC_PART][lane]; rE = oE[lane]; rQ = oQ[lane];
+            rCNT = L[DC_COUNT][lane]; rIN = L[DC_INACT][lane]; rPART = L[DC_PART][lane]; rE = oE[lane]; rQ = oQ[lane];
         }
         regs = true;
     };
     auto spill_regs = [&]() {
-        if (regs && lane < nlive) {
-            L[DC_COUNT][lane] = rCNT; L[DC_PHASE][lane] = rPH; L[DC_INACT][lane] = rIN; L[DC_PART][lane] = rPART; oE[lane] = rE; oQ[lane] = rQ;
-        }
+        if (regs && lane < nlive) { L[DC_COUNT][lane] = rCNT; L[DC_INACT][lane] = rIN; L[DC_PART][lane] = rPART; oE[lane] = rE; oQ[lane] = rQ; }
         regs = false;
     };
     auto mkpdu = [&](int m, int idx, int own, int q0, int q1, int cnt, int id, int part, bool fin, int cls, int es, int tlo, int thi) {
@@ -327,32 +368,23 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
         if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
         return true;
     };
-    auto append = [&](int c, int id, int2 pc, int es, int cls, int own) {       // a new entry of the list in LDS
+    auto append = [&](int c, int id, int2 pc, int es, int cls, int own, int m) {    // a new entry of the list in LDS
         L[DC_ID][c] = id; L[DC_DSTART][c] = pc.x; L[DC_DSTOP][c] = pc.y; L[DC_ESTART][c] = es; L[DC_CLS][c] = cls;
         L[DC_COUNT][c] = 0; L[DC_PHASE][c] = 0; L[DC_PINC][c] = es & rm; L[DC_INACT][c] = -1; L[DC_PART][c] = 0;
         L[DC_OWNER][c] = own; L[DC_TAIL][c] = 0;
         L[DC_TIME_LO][c] = (int)(unsigned)(now & 0xFFFFFFFFll); L[DC_TIME_HI][c] = (int)(now >> 32);
         oE[c] = 0; oQ[c] = 0; oC[c] = 0; oP[c] = 0;
+        oS[c] = m; oH[c] = 0;                                               // process_channel_hist(): the block before (slot m) comes first
     };
     // One channel's share of extract_channels_in_segments_singlethread() (:306-337) in pass `pass` (SegmentDetection emits the
     // partial PDUs in a pass of its own, :359-362); every lane of the wave calls it.  Returns the lanes that finalised.
-    auto step = [&](int m, int pass, int c, bool in, int &cnt, int &ph, int &inact, int &part, int &E, int &Q, int cls, int es, int own,
-                    int pinc, int id, int tlo, int thi, int wo) -> unsigned long long {
-        const int ew = 1 << cls;
-        bool isnew = false, fin = false, proc = false;
-        if (pass == 0) { isnew = in && inact < 0; fin = in && !isnew && inact > dp.delay; proc = in && !isnew && !fin; }
-        const unsigned long long b1 = __ballot(isnew || proc), b2 = __ballot(isnew);
-        if (b1) {
-            const int pos = tcur + __popcll(b1 & lt) + __popcll(b2 & lt);
-            if (isnew) {                                                    // process_channel_hist(), :399-403
-                tl[pos] = SinkTask{ow0 + own, Q, m, es, wo, cls};
-                tl[pos + 1] = SinkTask{ow0 + own, Q + 1, m + 1, es, wo + pinc * ew, cls};
-                Q += 2; cnt = 2; ph = (2 * pinc) & rm; inact = 0;
-            } else if (proc) {                                              // process_channel(), :373-397
-                tl[pos] = SinkTask{ow0 + own, Q, m + 1, es, wo + ph * ew, cls};
-                Q += 1; cnt += 1; ph = (ph + pinc) & rm;
-            }
-            tcur += __popcll(b1) + __popcll(b2);
+    auto step = [&](int m, int pass, int c, bool in, int &cnt, int &inact, int &part, int &E, int &Q, int cls, int es, int own, int id,
+                    int tlo, int thi) -> unsigned long long {
+        bool fin = false;
+        if (pass == 0 && in) {
+            if (inact < 0) { Q += 2; cnt = 2; inact = 0; }                  // process_channel_hist(), :399-403
+            else if (inact > dp.delay) fin = true;                          // emit_channel(), :309
+            else { Q += 1; cnt += 1; }                                      // process_channel(), :373-397
         }
         // partial emission: inline behind the channel in the vcm block (:317-318), a pass of its own in SegmentDetection
         const bool pcheck = in && dp.maxblocks >= 0 && (dp.variant == 1 ? pass == 1 : true) && !fin;
@@ -373,6 +405,13 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
         }
         return bf;
     };
+    auto owner_record = [&](int c) {                                        // list entry c (everything in LDS) -> its stream record
+        SinkOwner o{};
+        const int cls = L[DC_CLS][c], w = 1 << cls;
+        o.len = w - w / dp.R; o.cls = cls; o.carried = oC[c]; o.emitted = oE[c]; o.total = oQ[c]; o.prev_off = oP[c];
+        o.slot0 = oS[c]; o.phase0 = oH[c]; o.pinc = L[DC_PINC][c]; o.estart = L[DC_ESTART][c]; o.win0 = wofs[cls];
+        ow[L[DC_OWNER][c]] = o;
+    };
     // clear_inactive_channels(), :512-524, on the list in LDS (everything spilled): finalised channels leave their stream record
     auto compact = [&]() {
         int keep = 0;
@@ -380,88 +419,137 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
             const int c = c0 + lane;
             const bool in = c < nlive;
             const bool gone = in && L[DC_INACT][c] > dp.delay;
-            int v[kDetFields], e = 0, qq = 0, cc = 0;
+            int v[kDetFields], e = 0, qq = 0, cc = 0, ss = 0, hh = 0;
             long long pp = 0;
+            if (gone) owner_record(c);
             if (in) {
 #pragma unroll
                 for (int f = 0; f < kDetFields; f++) v[f] = L[f][c];
-                e = oE[c]; qq = oQ[c]; cc = oC[c]; pp = oP[c];
-            }
-            if (gone) {
-                SinkOwner o{};
-                o.len = (1 << v[DC_CLS]) - (1 << v[DC_CLS]) / dp.R; o.cls = v[DC_CLS]; o.carried = cc; o.emitted = e; o.total = qq; o.prev_off = pp;
-                ow[v[DC_OWNER]] = o;
+                e = oE[c]; qq = oQ[c]; cc = oC[c]; pp = oP[c]; ss = oS[c]; hh = oH[c];
             }
             const unsigned long long bk = __ballot(in && !gone);
-            __syncthreads();
+            lds_sync();
             if (in && !gone) {
                 const int d = keep + __popcll(bk & lt);
 #pragma unroll
                 for (int f = 0; f < kDetFields; f++) L[f][d] = v[f];
-                oE[d] = e; oQ[d] = qq; oC[d] = cc; oP[d] = pp;
+                oE[d] = e; oQ[d] = qq; oC[d] = cc; oP[d] = pp; oS[d] = ss; oH[d] = hh;
             }
             keep += __popcll(bk);
-            __syncthreads();
+            lds_sync();
         }
         nlive = keep;
     };
     for (int m = 0; m < nb; m++) {
         if ((m & (kDetStage - 1)) == 0) {                                   // candidate lists of the next kDetStage blocks -> LDS
             const int nst = nb - m < kDetStage ? nb - m : kDetStage;
-            __syncthreads();
+            lds_sync();
             if (lane < nst) stk[lane] = kc[m + lane];
             const int cc = g.cand_cap < 64 ? g.cand_cap : 64;
-            for (int t = 0; t < nst; t++) if (lane < cc) stc[t * 64 + lane] = cbase[(size_t)(m + t) * g.cand_cap + lane];
-            __syncthreads();
+            int2 tmp[kDetStage];                                            // all loads in flight before the first is used
+#pragma unroll
+            for (int t = 0; t < kDetStage; t++)
+                tmp[t] = (t < nst && lane < cc) ? cbase[(size_t)(m + t) * g.cand_cap + lane] : make_int2(0, 0);
+#pragma unroll
+            for (int t = 0; t < kDetStage; t++) stc[t * 64 + lane] = tmp[t];
+            lds_sync();
         }
         const int k = stk[m & (kDetStage - 1)];
+        DSTAMP(tS);
+#ifdef FDC_DET_STAMPS
+        sK += k; sL += nlive;
+#endif
         if (nlive <= 64 && k <= 64) {
             const int2 cme = stc[(m & (kDetStage - 1)) * 64 + lane];
-            if (!regs) load_regs();
-            bool clm = false;
-            unsigned long long hitm = 0;
-            if (k) {
-                for (int c = 0; c < nlive; c++) {                           // channel c takes every candidate it overlaps (:757-766)
-                    const int ds = __builtin_amdgcn_readlane(rDS, c), de = __builtin_amdgcn_readlane(rDE, c);
-                    const bool ov = lane < k && !clm && cme.x < de && cme.y >= ds;
-                    if (__ballot(ov)) { hitm |= 1ull << c; clm = clm || ov; }
+            if (!regs) { load_regs(); pairs = false; }
+            if (!pairs) {                                                   // pair layout of the matching: lane = (candidate pj, channel pc)
+                plw = 0;
+                while ((1 << plw) < nlive) plw++;
+                pc_ = lane & ((1 << plw) - 1); pj_ = lane >> plw;
+                pDS = __shfl(rDS, pc_, 64); pDE = __shfl(rDE, pc_, 64);
+                // bits c, c + W, c + 2 W, ... of the pair mask: everything channel `lane` overlaps
+                pstr = 0;
+                for (int b_ = lane; b_ < 64; b_ += 1 << plw) pstr |= 1ull << b_;
+                pairs = true;
+            }
+            // a candidate goes to the FIRST live channel it overlaps (the reference erases it from the list there, :757-766)
+            unsigned long long hitm = 0, clmm = 0;                           // channels hit, candidates claimed
+            if (k && nlive) {
+                if ((k << plw) <= 64) {                                      // all pairs at once
+                    const int cx = __shfl(cme.x, pj_, 64), cy = __shfl(cme.y, pj_, 64);
+                    const unsigned long long ov = __ballot(pc_ < nlive && pj_ < k && cx < pDE && cy >= pDS);
+                    const unsigned long long gm = plw == 6 ? ~0ull : (1ull << (1 << plw)) - 1ull;
+                    const unsigned long long grp = lane < k ? ((ov >> (lane << plw)) & gm) : 0ull;     // channels candidate `lane` overlaps
+                    clmm = __ballot(grp != 0);
+                    if (!__ballot(grp & (grp - 1))) hitm = __ballot((ov & pstr) != 0);                   // nobody overlaps two: first = only
+                    else
+                        for (int jj = 0; jj < k; jj++) {
+                            const unsigned long long gj = plw == 6 ? ov : ((ov >> (jj << plw)) & gm);
+                            if (gj) hitm |= 1ull << __builtin_ctzll(gj);
+                        }
+                } else {
+                    bool clm = false;
+                    for (int c = 0; c < nlive; c++) {                       // channel c takes every candidate it overlaps
+                        const int ds = __builtin_amdgcn_readlane(rDS, c), de = __builtin_amdgcn_readlane(rDE, c);
+                        const bool ov = lane < k && !clm && cme.x < de && cme.y >= ds;
+                        if (__ballot(ov)) { hitm |= 1ull << c; clm = clm || ov; }
+                    }
+                    clmm = __ballot(clm);
                 }
             }
+            {   // the quiet block — every candidate claimed, no channel past its delay — in a handful of instructions
+                const int nin = (k != 0 && ((hitm >> lane) & 1ull)) ? 0 : rIN + 1;
+                const bool inl = lane < nlive;
+                if (!__ballot((lane < k && !((clmm >> lane) & 1ull)) || (inl && nin > dp.delay)) &&
+                    (dp.maxblocks < 0 || !__ballot(inl && rQ + 1 - rE >= dp.maxblocks))) {
+                    if (inl) { rIN = nin; rQ += 1; rCNT += 1; }
+                    DSTAMP(tM);
+                    continue;
+                }
+            }
+            DSTAMP(tM);
             int nes = 0, ncls = 0;
-            const bool ok = lane < k && !clm && new_geom(cme, nes, ncls);   // what is left becomes new channels, in candidate order
+            const bool ok = lane < k && !((clmm >> lane) & 1ull) && new_geom(cme, nes, ncls);   // the rest: new channels, in candidate order
             const unsigned long long bo = __ballot(ok);
             const int nnew = __popcll(bo);
             if (nlive + nnew <= 64) {
                 if (lane < nlive) rIN = (k != 0 && ((hitm >> lane) & 1ull)) ? 0 : rIN + 1;      // :748-752, :768-771
                 if (nnew) {
                     const int r = __popcll(bo & lt);
-                    if (ok) append(nlive + r, counter + r, cme, nes, ncls, nown + r);
-                    __syncthreads();
-                    if (lane >= nlive && lane < nlive + nnew) { load_static(); rCNT = 0; rPH = 0; rIN = -1; rPART = 0; rE = 0; rQ = 0; }
-                    nlive += nnew; counter += nnew; nown += nnew;
+                    if (ok) append(nlive + r, counter + r, cme, nes, ncls, nown + r, m);
+                    lds_sync();
+                    if (lane >= nlive && lane < nlive + nnew) { load_static(); rCNT = 0; rIN = -1; rPART = 0; rE = 0; rQ = 0; }
+                    nlive += nnew; counter += nnew; nown += nnew; pairs = false;
                 }
                 unsigned long long anyfin = 0;
                 for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
-                    anyfin |= step(m, pass, lane, lane < nlive, rCNT, rPH, rIN, rPART, rE, rQ, rCLS, rES, rOWN, rPI, rID, rTL, rTH, rWO);
+                    anyfin |= step(m, pass, lane, lane < nlive, rCNT, rIN, rPART, rE, rQ, rCLS, rES, rOWN, rID, rTL, rTH);
+                DSTAMP(tX);
                 if (anyfin) {
                     spill_regs();
-                    __syncthreads();
+                    lds_sync();
                     compact();
+#ifdef FDC_DET_STAMPS
+                    nC++;
+#endif
+                    DSTAMP(tC);
                 }
                 continue;
             }
         }
         // ---- general form: any number of channels and candidates, the list in LDS
+#ifdef FDC_DET_STAMPS
+        nG++;
+#endif
         spill_regs();
-        __syncthreads();
+        lds_sync();
         if (k == 0) {                                                       // :748-752
             for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] += 1;
         } else {
             const int2 *cs = cbase + (size_t)m * g.cand_cap;
             for (int j = lane; j < k; j += 64) { cd[j] = cs[j]; claimed[j] = 0; }
             for (int c = lane; c < nlive; c += 64) hit[c] = 0;
-            __syncthreads();
-            // a candidate goes to the FIRST live channel it overlaps (the reference erases it from the list there, :757-766)
+            lds_sync();
             for (int j = 0; j < k; j++) {
                 const int2 pc = cd[j];
                 for (int c0 = 0; c0 < nlive; c0 += 64) {
@@ -473,7 +561,7 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
                     }
                 }
             }
-            __syncthreads();
+            lds_sync();
             for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] = hit[c] ? 0 : L[DC_INACT][c] + 1;
             for (int j0 = 0; j0 < k; j0 += 64) {                            // new channels, in candidate order (:785-841)
                 const int j = j0 + lane;
@@ -484,37 +572,80 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
                 const unsigned long long bo = __ballot(ok);
                 const int nnew = __popcll(bo);
                 if (nlive + nnew > kDetMaxCells) { err = 1; break; }
-                if (ok) { const int r = __popcll(bo & lt); append(nlive + r, counter + r, pc, es, cls, nown + r); }
+                if (ok) { const int r = __popcll(bo & lt); append(nlive + r, counter + r, pc, es, cls, nown + r, m); }
                 nlive += nnew; counter += nnew; nown += nnew;
             }
             if (err) break;
-            __syncthreads();
+            lds_sync();
         }
         unsigned long long anyfin = 0;
         for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
             for (int c0 = 0; c0 < nlive; c0 += 64) {
                 const int c = c0 + lane, cc = c < kDetMaxCells ? c : kDetMaxCells - 1;
-                const int cls = L[DC_CLS][cc] & 31;
-                anyfin |= step(m, pass, c, c < nlive, L[DC_COUNT][cc], L[DC_PHASE][cc], L[DC_INACT][cc], L[DC_PART][cc], oE[cc], oQ[cc], cls,
-                               L[DC_ESTART][cc], L[DC_OWNER][cc], L[DC_PINC][cc], L[DC_ID][cc], L[DC_TIME_LO][cc], L[DC_TIME_HI][cc], wofs[cls]);
+                anyfin |= step(m, pass, c, c < nlive, L[DC_COUNT][cc], L[DC_INACT][cc], L[DC_PART][cc], oE[cc], oQ[cc], L[DC_CLS][cc] & 31,
+                               L[DC_ESTART][cc], L[DC_OWNER][cc], L[DC_ID][cc], L[DC_TIME_LO][cc], L[DC_TIME_HI][cc]);
             }
-        __syncthreads();
+        lds_sync();
         if (anyfin) compact();
     }
     spill_regs();
-    __syncthreads();
+    lds_sync();
     for (int c = lane; c < nlive; c += 64) {
-        SinkOwner o{};
-        const int cls = L[DC_CLS][c];
-        o.len = (1 << cls) - (1 << cls) / dp.R; o.cls = cls; o.carried = oC[c]; o.emitted = oE[c]; o.total = oQ[c]; o.prev_off = oP[c];
-        ow[L[DC_OWNER][c]] = o;
+        L[DC_PHASE][c] = (L[DC_COUNT][c] * L[DC_PINC][c]) & rm;             // window phase of the next block (:396)
+        owner_record(c);
         for (int f = 0; f < kDetFields; f++) Lg[f * kDetMaxCells + c] = L[f][c];
     }
     if (lane == 0) {
         sst[sg].nlive = nlive; sst[sg].counter = counter;
-        ntask[lst] = tcur; npdu[lst] = pcur; nowner[sg] = nown;
+        npdu[lst] = pcur; nowner[sg] = nown;
         if (err) *error = 1;
+#ifdef FDC_DET_STAMPS
+        if (dbg) {
+            long long *o = dbg + sg * 16;
+            o[0] = __builtin_readcyclecounter() - t00; o[1] = tS; o[2] = tM; o[3] = tX; o[4] = tC; o[5] = nG; o[6] = nC; o[7] = sK; o[8] = sL; o[9] = nb;
+        }
+#endif
     }
+}
+
+// The extractions of the detected channels of a call, written out from their stream records: block t of the run is spectrum
+// slot slot0 + t, stream position carried + t, window phase (phase0 + t pinc) mod R (process_channel(), …vcm_impl.cc:373-397).
+__global__ __launch_bounds__(1024) void k_det_expand(int npac, int R, const SinkOwner *__restrict__ owners, const int64_t *__restrict__ owner_base,
+                                                     const int32_t *__restrict__ nowner, SinkTask *__restrict__ tasks,
+                                                     const int64_t *__restrict__ task_base, int32_t *__restrict__ ntask)
+{
+    __shared__ long long sh[16];
+    __shared__ int obase[1024];
+    const int sg = blockIdx.x, tid = threadIdx.x, lst = npac + sg, rm = R - 1;
+    const SinkOwner *ow = owners + owner_base[sg];
+    const int ow0 = (int)owner_base[sg], cnt = nowner[sg];
+    SinkTask *tl = tasks + task_base[lst];
+    int acc = 0;
+    for (int c0 = 0; c0 < cnt; c0 += 1024) {
+        const int c = c0 + tid;
+        const int n = c < cnt ? ow[c].total - ow[c].carried : 0;
+        long long tot;
+        obase[tid] = acc + (int)block_exscan((long long)n, &tot, sh);
+        __syncthreads();
+        const int lim = cnt - c0 < 1024 ? cnt - c0 : 1024, wv = tid >> 6, ln = tid & 63;
+        for (int cc = wv; cc < lim; cc += 16) {
+            const SinkOwner o = ow[c0 + cc];
+            const int nn = o.total - o.carried, w = 1 << o.cls;
+            for (int t = ln; t < nn; t += 64)
+                tl[obase[cc] + t] = SinkTask{ow0 + c0 + cc, o.carried + t, o.slot0 + t, o.estart, o.win0 + ((o.phase0 + t * o.pinc) & rm) * w, o.cls};
+        }
+        acc += (int)tot;
+        __syncthreads();
+    }
+    if (tid == 0) ntask[lst] = acc;
+}
+
+hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const int64_t *owner_base, const int32_t *nowner, SinkTask *tasks,
+                             const int64_t *task_base, int32_t *ntask, hipStream_t s)
+{
+    if (nseg <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_det_expand, dim3((unsigned)nseg), dim3(1024), 0, s, npac, R, owners, owner_base, nowner, tasks, task_base, ntask);
+    return hipGetLastError();
 }
 
 hipError_t init_sink_kernels();
@@ -525,8 +656,24 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
                             int32_t *nowner, int32_t *error, hipStream_t s)
 {
     if (dp.nseg <= 0) return hipSuccess;
+    long long *dbg = nullptr;
+#ifdef FDC_DET_STAMPS
+    static long long *d_dbg = nullptr;
+    if (!d_dbg) (void)hipMalloc(reinterpret_cast<void **>(&d_dbg), sizeof(long long) * 16 * 64);
+    dbg = d_dbg;
+#endif
     hipLaunchKernelGGL(k_det_track, dim3((unsigned)dp.nseg), dim3(64), kDetLds, s, dp, nb, geom, sst, live, live_off, cand, cand_base, ncand,
-                       win_off, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners, owner_base, nowner, error);
+                       win_off, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners, owner_base, nowner, error, dbg);
+#ifdef FDC_DET_STAMPS
+    {
+        long long h[32];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+        for (int g = 0; g < dp.nseg && g < 2; g++)
+            std::fprintf(stderr, "[det_track seg %d] total %lld cyc; stage %lld match %lld step %lld compact %lld | general %lld compactions %lld sum k %lld sum live %lld of %lld blocks\n",
+                         g, h[g * 16], h[g * 16 + 1], h[g * 16 + 2], h[g * 16 + 3], h[g * 16 + 4], h[g * 16 + 5], h[g * 16 + 6], h[g * 16 + 7], h[g * 16 + 8], h[g * 16 + 9]);
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -534,21 +681,6 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
 // One workgroup.  Owner table = regions: [0, npac) and, per segment s, [owner_base[s], owner_base[s] + nowner[s]).
 // Landing buffer of the call: the emitted prefixes of all streams one behind the other (what goes to the host), then the
 // buffered rests.
-__device__ long long block_exscan(long long v, long long *tot, long long *sh /* [1024 / 64] */)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    long long x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    __syncthreads();
-    if (lane == 63) sh[wv] = x;
-    __syncthreads();
-    long long base = 0, all = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { if (w < wv) base += sh[w]; all += sh[w]; }
-    *tot = all;
-    return base + x - v;
-}
-
 __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *__restrict__ task_base, const int64_t *__restrict__ pdu_base,
                                                       const int32_t *__restrict__ ntask, const int32_t *__restrict__ npdu,
                                                       const SinkTask *__restrict__ tasks, const SinkPdu *__restrict__ pdus,
