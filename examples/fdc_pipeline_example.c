@@ -15,7 +15,7 @@ int main(void)
     const int H = N - N / R;
     /* (f, l, passbw, stopbw) as get_opt_channelparams derives them for [[0.12,0.05],[0.22,0.1],[-0.14,0.12],[0,0.081]] */
     const fdc_channel chans[C] = {{2412, 256, 0.88f, 1.0f}, {2693, 512, 0.88f, 1.0f}, {963, 1024, 0.528f, 0.778f}, {1792, 512, 0.7128f, 1.0f}};
-    fdc_pipeline_cfg cfg = {0, N, R, FDC_WIN_HANN, C, chans, NB, 0, 0};
+    fdc_pipeline_cfg cfg = {0, N, R, FDC_WIN_HANN, C, chans, NB, 0, 0, 0, 0, 0};   /* flags 0: the library picks the kernels */
     fdc_pipeline *p = NULL;
     if (fdc_pipeline_create(&cfg, &p) != FDC_OK) { fprintf(stderr, "create: %s\n", fdc_last_error()); return 1; }
 

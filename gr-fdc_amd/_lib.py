@@ -26,7 +26,11 @@ class fdc_channel(C.Structure):
 class fdc_pipeline_cfg(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("blocklen", C.c_int32), ("relinvovl", C.c_int32),
                 ("windowtype", C.c_int32), ("nchannels", C.c_int32), ("channels", C.POINTER(fdc_channel)),
-                ("max_blocks", C.c_int32), ("chunk_blocks", C.c_int32), ("keep_spectrum", C.c_int32)]
+                ("max_blocks", C.c_int32), ("chunk_blocks", C.c_int32), ("keep_spectrum", C.c_int32),
+                ("flags", C.c_int32), ("min_block_launch", C.c_int32), ("host_sub_blocks", C.c_int32)]
+
+
+FDC_PIPE_FORCE_GENERIC, FDC_PIPE_NO_POLY, FDC_PIPE_NO_BLOCK, FDC_PIPE_PLAIN_STORES, FDC_PIPE_NT_LOADS = 1, 2, 4, 8, 16
 
 
 class fdc_pac_cfg(C.Structure):
@@ -65,6 +69,7 @@ SYMBOLS = {
     "fdc_last_error": (C.c_char_p, []),
     "fdc_version": (C.c_char_p, []),
     "fdc_device_count": (C.c_int, []),
+    "fdc_selftest_devices": (C.c_int, []),
     "fdc_pipeline_create": (C.c_int, [C.POINTER(fdc_pipeline_cfg), C.POINTER(_vp)]),
     "fdc_pipeline_destroy": (None, [_vp]),
     "fdc_pipeline_input_samples": (C.c_int64, [_vp, C.c_int]),

@@ -51,13 +51,23 @@ def get_opt_channelparams(blocksize, relinvovl, freq, bw):
     elif passband < 0.7:
         stopband = passband + 0.25
     # round(): the reference runs under Python 2 (half away from zero); Python 3's round() goes half to even
-    centre = int(math.floor(abs(freq * blocksize) + 0.5) * (1 if freq >= 0 else -1)) % blocksize
+    centre = int(_round_half_away(freq * blocksize)) % blocksize
     first = centre - l / 2
     if first < 0:
         first = (first + blocksize) % blocksize
     if first + l > blocksize:
         first = blocksize - l
     return int(first), int(l), int(l) - int(l) // relinvovl, float(passband), float(stopband)
+
+
+def _round_half_away(x):
+    """Python 2's round() (and C's round()): to the nearest integer, ties away from zero — decided on the fraction itself,
+    not on x + 0.5 (0.49999999999999994 + 0.5 rounds up to 1.0 in double; odd integers from 2^52 on would move too)."""
+    ax = abs(x)
+    r = math.floor(ax)
+    if ax - r >= 0.5:
+        r += 1.0
+    return r if x >= 0 else -r
 
 
 def freq_converters(freqmode, fs=1.0, centerfrequency=0.0):
@@ -85,19 +95,43 @@ def unregister_host(arr):
     _lib.check(_lib.lib().fdc_host_unregister(arr.ctypes.data))
 
 
+# Process-wide defaults for the kernel-choice fields of fdc_pipeline_cfg (flags, min_block_launch, host_sub_blocks) of pipelines
+# created without them: how tests and A/B tools force a path.  Keys (the library itself reads no environment variable):
+#   "FDC_FORCE_GENERIC" / "FDC_NO_POLY" / "FDC_NO_BLOCK" -> FDC_PIPE_* flags, "FDC_BLOCK_MIN_BLOCKS" -> min_block_launch,
+#   "FDC_HOST_SUB" -> host_sub_blocks, "FDC_BLOCK_HINTS" (bit 0 nt stores, bit 1 nt loads)
+defaults = {}
+
+
+def _default_cfg_fields():
+    flags = 0
+    if defaults.get("FDC_FORCE_GENERIC"):
+        flags |= _lib.FDC_PIPE_FORCE_GENERIC
+    if defaults.get("FDC_NO_POLY"):
+        flags |= _lib.FDC_PIPE_NO_POLY
+    if defaults.get("FDC_NO_BLOCK"):
+        flags |= _lib.FDC_PIPE_NO_BLOCK
+    if "FDC_BLOCK_HINTS" in defaults:
+        h = int(defaults["FDC_BLOCK_HINTS"])
+        flags |= (0 if h & 1 else _lib.FDC_PIPE_PLAIN_STORES) | (_lib.FDC_PIPE_NT_LOADS if h & 2 else 0)
+    return flags, int(defaults.get("FDC_BLOCK_MIN_BLOCKS", 0) or 0), int(defaults.get("FDC_HOST_SUB", 0) or 0)
+
+
 class Pipeline:
     """fdc_pipeline handle: channels = [(f, l, passbw, stopbw), ...]."""
 
     def __init__(self, blocklen, relinvovl, channels, windowtype=WINDOWTYPES.HANN, max_blocks=64,
-                 device_id=0, chunk_blocks=0, keep_spectrum=False):
+                 device_id=0, chunk_blocks=0, keep_spectrum=False, flags=None, min_block_launch=None, host_sub_blocks=None):
         self._h = C.c_void_p()
         self.N, self.R = int(blocklen), int(relinvovl)
         self.channels = [(int(f), int(l), float(p), float(s)) for (f, l, p, s) in channels]
         arr = (_lib.fdc_channel * max(1, len(self.channels)))()
         for i, (f, l, p, s) in enumerate(self.channels):
             arr[i].f, arr[i].l, arr[i].passbw, arr[i].stopbw = f, l, p, s
+        dflags, dmin, dsub = _default_cfg_fields()
         cfg = _lib.fdc_pipeline_cfg(device_id, self.N, self.R, int(windowtype), len(self.channels), arr,
-                                    int(max_blocks), int(chunk_blocks), int(bool(keep_spectrum)))
+                                    int(max_blocks), int(chunk_blocks), int(bool(keep_spectrum)),
+                                    dflags if flags is None else int(flags), dmin if min_block_launch is None else int(min_block_launch),
+                                    dsub if host_sub_blocks is None else int(host_sub_blocks))
         rc = _lib.lib().fdc_pipeline_create(C.byref(cfg), C.byref(self._h))
         if rc == -1:
             raise ValueError(_lib.lib().fdc_last_error().decode())
@@ -261,6 +295,13 @@ class FrequencyDomainChannelizer:
         self.inpblocklen = self.blocksize - self.ovllen         # :141
         if self.inpveclen != 1 and self.inpveclen != self.blocksize:
             raise ValueError("inpveclen must be 1 (sample stream) or blocksize (items already transformed, :284-290)")
+        if self.itemsize == 4:
+            # Float input is the fft_vfc front end on a sample stream; items that are already spectra are complex, and the sink
+            # blocks hang on the complex chain only — refuse here, not at the first work() call
+            if self.inpveclen != 1:
+                raise ValueError("Float input (itemsize 4) needs inpveclen 1: pre-transformed items are complex spectra")
+            if self.activity_controlled_channels or self.activity_detection_segments:
+                raise ValueError("Float input (itemsize 4) cannot feed activity-controlled channels or detection segments")
 
         if self.verbose:                                        # runtime information, :176-193
             bar = '\n' + '#' * 32 + '\n'

@@ -93,6 +93,12 @@ bool host_registered(const void *ptr, size_t bytes, void **devptr = nullptr)
 }  // namespace
 
 namespace fdc {
+// Environment variables are a debugging override only: nothing is read unless FDC_DEBUG_ENV=1 (include/fdc_amd.h)
+const char *debug_env(const char *name)
+{
+    static const bool on = [] { const char *d = getenv("FDC_DEBUG_ENV"); return d && d[0] == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
 // shared with fdc_sinks.hip
 int set_error(int code, const char *fmt, ...)
 {
@@ -185,6 +191,46 @@ int fdc_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int fdc_selftest_devices(void)
+{
+    const int ndev = fdc_device_count();
+    if (ndev <= 0) return fail(FDC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    constexpr int N = 65536, R = 2, C = 256, NB = 96, H = N - N / R, LOUT = 128;
+    std::vector<fdc_channel> ch(C);
+    for (int c = 0; c < C; c++) ch[(size_t)c] = fdc_channel{256 * c, 256, 0.88f, 1.0f};
+    std::vector<float> x((size_t)2 * NB * H);
+    uint32_t lcg = 12345u;
+    for (float &v : x) { lcg = lcg * 1664525u + 1013904223u; v = (float)((int32_t)(lcg >> 8) - (1 << 23)) * (1.0f / (1 << 23)); }
+    std::vector<std::vector<float>> out((size_t)C, std::vector<float>((size_t)2 * NB * LOUT));
+    std::vector<void *> outs((size_t)C);
+    for (int c = 0; c < C; c++) outs[(size_t)c] = out[(size_t)c].data();
+    uint64_t ref = 0;
+    for (int d = 0; d < ndev; d++) {
+        fdc_pipeline_cfg cfg{};
+        cfg.device_id = d; cfg.blocklen = N; cfg.relinvovl = R; cfg.windowtype = FDC_WIN_HANN; cfg.nchannels = C; cfg.channels = ch.data();
+        cfg.max_blocks = NB; cfg.host_sub_blocks = NB;
+        fdc_pipeline *p = nullptr;
+        int rc = fdc_pipeline_create(&cfg, &p);
+        if (rc != FDC_OK) return fail(rc, "selftest: device %d: create failed: %s", d, std::string(g_err).c_str());
+        if (fdc_pipeline_path(p) != 3) { fdc_pipeline_destroy(p); return fail(FDC_ERR_UNSUPPORTED, "selftest: device %d: not on the one-kernel path", d); }
+        rc = fdc_pipeline_work(p, x.data(), NB, outs.data(), nullptr);
+        fdc_pipeline_destroy(p);
+        if (rc != NB) return fail(rc < 0 ? rc : FDC_ERR_HIP, "selftest: device %d: work failed: %s", d, std::string(g_err).c_str());
+        uint64_t h = 1469598103934665603ull;                    // FNV-1a over every output byte
+        double energy = 0.0;
+        for (int c = 0; c < C; c++) {
+            const unsigned char *b = reinterpret_cast<const unsigned char *>(out[(size_t)c].data());
+            for (size_t i = 0; i < out[(size_t)c].size() * sizeof(float); i++) { h ^= b[i]; h *= 1099511628211ull; }
+            for (float v : out[(size_t)c]) energy += (double)v * v;
+        }
+        if (!(energy > 0.0)) return fail(FDC_ERR_HIP, "selftest: device %d produced no output", d);
+        if (d == 0) ref = h;
+        else if (h != ref) return fail(FDC_ERR_HIP, "selftest: device %d differs from device 0 (checksum %016llx vs %016llx)", d,
+                                       (unsigned long long)h, (unsigned long long)ref);
+    }
+    return ndev;
 }
 
 int fdc_window_table(int windowtype, int blocklen, float passbw, float stopbw, int numphasestates, int step,
@@ -293,7 +339,20 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->chans.push_back(d);
     }
     p->sum_lout = off;
-    { const char *fg = getenv("FDC_FORCE_GENERIC"); p->cfg_generic = fg && fg[0] == '1'; }
+    int flags = cfg->flags;
+    {
+        auto on = [](const char *n) { const char *v = fdc::debug_env(n); return v && v[0] == '1'; };
+        if (on("FDC_FORCE_GENERIC")) flags |= FDC_PIPE_FORCE_GENERIC;
+        if (on("FDC_NO_POLY")) flags |= FDC_PIPE_NO_POLY;
+        if (on("FDC_NO_BLOCK")) flags |= FDC_PIPE_NO_BLOCK;
+        if (const char *bh = fdc::debug_env("FDC_BLOCK_HINTS")) {
+            flags &= ~(FDC_PIPE_PLAIN_STORES | FDC_PIPE_NT_LOADS);
+            if (!(atoi(bh) & 1)) flags |= FDC_PIPE_PLAIN_STORES;
+            if (atoi(bh) & 2) flags |= FDC_PIPE_NT_LOADS;
+        }
+    }
+    p->cfg.flags = flags;
+    p->cfg_generic = (flags & FDC_PIPE_FORCE_GENERIC) != 0;
     std::map<int, std::vector<int32_t>> bylen;
     for (int c = 0; c < p->C; c++) bylen[p->chans[c].l].push_back(c);
     std::vector<int32_t> flat;
@@ -312,13 +371,11 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
     {
-        const char *np = getenv("FDC_NO_POLY");
-        bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(np && np[0] == '1');
+        bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(flags & FDC_PIPE_NO_POLY);
         // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
         // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
         // classes: same offset r = f mod 256, same window, every slot at most once
-        const char *nbk = getenv("FDC_NO_BLOCK"), *bh = getenv("FDC_BLOCK_HINTS");
-        const bool block_form = N == 65536 && R == 2 && !(nbk && nbk[0] == '1');
+        const bool block_form = N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK);
         constexpr size_t kMaxPolyClasses = 3;
         std::vector<std::vector<char>> used;
         for (int c = 0; ok && c < p->C; c++) {
@@ -348,8 +405,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
         if (!ok) p->classes.clear();
-        if (bh) p->block_hints = atoi(bh) & 3;
-        if (const char *bm = getenv("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
+        p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
+        if (cfg->min_block_launch >= 1) p->block_min = cfg->min_block_launch;
+        if (const char *bm = fdc::debug_env("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
@@ -445,10 +503,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipMemcpy(p->d_tw1024, t1k.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
         }
     }
-    {
-        const char *nbk = getenv("FDC_NO_BLOCK");
-        p->fwd_block = N == 65536 && !p->cfg_generic && !(nbk && nbk[0] == '1');
-    }
+    p->fwd_block = N == 65536 && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
     if (p->fwd_block) {
         // the block kernel as a forward transform: twq / cbt as on the uniform path with r = 0, a flat "window" 1/N, and the
         // slots of stage 2 mapped to the bins 256 c (+ k2) of the shifted spectrum
@@ -480,7 +535,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     }
     if (p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->poly_block) {
-        if (const char *dg = getenv("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
+        if (const char *dg = fdc::debug_env("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
             CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
             CHK_OR_FREE(hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 32));
         }
@@ -741,7 +796,8 @@ static int work_io_setup(fdc_pipeline *p)
     // sub-batch: about 8 MiB of input (measured best of 2-16 MiB on MI355X/PCIe5, staged and pinned): long against a
     // transfer's launch cost, short against the call
     int64_t sub = (8ll << 20) / ((int64_t)p->H * 8);
-    if (const char *e = getenv("FDC_HOST_SUB")) if (atoi(e) > 0) sub = atoi(e);
+    if (p->cfg.host_sub_blocks > 0) sub = p->cfg.host_sub_blocks;
+    if (const char *e = fdc::debug_env("FDC_HOST_SUB")) if (atoi(e) > 0) sub = atoi(e);
     p->sub = (int)std::max<int64_t>(1, std::min<int64_t>(sub, p->cfg.max_blocks));
     if (p->C > 0) {
         // scatter table: pinned and device-mapped, the scatter kernel reads it in place (no per-call upload)

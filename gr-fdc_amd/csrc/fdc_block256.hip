@@ -163,6 +163,9 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 #else
 #define FDC_STAMP(i) do { } while (0)
 #endif
+#ifdef FDC_BLK_L2PF
+    unsigned pfd = 0;
+#endif
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
 #ifdef FDC_BLK_STAMPS
@@ -183,6 +186,16 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // are requested first, unconditionally (a conditional request costs a second set of register copies).
 #pragma nounroll
         for (int ps = 0; ps < 8; ps++) {
+#ifdef FDC_BLK_L2PF
+            // experiment: touch every 128-byte line of the pass after next (this block's, or the next block's) once, two passes ahead
+            {
+                asm volatile("" :: "v"(pfd));
+                const int p2 = (ps + 2) & 7;
+                const int mb2 = ps < 6 ? m : mnext;
+                const __amdgpu_buffer_rsrc_t rpf = make_rsrc(in + (size_t)mb2 * in_stride + 32 * p2, inbytes);
+                pfd = __builtin_amdgcn_raw_buffer_load_b32(rpf, (unsigned)((tid >> 1) * 2048 + (tid & 1) * 128), 0u, 0);
+            }
+#endif
             const cf cb = OFF ? cbn * sgn : cbn;
             cf cur[16];
 #pragma unroll
@@ -195,7 +208,11 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 32 * pn, inbytes);
                 if (hints & 2) {
 #pragma unroll
+#ifdef FDC_BLK_SC1LOADS
+                    for (int a = 0; a < 16; a++) L[a] = bld2_sc1(rin, voff, (unsigned)a * 32768u);
+#else
                     for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * 32768u);
+#endif
                 } else {
 #pragma unroll
                     for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);

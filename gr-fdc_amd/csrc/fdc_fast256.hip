@@ -638,17 +638,18 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
     return hipGetLastError();
 }
 
+const char *debug_env(const char *name);     // fdc_api.hip: nullptr unless FDC_DEBUG_ENV=1
 // FDC_NT bits (A/B testing): 1 = stage-2 output stores nt, 2 = stage-1 input loads nt, 4 = stage-2 G loads nt, 8 = stage-1 G stores nt
 static int nt_hints()
 {
     static int h = -1;
-    if (h < 0) { const char *t = getenv("FDC_NT"); h = t ? atoi(t) & 15 : kDefaultNtHints; }
+    if (h < 0) { const char *t = debug_env("FDC_NT"); h = t ? atoi(t) & 15 : kDefaultNtHints; }
     return h;
 }
 static int poly_tile(int lout)
 {
     static int tcfg = -1;                                   // FDC_POLY_TILE=16|32 (A/B testing); default 16
-    if (tcfg < 0) { const char *t = getenv("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
+    if (tcfg < 0) { const char *t = debug_env("FDC_POLY_TILE"); tcfg = (t && atoi(t) == 32) ? 32 : 16; }
     return (lout % tcfg) ? 16 : tcfg;                       // stage-2 tiles are TC whole rows of one block
 }
 hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int N1, int R, int nb_chunk,
@@ -666,7 +667,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     if (slots < ct) slots = ct;
     // every workgroup keeps one column tile and takes runs of bpg consecutive blocks (FDC_POLY_BPG: run length, A/B testing)
     static int bpg_cfg = -1;
-    if (bpg_cfg < 0) { const char *t = getenv("FDC_POLY_BPG"); bpg_cfg = t ? atoi(t) : 0; }
+    if (bpg_cfg < 0) { const char *t = debug_env("FDC_POLY_BPG"); bpg_cfg = t ? atoi(t) : 0; }
     int groups = slots / ct;
     if (groups > nb_chunk) groups = nb_chunk;
     int bpg = (nb_chunk + groups - 1) / groups;
@@ -677,8 +678,8 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     const size_t lds1 = 256 * TC * 8 + 2304 + TC * 144 + 1024;
     static int abl = -1, noreuse = 0;
     if (abl < 0) {
-        const char *t = getenv("FDC_ABLATE"); abl = t ? atoi(t) : 0;
-        const char *g4 = getenv("FDC_POLY_NOREUSE"); noreuse = g4 ? atoi(g4) : 0;
+        const char *t = debug_env("FDC_ABLATE"); abl = t ? atoi(t) : 0;
+        const char *g4 = debug_env("FDC_POLY_NOREUSE"); noreuse = g4 ? atoi(g4) : 0;
     }
     // the overlap of consecutive blocks travels in registers when the items are exactly N - N/R apart
     const bool reuse = !noreuse && abl == 0 && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
@@ -711,7 +712,7 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1, int R, int n
     }
     const int TCG = poly_tile(lout);                        // column-tile width stage 1 wrote G with
     static int rows_cfg = -1;                               // FDC_POLY_ROWS=16|32: rows per stage-2 tile (A/B testing)
-    if (rows_cfg < 0) { const char *t = getenv("FDC_POLY_ROWS"); rows_cfg = t ? atoi(t) : 0; }
+    if (rows_cfg < 0) { const char *t = debug_env("FDC_POLY_ROWS"); rows_cfg = t ? atoi(t) : 0; }
     int TR = rows_cfg == 16 || rows_cfg == 32 ? rows_cfg : TCG;
     if (lout % TR) TR = 16;
     if (TCG == 32 && TR == 16) TR = 32;                     // 32-column G tiles are read 32 rows at a time

@@ -33,7 +33,7 @@
 #include <vector>
 
 extern "C" const char *fdc_last_error(void);
-namespace fdc { int set_error(int code, const char *fmt, ...); int pick_device(int device_id); }
+namespace fdc { int set_error(int code, const char *fmt, ...); int pick_device(int device_id); const char *debug_env(const char *name); }
 
 namespace {
 
@@ -101,17 +101,19 @@ struct WorkerLists {
 class WorkerPool {
 public:
     ~WorkerPool() { stop(); }
-    void run(int n, const std::function<void(int)> &fn)
+    // false: a job threw (std::bad_alloc from a growing list, normally): the batch is lost, the process is not
+    bool run(int n, const std::function<void(int)> &fn)
     {
         if ((int)th_.size() < n) grow(n);
         {
             std::lock_guard<std::mutex> g(m_);
-            job_ = &fn; njob_ = n; pending_ = n; gen_++;
+            job_ = &fn; njob_ = n; pending_ = n; gen_++; failed_ = false;
         }
         cv_.notify_all();
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return pending_ == 0; });
         job_ = nullptr;
+        return !failed_;
     }
     void stop()
     {
@@ -137,9 +139,11 @@ private:
                         if (quit_) return;
                         seen = gen_; fn = job_;
                     }
-                    (*fn)(i);
+                    bool ok = true;
+                    try { (*fn)(i); } catch (...) { ok = false; }     // nothing may unwind out of a worker thread
                     {
                         std::lock_guard<std::mutex> g(m_);
+                        if (!ok) failed_ = true;
                         pending_--;
                     }
                     done_.notify_one();
@@ -152,7 +156,7 @@ private:
     const std::function<void(int)> *job_ = nullptr;
     int njob_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
-    bool quit_ = false;
+    bool quit_ = false, failed_ = false;
 };
 
 }  // namespace
@@ -220,6 +224,7 @@ struct fdc_sinks {
 
 namespace {
 
+std::mutex g_log_mu;
 fdc_log_fn g_log_fn = nullptr;
 void *g_log_user = nullptr;
 
@@ -245,7 +250,11 @@ const std::string &current_time_string()
 // log(), PowerActivationChannel_impl.cc:396-408 / …vcm_impl.cc:578-591: a line to stdout or appended to the log file
 void sink_log(const fdc_sinks *s, const std::string &file, const std::string &line)
 {
-    if (g_log_fn) g_log_fn(line.c_str(), g_log_user);
+    {
+        fdc_log_fn fn; void *user;
+        { std::lock_guard<std::mutex> g(g_log_mu); fn = g_log_fn; user = g_log_user; }
+        if (fn) fn(line.c_str(), user);
+    }
     if (s->cfg.verbose == 1) { std::fputs(line.c_str(), stdout); std::fputc('\n', stdout); }
     else if (s->cfg.verbose == 2) {
         FILE *f = std::fopen(file.c_str(), "a");
@@ -746,8 +755,7 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
     }
     raw->host_threads = cfg->threads > 0 ? std::min(cfg->threads, 32) : 0;
-    if (const char *dbg = getenv("FDC_DEBUG_ENV")) if (dbg[0] == '1')       // debugging override only (the knob is cfg.threads)
-        if (const char *t = getenv("FDC_SINKS_THREADS")) if (atoi(t) >= 1) raw->host_threads = std::min(atoi(t), 32);
+    if (const char *t = fdc::debug_env("FDC_SINKS_THREADS")) if (atoi(t) >= 1) raw->host_threads = std::min(atoi(t), 32);   // debugging override
     {
         const int rcd = dev_setup(raw);
         if (rcd != FDC_OK) { fdc_sinks_destroy(raw); return rcd; }
@@ -855,7 +863,7 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
 
 static int host_work_device(fdc_sinks *s, int nblocks)
 {
-    static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;      // phase times on stderr (diagnostics)
+    static const bool trace = fdc::debug_env("FDC_SINKS_TRACE") != nullptr;      // phase times on stderr (diagnostics)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
     auto lap = [&](const char *what) {
@@ -866,6 +874,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
     };
     s->pdus.clear();
     lap("previous PDUs released");
+    bool pool_ok = true;
     const int N = s->N, ncells = (int)s->cells.size();
     // phase 1: power of every cell of every block
     if (ncells) {
@@ -919,7 +928,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
         std::vector<int> lo((size_t)nthr + 1);
         for (int t = 0; t <= nthr; t++) lo[(size_t)t] = (int)((int64_t)npac * t / nthr);
         std::vector<double> tms((size_t)nthr, 0.0);
-        s->pool.run(nthr, [&](int t) {
+        pool_ok = s->pool.run(nthr, [&](int t) {
             const auto a0 = now();
             WorkerLists &L = *s->wl[(size_t)t];
             L.clear();
@@ -936,7 +945,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
             s->ext_used += s->wl[(size_t)t]->used;
         }
         s->tasks.resize((size_t)base[(size_t)nthr]); s->task_w.resize((size_t)base[(size_t)nthr]); s->task_skip.resize((size_t)base[(size_t)nthr]);
-        s->pool.run(nthr, [&](int t) {
+        pool_ok = s->pool.run(nthr, [&](int t) {
             WorkerLists &L = *s->wl[(size_t)t];
             const int64_t b0 = base[(size_t)t];
             std::copy(L.tasks.begin(), L.tasks.end(), s->tasks.begin() + b0);
@@ -960,7 +969,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
         // The segments of a detection block do not interact either (…vcm_impl.cc:558-562 loops over them per item): a worker
         // takes whole segments through the batch; the order key (block, then segment, then emission) restores the reference's order.
         while ((int)s->wl.size() < nthr_s) s->wl.emplace_back(new WorkerLists());
-        s->pool.run(nthr_s, [&](int t) {
+        pool_ok = s->pool.run(nthr_s, [&](int t) {
             WorkerLists &L = *s->wl[(size_t)t];
             L.clear();
             Emit e{&L.tasks, &L.w, &L.skip, &L.used, &L.pdus, bc0, 0};
@@ -980,7 +989,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
             s->ext_used += s->wl[(size_t)t]->used;
         }
         s->tasks.resize((size_t)base[(size_t)nthr_s]); s->task_w.resize((size_t)base[(size_t)nthr_s]); s->task_skip.resize((size_t)base[(size_t)nthr_s]);
-        s->pool.run(nthr_s, [&](int t) {
+        pool_ok = s->pool.run(nthr_s, [&](int t) {
             WorkerLists &L = *s->wl[(size_t)t];
             const int64_t b0 = base[(size_t)t];
             std::copy(L.tasks.begin(), L.tasks.end(), s->tasks.begin() + b0);
@@ -1003,6 +1012,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
             for (auto &g : s->segs) seg_extract(s, em, g, m + 1);                   // :562
         }
     s->blockcount = bc0 + nblocks;
+    if (!pool_ok) return fdc::set_error(FDC_ERR_NOMEM, "a decision worker failed (out of memory?): the batch is lost");
     if ((npac && (nthr > 1 || nseg)) || nthr_s > 1)
         std::stable_sort(s->pdus.begin(), s->pdus.end(), [](const PduRec &a, const PduRec &b) { return a.key < b.key; });
     lap("decisions (host)");
@@ -1095,7 +1105,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
     const int npdu = (int)s->pdus.size();
     const int nasm = std::max(nthr, nthr_s);
     if (nasm > 1 && (npdu >= 64 || npac >= 64)) {
-        s->pool.run(nasm, [&](int t) {
+        pool_ok = s->pool.run(nasm, [&](int t) {
             for (int i = (int)((int64_t)npdu * t / nasm), e = (int)((int64_t)npdu * (t + 1) / nasm); i < e; i++) finish_pdu(s->pdus[(size_t)i]);
             for (int i = (int)((int64_t)npac * t / nasm), e = (int)((int64_t)npac * (t + 1) / nasm); i < e; i++)
                 for (auto &b : s->pacs[(size_t)i].blocks) resolve(b, s->pacs[(size_t)i].output_len);
@@ -1105,6 +1115,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
         for (auto &p : s->pacs) for (auto &b : p.blocks) resolve(b, p.output_len);
     }
     for (auto &g : s->segs) for (auto &c : g.chans) for (auto &b : c.data) resolve(b, c.outputsamples);
+    if (!pool_ok) return fdc::set_error(FDC_ERR_NOMEM, "a payload worker failed (out of memory?): the batch is lost");
     lap("payload assembly");
     if (trace) std::fprintf(stderr, "[fdc_sinks] %zu tasks, %lld samples extracted, %zu PDUs\n", nt, (long long)s->ext_used, s->pdus.size());
     return nblocks;
@@ -1149,7 +1160,7 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
 static int dev_launch_extractions(fdc_sinks *s, int nblocks)
 {
     auto &d = s->dev;
-    static const bool trace = getenv("FDC_SINKS_TRACE") != nullptr;
+    static const bool trace = fdc::debug_env("FDC_SINKS_TRACE") != nullptr;
     const int N = s->N, npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     HIPCHK(hipEventSynchronize(d.ev_decide));
     const int b = d.cur ^ 1;                                   // this call's landing buffer; d.cur still names the previous call's
@@ -1334,7 +1345,7 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     return fdc_sinks_work_device(s, nitems);
 }
 
-void fdc_set_log_callback(fdc_log_fn fn, void *user) { g_log_fn = fn; g_log_user = user; }
+void fdc_set_log_callback(fdc_log_fn fn, void *user) { std::lock_guard<std::mutex> g(g_log_mu); g_log_fn = fn; g_log_user = user; }
 
 int fdc_sinks_pdu_count(const fdc_sinks *s) { return s ? (int)s->pdus.size() : 0; }
 

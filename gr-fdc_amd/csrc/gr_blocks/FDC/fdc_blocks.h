@@ -15,6 +15,30 @@
 #define FDC_API __attribute__((visibility("default")))
 #endif
 
+// The smart pointer of the block API follows the GNU Radio it is built against: boost::shared_ptr up to 3.8 (what the
+// reference targets, include/FDC/overlap_save.h:39 `typedef boost::shared_ptr<overlap_save> sptr`, GNU Radio >= 3.7.2 per
+// its CMakeLists.txt:148), std::shared_ptr from 3.9 on and in the stand-alone build.  FDC_SPTR_BOOST=0/1 overrides the
+// detection.
+#if !defined(FDC_SPTR_BOOST)
+#if defined(FDC_HAVE_GNURADIO) && __has_include(<gnuradio/api.h>)
+#include <gnuradio/api.h>
+#endif
+#if defined(FDC_HAVE_GNURADIO) && defined(GR_VERSION_MAJOR)
+#define FDC_SPTR_BOOST ((GR_VERSION_MAJOR * 100 + GR_VERSION_API) < 309)
+#elif defined(FDC_HAVE_GNURADIO) && !__has_include(<gnuradio/buffer_type.h>) && __has_include(<boost/shared_ptr.hpp>)
+#define FDC_SPTR_BOOST 1      /* no version macros: 3.7 / 3.8 headers (buffer_type.h came with 3.10) and boost at hand */
+#else
+#define FDC_SPTR_BOOST 0
+#endif
+#endif
+#if FDC_SPTR_BOOST
+#include <boost/shared_ptr.hpp>
+#include <boost/make_shared.hpp>
+#define FDC_SHARED_PTR boost::shared_ptr
+#else
+#define FDC_SHARED_PTR std::shared_ptr
+#endif
+
 namespace gr {
 namespace FDC {
 
@@ -26,32 +50,32 @@ FDC_API amd_options &options();
 
 class FDC_API overlap_save : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<overlap_save> sptr;
+    typedef FDC_SHARED_PTR<overlap_save> sptr;
     static sptr make(int itemsize, int outputlen, int overlaplen);
 };
 
 class FDC_API vector_cut_vxx : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<vector_cut_vxx> sptr;
+    typedef FDC_SHARED_PTR<vector_cut_vxx> sptr;
     static sptr make(int itemsize, int veclen, int offset, int blocklen);
 };
 
 class FDC_API phase_shifting_windowing_vcc : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<phase_shifting_windowing_vcc> sptr;
+    typedef FDC_SHARED_PTR<phase_shifting_windowing_vcc> sptr;
     static sptr make(int blocklen, int numphasestates, int shifts, float passbw, float stopbw, int windowtype);
 };
 
 class FDC_API PowerActivationChannel : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<PowerActivationChannel> sptr;
+    typedef FDC_SHARED_PTR<PowerActivationChannel> sptr;
     static sptr make(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
                      int deactivation_delay, bool msg, bool fileoutput, std::string path, int verbose, int ID);
 };
 
 class FDC_API activity_detection_channelizer_vcm : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<activity_detection_channelizer_vcm> sptr;
+    typedef FDC_SHARED_PTR<activity_detection_channelizer_vcm> sptr;
     static sptr make(int blocklen, std::vector<std::vector<float>> segments, float thresh, int relinvovl, int maxblocks,
                      bool message, bool fileoutput, std::string path, bool threads, float minchandist,
                      int channel_deactivation_delay, double window_flank_puffer, int verbose);
@@ -59,7 +83,7 @@ public:
 
 class FDC_API SegmentDetection : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<SegmentDetection> sptr;
+    typedef FDC_SHARED_PTR<SegmentDetection> sptr;
     static sptr make(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh, float minchandist,
                      float window_flank_puffer, int maxblocks_to_emit, int channel_deactivation_delay, bool messageoutput,
                      bool fileoutput, std::string path, bool threads, int verbose);
@@ -73,7 +97,7 @@ public:
 // flowgraph.
 class FDC_API fdc_pipeline_vcc : virtual public gr::sync_block {
 public:
-    typedef std::shared_ptr<fdc_pipeline_vcc> sptr;
+    typedef FDC_SHARED_PTR<fdc_pipeline_vcc> sptr;
     // channels: rows (f, l, passbw, stopbw) as produced by get_opt_channelparams (py:322-345)
     static sptr make(int blocklen, int relinvovl, std::vector<std::vector<float>> channels, int windowtype, int max_items);
     // optional: pin the scheduler's buffers of this block's ports once the flowgraph has allocated them (start()), so

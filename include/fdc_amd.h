@@ -39,6 +39,12 @@ enum { FDC_WIN_RECTANGULAR = 0, FDC_WIN_HANN = 1, FDC_WIN_RAMP = 2 };
 const char *fdc_last_error(void);            /* thread-local text of the last failure */
 const char *fdc_version(void);
 int fdc_device_count(void);                  /* number of visible HIP devices (0 if none) */
+/* Runs the headline geometry (65536-point blocks, R = 2, 256 channels of 256 bins, 96 blocks: the one-kernel path) through
+ * fdc_pipeline_work() on EVERY visible device and compares a checksum of all output samples with device 0's (same kernels,
+ * same input: the bytes must be identical).  Returns the number of devices verified, or a negative fdc_status with the
+ * device and the mismatch in fdc_last_error().  A multi-GPU launcher calls it once before sharding block spans over the
+ * devices (the kernel attributes are set per device: this is what exercises device_id > 0). */
+int fdc_selftest_devices(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused throughput pipeline = the chain python/FrequencyDomainChannelizer.py:200-231 wires:
@@ -68,7 +74,24 @@ typedef struct {
     int32_t chunk_blocks;   /* blocks per internal launch group (0 = as many as a 2 GiB scratch budget
                                allows: long launches measured faster than cache-sized ones)          */
     int32_t keep_spectrum;  /* != 0: keep the whole normalised spectrum of a call (debug port, py:314) */
+    int32_t flags;          /* FDC_PIPE_* bits, 0 = the library picks the fastest kernels for the plan            */
+    int32_t min_block_launch; /* launch groups of fewer blocks than this do not take the one-block-per-compute-unit
+                               kernels (0 = default 96: such a kernel gives a whole block to ONE compute unit, so a short
+                               call would leave most of the device idle; 1 = always take them)                  */
+    int32_t host_sub_blocks;  /* fdc_pipeline_work(): blocks per sub-batch whose transfers and kernels overlap (0 = about
+                               8 MiB of input)                                                                */
 } fdc_pipeline_cfg;
+/* fdc_pipeline_cfg.flags: restrict the choice of kernels (A/B measurements, tests of the slower forms; results are the same
+ * to rounding).  The library reads NO environment variable unless FDC_DEBUG_ENV=1 is set, and then only as a debugging
+ * override of these fields (FDC_FORCE_GENERIC, FDC_NO_POLY, FDC_NO_BLOCK, FDC_BLOCK_HINTS, FDC_BLOCK_MIN_BLOCKS,
+ * FDC_HOST_SUB, FDC_SINKS_THREADS, FDC_SINKS_TRACE, and the tile knobs of the two-launch kernels). */
+enum {
+    FDC_PIPE_FORCE_GENERIC = 1,   /* generic LDS Stockham kernels only                                              */
+    FDC_PIPE_NO_POLY = 2,         /* no uniform-plan commutation: forward transform to a spectrum in memory + channel kernels */
+    FDC_PIPE_NO_BLOCK = 4,        /* no one-block-per-compute-unit kernels (two-launch uniform path / two-pass transform)   */
+    FDC_PIPE_PLAIN_STORES = 8,    /* block kernels: ordinary instead of streamed (nt) output stores                 */
+    FDC_PIPE_NT_LOADS = 16        /* block kernels: streamed (nt) input loads                                       */
+};
 
 int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out);
 void fdc_pipeline_destroy(fdc_pipeline *p);

@@ -15,7 +15,7 @@ for c in 1 3 4 5; do
   python3 bench.py --config $c --steps 20 --warmup 3 > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err || echo "bench cfg$c failed"
 done
 python3 bench.py --offset 37 --no-cpu-baseline > $OUT/bench_offset37.json 2> $OUT/bench_offset.err || echo "bench offset failed"
-FDC_NO_BLOCK=1 python3 bench.py --no-cpu-baseline > $OUT/bench_two_launch.json 2> /dev/null || echo "bench two-launch failed"
+python3 bench.py --no-cpu-baseline --force-path no-block > $OUT/bench_two_launch.json 2> /dev/null || echo "bench two-launch failed"
 # steps of 4096 blocks: nothing of the 1 GiB of input is left in the 256 MiB memory-side cache from the step before
 python3 bench.py --blocks 4096 --chunk 4096 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_blocks4096.json 2> /dev/null || echo "bench 4096 failed"
 cd /tmp && export TMPDIR=/tmp

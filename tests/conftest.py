@@ -10,7 +10,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # The library sends launch groups of fewer than 96 blocks to the tiled kernels (a block kernel gives one compute unit a whole
 # block; fdc_api.hip, kBlockMinBlocks).  The parity tests use a handful of blocks and are about the block kernels too:
 # they run with the threshold at 1; test_short_calls_take_the_tiled_kernels checks the default.
-os.environ.setdefault("FDC_BLOCK_MIN_BLOCKS", "1")
+import gr_fdc_amd as _G                                # noqa: E402  (does not load the library yet)
+_G.defaults.setdefault("FDC_BLOCK_MIN_BLOCKS", "1")     # -> fdc_pipeline_cfg.min_block_launch of every pipeline the tests create
+for _k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK"):     # the whole suite under a forced path: FDC_TEST_FORCE=FDC_NO_POLY pytest ...
+    if os.environ.get("FDC_TEST_FORCE") == _k:
+        _G.defaults[_k] = "1"
 
 
 def pytest_configure(config):

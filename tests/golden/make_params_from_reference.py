@@ -51,7 +51,11 @@ def load_reference():
 
 def py2_round(x):
     """Python 2's round(): half away from zero, returns float."""
-    return float(math.floor(abs(x) + 0.5)) * (1.0 if x >= 0 else -1.0)
+    ax = abs(x)                                  # decided on the fraction itself: abs(x) + 0.5 rounds 0.49999999999999994 up
+    r = math.floor(ax)
+    if ax - r >= 0.5:
+        r += 1.0
+    return float(r) * (1.0 if x >= 0 else -1.0)
 
 
 def instance(mod, freqmode, fs, cf, channels, segments):

@@ -136,3 +136,17 @@ def test_header_is_plain_c_and_example_compiles(tmp_path):
     obj = str(tmp_path / "ex.o")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            "-c", os.path.join(root, "examples", "fdc_pipeline_example.c"), "-o", obj])
+
+
+def test_round_half_away_is_c_round_on_the_edges():
+    """get_opt_channelparams rounds like the Python-2 reference (half away from zero), which is C's round(): the product's
+    helper must agree with libm on the values where `floor(abs(x) + 0.5)` does not."""
+    import ctypes
+    import ctypes.util
+    from gr_fdc_amd.channelizer import _round_half_away
+    m = ctypes.CDLL(ctypes.util.find_library("m"))
+    m.round.restype = ctypes.c_double
+    m.round.argtypes = [ctypes.c_double]
+    for x in (0.49999999999999994, -0.49999999999999994, 0.5, -0.5, 1.5, 2.5, -2.5, 4503599627370497.0, -4503599627370497.0,
+              4503599627370495.5, 1e300, 0.0, 123.49999999999999, 123.5):
+        assert _round_half_away(x) == m.round(x), x

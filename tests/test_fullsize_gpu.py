@@ -32,16 +32,16 @@ def bits(a):
     return a.view(np.uint32)
 
 
-FORCED = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK"))     # the suite itself run under a forced path
+FORCED = any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK"))     # the suite itself run under a forced path
 
 
 def run(N, R, plan, x, nb, sub=None, force=None):
     """force: None = the default path (uniform plan: one kernel at N = 65536, two launches otherwise), "FDC_NO_BLOCK" = the
     two-launch uniform path, "FDC_NO_POLY" = spectrum in memory, "FDC_FORCE_GENERIC" = generic kernels"""
     if sub is not None:
-        os.environ["FDC_HOST_SUB"] = str(sub)
+        G.defaults["FDC_HOST_SUB"] = str(sub)
     if force:
-        os.environ[force] = "1"
+        G.defaults[force] = "1"
     try:
         p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
         if not FORCED:
@@ -49,9 +49,9 @@ def run(N, R, plan, x, nb, sub=None, force=None):
                                 "FDC_NO_POLY": 1 if N == 65536 else 0, "FDC_FORCE_GENERIC": 0}[force]
         return p.work(x)
     finally:
-        os.environ.pop("FDC_HOST_SUB", None)
+        G.defaults.pop("FDC_HOST_SUB", None)
         if force:
-            os.environ.pop(force, None)
+            G.defaults.pop(force, None)
 
 
 @pytest.mark.parametrize("N,C,nb", [(65536, 256, 1024), (262144, 1024, 256)])

@@ -184,11 +184,11 @@ def test_fast_and_generic_paths_agree(oracle):
     chans = [(256 * c, 256, 0.88, 1.0) for c in range(0, 256, 17)] + [(1, 256, 0.88, 1.0)]
     x = noise(nb * (N - N // R), 77)
     fast = G.Pipeline(N, R, chans, max_blocks=nb, keep_spectrum=True).work(x, want_spectrum=True)
-    os.environ["FDC_FORCE_GENERIC"] = "1"
+    G.defaults["FDC_FORCE_GENERIC"] = "1"
     try:
         slow = G.Pipeline(N, R, chans, max_blocks=nb, keep_spectrum=True).work(x, want_spectrum=True)
     finally:
-        del os.environ["FDC_FORCE_GENERIC"]
+        del G.defaults["FDC_FORCE_GENERIC"]
     assert_close(fast[1], slow[1], "spectrum")
     for a, b in zip(fast[0], slow[0]):
         assert_close(a, b)
@@ -210,19 +210,19 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
-    forced = any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
-    assert forced or p.path() == (3 if (N, R) == (65536, 2) and not os.environ.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2: the one-kernel form
+    forced = any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
+    assert forced or p.path() == (3 if (N, R) == (65536, 2) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
         assert_close(outs[c], ref[c], "slot %d" % slots[c])
-    os.environ["FDC_NO_POLY"] = "1"
+    G.defaults["FDC_NO_POLY"] = "1"
     try:
         q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
         assert forced or q.path() == (1 if N == 65536 else 0)
         outs3 = q.work(x)
     finally:
-        del os.environ["FDC_NO_POLY"]
+        del G.defaults["FDC_NO_POLY"]
     for a, b in zip(outs, outs3):
         assert_close(a, b)
     # first_block / history handling on the two-stage path: ragged calls equal one call
@@ -243,15 +243,15 @@ def test_uniform_plan_one_kernel_path(oracle, nslots, nb, chunk):
     slots = [int(v) for v in rng.permutation(256)[:nslots]]
     chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * H, 77 + nb)
-    os.environ["FDC_HOST_SUB"] = str(nb)              # the whole call as one device batch (launch groups of `chunk` blocks)
+    G.defaults["FDC_HOST_SUB"] = str(nb)              # the whole call as one device batch (launch groups of `chunk` blocks)
     p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     assert p.path() == 3
     try:
         outs = p.work(x)
     finally:
-        os.environ.pop("FDC_HOST_SUB", None)
+        G.defaults.pop("FDC_HOST_SUB", None)
     k = min(nb, 3)
     ref, _ = oracle.channelizer(N, R, 1, chans, x[:k * H], nthreads=8)
     for c in range(len(chans)):
@@ -261,13 +261,13 @@ def test_uniform_plan_one_kernel_path(oracle, nslots, nb, chunk):
         ref2, _ = oracle.channelizer(N, R, 1, chans, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
         for c in range(len(chans)):
             assert_close(outs[c][t0 * 128:], ref2[c], "slot %d tail" % slots[c])
-    os.environ["FDC_NO_BLOCK"] = "1"
+    G.defaults["FDC_NO_BLOCK"] = "1"
     try:
         q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
         assert q.path() == 2
         outs2 = q.work(x)
     finally:
-        del os.environ["FDC_NO_BLOCK"]
+        del G.defaults["FDC_NO_BLOCK"]
     for c in range(len(chans)):
         assert_close(outs[c], outs2[c], "slot %d vs two-launch path" % slots[c])
 
@@ -284,7 +284,7 @@ def test_offset_uniform_plan_one_kernel_path(oracle, r, nslots):
     slots = [int(v) for v in rng.permutation(255)[:nslots]]          # slot 255 would leave the spectrum for r > 0
     chans = [(256 * c + r, 256, 0.88, 1.0) for c in slots]
     x = noise(nb * H, 11 + r)
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
     assert p.path() == 3
@@ -292,13 +292,13 @@ def test_offset_uniform_plan_one_kernel_path(oracle, r, nslots):
     ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
     for c in range(0, len(chans), max(1, len(chans) // 16)):
         assert_close(outs[c], ref[c], "slot %d offset %d" % (slots[c], r))
-    os.environ["FDC_NO_POLY"] = "1"
+    G.defaults["FDC_NO_POLY"] = "1"
     try:
         q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
         assert q.path() == 1
         outs3 = q.work(x)
     finally:
-        del os.environ["FDC_NO_POLY"]
+        del G.defaults["FDC_NO_POLY"]
     for a, b in zip(outs, outs3):
         assert_close(a, b)
     p.reset()
@@ -306,11 +306,11 @@ def test_offset_uniform_plan_one_kernel_path(oracle, r, nslots):
     for c in range(len(chans)):
         assert_close(np.concatenate([q_[c] for q_ in parts]), outs[c])
     # without the one-kernel form an offset plan is not a uniform plan
-    os.environ["FDC_NO_BLOCK"] = "1"
+    G.defaults["FDC_NO_BLOCK"] = "1"
     try:
         assert G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb).path() == 1
     finally:
-        del os.environ["FDC_NO_BLOCK"]
+        del G.defaults["FDC_NO_BLOCK"]
 
 
 def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
@@ -327,7 +327,7 @@ def test_cfg4_262144_tiled_1024_channels_sharded_spans(oracle):
     x = noise(nb * H, 2027)
     ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
     pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
-    assert pipe.path() == 2 or any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # two-stage path, 1024 slots
+    assert pipe.path() == 2 or any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # two-stage path, 1024 slots
     whole = pipe.work(x)
     for c in range(0, Cn, 37):
         assert_close(whole[c], ref[c], "whole ch%d" % c)
@@ -377,7 +377,7 @@ def test_host_path_sub_batches_staged_and_pinned(oracle, sub):
     chans = [(8, 512, 0.8, 1.0), (1031, 64, 0.7, 0.9), (3000, 1024, 0.5, 0.75), (777, 1, 0.5, 1.0), (2048, 256, 0.9, 1.0)]
     x = noise(2 * nb * H, 77)
     ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=2)
-    os.environ["FDC_HOST_SUB"] = sub
+    G.defaults["FDC_HOST_SUB"] = sub
     try:
         p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
         los = p.lout
@@ -399,7 +399,7 @@ def test_host_path_sub_batches_staged_and_pinned(oracle, sub):
         finally:
             G.unregister_host(xin); G.unregister_host(pool)
     finally:
-        del os.environ["FDC_HOST_SUB"]
+        del G.defaults["FDC_HOST_SUB"]
     for c, lo in enumerate(los):
         assert_close(np.concatenate([o1[c], o2[c]]), ref[c], "ch%d" % c)
         assert_close(np.concatenate([o3[c], o4[c]]), ref[c], "ch%d (mixed)" % c)
@@ -533,7 +533,7 @@ def test_spectrum_path_block_forward_kernel_vs_two_pass(oracle, R):
     """N = 65536 with a mixed channel plan (spectrum in memory): the forward transform runs on the block kernel (both halves of
     k2 in one launch, fdc_block256.hip FWD); the two-pass kernels k_a256/k_b256 (FDC_NO_BLOCK=1) must give the same spectrum
     and the same channel outputs, and both must match the oracle.  R = 4: nothing in the forward kernel depends on R."""
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     N, nb = 65536, 5
     chans = [(37, 256, 0.88, 1.0), (300, 512, 0.9, 1.0), (4096, 1024, 0.88, 1.0), (65536 - 256, 256, 0.8, 0.95), (32768 - 64, 128, 0.88, 1.0)]
@@ -542,14 +542,14 @@ def test_spectrum_path_block_forward_kernel_vs_two_pass(oracle, R):
     res = {}
     for force in (None, "FDC_NO_BLOCK"):
         if force:
-            os.environ[force] = "1"
+            G.defaults[force] = "1"
         try:
             p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, keep_spectrum=True)
             assert p.path() == 1
             res[force] = p.work(x, want_spectrum=True)
         finally:
             if force:
-                del os.environ[force]
+                del G.defaults[force]
     for force, (outs, spec) in res.items():
         assert_close(spec.reshape(-1), sref.reshape(-1), "spectrum (%s)" % force)
         for c in range(len(chans)):
@@ -563,7 +563,7 @@ def test_plan_classes_one_kernel_path(oracle):
     (b) the same slots with two different windows, (c) the same slot twice with the same window (two classes).  Plans whose
     classes would cost more than the spectrum path (few channels in several classes, or more than three classes) fall back.
     Every output is checked against the oracle and against the spectrum path."""
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     N, R, nb = 65536, 2, 5
     H = N - N // R
@@ -582,11 +582,11 @@ def test_plan_classes_one_kernel_path(oracle):
         ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
         for c in list(range(0, len(plan), 23)) + [len(plan) - 1]:
             assert_close(outs[c], ref[c], "%s: channel %d" % (name, c))
-        os.environ["FDC_NO_POLY"] = "1"
+        G.defaults["FDC_NO_POLY"] = "1"
         try:
             outs3 = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb).work(x)
         finally:
-            del os.environ["FDC_NO_POLY"]
+            del G.defaults["FDC_NO_POLY"]
         for a, b in zip(outs, outs3):
             assert_close(a, b, name)
         p.reset()                                       # ragged calls: the odd offset's sign follows the global block index
@@ -603,7 +603,7 @@ def test_short_calls_take_the_tiled_kernels(oracle):
     """Default dispatch (no FDC_BLOCK_MIN_BLOCKS): a launch group of fewer than 96 blocks runs on the tiled kernels (two-launch
     uniform path, two-pass forward transform), 96 and more on the block kernels; a call of 100 blocks cut into groups of
     96 + 4 uses both.  All of them must agree with the oracle — and the path id stays what the plan qualifies for."""
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     N, R, nb = 65536, 2, 100
     H = N - N // R
@@ -612,7 +612,7 @@ def test_short_calls_take_the_tiled_kernels(oracle):
     x = noise(nb * H, 99)
     ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
     refm, _ = oracle.channelizer(N, R, 1, mixed, x, nthreads=8)
-    saved = os.environ.pop("FDC_BLOCK_MIN_BLOCKS", None)
+    saved = G.defaults.pop("FDC_BLOCK_MIN_BLOCKS", None)
     try:
         for chunk in (0, 96):
             p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
@@ -629,13 +629,13 @@ def test_short_calls_take_the_tiled_kernels(oracle):
                 assert_close(np.concatenate([q_[c] for q_ in parts]), refm[c], "mixed plan channel %d" % c)
     finally:
         if saved is not None:
-            os.environ["FDC_BLOCK_MIN_BLOCKS"] = saved
+            G.defaults["FDC_BLOCK_MIN_BLOCKS"] = saved
 
 
 def test_every_offset_of_the_one_kernel_path(oracle):
     """All 255 non-zero offsets r (f = 256*slot + r): the rotation of the exchange slots by r mod 16, the second twiddle row
     table, the cbt table with (b + r) and the per-block sign of odd r, each against the oracle on three blocks."""
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     N, R, nb = 65536, 2, 3
     x = noise(nb * (N - N // R), 2718)
@@ -657,7 +657,7 @@ def test_randomized_plans_and_call_patterns():
     spectrum-in-memory path on every sample, mixed plans and every fifth case against the oracle."""
     import subprocess
     import sys
-    if any(os.environ.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paths.py"), "24", "7"], capture_output=True, text=True,

@@ -5,6 +5,7 @@ The stamps are compiled in only with -DFDC_BLK_STAMPS (they cost registers the k
   tools/build_variant.sh stamps -DFDC_BLK_STAMPS && FDC_AMD_LIB=gr-fdc_amd/libfdc_amd_stamps.so python tools/block_probe.py"""
 import os
 import sys
+os.environ["FDC_DEBUG_ENV"] = "1"
 os.environ["FDC_BLOCK_DEBUG"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

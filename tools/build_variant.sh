@@ -5,5 +5,5 @@ set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../gr-fdc_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall "$@" -c fdc_block256.hip -o /tmp/fdc_block256_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libfdc_amd_$TAG.so fdc_api.o fdc_kernels.o fdc_fast256.o /tmp/fdc_block256_$TAG.o fdc_chanwide.o fdc_sinks.o -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libfdc_amd_$TAG.so fdc_api.o fdc_kernels.o fdc_fast256.o /tmp/fdc_block256_$TAG.o fdc_chanwide.o fdc_sinks.o fdc_sinks_dev.o -Wl,-rpath,/opt/rocm/lib
 echo built ../libfdc_amd_$TAG.so

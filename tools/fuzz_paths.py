@@ -65,18 +65,18 @@ def main():
         x = (rng.standard_normal(nb * H) + 1j * rng.standard_normal(nb * H)).astype(np.complex64)
         cuts = sorted(set([0, nb] + [int(v) for v in rng.integers(0, nb + 1, size=int(rng.integers(0, 3)))]))
         if rng.integers(0, 2):
-            os.environ["FDC_BLOCK_MIN_BLOCKS"] = "1"
+            G.defaults["FDC_BLOCK_MIN_BLOCKS"] = "1"
         else:
-            os.environ.pop("FDC_BLOCK_MIN_BLOCKS", None)
+            G.defaults.pop("FDC_BLOCK_MIN_BLOCKS", None)
         p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
         path = p.path()
         parts = [p.work(x[a * H:b * H]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         outs = [np.concatenate([q[c] for q in parts]) for c in range(len(plan))]
-        os.environ["FDC_NO_POLY"] = "1"
+        G.defaults["FDC_NO_POLY"] = "1"
         try:
             ref = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb).work(x)
         finally:
-            del os.environ["FDC_NO_POLY"]
+            del G.defaults["FDC_NO_POLY"]
         e = max(rel(a, b) for a, b in zip(outs, ref))
         eo = 0.0
         if case % 5 == 0 or path == 1:                # the comparison above is vacuous when both runs take the spectrum path
