@@ -1243,15 +1243,16 @@ static int dev_complete(fdc_sinks *s, int b)
         m = fdc_pdu{};
         const bool det = (r.flags >> 16) & 1;
         const int64_t blk = r.key >> 24;                       // block index inside the batch
-        int width, vstart;
+        int width, vstart, vend;
         if (!det) {
             const Pac &p = s->pacs[(size_t)r.owner];
-            width = p.extract_width; vstart = p.extract_start;
+            // extract_stop, not extract_start + extract_width: they differ after the reference's clamp (…_impl.cc:333-336, :226)
+            width = p.extract_width; vstart = p.extract_start; vend = p.extract_stop;
             m.kind = 0; m.source = p.ID; m.has_part = 1;
             m.blockend = d.bc0[b] + blk;                       // blockcount while the item is processed (:226-227)
         } else {
             const int sgi = (int)((r.key >> 12) & 0x7FF);
-            width = 1 << ((r.flags >> 8) & 0xFF); vstart = r.vstart;
+            width = 1 << ((r.flags >> 8) & 0xFF); vstart = r.vstart; vend = vstart + width;
             m.kind = 1;
             m.source = (sd && s->cfg.det_id >= 0 && s->segs.size() == 1) ? s->cfg.det_id : s->segs[(size_t)sgi].ID;
             m.has_part = (r.flags & 1) ? (r.part > 0) : 1;     // …vcm_impl.cc:419-420
@@ -1261,8 +1262,8 @@ static int dev_complete(fdc_sinks *s, int b)
         o.blocklen = width - width / s->R;
         m.chan_id = r.chan_id; m.finalized = r.flags & 1; m.part = r.part;
         m.rel_bw = (double)width / (double)s->N;
-        m.rel_cfreq = (double)(vstart + vstart + width) / 2.0 / (double)s->N;
-        m.blockstart = m.blockend - r.count; m.vectorstart = vstart; m.vectorend = vstart + width;
+        m.rel_cfreq = (double)(vstart + vend) / 2.0 / (double)s->N;
+        m.blockstart = m.blockend - r.count; m.vectorstart = vstart; m.vectorend = vend;
         m.nsamples = (int64_t)(r.q1 - r.q0) * o.blocklen;
         m.samples = m.nsamples ? base + sizeof(float2) * (size_t)r.off : nullptr;
         if ((time_t)r.act_time != last_t) {                    // create_ID() / get_ID_for_msg(): local time of the activation

@@ -28,3 +28,11 @@ def test_oracle_segment_detection(oracle, sc):
     blk = oracle.SegmentDetection(ident, S.N, S.R, a, b, 10.0, 0.0625, sc["puffer"], sc["maxblocks"], sc["delay"])
     assert blk.segments[0] == sc["geometry"]
     S.check(sc["name"], _pairs(blk.work(sc["spec"])), sc["expect"])
+
+
+@pytest.mark.parametrize("sc", S.PAC_GEOM, ids=[s["name"] for s in S.PAC_GEOM])
+def test_oracle_pac_geometry_and_payload(oracle, sc):
+    cf, bw = sc["pac"]
+    blk = oracle.PowerActivationChannel(S.N, cf, bw, S.R, 6.0, sc["maxblocks"], 0, 9)
+    assert (blk.extract_start, blk.extract_stop, blk.measure_start, blk.measure_stop, blk.output_len) == sc["params"]
+    S.check(sc["name"], _pairs(blk.work(sc["spec"])), sc["expect"])

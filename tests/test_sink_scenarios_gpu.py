@@ -31,6 +31,18 @@ def test_hip_pac(sc):
         assert all(m["id"].endswith(".PowActChan.9.%d" % m["chan_id"]) for m, _s in got)
 
 
+@pytest.mark.parametrize("engine", ["device", "host"])
+@pytest.mark.parametrize("sc", S.PAC_GEOM, ids=[s["name"] for s in S.PAC_GEOM])
+def test_hip_pac_geometry_and_payload(sc, engine):
+    cf, bw = sc["pac"]
+    for mb in (3, 16):
+        bank = G.Sinks(S.N, S.R, pac=[(cf, bw, 9)], pac_thresh=6.0, pac_maxblocks=sc["maxblocks"], max_blocks=mb,
+                       host_decisions=engine == "host")
+        p = bank.pac_params(0)
+        assert (p["extract_start"], p["extract_stop"], p["measure_start"], p["measure_stop"], p["output_len"]) == sc["params"]
+        S.check(sc["name"] + " / " + engine, bank.work(sc["spec"]), sc["expect"])
+
+
 @pytest.mark.parametrize("sc", S.SD, ids=[s["name"] for s in S.SD])
 def test_hip_segment_detection(sc):
     ident, a, b = sc["sd"]
