@@ -32,6 +32,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")     # CPU baseline legs: one leg's idle OpenMP team must not spin into the next
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = "complex Msamples/s in, 64k-FFT/256-ch overlap-save; achieved HBM GB/s vs peak"
@@ -239,6 +240,10 @@ def cpu_baseline(N, R, plan, blocks, budget_s):
         bt = max(2, min(blocks, 16))
         xt = torch.from_numpy(np.concatenate([np.zeros(N // R, np.complex64), x[:bt * H]]))
         torch.set_num_threads(share)
+        try:
+            torch.set_num_interop_threads(1)
+        except RuntimeError:
+            pass                                  # already started: stays as it is
 
         def chain():
             blk = xt.unfold(0, N, H)[:bt]
@@ -249,10 +254,22 @@ def cpu_baseline(N, R, plan, blocks, budget_s):
         tv, st, rt = timed(chain, budget_s * 0.2, bt)
         out["torch_fft"] = {"value": round(tv, 3), "cores": share,
                             "sample": "%d passes over %d blocks, torch.fft (CPU) for both transforms, %.1f s" % (rt, bt, st)}
-    import ctypes.util
-    have = [n for n in ("fftw3f", "volk") if ctypes.util.find_library(n)]      # SURVEY.md §8d start-up probe
-    out["reference_libraries_found"] = have if have else "none (no FFTW3f, no VOLK on this box): the reference's own CPU path " \
-                                                         "cannot be timed here, the port is the reported baseline"
+    # The reference's own arithmetic libraries, if this host has them: the chain with FFTW3f (4
+    # threads on the forward transform, py:206) and VOLK behind the reference's stage boundaries (oracle/ref_equiv.c, dlopen)
+    why = O.refequiv_probe()
+    if why is None:
+        try:
+            vr, pr, o0 = O.refequiv_run(N, R, 1, plan, x, 4, budget_s * 0.2)
+            ref0, _ = O.channelizer(N, R, 1, plan[:1], x, nthreads=share)
+            dev = float(np.abs(o0 - ref0[0]).max() / max(1e-30, np.abs(ref0[0]).max()))
+            out["reference_equivalent"] = {"value": round(vr, 3), "unit": "Msamples/s", "cores": share, "kind": "reference-equivalent",
+                                           "sample": "%d passes over %d blocks: FFTW3f (forward transform on 4 threads) + VOLK behind the "
+                                                     "reference's stage boundaries, channel branches over %d OpenMP threads" % (pr, blocks, share),
+                                           "max_rel_dev_from_oracle_channel0": dev}
+        except Exception as e:      # noqa: BLE001  (a baseline leg must not take the bench line down)
+            out["reference_equivalent"] = {"error": str(e)}
+    out["reference_libraries_found"] = "libfftw3f + libvolk" if why is None else \
+        "%s: the reference's own CPU path cannot be timed on this box, the port is the reported baseline" % why
     return out
 
 
@@ -502,6 +519,36 @@ def main():
                     "Msamples_per_s": round(world * small * H * a.steps / d1 / 1e6, 3),
                     "pipeline_frac": round((8 * H + 8 * sum_lout) * small * a.steps / d1 / 1e9 / HBM_PEAK_GBS, 4),
                     "note": "input re-read from the memory-side cache (268 MB ring, 256 MiB cache): the round-1/2 default"}
+    # "also report an end-to-end number with H2D": the host-buffer entry sync_block::work() calls
+    # (fdc_pipeline_work: input H2D, kernels, outputs D2H), 256 blocks per call, caller buffers pinned once with
+    # fdc_host_register.  PCIe-bound; never `value`.
+    end_to_end = None
+    if sinks is None and a.config == 2 and world == 1 and not a.no_kernel_timing:
+        import ctypes as ct
+        nbh = 256
+        ph = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nbh, device_id=local)
+        rng_h = np.random.default_rng(7)
+        xh = (rng_h.standard_normal(nbh * H) + 1j * rng_h.standard_normal(nbh * H)).astype(np.complex64)
+        pool = np.zeros(nbh * sum_lout, np.complex64)
+        ptrs, off = (ct.c_void_p * len(plan))(), 0
+        for c, lo in enumerate(ph.lout):
+            ptrs[c] = pool.ctypes.data + 8 * off
+            off += nbh * lo
+        G.register_host(xh); G.register_host(pool)
+        try:
+            for _ in range(2):
+                ph.work_raw(xh.ctypes.data, nbh, ptrs)
+            th = time.perf_counter()
+            reps_h = 8
+            for _ in range(reps_h):
+                ph.work_raw(xh.ctypes.data, nbh, ptrs)
+            dth = (time.perf_counter() - th) / reps_h
+            end_to_end = {"value": round(nbh * H / dth / 1e6, 3), "unit": "Msamples/s", "blocks_per_call": nbh, "ms_per_call": round(dth * 1e3, 3),
+                          "entry": "fdc_pipeline_work (H2D of the input + kernels + D2H of every channel output per call; buffers "
+                                   "pinned with fdc_host_register)"}
+        finally:
+            G.unregister_host(xh); G.unregister_host(pool)
+            del ph
     msps = world * nb * H * a.steps / dt / 1e6
     chunk = pipe.chunk_blocks()
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
@@ -556,6 +603,8 @@ def main():
                      "frac_of_achievable_6300": round(achieved / 6300.0, 4),
                      "pipeline_frac_of_achievable_6300": round(pipe_gbs / 6300.0, 4)},
     }
+    if end_to_end is not None:
+        res["end_to_end_h2d"] = end_to_end
     if sinks is not None:
         res["config"]["pdus_per_step"] = round(extracted[1] / max(1, extracted[2]), 1)
         res["config"]["extracted_samples_per_step"] = round(extracted[0] / max(1, extracted[2]), 1)

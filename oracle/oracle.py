@@ -64,6 +64,57 @@ def have_ref():
     return os.path.exists(_REF)
 
 
+# ---- bench.py's "reference-equivalent" CPU leg (oracle/ref_equiv.c): the chain with FFTW3f + VOLK found by dlopen()
+_REFEQ = os.path.join(_HERE, "libfdc_refequiv.so")
+_refeq = None
+
+
+def _refequiv():
+    global _refeq
+    if _refeq is None:
+        if not os.path.exists(_REFEQ):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libfdc_refequiv.so"])
+        h = C.CDLL(_REFEQ)
+        h.fdco_refequiv_probe.restype = C.c_int
+        h.fdco_refequiv_probe.argtypes = [C.c_char_p, C.c_int]
+        h.fdco_refequiv_run.restype = C.c_int
+        h.fdco_refequiv_run.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int, C.c_int,
+                                        C.c_double, _dp, _ip, C.c_void_p, C.c_char_p, C.c_int]
+        _refeq = h
+    return _refeq
+
+
+def refequiv_probe():
+    """None when libfftw3f and libvolk can be loaded on this host, else the reason why not."""
+    err = C.create_string_buffer(256)
+    return None if _refequiv().fdco_refequiv_probe(err, 256) == 0 else err.value.decode()
+
+
+def refequiv_run(N, R, wintype, chans, x, fwd_threads, budget_s):
+    """(Msamples/s in, passes, channel-0 output of the last pass) of the reference-equivalent chain on x (whole blocks)."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    H = N - N // R
+    nb = x.size // H
+    f = (C.c_int * len(chans))(*[int(c[0]) for c in chans])
+    l = (C.c_int * len(chans))(*[int(c[1]) for c in chans])
+    tabs, offs, off = [], [], 0
+    for c in chans:
+        w = window(wintype, int(c[1]), np.float32(c[2]), np.float32(c[3]), R)
+        tabs.append(np.ascontiguousarray(w, dtype=np.complex64).reshape(-1))
+        offs.append(off)
+        off += tabs[-1].size
+    wins = np.concatenate(tabs)
+    woff = (C.c_long * len(chans))(*offs)
+    out0 = np.empty(nb * (int(chans[0][1]) - int(chans[0][1]) // R), np.complex64)
+    msps, passes = C.c_double(), C.c_int()
+    err = C.create_string_buffer(256)
+    rc = _refequiv().fdco_refequiv_run(N, R, len(chans), f, l, wins.ctypes.data, woff, x.ctypes.data, nb, int(fwd_threads), float(budget_s),
+                                       C.byref(msps), C.byref(passes), out0.ctypes.data, err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return msps.value, passes.value, out0
+
+
 def nextpow2(k):
     r = lib().fdco_nextpow2(float(k))
     if r < 0:
