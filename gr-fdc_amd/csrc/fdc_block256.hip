@@ -30,6 +30,7 @@
 // The arithmetic is the uniform-plan commutation of fdc_fast256.hip (same tables, same rounding points), so the
 // result matches k_p1 + k_p2 to the last few ulps; parity against the oracle: tests/test_parity_gpu.py.
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
 #include "fdc_devutil.hpp"
@@ -77,7 +78,11 @@ static_assert(kBlkOffCt >= kBlkOffX && kBlkOffCt + 32 * 8 * 8 <= kBlkOffWrow, "s
 // twice, its "slots" are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 =
 // fftshift), 64 consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans,
 // the sinks, the debug port) use instead of two passes through a scratch buffer of the whole batch.
-template <bool NT, bool OFF, bool FWD>
+// R4 = true: the channelizer at relinvovl = 4 (the reference's default overlap, grc/FDC_FrequencyDomainChannelizer.xml:61): three
+// quarters of every inverse transform are kept, G is 192 rows x 256 columns = 384 KiB.  The rows t >= 128 stay in the G registers
+// as for R = 2; the rows 64 <= t < 128 take the route of the forward-transform variant: 128 KiB of per-workgroup scratch (L2),
+// read back for a third 64-row run of stage 2.  On-grid plans only (f = 256 slot: the window phase stays 0).
+template <bool NT, bool OFF, bool FWD, bool R4 = false>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -149,7 +154,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     const float2 *const btr = Bt + c5 * 18;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
     // FWD: this workgroup's scratch for the second half of k2, [pass][j][thread]
-    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(FWD ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, FWD ? 32768u * 8u : 0u);
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc((FWD || R4) ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, (FWD || R4) ? 32768u * 8u : 0u);
 
     // Two waves share a SIMD (waves w and w + 4).  The older one wins the issue arbitration and finishes stage 1 ~10 k cycles
     // earlier; s_setprio (either half favoured, or alternating per pass) changes nothing about that (profiles/r02/NOTES.md).
@@ -285,6 +290,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 dft16<true>(u);                                       // y[t = b + 16 q] in u[rev16(q)]; keep q >= 8 (R = 2)
 #pragma unroll
                 for (int j = 0; j < 8; j++) FDC_GPUT(j, ps, u[rev16(8 + j)]);
+                if constexpr (R4) {                                   // R = 4 keeps q >= 4: rows 64..127 go to the scratch, [pass][q - 4][thread]
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bst2(rscr, (unsigned)tid * 8u + (unsigned)j * 4096u, (unsigned)ps * 16384u, u[rev16(4 + j)]);
+                }
             }
             FDC_STAMP(1 + ps);
         }
@@ -294,7 +303,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // What is left is a DFT-32 over c5 = 4 wave + col, i.e. across the whole workgroup: ONE trip through LDS per value
         // (two chunks of 64 rows: [row][klo][c5], rows 262 apart), read back as whole 32-point runs by lane = row, wave = klo,
         // transformed in registers.  A wave's store is 64 consecutive samples of one channel (512 B).
-        auto stage2 = [&](auto get, const int h) __attribute__((always_inline)) {
+        // rowbase: first output row (sample index inside the block's lout rows, or bin offset 128 h of a forward transform) of the
+        // run; nchc: its number of 64-row chunks
+        auto stage2 = [&](auto get, const int rowbase, auto nchc) __attribute__((always_inline)) {
+            constexpr int kNch = decltype(nchc)::value;
             __syncthreads();                                          // every wave is done with its stage-1 scratch
             FDC_STAMP(9);
             // the stage-2 roles are worked out here, from a thread index the compiler cannot trace back: loop-invariant address
@@ -311,7 +323,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
             const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
 #pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
+            for (int ch = 0; ch < kNch; ch++) {
                 cf ct[8];                                             // W_256^(c5 klo): read per chunk, not held across the DFT-32 phase
                 {
                     const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
@@ -356,7 +368,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
                 // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
                 // dropped by the range check of the descriptor (no branch per store).
-                const unsigned rb = (unsigned)(m * (FWD ? 65536 : 128) + (FWD ? 128 * h : 0) + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
+                const unsigned rb = (unsigned)(m * (FWD ? 65536 : (R4 ? 192 : 128)) + rowbase + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint4 t = sow[q];
@@ -369,11 +381,18 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, 0);
+        stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, R4 ? 64 : 0, std::integral_constant<int, 2>{});
         if constexpr (FWD) {
             // second half of k2: the values stage 1 put aside are this lane's own stores; sc1 loads are served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 32768), 0u); }, 1);
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 32768), 0u); }, 128,
+                   std::integral_constant<int, 2>{});
+        }
+        if constexpr (R4) {
+            // rows 64..127 of the inverse transforms = output rows 0..63: this lane's own stores, served by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
+                   std::integral_constant<int, 1>{});
         }
         FDC_STAMP(30);
 #ifdef FDC_BLK_STAMPS
@@ -394,15 +413,31 @@ hipError_t init_block_kernels()
     FDC_SETB(true, false, false) FDC_SETB(false, false, false) FDC_SETB(true, true, false) FDC_SETB(false, true, false)
     FDC_SETB(true, false, true) FDC_SETB(false, false, true)
 #undef FDC_SETB
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
+    if (e != hipSuccess) return e;
     return hipSuccess;
 }
 
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                             unsigned long long *dbg, int r, long long first_block, hipEvent_t ev_start, hipEvent_t ev_stop)
+                             unsigned long long *dbg, int r, long long first_block, hipEvent_t ev_start, hipEvent_t ev_stop, int R,
+                             float2 *scratch)
 {
     if (nb_chunk <= 0) return hipSuccess;
+    if (R == 4) {                                           // three quarters of every inverse transform kept: 192 rows, 64 of them via the scratch
+        int grid = ncu > 0 ? ncu : 256;
+        if (grid > nb_chunk) grid = nb_chunk;
+#define FDC_LB4(A) \
+        hipExtLaunchKernelGGL((k_blk256<A, false, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
+                              tw256, twq, cbt, shn, slot_off, (long long)mbase * 192, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, 0, first_block, \
+                              scratch)
+        if (hints & 1) FDC_LB4(true); else FDC_LB4(false);
+#undef FDC_LB4
+        return hipGetLastError();
+    }
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: 159.5 KiB each)
     if (grid > nb_chunk) grid = nb_chunk;
     // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)

@@ -45,7 +45,7 @@ def run(N, R, plan, x, nb, sub=None, force=None):
     try:
         p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
         if not FORCED:
-            assert p.path() == {None: 3 if (N, R) == (65536, 2) else 2, "FDC_NO_BLOCK": 2,
+            assert p.path() == {None: 3 if N == 65536 and R in (2, 4) else 2, "FDC_NO_BLOCK": 2,
                                 "FDC_NO_POLY": 1 if N == 65536 else 0, "FDC_FORCE_GENERIC": 0}[force]
         return p.work(x)
     finally:

@@ -211,7 +211,7 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
     forced = any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
-    assert forced or p.path() == (3 if (N, R) == (65536, 2) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2: the one-kernel form
+    assert forced or p.path() == (3 if N == 65536 and R in (2, 4) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2 or 4: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
@@ -664,3 +664,36 @@ def test_randomized_plans_and_call_patterns():
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "all 24 cases within" in out.stdout
+
+
+@pytest.mark.parametrize("wt", [0, 1, 2])
+def test_one_kernel_form_at_relinvovl_4(oracle, wt):
+    """R = 4 (the reference's default overlap, grc/FDC_FrequencyDomainChannelizer.xml:61) on the one-kernel path: 192 of the 256
+    rows of every inverse transform are kept — 128 in registers, 64 through the per-workgroup scratch and a third run of
+    stage 2.  All 256 slots and a scattered subset, against the oracle and against the two-launch form on every sample;
+    several workgroup rounds (more blocks than a small grid would take at once), ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 4, 7
+    x = noise(nb * (N - N // R), 77 + wt)
+    for slots in (list(range(256)), [255, 0, 3, 128, 64, 200, 17]):
+        chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = range(len(chans)) if len(chans) < 16 else (0, 1, 100, 127, 128, 254, 255)
+        ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * 192
+            assert_close(outs[c], ref[i], "slot %d" % slots[c])
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+        assert q.path() == 2
+        for a, b in zip(outs, q.work(x)):
+            assert_close(a, b, "one kernel vs two launches")
+        p.reset()
+        parts = [p.work(x[a * p.H:b * p.H]) for a, b in [(0, 3), (3, 4), (4, 7)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+    # an offset tiling at R = 4 keeps the spectrum path (the window phase would rotate from block to block)
+    off = G.Pipeline(N, R, [(256 * c + 37, 256, 0.88, 1.0) for c in range(8)], windowtype=1, max_blocks=2)
+    assert off.path() == 1
