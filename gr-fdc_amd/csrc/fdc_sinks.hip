@@ -480,7 +480,11 @@ int dev_setup(fdc_sinks *s)
     if ((cfg.flags & FDC_SINKS_HOST_DECISIONS) || cfg.verbose != 0) return FDC_OK;
     const int npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     if (npac + nseg == 0) return FDC_OK;
-    for (const Segment &g : s->segs) if (g.ncell > fdc::kDetMaxCells) return FDC_OK;
+    {
+        int capmax = 1;
+        for (const Segment &g : s->segs) { if (g.ncell > fdc::kDetMaxCells) return FDC_OK; capmax = std::max(capmax, g.ncell / 2 + 1); }
+        if (nseg && (capmax > 512 || fdc::det_track_staged(cfg.max_blocks, capmax) < 0)) return FDC_OK;   // the tracker's tables would not fit
+    }
     const int64_t nbmax = cfg.max_blocks;
     d.npw = npac;                                                              // one list per PowerActivationChannel (one wave each)
     d.nlist = d.npw + nseg;
@@ -1141,6 +1145,9 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
         fdc::DetParams dp{};
         dp.N = N; dp.R = s->R; dp.dec = s->dec; dp.variant = sd; dp.maxblocks = s->cfg.det_maxblocks; dp.delay = s->cfg.det_deactivation_delay;
         dp.nseg = nseg; dp.npac = npac; dp.nbmax = s->cfg.max_blocks; dp.puffer = s->cfg.window_flank_puffer;
+        dp.mb_shift = (dp.maxblocks >= 2 && (dp.maxblocks & (dp.maxblocks - 1)) == 0) ? 31 - __builtin_clz((unsigned)dp.maxblocks) : -1;
+        dp.max_cand_cap = 1;
+        for (const Segment &g : s->segs) dp.max_cand_cap = std::max(dp.max_cand_cap, g.ncell / 2 + 1);
         dp.segname0 = s->cfg.det_id;
         HIPCHK(fdc::launch_det_track(dp, nblocks, d.d_dgeom, d.d_sst, d.d_live, d.d_live_off, d.d_cand, d.d_cand_base, d.d_ncand, d.d_winoff,
                                      bc0, now, d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners,
@@ -1242,7 +1249,7 @@ static int dev_complete(fdc_sinks *s, int b)
         fdc_pdu &m = o.meta;
         m = fdc_pdu{};
         const bool det = (r.flags >> 16) & 1;
-        const int64_t blk = r.key >> 24;                       // block index inside the batch
+        const int64_t blk = r.key >> 40;                       // block index inside the batch
         int width, vstart, vend;
         if (!det) {
             const Pac &p = s->pacs[(size_t)r.owner];
@@ -1251,7 +1258,7 @@ static int dev_complete(fdc_sinks *s, int b)
             m.kind = 0; m.source = p.ID; m.has_part = 1;
             m.blockend = d.bc0[b] + blk;                       // blockcount while the item is processed (:226-227)
         } else {
-            const int sgi = (int)((r.key >> 12) & 0x7FF);
+            const int sgi = (int)((r.key >> 28) & 0x7FF);
             width = 1 << ((r.flags >> 8) & 0xFF); vstart = r.vstart; vend = vstart + width;
             m.kind = 1;
             m.source = (sd && s->cfg.det_id >= 0 && s->segs.size() == 1) ? s->cfg.det_id : s->segs[(size_t)sgi].ID;

@@ -33,7 +33,8 @@ struct SinkTask { int32_t owner, q, slot, start, win_off, cls; };
 // host can work out itself — the dictionary's block numbers from the block index in `key` and `count`, the geometry of a
 // PowerActivationChannel from `owner` — is not in it.
 struct SinkPdu {
-    int64_t key;                 // emission order inside a call: block << 24 | (PowerActivationChannel index, or 1 << 23 | segment << 12 | n)
+    int64_t key;                 // emission order inside a call: block << 40 | (PowerActivationChannel index, or 1 << 39 | segment << 28 |
+                                 // pass << 27 | 2 * channel sequence + (partial ? 1 : 0))
     int64_t act_time;            // time() of the call that activated the channel (create_ID / get_ID_for_msg)
     int64_t off;                 // k_sink_layout: samples into the landing buffer
     int32_t owner, q0, q1, count;
@@ -81,8 +82,10 @@ hipError_t launch_det_cands(const float *power, int ncells, int nb, const DetGeo
                             int2 *cand, const int64_t *cand_base /* [nseg] */, int32_t *ncand /* [nseg][nbmax] */, int nbmax,
                             hipStream_t s);
 
+int det_track_staged(int nbmax, int max_cand_cap);   // < 0: the tracker's LDS tables do not fit (host engine)
 struct DetParams {
-    int N, R, dec, variant, maxblocks, delay, nseg, npac, nbmax;
+    int N, R, dec, variant, maxblocks, delay, nseg, npac, nbmax, max_cand_cap;
+    int mb_shift;                // log2(maxblocks) when it is a power of two >= 2, else -1
     double puffer;
     int segname0;                // SegmentDetection with one segment: the ID argument, else -1
 };

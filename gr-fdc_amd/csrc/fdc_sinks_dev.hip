@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_pac_decide(const float *__restrict__ pow
             const int pe = last_bit_below(EM, lane);                         // the emission before this one flushed everything up to there
             const int q0 = pe >= 0 ? q + __popcll(PROC & mask_lt(pe + 1)) + __popcll(RISE & mask_lt(pe + 1)) : E;
             SinkPdu r;
-            r.key = ((long long)m << 24) | i; r.act_time = mine ? now : act_time; r.off = 0;
+            r.key = ((long long)m << 40) | i; r.act_time = mine ? now : act_time; r.off = 0;
             r.owner = i; r.q0 = q0; r.q1 = qpos + 1; r.count = cnt;
             r.chan_id = mine ? finished + __popcll(FALL & mask_lt(a)) : id_at;
             r.part = emissions_before(cnt, mb);
@@ -258,24 +258,35 @@ __device__ long long block_exscan(long long v, long long *tot, long long *sh /* 
 
 // ---------------------------------------------------------------- detection, phase 2
 // match_active_channels() + activation (…vcm_impl.cc:741-841), extract_channels_in_segments_singlethread() (:306-337) and
-// clear_inactive_channels() (:512-524) for one segment: a loop over the blocks of the call.
+// clear_inactive_channels() (:512-524) for one segment and a whole call.
 //
-// This loop is a dependence chain (the list of live channels of block m decides what block m + 1 sees) run by ONE wave, so what
-// counts is the number of instructions per block.  Three things keep it short:
-//  * a live channel is extracted from EVERY block between its activation and its end, so no per-block extraction record is
-//    written here: the channel's stream record says where its run starts, k_det_expand writes the tasks afterwards, in parallel;
-//  * up to 64 live channels and 64 candidates (the normal case) a block is worked on from registers: lane c holds live channel c,
-//    lane j candidate j; candidates x channels are compared as pairs in one step when they fit the wave;
-//  * a workgroup is one wave: LDS needs no barrier (lds_sync), and nothing waits for stores.
-// The list in LDS is the master copy (channels are appended and compacted there); count, inactivity, part and the stream
-// counters live in registers until a compaction or the general form (more than 64 channels or candidates) needs them back.
-constexpr int kDetStage = 32;        // blocks whose candidate lists are staged in LDS at a time (first 64 candidates of each)
-constexpr int kDetLds = (int)(sizeof(int) * kDetFields * kDetMaxCells + sizeof(long long) * kDetMaxCells + sizeof(int) * 6 * kDetMaxCells +
-                              sizeof(int) * (kDetMaxCells / 2 + 2) + sizeof(int2) * (kDetMaxCells / 2 + 2) +
-                              sizeof(int2) * kDetStage * 64 + sizeof(int) * (kDetStage + 32));
-static_assert(kDetLds <= 160 * 1024, "LDS budget of the detection tracker");
+// The reference walks the blocks and, inside a block, the list of live channels.  Walking it that way on a GPU is a chain of a
+// thousand dependent, branchy steps run by one wave (measured: 1.3 us per block).  The same result comes out CHANNEL BY CHANNEL:
+//   * a candidate of block m belongs to the first channel of the list that overlaps it (:757-766); the list is ordered by
+//     activation, so if channels are handled in list order and each one marks the candidates it takes, a channel sees exactly
+//     the candidates the reference would have left for it — in EVERY block of its life at once (lanes = blocks);
+//   * its life ends at the first block where it has missed delay + 1 times in a row (:309) — a bit scan over the hit mask;
+//   * everything else about it — its extractions (one run, k_det_expand), count, the partial emissions (:317-318, :454-470),
+//     the final one — follows from (activation block, end block) in closed form;
+//   * new channels are the candidates nobody took (:785-841): the sweep finds the first block that still has one once every
+//     channel activated before that block has been handled.
+// Per call the wave does work proportional to the number of channels (each a few 64-block steps), not to the number of blocks.
+// Emission order inside a block is restored from the key: block, segment, pass (SegmentDetection sends its partial PDUs in a
+// pass of their own, :359-362), position of the channel in the list (its sequence number: the list is ordered by activation).
+constexpr int kDetQueue = kDetMaxCells / 2 + 1;      // candidates of ONE block that can become channels
+__host__ __device__ constexpr size_t det_lds_bytes(int nb, int words, int staged)
+{
+    return (size_t)nb * (size_t)words * 8 + (size_t)nb * 4 + (size_t)nb * (size_t)staged * 8 + (size_t)kDetQueue * 16 + 32 * 4 + 64;
+}
 __device__ __forceinline__ int pow2ceil_dev(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 
+struct DetChanRegs {          // one channel while it is handled (wave-uniform)
+    int id, ds, de, es, cls, cnt0, inact0, part0, buf0, a /* activation block, -1 = alive before the call */, own;
+    int phase0, tlo, thi;
+    long long prev_off;
+};
+
+template <int WORDS>        // 64-bit words of a block's taken-mask: 1, 2 or up to 8 (compile time: the word loops vanish for 1 and 2)
 __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const DetGeom *__restrict__ geom, DetSegState *__restrict__ sst,
                                                   int32_t *__restrict__ live_g, int64_t *__restrict__ live_off_g,
                                                   const int2 *__restrict__ cand, const int64_t *__restrict__ cand_base,
@@ -284,327 +295,242 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
                                                   const int64_t *__restrict__ task_base, const int64_t *__restrict__ pdu_base,
                                                   int32_t *__restrict__ ntask, int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners,
                                                   const int64_t *__restrict__ owner_base, int32_t *__restrict__ nowner,
-                                                  int32_t *__restrict__ error, long long *__restrict__ dbg)
+                                                  int32_t *__restrict__ error, int staged)
 {
-#ifdef FDC_DET_STAMPS
-    long long tS = 0, tM = 0, tX = 0, tC = 0, nG = 0, nC = 0, sK = 0, sL = 0;
-    const long long t00 = __builtin_readcyclecounter();
-#define DSTAMP(v) do { const long long _t = __builtin_readcyclecounter(); v += _t - tlast; tlast = _t; } while (0)
-    long long tlast = t00;
-#else
-#define DSTAMP(v) do { } while (0)
-#endif
-    // LDS (dynamic, kDetLds bytes): the live list (DetCol columns), the stream bookkeeping of each live channel, the candidates
+    constexpr int words = WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdc_det_smem[];
-    int (*L)[kDetMaxCells] = reinterpret_cast<int (*)[kDetMaxCells]>(fdc_det_smem);                 // [kDetFields][cap]
-    long long *oP = reinterpret_cast<long long *>(fdc_det_smem + sizeof(int) * kDetFields * kDetMaxCells);   // where its carried blocks lie
-    int *oE = reinterpret_cast<int *>(oP + kDetMaxCells), *oQ = oE + kDetMaxCells, *oC = oQ + kDetMaxCells;  // emitted, total, carried
-    int *oS = oC + kDetMaxCells, *oH = oS + kDetMaxCells;                    // first spectrum slot of the call's run, its window phase
-    int *hit = oH + kDetMaxCells, *claimed = hit + kDetMaxCells;
-    int2 *cd = reinterpret_cast<int2 *>(claimed + kDetMaxCells / 2 + 2);
-    int2 *stc = cd + kDetMaxCells / 2 + 2;                                   // [kDetStage][64]: staged candidates
-    int *stk = reinterpret_cast<int *>(stc + kDetStage * 64);                // [kDetStage]: staged candidate counts
-    int *wofs = stk + kDetStage;                                             // [32]: window table offsets per width class
-    (void)tasks; (void)task_base; (void)ntask; (void)bc0;
+    unsigned long long *CL = reinterpret_cast<unsigned long long *>(fdc_det_smem);       // [nb][words]: candidates taken
+    int2 *CS = reinterpret_cast<int2 *>(CL + (size_t)nb * words);                        // [nb][staged]: the first candidates of each block
+    int4 *QU = reinterpret_cast<int4 *>(CS + (size_t)nb * staged);                       // new channels of one block: (start, stop, extract start, class)
+    int *KM = reinterpret_cast<int *>(QU + kDetQueue);                                   // [nb]: candidates per block
+    int *wofs = KM + nb;                                                                 // [32]
+    (void)tasks; (void)task_base; (void)ntask; (void)bc0; (void)error;
     const int lane = threadIdx.x, sg = blockIdx.x;
     const DetGeom g = geom[sg];
-    const int lst = dp.npac + sg;                                           // list index of this segment
+    const int lst = dp.npac + sg;
     SinkPdu *const pl = pdus + pdu_base[lst];
     SinkOwner *const ow = owners + owner_base[sg];
     const int ow0 = (int)owner_base[sg];
     int32_t *const Lg = live_g + (size_t)sg * kDetFields * kDetMaxCells;
     int64_t *const Og = live_off_g + (size_t)sg * kDetMaxCells;
-    const unsigned long long lt = lanemask_lt();
-    const int rm = dp.R - 1;
-    int nlive = sst[sg].nlive, counter = sst[sg].counter;
-    for (int c = lane; c < nlive; c += 64) {
-        for (int f = 0; f < kDetFields; f++) L[f][c] = Lg[f * kDetMaxCells + c];
-        oE[c] = 0; oQ[c] = oC[c] = L[DC_TAIL][c]; oP[c] = Og[c];
-        oS[c] = 1; oH[c] = L[DC_PHASE][c];                                  // goes on with the first block of the call (slot 1)
-        L[DC_OWNER][c] = c;                                                 // owners of the channels alive at the start: 0 .. nlive-1
-    }
-    if (lane < 32) wofs[lane] = win_off[lane];
-    int nown = nlive, pcur = 0, err = 0;
-    lds_sync();
+    const unsigned long long ltm = lanemask_lt();
+    const int rm = dp.R - 1, mb = dp.maxblocks, sd = dp.variant == 1;
     const int32_t *const kc = ncand + (size_t)sg * dp.nbmax;
     const int2 *const cbase = cand + cand_base[sg];
-    int rDS = 0, rDE = 0, rES = 0, rCLS = 0, rCNT = 0, rIN = 0, rPART = 0, rOWN = 0, rE = 0, rQ = 0, rID = 0, rTL = 0, rTH = 0;
-    bool regs = false, pairs = false;
-    int plw = 0, pc_ = 0, pj_ = 0, pDS = 0, pDE = 0;
-    unsigned long long pstr = 0;
-    auto load_static = [&]() {
-        rDS = L[DC_DSTART][lane]; rDE = L[DC_DSTOP][lane]; rES = L[DC_ESTART][lane]; rCLS = L[DC_CLS][lane];
-        rOWN = L[DC_OWNER][lane]; rID = L[DC_ID][lane]; rTL = L[DC_TIME_LO][lane]; rTH = L[DC_TIME_HI][lane];
-    };
-    auto load_regs = [&]() {
-        if (lane < nlive) {
-            load_static();
-            rCNT = L[DC_COUNT][lane]; rIN = L[DC_INACT][lane]; rPART = L[DC_PART][lane]; rE = oE[lane]; rQ = oQ[lane];
-        }
-        regs = true;
-    };
-    auto spill_regs = [&]() {
-        if (regs && lane < nlive) { L[DC_COUNT][lane] = rCNT; L[DC_INACT][lane] = rIN; L[DC_PART][lane] = rPART; oE[lane] = rE; oQ[lane] = rQ; }
-        regs = false;
-    };
-    auto mkpdu = [&](int m, int idx, int own, int q0, int q1, int cnt, int id, int part, bool fin, int cls, int es, int tlo, int thi) {
-        SinkPdu r;
-        r.key = ((long long)m << 24) | (1ll << 23) | ((long long)sg << 12) | idx;
-        r.act_time = ((long long)thi << 32) | (unsigned)tlo; r.off = 0;
-        r.owner = ow0 + own; r.q0 = q0; r.q1 = q1; r.count = cnt; r.chan_id = id; r.part = part;
-        r.flags = (fin ? 1 : 0) | (cls << 8) | (1 << 16); r.vstart = es;
-        return r;
-    };
-    // geometry of a new channel from a candidate (:785-841); false = skipped (wider than the block, or no window table)
-    auto new_geom = [&](int2 pc, int &es, int &cls) {
-        const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
-        const int ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
-        if (ew > dp.N) return false;
-        cls = 31 - __clz(ew);
-        if (wofs[cls] < 0) return false;
-        es = mid - ew / 2;
-        int ee = mid + ew / 2;
-        if (es < 0) { es = 0; ee = ew; }
-        if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
-        return true;
-    };
-    auto append = [&](int c, int id, int2 pc, int es, int cls, int own, int m) {    // a new entry of the list in LDS
-        L[DC_ID][c] = id; L[DC_DSTART][c] = pc.x; L[DC_DSTOP][c] = pc.y; L[DC_ESTART][c] = es; L[DC_CLS][c] = cls;
-        L[DC_COUNT][c] = 0; L[DC_PHASE][c] = 0; L[DC_PINC][c] = es & rm; L[DC_INACT][c] = -1; L[DC_PART][c] = 0;
-        L[DC_OWNER][c] = own; L[DC_TAIL][c] = 0;
-        L[DC_TIME_LO][c] = (int)(unsigned)(now & 0xFFFFFFFFll); L[DC_TIME_HI][c] = (int)(now >> 32);
-        oE[c] = 0; oQ[c] = 0; oC[c] = 0; oP[c] = 0;
-        oS[c] = m; oH[c] = 0;                                               // process_channel_hist(): the block before (slot m) comes first
-    };
-    // One channel's share of extract_channels_in_segments_singlethread() (:306-337) in pass `pass` (SegmentDetection emits the
-    // partial PDUs in a pass of its own, :359-362); every lane of the wave calls it.  Returns the lanes that finalised.
-    auto step = [&](int m, int pass, int c, bool in, int &cnt, int &inact, int &part, int &E, int &Q, int cls, int es, int own, int id,
-                    int tlo, int thi) -> unsigned long long {
-        bool fin = false;
-        if (pass == 0 && in) {
-            if (inact < 0) { Q += 2; cnt = 2; inact = 0; }                  // process_channel_hist(), :399-403
-            else if (inact > dp.delay) fin = true;                          // emit_channel(), :309
-            else { Q += 1; cnt += 1; }                                      // process_channel(), :373-397
-        }
-        // partial emission: inline behind the channel in the vcm block (:317-318), a pass of its own in SegmentDetection
-        const bool pcheck = in && dp.maxblocks >= 0 && (dp.variant == 1 ? pass == 1 : true) && !fin;
-        int ntx = 0;
-        if (pcheck && Q - E >= dp.maxblocks) ntx = dp.maxblocks == 0 ? Q - E : dp.maxblocks;
-        const bool prt = ntx > 0;
-        const unsigned long long bf = __ballot(fin), bp = __ballot(prt);
-        if (bf | bp) {
-            if (fin || prt) {
-                const int idx = dp.variant == 1 ? (pass == 0 ? c : nlive + c) : 2 * c + (prt ? 1 : 0);
-                const int q1 = fin ? Q : E + ntx;
-                pl[pcur + __popcll(bf & lt) + __popcll(bp & lt)] =           // a lane emits at most one of the two in a pass
-                    mkpdu(m, idx, own, E, q1, cnt, id, part, fin, cls, es, tlo, thi);
-                E = q1;
-                if (prt) part += 1;
-            }
-            pcur += __popcll(bf) + __popcll(bp);
-        }
-        return bf;
-    };
-    auto owner_record = [&](int c) {                                        // list entry c (everything in LDS) -> its stream record
-        SinkOwner o{};
-        const int cls = L[DC_CLS][c], w = 1 << cls;
-        o.len = w - w / dp.R; o.cls = cls; o.carried = oC[c]; o.emitted = oE[c]; o.total = oQ[c]; o.prev_off = oP[c];
-        o.slot0 = oS[c]; o.phase0 = oH[c]; o.pinc = L[DC_PINC][c]; o.estart = L[DC_ESTART][c]; o.win0 = wofs[cls];
-        ow[L[DC_OWNER][c]] = o;
-    };
-    // clear_inactive_channels(), :512-524, on the list in LDS (everything spilled): finalised channels leave their stream record
-    auto compact = [&]() {
-        int keep = 0;
-        for (int c0 = 0; c0 < nlive; c0 += 64) {
-            const int c = c0 + lane;
-            const bool in = c < nlive;
-            const bool gone = in && L[DC_INACT][c] > dp.delay;
-            int v[kDetFields], e = 0, qq = 0, cc = 0, ss = 0, hh = 0;
-            long long pp = 0;
-            if (gone) owner_record(c);
-            if (in) {
-#pragma unroll
-                for (int f = 0; f < kDetFields; f++) v[f] = L[f][c];
-                e = oE[c]; qq = oQ[c]; cc = oC[c]; pp = oP[c]; ss = oS[c]; hh = oH[c];
-            }
-            const unsigned long long bk = __ballot(in && !gone);
-            lds_sync();
-            if (in && !gone) {
-                const int d = keep + __popcll(bk & lt);
-#pragma unroll
-                for (int f = 0; f < kDetFields; f++) L[f][d] = v[f];
-                oE[d] = e; oQ[d] = qq; oC[d] = cc; oP[d] = pp; oS[d] = ss; oH[d] = hh;
-            }
-            keep += __popcll(bk);
-            lds_sync();
-        }
-        nlive = keep;
-    };
-    for (int m = 0; m < nb; m++) {
-        if ((m & (kDetStage - 1)) == 0) {                                   // candidate lists of the next kDetStage blocks -> LDS
-            const int nst = nb - m < kDetStage ? nb - m : kDetStage;
-            lds_sync();
-            if (lane < nst) stk[lane] = kc[m + lane];
-            const int cc = g.cand_cap < 64 ? g.cand_cap : 64;
-            int2 tmp[kDetStage];                                            // all loads in flight before the first is used
-#pragma unroll
-            for (int t = 0; t < kDetStage; t++)
-                tmp[t] = (t < nst && lane < cc) ? cbase[(size_t)(m + t) * g.cand_cap + lane] : make_int2(0, 0);
-#pragma unroll
-            for (int t = 0; t < kDetStage; t++) stc[t * 64 + lane] = tmp[t];
-            lds_sync();
-        }
-        const int k = stk[m & (kDetStage - 1)];
-        DSTAMP(tS);
-#ifdef FDC_DET_STAMPS
-        sK += k; sL += nlive;
-#endif
-        if (nlive <= 64 && k <= 64) {
-            const int2 cme = stc[(m & (kDetStage - 1)) * 64 + lane];
-            if (!regs) { load_regs(); pairs = false; }
-            if (!pairs) {                                                   // pair layout of the matching: lane = (candidate pj, channel pc)
-                plw = 0;
-                while ((1 << plw) < nlive) plw++;
-                pc_ = lane & ((1 << plw) - 1); pj_ = lane >> plw;
-                pDS = __shfl(rDS, pc_, 64); pDE = __shfl(rDE, pc_, 64);
-                // bits c, c + W, c + 2 W, ... of the pair mask: everything channel `lane` overlaps
-                pstr = 0;
-                for (int b_ = lane; b_ < 64; b_ += 1 << plw) pstr |= 1ull << b_;
-                pairs = true;
-            }
-            // a candidate goes to the FIRST live channel it overlaps (the reference erases it from the list there, :757-766)
-            unsigned long long hitm = 0, clmm = 0;                           // channels hit, candidates claimed
-            if (k && nlive) {
-                if ((k << plw) <= 64) {                                      // all pairs at once
-                    const int cx = __shfl(cme.x, pj_, 64), cy = __shfl(cme.y, pj_, 64);
-                    const unsigned long long ov = __ballot(pc_ < nlive && pj_ < k && cx < pDE && cy >= pDS);
-                    const unsigned long long gm = plw == 6 ? ~0ull : (1ull << (1 << plw)) - 1ull;
-                    const unsigned long long grp = lane < k ? ((ov >> (lane << plw)) & gm) : 0ull;     // channels candidate `lane` overlaps
-                    clmm = __ballot(grp != 0);
-                    if (!__ballot(grp & (grp - 1))) hitm = __ballot((ov & pstr) != 0);                   // nobody overlaps two: first = only
-                    else
-                        for (int jj = 0; jj < k; jj++) {
-                            const unsigned long long gj = plw == 6 ? ov : ((ov >> (jj << plw)) & gm);
-                            if (gj) hitm |= 1ull << __builtin_ctzll(gj);
-                        }
-                } else {
-                    bool clm = false;
-                    for (int c = 0; c < nlive; c++) {                       // channel c takes every candidate it overlaps
-                        const int ds = __builtin_amdgcn_readlane(rDS, c), de = __builtin_amdgcn_readlane(rDE, c);
-                        const bool ov = lane < k && !clm && cme.x < de && cme.y >= ds;
-                        if (__ballot(ov)) { hitm |= 1ull << c; clm = clm || ov; }
-                    }
-                    clmm = __ballot(clm);
-                }
-            }
-            {   // the quiet block — every candidate claimed, no channel past its delay — in a handful of instructions
-                const int nin = (k != 0 && ((hitm >> lane) & 1ull)) ? 0 : rIN + 1;
-                const bool inl = lane < nlive;
-                if (!__ballot((lane < k && !((clmm >> lane) & 1ull)) || (inl && nin > dp.delay)) &&
-                    (dp.maxblocks < 0 || !__ballot(inl && rQ + 1 - rE >= dp.maxblocks))) {
-                    if (inl) { rIN = nin; rQ += 1; rCNT += 1; }
-                    DSTAMP(tM);
-                    continue;
-                }
-            }
-            DSTAMP(tM);
-            int nes = 0, ncls = 0;
-            const bool ok = lane < k && !((clmm >> lane) & 1ull) && new_geom(cme, nes, ncls);   // the rest: new channels, in candidate order
-            const unsigned long long bo = __ballot(ok);
-            const int nnew = __popcll(bo);
-            if (nlive + nnew <= 64) {
-                if (lane < nlive) rIN = (k != 0 && ((hitm >> lane) & 1ull)) ? 0 : rIN + 1;      // :748-752, :768-771
-                if (nnew) {
-                    const int r = __popcll(bo & lt);
-                    if (ok) append(nlive + r, counter + r, cme, nes, ncls, nown + r, m);
-                    lds_sync();
-                    if (lane >= nlive && lane < nlive + nnew) { load_static(); rCNT = 0; rIN = -1; rPART = 0; rE = 0; rQ = 0; }
-                    nlive += nnew; counter += nnew; nown += nnew; pairs = false;
-                }
-                unsigned long long anyfin = 0;
-                for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
-                    anyfin |= step(m, pass, lane, lane < nlive, rCNT, rIN, rPART, rE, rQ, rCLS, rES, rOWN, rID, rTL, rTH);
-                DSTAMP(tX);
-                if (anyfin) {
-                    spill_regs();
-                    lds_sync();
-                    compact();
-#ifdef FDC_DET_STAMPS
-                    nC++;
-#endif
-                    DSTAMP(tC);
-                }
-                continue;
-            }
-        }
-        // ---- general form: any number of channels and candidates, the list in LDS
-#ifdef FDC_DET_STAMPS
-        nG++;
-#endif
-        spill_regs();
-        lds_sync();
-        if (k == 0) {                                                       // :748-752
-            for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] += 1;
-        } else {
-            const int2 *cs = cbase + (size_t)m * g.cand_cap;
-            for (int j = lane; j < k; j += 64) { cd[j] = cs[j]; claimed[j] = 0; }
-            for (int c = lane; c < nlive; c += 64) hit[c] = 0;
-            lds_sync();
-            for (int j = 0; j < k; j++) {
-                const int2 pc = cd[j];
-                for (int c0 = 0; c0 < nlive; c0 += 64) {
-                    const int c = c0 + lane;
-                    const unsigned long long mk = __ballot(c < nlive && pc.x < L[DC_DSTOP][c] && pc.y >= L[DC_DSTART][c]);
-                    if (mk) {
-                        if (lane == 0) { hit[c0 + __builtin_ctzll(mk)] = 1; claimed[j] = 1; }
-                        break;
-                    }
-                }
-            }
-            lds_sync();
-            for (int c = lane; c < nlive; c += 64) L[DC_INACT][c] = hit[c] ? 0 : L[DC_INACT][c] + 1;
-            for (int j0 = 0; j0 < k; j0 += 64) {                            // new channels, in candidate order (:785-841)
-                const int j = j0 + lane;
-                int es = 0, cls = 0;
-                int2 pc = make_int2(0, 0);
-                bool ok = false;
-                if (j < k && !claimed[j]) { pc = cd[j]; ok = new_geom(pc, es, cls); }
-                const unsigned long long bo = __ballot(ok);
-                const int nnew = __popcll(bo);
-                if (nlive + nnew > kDetMaxCells) { err = 1; break; }
-                if (ok) { const int r = __popcll(bo & lt); append(nlive + r, counter + r, pc, es, cls, nown + r, m); }
-                nlive += nnew; counter += nnew; nown += nnew;
-            }
-            if (err) break;
-            lds_sync();
-        }
-        unsigned long long anyfin = 0;
-        for (int pass = 0; pass < (dp.variant == 1 ? 2 : 1); pass++)
-            for (int c0 = 0; c0 < nlive; c0 += 64) {
-                const int c = c0 + lane, cc = c < kDetMaxCells ? c : kDetMaxCells - 1;
-                anyfin |= step(m, pass, c, c < nlive, L[DC_COUNT][cc], L[DC_INACT][cc], L[DC_PART][cc], oE[cc], oQ[cc], L[DC_CLS][cc] & 31,
-                               L[DC_ESTART][cc], L[DC_OWNER][cc], L[DC_ID][cc], L[DC_TIME_LO][cc], L[DC_TIME_HI][cc]);
-            }
-        lds_sync();
-        if (anyfin) compact();
+    for (int m = lane; m < nb; m += 64) {
+        KM[m] = kc[m];
+        for (int w = 0; w < words; w++) CL[(size_t)m * words + w] = 0;
     }
-    spill_regs();
+    for (int e = lane; e < nb * staged; e += 64) {
+        const int m = e / staged, j = e - m * staged;
+        CS[e] = j < g.cand_cap ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
+    }
+    if (lane < 32) wofs[lane] = win_off[lane];
     lds_sync();
-    for (int c = lane; c < nlive; c += 64) {
-        L[DC_PHASE][c] = (L[DC_COUNT][c] * L[DC_PINC][c]) & rm;             // window phase of the next block (:396)
-        owner_record(c);
-        for (int f = 0; f < kDetFields; f++) Lg[f * kDetMaxCells + c] = L[f][c];
+    const int nlive0 = sst[sg].nlive;
+    int counter = sst[sg].counter, nown = nlive0, nout = 0, pcur = 0;
+
+    // ---- one channel over the blocks of the call
+    auto handle = [&](const DetChanRegs &c) {
+        const int w_ = 1 << c.cls, len = w_ - w_ / dp.R;
+        const int first = c.a < 0 ? 0 : c.a + 1;              // first block in which the channel is matched
+        int streak = c.inact0, end = -1;                       // misses in a row so far; block of the final emission
+        // stream bookkeeping: Q(m) = buffered before the call + blocks extracted up to block m; E = emitted prefix
+        // events: a new channel's activation block counts as one (two blocks buffered), every further block as one
+        auto qof = [&](int m) { return c.buf0 + (c.a < 0 ? m + 1 : m - c.a + 2); };            // stream length after block m
+        auto divmb = [&](int q) { return dp.mb_shift >= 0 ? q >> dp.mb_shift : q / mb; };     // maxblocks >= 2 (a shift when it is 2^k)
+        auto eof = [&](int q) { return mb < 0 ? 0 : mb == 0 ? q : mb == 1 ? (q > 0 ? q - 1 : 0) : divmb(q) * mb; };   // emitted after a block that left q
+        auto nem = [&](int m) {                                 // partial emissions up to and including block m (this call)
+            if (mb < 0) return 0;
+            const int ev = c.a < 0 ? m + 1 : m - c.a + 1;     // events so far
+            return mb <= 1 ? ev : divmb(qof(m));
+        };
+        // the activation block itself (no matching there, but the partial check behind process_channel_hist, :317 / :359)
+        if (c.a >= 0) {
+            const int q = qof(c.a), e1 = eof(q);
+            if (mb >= 0 && e1 > 0) {
+                if (lane == 0) {
+                    SinkPdu r;
+                    r.key = ((long long)c.a << 40) | (1ll << 39) | ((long long)sg << 28) | ((long long)(sd ? 1 : 0) << 27) | ((long long)c.own * 2 + 1);
+                    r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
+                    r.owner = ow0 + c.own; r.q0 = 0; r.q1 = e1; r.count = 2; r.chan_id = c.id; r.part = c.part0;
+                    r.flags = (c.cls << 8) | (1 << 16); r.vstart = c.es;
+                    pl[pcur] = r;
+                }
+                pcur += 1;
+            }
+        }
+        for (int m0 = first; m0 < nb && end < 0; m0 += 64) {
+            const int m = m0 + lane;
+            const bool valid = m < nb;
+            // candidates of block m this channel overlaps and nobody before it in the list has taken.  The first eight of a block
+            // come from LDS in one go (no dependent round trips), the taken-mask word too; more than that is rare.
+            const int k = valid ? KM[m] : 0;
+            int kmax = k;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+            int2 cs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cs[u] = (valid && u < staged) ? CS[(size_t)m * staged + u] : make_int2(0, 0);
+            unsigned long long ov[WORDS];
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                ov[w] = 0;
+                if (kmax > 64 * w) {
+                    const unsigned long long cl = valid ? CL[(size_t)m * words + w] : ~0ull;
+                    int j0 = 64 * w;
+                    if (w == 0) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (u < staged && u < k && cs[u].x < c.de && cs[u].y >= c.ds && !((cl >> u) & 1ull)) ov[0] |= 1ull << u;
+                        j0 = staged < 8 ? staged : 8;
+                    }
+                    const int j1 = kmax < 64 * w + 64 ? kmax : 64 * w + 64;
+                    for (int j = j0; j < j1; j++)
+                        if (j < k) {
+                            const int2 pc = j < staged ? CS[(size_t)m * staged + j] : cbase[(size_t)m * g.cand_cap + j];
+                            if (pc.x < c.de && pc.y >= c.ds && !((cl >> (j & 63)) & 1ull)) ov[w] |= 1ull << (j & 63);
+                        }
+                }
+            }
+            bool hit = false;
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) hit = hit || ov[w] != 0;
+            const unsigned long long H = __ballot(valid && hit);
+            // misses in a row after block m's update (:748-752, :768-771)
+            const unsigned long long hb = H & ltm;
+            const int lh = hb ? 63 - __clzll((long long)hb) : -1;
+            const int st = hit ? 0 : (lh >= 0 ? lane - lh : streak + lane + 1);
+            const unsigned long long F = __ballot(valid && !hit && st > dp.delay);
+            const int endlane = F ? __builtin_ctzll(F) : 64;
+            if (F) end = m0 + endlane;
+            if (valid && hit && lane < endlane) {
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) if (ov[w]) CL[(size_t)m * words + w] |= ov[w];
+            }
+            // partial emissions of the blocks the channel is extracted from (those before `end`)
+            if (mb >= 0) {
+                const bool procd = valid && lane < endlane;
+                const int q = qof(m), e1 = eof(q), qp = m == first ? (c.a < 0 ? c.buf0 : qof(c.a)) : qof(m - 1), e0 = m == first && c.a < 0 ? 0 : eof(qp);
+                const bool emit = procd && e1 > e0;
+                const unsigned long long EM = __ballot(emit);
+                if (emit) {
+                    SinkPdu r;
+                    r.key = ((long long)m << 40) | (1ll << 39) | ((long long)sg << 28) | ((long long)(sd ? 1 : 0) << 27) | ((long long)c.own * 2 + 1);
+                    r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
+                    r.owner = ow0 + c.own; r.q0 = e0; r.q1 = e1; r.count = c.cnt0 + (c.a < 0 ? m + 1 : m - c.a + 2); r.chan_id = c.id;
+                    r.part = c.part0 + nem(m) - 1;
+                    r.flags = (c.cls << 8) | (1 << 16); r.vstart = c.es;
+                    pl[pcur + __popcll(EM & ltm)] = r;
+                }
+                pcur += __popcll(EM);
+            }
+            const int lastv = (nb - m0 < 64 ? nb - m0 : 64) - 1;
+            streak = __shfl(st, lastv, 64);
+        }
+        // what the call leaves of the channel
+        const int firstproc = c.a < 0 ? 0 : c.a;                // first block it was extracted from, if any
+        const int lastm = end >= 0 ? end - 1 : nb - 1;          // last one (before firstproc: none in this call)
+        const bool any = lastm >= firstproc;
+        const int Qf = any ? qof(lastm) : c.buf0;
+        const int Ef = any ? eof(Qf) : 0;                        // partial emissions of this call
+        const int npart = any ? nem(lastm) : 0;
+        const int cntf = c.cnt0 + (Qf - c.buf0);
+        if (lane == 0) {
+            SinkOwner o{};
+            o.len = len; o.cls = c.cls; o.carried = c.buf0; o.total = Qf; o.emitted = end >= 0 ? Qf : Ef; o.prev_off = c.prev_off;
+            o.slot0 = c.a < 0 ? 1 : c.a; o.phase0 = c.phase0; o.pinc = c.es & rm; o.estart = c.es; o.win0 = wofs[c.cls];
+            ow[c.own] = o;
+            if (end >= 0) {                                      // emit_channel(), :406-452: everything that is left
+                SinkPdu r;
+                r.key = ((long long)end << 40) | (1ll << 39) | ((long long)sg << 28) | ((long long)c.own * 2);
+                r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
+                r.owner = ow0 + c.own; r.q0 = Ef; r.q1 = Qf; r.count = cntf; r.chan_id = c.id; r.part = c.part0 + npart;
+                r.flags = 1 | (c.cls << 8) | (1 << 16); r.vstart = c.es;
+                pl[pcur] = r;
+            } else {                                             // still alive: an entry of the list the next call starts from
+                const int d = nout;
+                Lg[DC_ID * kDetMaxCells + d] = c.id; Lg[DC_DSTART * kDetMaxCells + d] = c.ds; Lg[DC_DSTOP * kDetMaxCells + d] = c.de;
+                Lg[DC_ESTART * kDetMaxCells + d] = c.es; Lg[DC_CLS * kDetMaxCells + d] = c.cls; Lg[DC_COUNT * kDetMaxCells + d] = cntf;
+                Lg[DC_PHASE * kDetMaxCells + d] = (cntf * (c.es & rm)) & rm; Lg[DC_PINC * kDetMaxCells + d] = c.es & rm;
+                Lg[DC_INACT * kDetMaxCells + d] = streak; Lg[DC_PART * kDetMaxCells + d] = c.part0 + npart;
+                Lg[DC_OWNER * kDetMaxCells + d] = c.own; Lg[DC_TAIL * kDetMaxCells + d] = 0;
+                Lg[DC_TIME_LO * kDetMaxCells + d] = c.tlo; Lg[DC_TIME_HI * kDetMaxCells + d] = c.thi;
+            }
+        }
+        if (end >= 0) pcur += 1; else nout += 1;
+    };
+
+    // ---- the channels alive before the call, in list order
+    for (int i = 0; i < nlive0; i++) {
+        DetChanRegs c;
+        c.id = Lg[DC_ID * kDetMaxCells + i]; c.ds = Lg[DC_DSTART * kDetMaxCells + i]; c.de = Lg[DC_DSTOP * kDetMaxCells + i];
+        c.es = Lg[DC_ESTART * kDetMaxCells + i]; c.cls = Lg[DC_CLS * kDetMaxCells + i]; c.cnt0 = Lg[DC_COUNT * kDetMaxCells + i];
+        c.inact0 = Lg[DC_INACT * kDetMaxCells + i]; c.part0 = Lg[DC_PART * kDetMaxCells + i]; c.buf0 = Lg[DC_TAIL * kDetMaxCells + i];
+        c.phase0 = Lg[DC_PHASE * kDetMaxCells + i]; c.tlo = Lg[DC_TIME_LO * kDetMaxCells + i]; c.thi = Lg[DC_TIME_HI * kDetMaxCells + i];
+        c.prev_off = Og[i]; c.a = -1; c.own = i;
+        handle(c);
+    }
+    // ---- candidates nobody took become channels (:785-841), block after block
+    for (int ms = 0; ms < nb;) {
+        int found = -1;
+        for (int m0 = ms; m0 < nb && found < 0; m0 += 64) {
+            const int m = m0 + lane;
+            bool un = false;
+            if (m < nb) {
+                const int k = KM[m];
+                for (int w = 0; w < words; w++) {
+                    const int kk = k - 64 * w;
+                    const unsigned long long vm = kk >= 64 ? ~0ull : (kk > 0 ? (1ull << kk) - 1ull : 0ull);
+                    un = un || (vm & ~CL[(size_t)m * words + w]) != 0;
+                }
+            }
+            const unsigned long long U = __ballot(un);
+            if (U) found = m0 + __builtin_ctzll(U);
+        }
+        if (found < 0) break;
+        const int m = found, k = KM[m];
+        int nq = 0;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false;
+            int es = 0, cls = 0;
+            int2 pc = make_int2(0, 0);
+            if (j < k && !((CL[(size_t)m * words + (j >> 6)] >> (j & 63)) & 1ull)) {
+                pc = j < staged ? CS[(size_t)m * staged + j] : cbase[(size_t)m * g.cand_cap + j];
+                const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
+                const int ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
+                if (ew <= dp.N) {                                // wider than the block: logged and skipped in the reference
+                    cls = 31 - __clz(ew);
+                    if (wofs[cls] >= 0) {
+                        ok = true;
+                        es = mid - ew / 2;
+                        int ee = mid + ew / 2;
+                        if (es < 0) { es = 0; ee = ew; }
+                        if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
+                    }
+                }
+            }
+            const unsigned long long bo = __ballot(ok);
+            if (ok) QU[nq + __popcll(bo & ltm)] = make_int4(pc.x, pc.y, es, cls);
+            nq += __popcll(bo);
+        }
+        for (int w = lane; w < words; w += 64) CL[(size_t)m * words + w] = ~0ull;   // taken or skipped: nothing of this block is looked at again
+        lds_sync();
+        for (int i = 0; i < nq; i++) {
+            const int4 qv = QU[i];
+            DetChanRegs c;
+            c.id = counter + i; c.ds = qv.x; c.de = qv.y; c.es = qv.z; c.cls = qv.w; c.cnt0 = 0; c.inact0 = 0; c.part0 = 0; c.buf0 = 0;
+            c.phase0 = 0; c.tlo = (int)(unsigned)(now & 0xFFFFFFFFll); c.thi = (int)(now >> 32); c.prev_off = 0; c.a = m; c.own = nown + i;
+            handle(c);
+        }
+        counter += nq; nown += nq;
+        lds_sync();
+        ms = m + 1;
     }
     if (lane == 0) {
-        sst[sg].nlive = nlive; sst[sg].counter = counter;
+        sst[sg].nlive = nout; sst[sg].counter = counter;
         npdu[lst] = pcur; nowner[sg] = nown;
-        if (err) *error = 1;
-#ifdef FDC_DET_STAMPS
-        if (dbg) {
-            long long *o = dbg + sg * 16;
-            o[0] = __builtin_readcyclecounter() - t00; o[1] = tS; o[2] = tM; o[3] = tX; o[4] = tC; o[5] = nG; o[6] = nC; o[7] = sK; o[8] = sL; o[9] = nb;
-        }
-#endif
     }
 }
 
@@ -649,6 +575,14 @@ hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const
 }
 
 hipError_t init_sink_kernels();
+// candidates staged in LDS per block: as many as fit beside the taken-masks (8, 4, 2 or none)
+int det_track_staged(int nbmax, int max_cand_cap)
+{
+    const int w0 = (max_cand_cap + 63) / 64, words = w0 <= 2 ? w0 : 8;      // the kernel exists for 1, 2 and 8 words
+    if (w0 > 8) return -1;
+    for (int st : {8, 4, 2, 0}) if (det_lds_bytes(nbmax, words, st) <= (size_t)150 * 1024) return st;
+    return -1;                                          // does not fit: the bank takes the host engine
+}
 hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, DetSegState *sst, int32_t *live, int64_t *live_off,
                             const int2 *cand, const int64_t *cand_base, const int32_t *ncand, const int32_t *win_off,
                             long long bc0, long long now, SinkTask *tasks, SinkPdu *pdus, const int64_t *task_base,
@@ -656,24 +590,13 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
                             int32_t *nowner, int32_t *error, hipStream_t s)
 {
     if (dp.nseg <= 0) return hipSuccess;
-    long long *dbg = nullptr;
-#ifdef FDC_DET_STAMPS
-    static long long *d_dbg = nullptr;
-    if (!d_dbg) (void)hipMalloc(reinterpret_cast<void **>(&d_dbg), sizeof(long long) * 16 * 64);
-    dbg = d_dbg;
-#endif
-    hipLaunchKernelGGL(k_det_track, dim3((unsigned)dp.nseg), dim3(64), kDetLds, s, dp, nb, geom, sst, live, live_off, cand, cand_base, ncand,
-                       win_off, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners, owner_base, nowner, error, dbg);
-#ifdef FDC_DET_STAMPS
-    {
-        long long h[32];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
-        for (int g = 0; g < dp.nseg && g < 2; g++)
-            std::fprintf(stderr, "[det_track seg %d] total %lld cyc; stage %lld match %lld step %lld compact %lld | general %lld compactions %lld sum k %lld sum live %lld of %lld blocks\n",
-                         g, h[g * 16], h[g * 16 + 1], h[g * 16 + 2], h[g * 16 + 3], h[g * 16 + 4], h[g * 16 + 5], h[g * 16 + 6], h[g * 16 + 7], h[g * 16 + 8], h[g * 16 + 9]);
-    }
-#endif
+    const int words = (dp.max_cand_cap + 63) / 64, staged = det_track_staged(dp.nbmax, dp.max_cand_cap);
+    if (staged < 0 || words > 8) return hipErrorInvalidValue;
+#define FDC_LT(W) \
+    hipLaunchKernelGGL(k_det_track<W>, dim3((unsigned)dp.nseg), dim3(64), det_lds_bytes(nb, W, staged), s, dp, nb, geom, sst, live, live_off, cand, \
+                       cand_base, ncand, win_off, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners, owner_base, nowner, error, staged)
+    if (words == 1) FDC_LT(1); else if (words == 2) FDC_LT(2); else FDC_LT(8);
+#undef FDC_LT
     return hipGetLastError();
 }
 
@@ -855,7 +778,10 @@ hipError_t launch_carry_copy(const SinkOwner *owners, int nowner_cap, const int6
 
 hipError_t init_sink_kernels()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_det_track), hipFuncAttributeMaxDynamicSharedMemorySize, kDetLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_det_track<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_det_track<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_det_track<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    return e;
 }
 
 }  // namespace fdc
