@@ -40,7 +40,8 @@ for k in acc:
     w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
     allk[k] = {"fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w, "dispatches": len(acc[k]["FETCH_SIZE"])}
     base = k.split("<")[0]
-    if base == "fdc::k_blk256" and k.rstrip(">").endswith("true") and k.count(",") == 2:      # <NT, OFF, FWD = true>
+    targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+    if base == "fdc::k_blk256" and len(targs) >= 3 and targs[2] == "true":                      # <NT, OFF, FWD = true, R4>
         names[base + "_fwd"] = "block_fft(forward, one kernel)"
         base += "_fwd"
     if base in names:
