@@ -65,6 +65,10 @@ def parse():
                     help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 x 268 MB no input byte of "
                          "a step can still sit in the 256 MiB memory-side cache when its ring comes round again (1 = the round-1/2 "
                          "form, where it can)")
+    ap.add_argument("--one-ring-leg", action="store_true",
+                    help="config 2: after the timed region, the same steps on ONE 268 MB ring (the round-1/2 workload, whose input stays in "
+                         "the memory-side cache) reported as roofline.one_ring; off by default so that the rocprofv3 average of the dominant "
+                         "kernel over the default command is the average of the timed launches")
     ap.add_argument("--payload", choices=("host", "device"), default="host",
                     help="configs 3/5: PDU payloads copied to pinned host memory (default; PCIe-bound) or left in HBM (fdc_pdu.samples "
                          "are device pointers)")
@@ -499,7 +503,7 @@ def main():
     # configs[1] only: the same steps again on ONE ring (rounds 1-2 measured this: the ring then stays in the 256 MiB memory-side
     # cache from step to step) — reported beside the headline for continuity, never as `value`
     one_ring = None
-    if sinks is None and len(rings) > 1 and a.config == 2 and not a.no_kernel_timing:
+    if sinks is None and len(rings) > 1 and a.config == 2 and a.one_ring_leg:
         turn[0] = 0
         ring_ptrs[:] = ring_ptrs[:1]
         small = min(nb, 1024)

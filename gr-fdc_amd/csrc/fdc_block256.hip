@@ -110,6 +110,11 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     const bool xmap = (grid & 7) == 0;
     const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (first >= nb) return;
+#ifdef FDC_BLK_STAGGER
+    // experiment: half of the workgroups (by slot parity inside their XCD) start FDC_BLK_STAGGER x 8128 cycles late, so that the
+    // store bursts of one half meet the load phases of the other
+    if ((blockIdx.x >> 3) & 1) for (int i = 0; i < FDC_BLK_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+#endif
 
     const unsigned inbytes = 65536u * 8u;
     const unsigned voff = (unsigned)(b * 256 + c5) * 8u;          // row b, column c5 of pass 0; pass adds 256 B, row group a 32 KiB
@@ -369,6 +374,28 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
                 // dropped by the range check of the descriptor (no branch per store).
                 const unsigned rb = (unsigned)(m * (FWD ? 65536 : (R4 ? 192 : 128)) + rowbase + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
+#ifdef FDC_BLK_ST16
+                // 16-byte stores: the lanes of a pair (rows 2i, 2i + 1) trade half of their slots (DPP), so that each lane holds two
+                // consecutive rows of 16 slots: half the store instructions, 1-KiB runs per wave (8-byte accesses move at 0.54-0.70x
+                // the 16-byte rate, MI355X_MICROARCH.md)
+                {
+                    const bool odd = lane2 & 1;
+                    const unsigned rb2 = rb - (odd ? 8u : 0u);                  // row 2i of the pair
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint4 t = sow[q];
+                        const unsigned so[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const cf a = v[4 * q + e], b2 = v[4 * q + e + 1];
+                            const cf give = odd ? a : b2;                          // what the partner stores
+                            const cf got = mk(swap_pair(give.x), swap_pair(give.y));
+                            const unsigned o = odd ? so[e + 1] : so[e];
+                            bst4<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb2), odd ? got : a, odd ? b2 : got);
+                        }
+                    }
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint4 t = sow[q];
@@ -377,6 +404,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                     for (int e = 0; e < 4; e++)
                         bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
                 }
+#endif
                 FDC_STAMP(14 + 5 * ch);
                 __builtin_amdgcn_sched_barrier(0);
             }

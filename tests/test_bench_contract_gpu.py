@@ -33,7 +33,8 @@ def test_bench_json_line():
     nb = d["config"]["blocks_per_step_per_gpu"]
     assert nb == 2048 and d["config"]["input_rings"] >= 3      # the headline is cache-cold: no ring can survive in the 256 MiB cache
     assert d["value"] > 1e4 and abs(d["value"] - nb * 32768 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
-    assert r["one_ring"]["pipeline_frac"] > 0 and r["traffic_source"] is None or "pmc" in r["traffic_source"]
+    assert r["one_ring"] is None and (r["traffic_source"] is None or "pmc" in r["traffic_source"])
+    assert d["end_to_end_h2d"]["value"] > 0 and d["end_to_end_h2d"]["blocks_per_call"] == 256
     # one kernel: the dominant kernel is the step, so the contract's frac and the whole-step fraction agree to the launch gaps
     # (the driver's own arguments; a region of 20 launches still carries ~10 us of fixed cost)
     assert 0.75 < r["pipeline_frac"] / r["frac"] <= 1.05
