@@ -192,6 +192,72 @@ __global__ __launch_bounds__(256, 4) void k_c256(const float2 *__restrict__ spec
     }
 }
 
+// The same row machinery driven by extraction tasks of the sinks (width 256: a bank of 256-bin PowerActivationChannels, detected
+// carriers of that class): slice of spectrum slot `slot` from bin `start`, the task's phase-resolved window, halves swapped,
+// IFFT-256, the first 256/R samples dropped, results at the task's landing offset.  Replaces the generic LDS kernel k_extract<1>
+// for this width (1.9 -> ~4 TB/s).
+__global__ __launch_bounds__(256, 4) void k_x256(const float2 *__restrict__ spec, float2 *__restrict__ out,
+                                                 const ExtractTask *__restrict__ tasks, int ntasks, int N, int skip,
+                                                 const float2 *__restrict__ wins,
+                                                 const float2 *__restrict__ tw256)
+{
+    __shared__ RowInfo rows[16];
+    float2 *tile = reinterpret_cast<float2 *>(fdc_smem_fast);
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_fast + kCTileBytes);              // [b][p] = W256^(b p), 16 x 18
+    const int tid = threadIdx.x, r = tid >> 4, b = tid & 15;
+    if (tid < 16) {
+        const long long t = (long long)blockIdx.x * 16 + tid;
+        RowInfo ri{0, 0, 0, 0};
+        if (t < ntasks) {
+            const ExtractTask tk = tasks[t];
+            ri.src = (long long)tk.slot * N + tk.start;
+            ri.win = tk.win_off;
+            ri.dst = tk.out_off - skip;
+            ri.valid = 1;
+        }
+        rows[tid] = ri;
+    }
+    wrow[(tid >> 4) * 18 + (tid & 15)] = tw256[((tid >> 4) * (tid & 15)) & 255];
+    __syncthreads();
+    const RowInfo ri = rows[r];
+    cf v[16];
+    {
+        cf x[16], w[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            x[a] = mk(0.f, 0.f); w[a] = x[a];
+            if (ri.valid) { x[a] = ld2(spec + ri.src + 16 * a + b); w[a] = ld2(wins + ri.win + 16 * a + b); }
+        }
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a ^ 8] = cmul(x[a], w[a]);
+    }
+    dft16<true>(v);
+    float2 *row = tile + r * kCRowPts;
+    {
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&wrow[b * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
+        // element (b, p) of the row at p*16 + (b ^ p): writes of a fixed p and reads of a fixed b are both conflict-free
+#pragma unroll
+        for (int p = 0; p < 16; p++) st2(&row[p * 16 + (b ^ p)], cmulc(v[rev16(p)], w[p]));   // inverse: conjugate twiddles
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&row[b * 16 + (bb ^ b)]);      // this thread now plays p = b
+    dft16<true>(v);
+    if (ri.valid) {
+        // y[t], t = p + 16q; keep t >= w/R; no scaling (PowerActivationChannel_impl.cc:277-281, …vcm_impl.cc:390-394)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int tt = b + 16 * q;
+            if (tt >= skip) st2(out + ri.dst + tt, v[rev16(q)]);
+        }
+    }
+}
+
 // ---- uniform-plan path ("polyphase commutation") ------------------------------------------------------------
 // When every channel has l = 256 and f = 256*slot (the tiled plans of BASELINE configs[1] and [3]), pass B of the
 // forward transform (FFT over n1) commutes with the per-channel window + IFFT (which act on k2 only):
@@ -603,7 +669,7 @@ hipError_t init_fast_kernels()
 #define FDC_SETC(k) \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, c); \
     if (e != hipSuccess) return e;
-    FDC_SETC(k_c256)
+    FDC_SETC(k_c256) FDC_SETC(k_x256)
 #undef FDC_SETC
     return hipSuccess;
 }
@@ -639,6 +705,14 @@ hipError_t launch_channels256(const float2 *spec, float2 *out, const ChanDev *ch
 }
 
 const char *debug_env(const char *name);     // fdc_api.hip: nullptr unless FDC_DEBUG_ENV=1
+hipError_t launch_extract256(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int skip, const float2 *wins, float2 *out,
+                             const float2 *tw256, hipStream_t s)
+{
+    if (ntasks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_x256, dim3((unsigned)((ntasks + 15) / 16)), dim3(256), kCTileBytes + 2304, s, spec, out, tasks, ntasks, N, skip, wins, tw256);
+    return hipGetLastError();
+}
+
 // FDC_NT bits (A/B testing): 1 = stage-2 output stores nt, 2 = stage-1 input loads nt, 4 = stage-2 G loads nt, 8 = stage-1 G stores nt
 static int nt_hints()
 {

@@ -131,6 +131,10 @@ hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, 
 hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip,
                           const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 
+// width 256 on the register kernel of the l = 256 channels (fdc_fast256.hip); tw256: exp(-2 pi i j/256)
+hipError_t launch_extract256(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int skip, const float2 *wins, float2 *out,
+                             const float2 *tw256, hipStream_t s);
+
 // extractions wider than kMaxLdsFft, a whole width class at once: gather (slice * window) into [ntasks][w], batched two-pass
 // inverse transform (launch_fft), scatter of [skip, w) to the tasks' landing offsets
 hipError_t launch_extract_gather(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, const float2 *wins,

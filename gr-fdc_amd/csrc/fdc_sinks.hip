@@ -172,7 +172,7 @@ struct fdc_sinks {
     int64_t blockcount = 1;                  // both reference blocks start counting at 1 (hist is block 0)
     hipStream_t stream = nullptr;
     float2 *d_spec = nullptr;                // (max_blocks + 1) * N: slot 0 = history block
-    float2 *d_wins = nullptr, *d_tw = nullptr;
+    float2 *d_wins = nullptr, *d_tw = nullptr, *d_tw256 = nullptr;    // window pool, exp(-2 pi i k/N), exp(-2 pi i j/256)
     fdc::PowerCell *d_cells = nullptr;
     float *d_power = nullptr;
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
@@ -570,7 +570,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_cells);
+    (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
     {
@@ -752,6 +752,12 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         }
         CHKF(hipMalloc(&raw->d_tw, sizeof(float2) * (size_t)N));
         CHKF(hipMemcpy(raw->d_tw, tw.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
+        if (N >= 256) {                                                        // width-256 extractions run on the register kernel
+            std::vector<float2> t256(256);
+            for (int j = 0; j < 256; j++) t256[(size_t)j] = tw[(size_t)j * (size_t)(N / 256)];
+            CHKF(hipMalloc(&raw->d_tw256, sizeof(float2) * 256));
+            CHKF(hipMemcpy(raw->d_tw256, t256.data(), sizeof(float2) * 256, hipMemcpyHostToDevice));
+        }
     }
     if (!raw->cells.empty()) {
         CHKF(hipMalloc(&raw->d_cells, sizeof(fdc::PowerCell) * raw->cells.size()));
@@ -838,7 +844,9 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
         const int w = 1 << k, skip = w / s->R;
         const size_t i = first[k], j = first[k] + cnt[k];
         if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
-        if (w <= fdc::kMaxLdsFft) {
+        if (w == 256 && s->d_tw256) {
+            HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, s->stream));
+        } else if (w <= fdc::kMaxLdsFft) {
             HIPCHK(fdc::launch_extract(s->d_spec, N, d_tasks + i, (int)(j - i), w, skip, s->d_wins, d_out, s->d_tw, N, s->stream));
         } else {
             // wider than one workgroup's transform (a carrier, or a run of merged carriers, over 1/8 of a 65536-bin band):
@@ -1226,15 +1234,26 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
     return FDC_OK;
 }
 
-// the PDUs of the batch in landing buffer b become the handle's current PDUs
-static int dev_complete(fdc_sinks *s, int b)
+// The PDUs of the batch in landing buffer b become the handle's current PDUs.  Two halves: dev_build() turns the emission records
+// into fdc_pdu (host work only: needs the records and the layout, not the payload bytes — it runs while the device works on the
+// next batch), dev_wait() waits for the payload (its copy to the host, or the extraction kernels when it stays on the device).
+static int dev_wait(fdc_sinks *s, int b)
 {
     auto &d = s->dev;
     if (!d.pend[b]) return 0;
     const bool devpay = (s->cfg.flags & FDC_SINKS_DEVICE_PAYLOAD) != 0;
-    if (devpay) HIPCHK(hipEventSynchronize(d.ev_extract[b]));
-    else if (d.sum[b].used_a) HIPCHK(hipEventSynchronize(d.ev_copied[b]));
+    if (!devpay && d.sum[b].used_a) HIPCHK(hipEventSynchronize(d.ev_copied[b]));
     else HIPCHK(hipEventSynchronize(d.ev_extract[b]));
+    d.pend[b] = false;
+    d.inflight = d.pend[0] || d.pend[1];
+    return d.nb_of[b];
+}
+
+static int dev_build(fdc_sinks *s, int b)
+{
+    auto &d = s->dev;
+    if (!d.pend[b]) return 0;
+    const bool devpay = (s->cfg.flags & FDC_SINKS_DEVICE_PAYLOAD) != 0;
     std::vector<fdc::SinkPdu> &recs = d.recs[b];
     std::sort(recs.begin(), recs.end(), [](const fdc::SinkPdu &a, const fdc::SinkPdu &c) { return a.key < c.key; });
     const char *base = devpay ? reinterpret_cast<const char *>(d.d_land[b]) : reinterpret_cast<const char *>(d.h_land[b]);
@@ -1282,9 +1301,13 @@ static int dev_complete(fdc_sinks *s, int b)
         if (!det) std::snprintf(m.id, sizeof m.id, "%s.PowActChan.%d.%d", tbuf, m.source, r.chan_id);
         else std::snprintf(m.id, sizeof m.id, "%s.DETECTED.%d.%d", tbuf, m.source, r.chan_id);
     }
-    d.pend[b] = false;
-    d.inflight = d.pend[0] || d.pend[1];
     return d.nb_of[b];
+}
+
+static int dev_complete(fdc_sinks *s, int b)
+{
+    const int rc = dev_build(s, b);
+    return rc <= 0 ? rc : dev_wait(s, b);
 }
 
 int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
@@ -1303,18 +1326,18 @@ int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
         if (done == 0) s->pdus.clear();
         return done;
     }
-    // this batch: everything enqueued (the one wait is for the layout summary, ~ the forward transform + decision kernels);
-    // then the batch before it: its payload copy has been running beside all of that
+    // This batch's decision kernels are enqueued; while the device runs them the PDUs of the batch before are built (host work);
+    // then the one wait for the layout summary, the extractions of this batch, and last the wait for the payload of the batch
+    // before — its copy has been running beside all of that.
     int rc = dev_enqueue(s, nblocks);
     if (rc != FDC_OK) return rc;
     const int before = d.cur;
+    const bool had = d.pend[before];
+    if (had) { rc = dev_build(s, before); if (rc < 0) return rc; }
+    else s->pdus.clear();
     rc = dev_launch_extractions(s, nblocks);
     if (rc != FDC_OK) return rc;
-    const bool had = d.pend[before];
-    const int done = dev_complete(s, before);
-    if (done < 0) return done;
-    if (!had) s->pdus.clear();
-    return done;
+    return had ? dev_wait(s, before) : 0;
 }
 
 int fdc_sinks_flush(fdc_sinks *s)
