@@ -25,7 +25,10 @@ __device__ __forceinline__ cf upk(unsigned long long u) { return mk(__uint_as_fl
 
 constexpr int kScrPts = 1084;
 
-template <int W>
+// DMA = true (W = 8 only, round 3): the rows of the next pass do not wait in 32 VGPRs but in LDS — every wave fills a private
+// 8-KiB strip ([256 rows][4 columns]) with eight `buffer_load_dwordx4 ... lds` (two lanes per row: 32 rows per instruction) and
+// reads its 16 values per lane back at the top of the next pass.  Private strips: no workgroup barrier, the waves keep drifting.
+template <int W, bool DMA = false>
 __global__ __attribute__((target("no-load-store-opt"))) __launch_bounds__(64 * W) void k_s1(const float2 *__restrict__ in, size_t in_stride,
                                                                                                  float2 *__restrict__ out, const float2 *__restrict__ tab,
                                                                                                  int nb)
@@ -50,7 +53,17 @@ __global__ __attribute__((target("no-load-store-opt"))) __launch_bounds__(64 * W
     const float2 *const btr = Bt + c5 * 18;
     cf acc = mk(0.f, 0.f);
     cf L[16];
-    if (W == 8) {
+    // DMA: this wave's strip behind the tables; lane -> (row inside an instruction's 32 rows, which half of the 32 bytes)
+    float2 *const dstrip = SA + PASSES * 16 * 18 + w * 1024;
+    const unsigned voffd = (unsigned)((lane >> 1) * 2048 + (lane & 1) * 16);
+    auto dma_issue = [&](int mb, int pn) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + COLS * pn + 4 * w, 65536u * 8u);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(dstrip + i * 128), 16, voffd, (unsigned)i * 65536u, 0, 0);
+    };
+    if (DMA) dma_issue(first, 0);
+    else if (W == 8) {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, 65536u * 8u);
 #pragma unroll
         for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
@@ -61,7 +74,13 @@ __global__ __attribute__((target("no-load-store-opt"))) __launch_bounds__(64 * W
 #pragma nounroll
         for (int ps = 0; ps < PASSES; ps++) {
             cf cur[16];
-            if (W == 8) {
+            if (DMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the strip is filled
+#pragma unroll
+                for (int a = 0; a < 16; a++) cur[a] = ld2(&dstrip[(16 * a + b) * 4 + col]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // ... and read out: the next pass may overwrite it
+                dma_issue(ps < PASSES - 1 ? m : mnext, ps < PASSES - 1 ? ps + 1 : 0);
+            } else if (W == 8) {
 #pragma unroll
                 for (int a = 0; a < 16; a++) cur[a] = L[a];
                 const int pn = ps < PASSES - 1 ? ps + 1 : 0;
@@ -120,16 +139,16 @@ __global__ __attribute__((target("no-load-store-opt"))) __launch_bounds__(64 * W
     out[(size_t)blockIdx.x * 64 * W + tid] = to2(acc);
 }
 
-template <int W>
+template <int W, bool DMA = false>
 static void run(const char *name, const float2 *in, float2 *out, const float2 *tab, int nb)
 {
-    const int lds = (W * kScrPts + 16 * 18 + 4 * W * 18 + (256 / (4 * W)) * 16 * 18) * 8;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_s1<W>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds = (W * kScrPts + 16 * 18 + 4 * W * 18 + (256 / (4 * W)) * 16 * 18 + (DMA ? 8 * 1024 : 0)) * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_s1<W, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_s1<W>, dim3(256), dim3(64 * W), lds, 0, in, (size_t)32768, out, tab, nb);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_s1<W, DMA>), dim3(256), dim3(64 * W), lds, 0, in, (size_t)32768, out, tab, nb);
     hipEventRecord(e0, 0);
     const int reps = 20;
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_s1<W>, dim3(256), dim3(64 * W), lds, 0, in, (size_t)32768, out, tab, nb);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_s1<W, DMA>), dim3(256), dim3(64 * W), lds, 0, in, (size_t)32768, out, tab, nb);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     printf("%-40s LDS %6d B   %.4f ms per %d blocks (stage 1 only)   %s\n", name, lds, ms / reps, nb, hipGetErrorString(hipGetLastError()));
@@ -148,5 +167,7 @@ int main()
     hipMemcpy(tab, t.data(), sizeof(float2) * 256, hipMemcpyHostToDevice);
     run<8>("W = 8  (512 threads, 2 waves per SIMD)", in, out, tab, nb);
     run<16>("W = 16 (1024 threads, 4 waves per SIMD)", in, out, tab, nb);
+    run<8, true>("W = 8, next pass by LDS-DMA (no prefetch VGPRs)", in, out, tab, nb);
+    run<8>("W = 8  again", in, out, tab, nb);
     return 0;
 }
