@@ -139,11 +139,12 @@ def test_combined_bank_two_deep_submission_and_device_payload():
 
 def test_randomised_banks_device_engine_equals_host_engine():
     """tools/fuzz_sinks.py (random banks, thresholds, maxblocks, delays, puffers, touching / merging carriers, zero-power stretches,
-    call patterns) for 30 cases: both engines, everything equal."""
+    call patterns) for 30 cases, in this process: both engines, everything equal."""
+    import importlib.util
     import os
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sinks.py"), "30", "7"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "all equal to the host engine" in out.stdout
+    spec = importlib.util.spec_from_file_location("fuzz_sinks", os.path.join(root, "tools", "fuzz_sinks.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ndev, npdu = mod.main(30, 7)
+    assert ndev >= 20 and npdu > 1000

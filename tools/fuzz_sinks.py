@@ -89,9 +89,9 @@ def run(bank, spec, cuts, max_blocks):
     return out
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def main(cases=None, seed=None):
+    cases = cases if cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 60)
+    seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     rng = np.random.default_rng(seed)
     npdu = ndev = 0
     for case in range(cases):
@@ -113,6 +113,7 @@ def main():
             assert da.size == db.size and (da == db).all(), (what, k, da.size, db.size)
         npdu += len(a)
     print("fuzz_sinks: %d cases on the device engine, %d PDUs, all equal to the host engine" % (ndev, npdu))
+    return ndev, npdu
 
 
 if __name__ == "__main__":
