@@ -424,8 +424,22 @@ __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restric
     if (cell >= ncells) return;
     const PowerCell pc = cells[cell];
     const float2 *x = spec + m * (size_t)N + pc.start;
-    float acc = 0.f;
-    for (int i = lane; i < pc.len; i += 64) { const float2 v = x[i]; acc += v.x * v.x + v.y * v.y; }
+    // two bins per 16-byte load from the first even bin on (the spectrum and N are 16-byte aligned), two loads in flight per lane
+    const int head = (pc.start & 1) && pc.len > 0 ? 1 : 0, n2 = (pc.len - head) >> 1;
+    float acc = 0.f, acc2 = 0.f;
+    if (lane == 0) {
+        if (head) { const float2 v = x[0]; acc += v.x * v.x + v.y * v.y; }
+        if ((pc.len - head) & 1) { const float2 v = x[pc.len - 1]; acc += v.x * v.x + v.y * v.y; }
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+    int i = lane;
+    for (; i + 64 < n2; i += 128) {
+        const float4 a = x4[i], b = x4[i + 64];
+        acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        acc2 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    if (i < n2) { const float4 a = x4[i]; acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+    acc += acc2;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) out[m * (size_t)ncells + cell] = acc * pc.scale;
