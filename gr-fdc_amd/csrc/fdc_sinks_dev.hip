@@ -278,7 +278,13 @@ __host__ __device__ constexpr size_t det_lds_bytes(int nb, int words, int staged
 {
     return (size_t)nb * (size_t)words * 8 + (size_t)nb * 4 + (size_t)nb * (size_t)staged * 8 + (size_t)kDetQueue * 16 + 32 * 4 + 64;
 }
-__device__ __forceinline__ int pow2ceil_dev(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+__device__ __forceinline__ int pow2ceil_dev(int k)
+{
+    if (k > (1 << 30)) return 0x7FFFFFFF;               // absurd flank puffer: wider than any block, the caller skips it (no overflow loop)
+    int p = 1;
+    while (p < k) p <<= 1;
+    return p;
+}
 
 struct DetChanRegs {          // one channel while it is handled (wave-uniform)
     int id, ds, de, es, cls, cnt0, inact0, part0, buf0, a /* activation block, -1 = alive before the call */, own;
