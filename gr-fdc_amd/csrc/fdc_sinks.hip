@@ -1165,8 +1165,7 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
     HIPCHK(fdc::launch_sink_layout(d.nlist, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_tasks, d.d_pdus, d.d_pdus_out, d.d_owners,
                                    npac, nseg, d.d_owner_base, d.d_nowner, d.d_pstate, d.d_sst, d.d_live, d.d_live_off, d.d_sum,
                                    d.d_class_fill, d.d_error, s->stream));
-    HIPCHK(hipMemcpyAsync(d.h_sum, d.d_sum, sizeof(fdc::SinkSummary), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(d.h_pdus, d.d_pdus_out, sizeof(fdc::SinkPdu) * kEagerPdus, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(fdc::launch_sink_publish(d.d_sum, d.d_pdus_out, d.h_sum, d.h_pdus, kEagerPdus, s->stream));
     HIPCHK(hipEventRecord(d.ev_decide, s->stream));
     s->blockcount = bc0 + nblocks;
     return FDC_OK;

@@ -108,6 +108,9 @@ hipError_t launch_sink_layout(int nlist, const int64_t *task_base, const int64_t
                               const int64_t *owner_base, const int32_t *nowner, PacState *pst, DetSegState *sst, int32_t *live,
                               int64_t *live_off, SinkSummary *sum, int32_t *class_fill, const int32_t *error, hipStream_t s);
 
+// summary and the first `eager` emission records into pinned host memory (kernel stores: no queueing behind a payload copy)
+hipError_t launch_sink_publish(const SinkSummary *sum, const SinkPdu *pdus, SinkSummary *h_sum, SinkPdu *h_pdus, int eager, hipStream_t s);
+
 // tasks -> ExtractTask grouped by width class (positions resolved through the owner table), order inside a class arbitrary
 hipError_t launch_task_scatter(int nlist, const int64_t *task_base, const int32_t *ntask, long long max_list, const SinkTask *tasks,
                                const SinkOwner *owners, const SinkSummary *sum, int32_t *class_fill, ExtractTask *sorted,

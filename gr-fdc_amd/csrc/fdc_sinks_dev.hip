@@ -713,6 +713,30 @@ hipError_t launch_sink_layout(int nlist, const int64_t *task_base, const int64_t
     return hipGetLastError();
 }
 
+// The layout summary and the first emission records go to the host by STORES of a kernel into pinned host memory, not by copies:
+// a copy would queue on the DMA engine behind the previous batch's payload (tens of MB, 1.6 ms and more) and hold back the
+// host's one wait of the call — and with it this batch's extractions — until that payload has left (measured: the step was
+// payload copy + extraction kernels, strictly one after the other).
+__global__ __launch_bounds__(256) void k_sink_publish(const SinkSummary *__restrict__ sum, const SinkPdu *__restrict__ pdus,
+                                                      SinkSummary *__restrict__ h_sum, SinkPdu *__restrict__ h_pdus, int eager)
+{
+    static_assert(sizeof(SinkSummary) % 4 == 0 && sizeof(SinkPdu) % 8 == 0, "word copies");
+    const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    const int n = sum->npdu < eager ? sum->npdu : eager;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pdus);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(h_pdus);
+    for (long long i = tid; i < (long long)n * (long long)(sizeof(SinkPdu) / 8); i += nthr) dst[i] = src[i];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (int)(sizeof(SinkSummary) / 4); i += 256)
+            reinterpret_cast<int32_t *>(h_sum)[i] = reinterpret_cast<const int32_t *>(sum)[i];
+}
+
+hipError_t launch_sink_publish(const SinkSummary *sum, const SinkPdu *pdus, SinkSummary *h_sum, SinkPdu *h_pdus, int eager, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sink_publish, dim3(8), dim3(256), 0, s, sum, pdus, h_sum, h_pdus, eager);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_task_scatter(const int64_t *__restrict__ task_base, const int32_t *__restrict__ ntask,
                                                       const SinkTask *__restrict__ tasks, const SinkOwner *__restrict__ owners,
                                                       const SinkSummary *__restrict__ sum, int32_t *__restrict__ class_fill,
