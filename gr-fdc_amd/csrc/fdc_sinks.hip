@@ -198,7 +198,8 @@ struct fdc_sinks {
         std::vector<int64_t> task_base, pdu_base, owner_base, cand_base;
         int64_t *d_task_base = nullptr, *d_pdu_base = nullptr, *d_owner_base = nullptr, *d_cand_base = nullptr;
         int32_t *d_ntask = nullptr, *d_npdu = nullptr, *d_nowner = nullptr, *d_error = nullptr, *d_class_fill = nullptr;
-        int32_t *d_ncand = nullptr, *d_winoff = nullptr, *d_live = nullptr;
+        int32_t *d_ncand = nullptr, *d_winoff = nullptr, *d_live = nullptr, *d_live2 = nullptr;
+        fdc::DetCh *d_detch = nullptr;        // tracker scratch: one life record per entry of the owner table
         int64_t *d_live_off = nullptr;
         int2 *d_cand = nullptr;
         fdc::PacGeom *d_pgeom = nullptr; fdc::PacState *d_pstate = nullptr;
@@ -543,6 +544,8 @@ int dev_setup(fdc_sinks *s)
         std::vector<fdc::DetSegState> st((size_t)nseg, fdc::DetSegState{0, 0});
         DUP(d.d_sst, st);
         DALLOC(d.d_live, (size_t)nseg * fdc::kDetFields * fdc::kDetMaxCells);
+        DALLOC(d.d_live2, (size_t)nseg * fdc::kDetFields * fdc::kDetMaxCells);
+        DALLOC(d.d_detch, nown);
         DALLOC(d.d_live_off, (size_t)nseg * fdc::kDetMaxCells);
         DALLOC(d.d_cand, ncand);
         DALLOC(d.d_ncand, (size_t)nseg * nbmax);
@@ -579,7 +582,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
         for (hipEvent_t e : {d.ev_decide, d.ev_extract[0], d.ev_extract[1], d.ev_copied[0], d.ev_copied[1]}) if (e) (void)hipEventDestroy(e);
         for (void *q : {(void *)d.d_task_base, (void *)d.d_pdu_base, (void *)d.d_owner_base, (void *)d.d_cand_base, (void *)d.d_ntask,
                         (void *)d.d_npdu, (void *)d.d_nowner, (void *)d.d_error, (void *)d.d_class_fill, (void *)d.d_ncand,
-                        (void *)d.d_winoff, (void *)d.d_live, (void *)d.d_live_off, (void *)d.d_cand, (void *)d.d_pgeom,
+                        (void *)d.d_winoff, (void *)d.d_live, (void *)d.d_live2, (void *)d.d_detch, (void *)d.d_live_off, (void *)d.d_cand, (void *)d.d_pgeom,
                         (void *)d.d_pstate, (void *)d.d_dgeom, (void *)d.d_sst, (void *)d.d_tasks, (void *)d.d_pdus,
                         (void *)d.d_pdus_out, (void *)d.d_owners, (void *)d.d_sorted, (void *)d.d_sum, (void *)d.d_land[0],
                         (void *)d.d_land[1]})
@@ -1158,8 +1161,8 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
         for (const Segment &g : s->segs) dp.max_cand_cap = std::max(dp.max_cand_cap, g.ncell / 2 + 1);
         dp.segname0 = s->cfg.det_id;
         HIPCHK(fdc::launch_det_track(dp, nblocks, d.d_dgeom, d.d_sst, d.d_live, d.d_live_off, d.d_cand, d.d_cand_base, d.d_ncand, d.d_winoff,
-                                     bc0, now, d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners,
-                                     d.d_owner_base, d.d_nowner, d.d_error, s->stream));
+                                     now, d.d_pdus, d.d_pdu_base, d.d_npdu, d.d_owners, d.d_owner_base, d.d_nowner, d.d_detch, d.d_live2,
+                                     s->stream));
         HIPCHK(fdc::launch_det_expand(nseg, npac, s->R, d.d_owners, d.d_owner_base, d.d_nowner, d.d_tasks, d.d_task_base, d.d_ntask, s->stream));
     }
     HIPCHK(fdc::launch_sink_layout(d.nlist, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_tasks, d.d_pdus, d.d_pdus_out, d.d_owners,

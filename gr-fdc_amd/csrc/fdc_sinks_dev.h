@@ -88,15 +88,17 @@ struct DetParams {
     int mb_shift;                // log2(maxblocks) when it is a power of two >= 2, else -1
     double puffer;
     int segname0;                // SegmentDetection with one segment: the ID argument, else -1
+    unsigned dec_magic;          // floor(2^32 / dec) + 1: n / dec = umulhi(n, dec_magic) for n * dec < 2^32 (set by launch_det_track)
 };
-// detection, phase 2 (sequential over the blocks of a call, one wave per segment): matching, activation, extraction
-// bookkeeping, emissions (…vcm_impl.cc:741-841, :306-337; SegmentDetection_impl.cc:245-362)
+// detection, phase 2 (one workgroup per segment; independent frequency regions of the segment in parallel waves): matching,
+// activation, extraction bookkeeping, emissions (…vcm_impl.cc:741-841, :306-337; SegmentDetection_impl.cc:245-362).
+// chs: scratch, one DetCh per entry of the owner table; live2: scratch of the size of `live`
+struct DetCh { int32_t ds, de, es, cls, a, j, end, streak; };   // a channel's life in a call: detect range, extraction, activation block / candidate, end block
 hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, DetSegState *sst, int32_t *live /* [nseg][kDetFields][kDetMaxCells] */,
                             int64_t *live_off /* [nseg][kDetMaxCells] */, const int2 *cand, const int64_t *cand_base,
-                            const int32_t *ncand, const int32_t *win_off /* [log2 N + 1] */, long long bc0, long long now,
-                            SinkTask *tasks, SinkPdu *pdus, const int64_t *task_base, const int64_t *pdu_base, int32_t *ntask,
-                            int32_t *npdu, SinkOwner *owners, const int64_t *owner_base /* [nseg + 1], first = npac */,
-                            int32_t *nowner /* [nseg] */, int32_t *error, hipStream_t s);
+                            const int32_t *ncand, const int32_t *win_off /* [log2 N + 1] */, long long now, SinkPdu *pdus,
+                            const int64_t *pdu_base, int32_t *npdu, SinkOwner *owners, const int64_t *owner_base /* [nseg + 1], first = npac */,
+                            int32_t *nowner /* [nseg] */, DetCh *chs, int32_t *live2, hipStream_t s);
 
 // extraction tasks of the detected channels of a call, from their stream records (one workgroup per segment)
 hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const int64_t *owner_base, const int32_t *nowner, SinkTask *tasks,

@@ -10,6 +10,7 @@
 // loop over the blocks with one lane per PowerActivationChannel / one wave per segment (lanes = live channels).
 // Output of a call: extraction tasks and emission records that name blocks of per-channel streams (fdc_sinks_dev.h); the layout
 // kernel places the streams in the landing buffer so that every PDU is one contiguous run and only emitted runs cross PCIe.
+#include <climits>
 #include "fdc_sinks_dev.h"
 #include <cfloat>
 #include <cstdio>
@@ -270,20 +271,32 @@ __device__ long long block_exscan(long long v, long long *tot, long long *sh /* 
 //     the final one — follows from (activation block, end block) in closed form;
 //   * new channels are the candidates nobody took (:785-841): the sweep finds the first block that still has one once every
 //     channel activated before that block has been handled.
-// Per call the wave does work proportional to the number of channels (each a few 64-block steps), not to the number of blocks.
+// Channel by channel is still a chain (0.8 ms for the ~480 channels of a configs[4] step with one wave), but only channels that
+// can compete for a candidate depend on each other, and only while both are alive.  So the workgroup (16 waves) takes the call
+// in slabs of 64 blocks (lanes = the blocks of the slab).  Per slab it marks, on the segment's cell grid, every cell some
+// candidate of the slab or some channel alive at its start covers; the maximal covered runs ("regions") cannot interact inside
+// the slab — an overlap (:757, closed intervals) needs a common cell — and each is worked through by ONE wave, in the order
+// above, the waves taking regions from a queue; the channels alive at the end of the slab, sorted by their place in the
+// reference's list, are the input of the next one.  That pass only decides lives: (activation block, candidate, end block,
+// misses in a row) per channel.  The sequence numbers the reference's order gives the new channels (block of activation, then
+// candidate order inside the block) come from a prefix sum over the per-block masks of activating candidates afterwards, and
+// then every channel's records — stream bookkeeping, emissions, its place in the next call's list — are written by whichever
+// wave gets to it: nothing in them depends on another channel.
 // Emission order inside a block is restored from the key: block, segment, pass (SegmentDetection sends its partial PDUs in a
 // pass of their own, :359-362), position of the channel in the list (its sequence number: the list is ordered by activation).
-constexpr int kDetQueue = kDetMaxCells / 2 + 1;      // candidates of ONE block that can become channels
-__host__ __device__ constexpr size_t det_lds_bytes(int nb, int words, int staged)
+constexpr int kDetWaves = 16;
+constexpr int kDetStaged = 8;                        // candidates per block held in LDS (more than that: read from memory)
+__host__ __device__ constexpr size_t det_lds_bytes(int nb, int words)
 {
-    return (size_t)nb * (size_t)words * 8 + (size_t)nb * 4 + (size_t)nb * (size_t)staged * 8 + (size_t)kDetQueue * 16 + 32 * 4 + 64;
+    // activation masks + activation prefix per block of the call; per slab: candidate counts, staged candidates;
+    // regions, two alive lists of five columns, small
+    return (size_t)nb * (size_t)words * 8 + (size_t)nb * 4 + 64 * (4 + kDetStaged * 8) + (size_t)(kDetMaxCells / 2 + 1) * 8 +
+           (size_t)kDetMaxCells * 40 + 16 * 8 + 16 * 8 + 32 * 4 + 64;
 }
 __device__ __forceinline__ int pow2ceil_dev(int k)
 {
-    if (k > (1 << 30)) return 0x7FFFFFFF;               // absurd flank puffer: wider than any block, the caller skips it (no overflow loop)
-    int p = 1;
-    while (p < k) p <<= 1;
-    return p;
+    if (k > (1 << 30)) return 0x7FFFFFFF;               // absurd flank puffer: wider than any block, the caller skips it
+    return k <= 1 ? 1 : 1 << (32 - __clz(k - 1));
 }
 
 struct DetChanRegs {          // one channel while it is handled (wave-uniform)
@@ -293,54 +306,316 @@ struct DetChanRegs {          // one channel while it is handled (wave-uniform)
 };
 
 template <int WORDS>        // 64-bit words of a block's taken-mask: 1, 2 or up to 8 (compile time: the word loops vanish for 1 and 2)
-__global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const DetGeom *__restrict__ geom, DetSegState *__restrict__ sst,
+__global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int nb, const DetGeom *__restrict__ geom, DetSegState *__restrict__ sst,
                                                   int32_t *__restrict__ live_g, int64_t *__restrict__ live_off_g,
                                                   const int2 *__restrict__ cand, const int64_t *__restrict__ cand_base,
-                                                  const int32_t *__restrict__ ncand, const int32_t *__restrict__ win_off, long long bc0,
-                                                  long long now, SinkTask *__restrict__ tasks, SinkPdu *__restrict__ pdus,
-                                                  const int64_t *__restrict__ task_base, const int64_t *__restrict__ pdu_base,
-                                                  int32_t *__restrict__ ntask, int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners,
+                                                  const int32_t *__restrict__ ncand, const int32_t *__restrict__ win_off,
+                                                  long long now, SinkPdu *__restrict__ pdus, const int64_t *__restrict__ pdu_base,
+                                                  int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners,
                                                   const int64_t *__restrict__ owner_base, int32_t *__restrict__ nowner,
-                                                  int32_t *__restrict__ error, int staged)
+                                                  DetCh *__restrict__ chs_g, int32_t *__restrict__ live2_g)
 {
-    constexpr int words = WORDS;
+    constexpr int words = WORDS, staged = kDetStaged;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdc_det_smem[];
-    unsigned long long *CL = reinterpret_cast<unsigned long long *>(fdc_det_smem);       // [nb][words]: candidates taken
-    int2 *CS = reinterpret_cast<int2 *>(CL + (size_t)nb * words);                        // [nb][staged]: the first candidates of each block
-    int4 *QU = reinterpret_cast<int4 *>(CS + (size_t)nb * staged);                       // new channels of one block: (start, stop, extract start, class)
-    int *KM = reinterpret_cast<int *>(QU + kDetQueue);                                   // [nb]: candidates per block
-    int *wofs = KM + nb;                                                                 // [32]
-    (void)tasks; (void)task_base; (void)ntask; (void)bc0; (void)error;
-    const int lane = threadIdx.x, sg = blockIdx.x;
+    unsigned long long *NM = reinterpret_cast<unsigned long long *>(fdc_det_smem);       // [nb][words]: candidates that became channels
+    int2 *CS = reinterpret_cast<int2 *>(NM + (size_t)nb * words);                        // [64][staged]: the first candidates of each block of the slab
+    int2 *REG = CS + 64 * staged;                                                        // regions: (first cell, last cell)
+    unsigned long long *COV = reinterpret_cast<unsigned long long *>(REG + (kDetMaxCells / 2 + 1));   // [16]: covered cells
+    long long *sh = reinterpret_cast<long long *>(COV + 16);                             // [16]: block_exscan
+    int *AL = reinterpret_cast<int *>(sh + 16);                                          // alive at the start of the slab, list order: 5 columns
+    int *TL = AL + 5 * kDetMaxCells;                                                     // alive at its end, in the order the waves got there
+    int *SV = AL, *SVS = TL;                                                             // afterwards: sequence numbers of the survivors, sorted positions
+    int *NB = TL + 5 * kDetMaxCells;                                                     // [nb]: channels activated in earlier blocks
+    int *KM = NB + nb;                                                                   // [64]: candidates per block of the slab
+    int *wofs = KM + 64;                                                                 // [32]
+    int *cnt = wofs + 32;                                                                // [0] regions [1] queue [2] new [3] records [4] survivors [5] alive (end of slab)
+    enum { A_T = 0, A_KEY = kDetMaxCells, A_DS = 2 * kDetMaxCells, A_DE = 3 * kDetMaxCells, A_STK = 4 * kDetMaxCells };
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, sg = blockIdx.x;
     const DetGeom g = geom[sg];
     const int lst = dp.npac + sg;
     SinkPdu *const pl = pdus + pdu_base[lst];
     SinkOwner *const ow = owners + owner_base[sg];
     const int ow0 = (int)owner_base[sg];
+    DetCh *const chs = chs_g + owner_base[sg];
     int32_t *const Lg = live_g + (size_t)sg * kDetFields * kDetMaxCells;
+    int32_t *const L2 = live2_g + (size_t)sg * kDetFields * kDetMaxCells;
     int64_t *const Og = live_off_g + (size_t)sg * kDetMaxCells;
     const unsigned long long ltm = lanemask_lt();
     const int rm = dp.R - 1, mb = dp.maxblocks, sd = dp.variant == 1;
     const int32_t *const kc = ncand + (size_t)sg * dp.nbmax;
     const int2 *const cbase = cand + cand_base[sg];
-    for (int m = lane; m < nb; m += 64) {
-        KM[m] = kc[m];
-        for (int w = 0; w < words; w++) CL[(size_t)m * words + w] = 0;
-    }
-    for (int e = lane; e < nb * staged; e += 64) {
-        const int m = e / staged, j = e - m * staged;
-        CS[e] = j < g.cand_cap ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
-    }
-    if (lane < 32) wofs[lane] = win_off[lane];
-    lds_sync();
-    const int nlive0 = sst[sg].nlive;
-    int counter = sst[sg].counter, nown = nlive0, nout = 0, pcur = 0;
+    int m0 = 0;                                                                          // first block of the slab
+    auto cand_of = [&](int m, int j) { return j < staged ? CS[(m - m0) * staged + j] : cbase[(size_t)m * g.cand_cap + j]; };
+    auto cell_of = [&](int bin) {                                                        // (bin - start) / dec, clamped to the segment's cells
+        const int n = bin - g.start;
+        const int c = n <= 0 ? 0 : (dp.dec_magic ? (int)__umulhi((unsigned)n, dp.dec_magic) : n / dp.dec);
+        return c >= g.ncell ? g.ncell - 1 : c;
+    };
+    auto cover = [&](int a, int b) {                                                     // cells a..b
+        for (int w = a >> 6; w <= (b >> 6); w++) {
+            const int lo = w == (a >> 6) ? (a & 63) : 0, hi = w == (b >> 6) ? (b & 63) : 63;
+            const unsigned long long mk = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+            atomicOr(&COV[w], mk);
+        }
+    };
 
-    // ---- one channel over the blocks of the call
-    auto handle = [&](const DetChanRegs &c) {
+    for (int m = tid; m < nb; m += 64 * kDetWaves)
+        for (int w = 0; w < words; w++) NM[(size_t)m * words + w] = 0;
+    if (tid < 32) wofs[tid] = win_off[tid];
+    if (tid < 8) cnt[tid] = 0;
+    const int nlive0 = sst[sg].nlive, counter0 = sst[sg].counter;
+    for (int i = tid; i < nlive0; i += 64 * kDetWaves) {                                 // the list the call starts from
+        AL[A_T + i] = i; AL[A_KEY + i] = i; AL[A_DS + i] = Lg[DC_DSTART * kDetMaxCells + i]; AL[A_DE + i] = Lg[DC_DSTOP * kDetMaxCells + i];
+        AL[A_STK + i] = Lg[DC_INACT * kDetMaxCells + i];
+        DetCh h{}; h.a = -1; h.end = -1; chs[i] = h;
+    }
+    int nal = nlive0;
+    __syncthreads();
+
+    // a channel of the slab is either done (its end block is known) or goes on the list of the next slab
+    auto settle = [&](int t, int key, int ds, int de, int end, int streak) {
+        if (lane == 0) {
+            if (end >= 0) chs[t].end = end;
+            else {
+                const int d = atomicAdd(&cnt[5], 1);
+                if (d < kDetMaxCells) { TL[A_T + d] = t; TL[A_KEY + d] = key; TL[A_DS + d] = ds; TL[A_DE + d] = de; TL[A_STK + d] = streak; }
+            }
+        }
+    };
+
+#ifdef FDC_DET_STATS
+    unsigned long long tacc[8] = {}, tlast = __builtin_readcyclecounter();
+    int nregsum = 0;
+#define FDC_DT(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define FDC_DT(i) do { } while (0)
+#endif
+    for (m0 = 0; m0 < nb; m0 += 64) {
+        // ---- the slab's tables; cells covered by one of its candidates or by a channel alive at its start
+        if (tid < 64) KM[tid] = m0 + tid < nb ? kc[m0 + tid] : 0;
+        for (int e = tid; e < 64 * staged; e += 64 * kDetWaves) {
+            const int m = m0 + e / staged, j = e % staged;
+            CS[e] = (m < nb && j < g.cand_cap) ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
+        }
+        if (tid < 16) COV[tid] = 0;
+        if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[5] = 0; }
+        __syncthreads();
+        FDC_DT(0);
+        for (int q = wv; q < 64 && m0 + q < nb; q += kDetWaves) {
+            const int k = KM[q];
+            for (int j = lane; j < k; j += 64) { const int2 pc = cand_of(m0 + q, j); cover(cell_of(pc.x), cell_of(pc.y)); }
+        }
+        for (int i = tid; i < nal; i += 64 * kDetWaves) cover(cell_of(AL[A_DS + i]), cell_of(AL[A_DE + i]));
+        __syncthreads();
+        FDC_DT(1);
+        if (wv == 0) {
+            // regions = maximal runs of covered cells: lane w looks at word w (ncell <= 1024 = 16 words)
+            const unsigned long long c = lane < 16 ? COV[lane] : 0ull;
+            const unsigned long long up = __shfl_up(c, 1, 64), dn = __shfl_down(c, 1, 64);
+            const unsigned long long prev = (c << 1) | ((lane > 0 && lane < 16) ? up >> 63 : 0ull);
+            const unsigned long long next = (c >> 1) | ((lane < 15) ? dn << 63 : 0ull);
+            unsigned long long st = c & ~prev, en = c & ~next;              // first / last cell of a run
+            int x = __popcll(st), base = x;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(base, o, 64); if (lane >= o) base += y; }
+            const int tot = __shfl(base, 15, 64);
+            int is = base - x, ie = is + 0;
+            // the k-th start and the k-th end belong together; runs may span words, so the ends are counted on their own
+            int xe = __popcll(en), be = xe;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(be, o, 64); if (lane >= o) be += y; }
+            ie = be - xe;
+            while (st) { REG[is++].x = 64 * lane + __builtin_ctzll(st); st &= st - 1; }
+            while (en) { REG[ie++].y = 64 * lane + __builtin_ctzll(en); en &= en - 1; }
+            if (lane == 0) cnt[0] = tot;
+        }
+        __syncthreads();
+        const int nreg = cnt[0];
+        FDC_DT(2);
+#ifdef FDC_DET_STATS
+        nregsum += nreg;
+#endif
+        for (;;) {
+            int r = 0;
+            if (lane == 0) r = atomicAdd(&cnt[1], 1);
+            r = __builtin_amdgcn_readfirstlane(r);
+            if (r >= nreg) break;
+            // a candidate / channel belongs to the region its first bin lies in (bins of the region's cells: no division per test)
+            const int b_lo = REG[r].x == 0 ? INT_MIN : g.start + REG[r].x * dp.dec;
+            const int b_hi = REG[r].y >= g.ncell - 1 ? INT_MAX : g.start + (REG[r].y + 1) * dp.dec - 1;
+            auto inreg = [&](int bin) { return bin >= b_lo && bin <= b_hi; };
+            // This wave is the only one that looks at the region's candidates in this slab, and lane = block: what a block's
+            // candidates are, which of them are the region's (RM), taken (cl) or have become channels (nm) stays in the lane's
+            // registers for the whole region — a channel's pass over the slab is compares and ballots, no memory round trip.
+            const int m = m0 + lane;
+            const int k = KM[lane];
+            int2 cs[staged];
+#pragma unroll
+            for (int u = 0; u < staged; u++) cs[u] = CS[lane * staged + u];
+            const bool deep = __ballot(k > staged) != 0;             // some block has more candidates than are staged (rare)
+            int kmax = k;
+            if (deep) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+            }
+            unsigned long long RM[WORDS], cl[WORDS], nm[WORDS];
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) { RM[w] = 0; cl[w] = 0; nm[w] = 0; }
+#pragma unroll
+            for (int u = 0; u < staged; u++) if (u < k && inreg(cs[u].x)) RM[0] |= 1ull << u;
+            if (deep)
+                for (int j = staged; j < k; j++)
+                    if (inreg(cbase[(size_t)m * g.cand_cap + j].x)) {
+#pragma unroll
+                        for (int w = 0; w < WORDS; w++) if ((j >> 6) == w) RM[w] |= 1ull << (j & 63);
+                    }
+            // One channel over the blocks of the slab from `first` on: the candidates it takes (marked), the block of its end
+            // (-1: it lives on), its misses in a row after the last block
+            auto scan = [&](int ds, int de, int first, int inact0, int &end_out, int &streak_out) {
+                const int f = first > m0 ? first - m0 : 0;     // first lane that takes part
+                const bool valid = lane >= f && m < nb;
+                unsigned long long ov[WORDS];
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) ov[w] = 0;
+#pragma unroll
+                for (int u = 0; u < staged; u++)
+                    if (u < k && cs[u].x < de && cs[u].y >= ds && !((cl[0] >> u) & 1ull)) ov[0] |= 1ull << u;
+                if (deep)
+                    for (int j = staged; j < kmax; j++)
+                        if (j < k) {
+                            const int2 pc = cbase[(size_t)m * g.cand_cap + j];
+#pragma unroll
+                            for (int w = 0; w < WORDS; w++)
+                                if ((j >> 6) == w && pc.x < de && pc.y >= ds && !((cl[w] >> (j & 63)) & 1ull)) ov[w] |= 1ull << (j & 63);
+                        }
+                bool hit = false;
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) hit = hit || ov[w] != 0;
+                hit = hit && valid;
+                const unsigned long long H = __ballot(hit);
+                // misses in a row after block m's update (:748-752, :768-771)
+                const unsigned long long hb = H & ltm;
+                const int lh = hb ? 63 - __clzll((long long)hb) : -1;
+                const int st = hit ? 0 : (lh >= 0 ? lane - lh : inact0 + (lane - f) + 1);
+                const unsigned long long F = __ballot(valid && !hit && st > dp.delay);
+                const int endlane = F ? __builtin_ctzll(F) : 64;
+                if (hit && lane < endlane) {
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) cl[w] |= ov[w];
+                }
+                const int lastv = (nb - m0 < 64 ? nb - m0 : 64) - 1;
+                end_out = F ? m0 + endlane : -1;
+                streak_out = lastv >= f ? __shfl(st, lastv, 64) : inact0;
+            };
+            // the channels alive at the start of the slab, in list order
+            for (int i0 = 0; i0 < nal; i0 += 64) {
+                const int i = i0 + lane;
+                unsigned long long B = __ballot(i < nal && inreg(AL[A_DS + (i < nal ? i : 0)]));
+                while (B) {
+                    const int ii = i0 + __builtin_ctzll(B);
+                    B &= B - 1;
+                    const int ds = AL[A_DS + ii], de = AL[A_DE + ii];
+                    int end, streak;
+                    scan(ds, de, m0, AL[A_STK + ii], end, streak);
+                    settle(AL[A_T + ii], AL[A_KEY + ii], ds, de, end, streak);
+                }
+            }
+            // candidates of the region nobody took become channels (:785-841), block after block
+            for (int ms = m0;;) {
+                bool un = false;
+                if (m < nb && m >= ms) {
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) un = un || (RM[w] & ~cl[w]) != 0;
+                }
+                const unsigned long long U = __ballot(un);
+                if (!U) break;
+                const int fl = __builtin_ctzll(U), mf = m0 + fl, kf = __shfl(k, fl, 64);
+                // the activating candidates of block mf; everything of the region in this block is now settled
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) {
+                    const int j = 64 * w + lane;
+                    bool ok = false;
+                    const unsigned long long rmw = __shfl(RM[w], fl, 64), clw = __shfl(cl[w], fl, 64);
+                    int2 pc = make_int2(0, 0);
+                    int es = 0, cls = 0;
+                    if (j < kf && ((rmw >> lane) & 1ull) && !((clw >> lane) & 1ull)) {
+                        pc = cand_of(mf, j);
+                        const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
+                        const int ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
+                        if (ew <= dp.N) {                        // wider than the block: logged and skipped in the reference
+                            cls = 31 - __clz(ew);
+                            if (wofs[cls] >= 0) {
+                                ok = true;
+                                es = mid - ew / 2;
+                                int ee = mid + ew / 2;
+                                if (es < 0) { es = 0; ee = ew; }
+                                if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
+                            }
+                        }
+                    }
+                    unsigned long long q = __ballot(ok);
+                    if (lane == fl) { nm[w] |= q; cl[w] |= rmw; }
+                    if (!q) continue;
+                    int t0 = 0;
+                    if (lane == 0) t0 = atomicAdd(&cnt[2], __popcll(q));
+                    t0 = __builtin_amdgcn_readfirstlane(t0);
+                    while (q) {
+                        const int jl = __builtin_ctzll(q);
+                        q &= q - 1;
+                        const int cx = __shfl(pc.x, jl, 64), cy = __shfl(pc.y, jl, 64), ces = __shfl(es, jl, 64), ccls = __shfl(cls, jl, 64);
+                        int end, streak;
+                        scan(cx, cy, mf + 1, 0, end, streak);
+                        const int t = nlive0 + t0;
+                        t0++;
+                        if (lane == 0) chs[t] = DetCh{cx, cy, ces, ccls, mf, 64 * w + jl, -1, 0};
+                        settle(t, nlive0 + mf * g.cand_cap + 64 * w + jl, cx, cy, end, streak);
+                    }
+                }
+                ms = mf + 1;
+            }
+            // the activation masks of the region's blocks join the call's (ranks of the new channels, below)
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) if (nm[w]) atomicOr(&NM[(size_t)m * words + w], nm[w]);
+        }
+        FDC_DT(3);
+        __syncthreads();
+        FDC_DT(4);
+        // ---- the list of the next slab: who is still alive, in the reference's list order (old ones, then by activation)
+        const int nt = cnt[5] < kDetMaxCells ? cnt[5] : kDetMaxCells;
+        if (tid < nt) {
+            const int me = TL[A_KEY + tid];
+            int d = 0;
+            for (int u = 0; u < nt; u++) d += TL[A_KEY + u] < me ? 1 : 0;
+            AL[A_T + d] = TL[A_T + tid]; AL[A_KEY + d] = me; AL[A_DS + d] = TL[A_DS + tid]; AL[A_DE + d] = TL[A_DE + tid]; AL[A_STK + d] = TL[A_STK + tid];
+        }
+        nal = nt;
+        __syncthreads();
+        FDC_DT(5);
+    }
+    // the channels that outlive the call: their misses in a row go into the next call's list
+    for (int i = tid; i < nal; i += 64 * kDetWaves) chs[AL[A_T + i]].streak = AL[A_STK + i];
+    __syncthreads();
+
+    // ---- sequence numbers of the new channels: block of activation, then candidate order inside the block
+    const int nnew = cnt[2], nown = nlive0 + nnew;
+    {
+        int acc = 0;
+        for (int m0 = 0; m0 < nb; m0 += 64 * kDetWaves) {
+            const int m = m0 + tid;
+            int n = 0;
+            if (m < nb) for (int w = 0; w < words; w++) n += __popcll(NM[(size_t)m * words + w]);
+            long long tot;
+            const int ex = (int)block_exscan(n, &tot, sh);
+            if (m < nb) NB[m] = acc + ex;
+            acc += (int)tot;
+        }
+    }
+    __syncthreads();
+
+    // ---- the records of every channel (a wave each, any order)
+    auto emit = [&](const DetChanRegs &c, const int end, const int streak) {
         const int w_ = 1 << c.cls, len = w_ - w_ / dp.R;
         const int first = c.a < 0 ? 0 : c.a + 1;              // first block in which the channel is matched
-        int streak = c.inact0, end = -1;                       // misses in a row so far; block of the final emission
         // stream bookkeeping: Q(m) = buffered before the call + blocks extracted up to block m; E = emitted prefix
         // events: a new channel's activation block counts as one (two blocks buffered), every further block as one
         auto qof = [&](int m) { return c.buf0 + (c.a < 0 ? m + 1 : m - c.a + 2); };            // stream length after block m
@@ -351,89 +626,46 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
             const int ev = c.a < 0 ? m + 1 : m - c.a + 1;     // events so far
             return mb <= 1 ? ev : divmb(qof(m));
         };
+        auto take = [&](int n) {                                // n places in the segment's record list
+            int p = 0;
+            if (lane == 0) p = atomicAdd(&cnt[3], n);
+            return __builtin_amdgcn_readfirstlane(p);
+        };
         // the activation block itself (no matching there, but the partial check behind process_channel_hist, :317 / :359)
         if (c.a >= 0) {
             const int q = qof(c.a), e1 = eof(q);
             if (mb >= 0 && e1 > 0) {
+                const int p = take(1);
                 if (lane == 0) {
                     SinkPdu r;
                     r.key = ((long long)c.a << 40) | (1ll << 39) | ((long long)sg << 28) | ((long long)(sd ? 1 : 0) << 27) | ((long long)c.own * 2 + 1);
                     r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
                     r.owner = ow0 + c.own; r.q0 = 0; r.q1 = e1; r.count = 2; r.chan_id = c.id; r.part = c.part0;
                     r.flags = (c.cls << 8) | (1 << 16); r.vstart = c.es;
-                    pl[pcur] = r;
+                    pl[p] = r;
                 }
-                pcur += 1;
             }
         }
-        for (int m0 = first; m0 < nb && end < 0; m0 += 64) {
-            const int m = m0 + lane;
-            const bool valid = m < nb;
-            // candidates of block m this channel overlaps and nobody before it in the list has taken.  The first eight of a block
-            // come from LDS in one go (no dependent round trips), the taken-mask word too; more than that is rare.
-            const int k = valid ? KM[m] : 0;
-            int kmax = k;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
-            int2 cs[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) cs[u] = (valid && u < staged) ? CS[(size_t)m * staged + u] : make_int2(0, 0);
-            unsigned long long ov[WORDS];
-#pragma unroll
-            for (int w = 0; w < WORDS; w++) {
-                ov[w] = 0;
-                if (kmax > 64 * w) {
-                    const unsigned long long cl = valid ? CL[(size_t)m * words + w] : ~0ull;
-                    int j0 = 64 * w;
-                    if (w == 0) {
-#pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            if (u < staged && u < k && cs[u].x < c.de && cs[u].y >= c.ds && !((cl >> u) & 1ull)) ov[0] |= 1ull << u;
-                        j0 = staged < 8 ? staged : 8;
-                    }
-                    const int j1 = kmax < 64 * w + 64 ? kmax : 64 * w + 64;
-                    for (int j = j0; j < j1; j++)
-                        if (j < k) {
-                            const int2 pc = j < staged ? CS[(size_t)m * staged + j] : cbase[(size_t)m * g.cand_cap + j];
-                            if (pc.x < c.de && pc.y >= c.ds && !((cl >> (j & 63)) & 1ull)) ov[w] |= 1ull << (j & 63);
-                        }
-                }
-            }
-            bool hit = false;
-#pragma unroll
-            for (int w = 0; w < WORDS; w++) hit = hit || ov[w] != 0;
-            const unsigned long long H = __ballot(valid && hit);
-            // misses in a row after block m's update (:748-752, :768-771)
-            const unsigned long long hb = H & ltm;
-            const int lh = hb ? 63 - __clzll((long long)hb) : -1;
-            const int st = hit ? 0 : (lh >= 0 ? lane - lh : streak + lane + 1);
-            const unsigned long long F = __ballot(valid && !hit && st > dp.delay);
-            const int endlane = F ? __builtin_ctzll(F) : 64;
-            if (F) end = m0 + endlane;
-            if (valid && hit && lane < endlane) {
-#pragma unroll
-                for (int w = 0; w < WORDS; w++) if (ov[w]) CL[(size_t)m * words + w] |= ov[w];
-            }
-            // partial emissions of the blocks the channel is extracted from (those before `end`)
-            if (mb >= 0) {
-                const bool procd = valid && lane < endlane;
+        // partial emissions of the blocks the channel is extracted from (those before `end`)
+        const int lim = end >= 0 ? end : nb;
+        if (mb >= 0)
+            for (int m0 = first; m0 < lim; m0 += 64) {
+                const int m = m0 + lane;
                 const int q = qof(m), e1 = eof(q), qp = m == first ? (c.a < 0 ? c.buf0 : qof(c.a)) : qof(m - 1), e0 = m == first && c.a < 0 ? 0 : eof(qp);
-                const bool emit = procd && e1 > e0;
-                const unsigned long long EM = __ballot(emit);
-                if (emit) {
+                const bool em = m < lim && e1 > e0;
+                const unsigned long long EM = __ballot(em);
+                if (!EM) continue;
+                const int p = take(__popcll(EM));
+                if (em) {
                     SinkPdu r;
                     r.key = ((long long)m << 40) | (1ll << 39) | ((long long)sg << 28) | ((long long)(sd ? 1 : 0) << 27) | ((long long)c.own * 2 + 1);
                     r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
                     r.owner = ow0 + c.own; r.q0 = e0; r.q1 = e1; r.count = c.cnt0 + (c.a < 0 ? m + 1 : m - c.a + 2); r.chan_id = c.id;
                     r.part = c.part0 + nem(m) - 1;
                     r.flags = (c.cls << 8) | (1 << 16); r.vstart = c.es;
-                    pl[pcur + __popcll(EM & ltm)] = r;
+                    pl[p + __popcll(EM & ltm)] = r;
                 }
-                pcur += __popcll(EM);
             }
-            const int lastv = (nb - m0 < 64 ? nb - m0 : 64) - 1;
-            streak = __shfl(st, lastv, 64);
-        }
         // what the call leaves of the channel
         const int firstproc = c.a < 0 ? 0 : c.a;                // first block it was extracted from, if any
         const int lastm = end >= 0 ? end - 1 : nb - 1;          // last one (before firstproc: none in this call)
@@ -442,6 +674,8 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
         const int Ef = any ? eof(Qf) : 0;                        // partial emissions of this call
         const int npart = any ? nem(lastm) : 0;
         const int cntf = c.cnt0 + (Qf - c.buf0);
+        int p = 0;
+        if (end >= 0) p = take(1);
         if (lane == 0) {
             SinkOwner o{};
             o.len = len; o.cls = c.cls; o.carried = c.buf0; o.total = Qf; o.emitted = end >= 0 ? Qf : Ef; o.prev_off = c.prev_off;
@@ -453,90 +687,62 @@ __global__ __launch_bounds__(64) void k_det_track(DetParams dp, int nb, const De
                 r.act_time = ((long long)c.thi << 32) | (unsigned)c.tlo; r.off = 0;
                 r.owner = ow0 + c.own; r.q0 = Ef; r.q1 = Qf; r.count = cntf; r.chan_id = c.id; r.part = c.part0 + npart;
                 r.flags = 1 | (c.cls << 8) | (1 << 16); r.vstart = c.es;
-                pl[pcur] = r;
-            } else {                                             // still alive: an entry of the list the next call starts from
-                const int d = nout;
-                Lg[DC_ID * kDetMaxCells + d] = c.id; Lg[DC_DSTART * kDetMaxCells + d] = c.ds; Lg[DC_DSTOP * kDetMaxCells + d] = c.de;
-                Lg[DC_ESTART * kDetMaxCells + d] = c.es; Lg[DC_CLS * kDetMaxCells + d] = c.cls; Lg[DC_COUNT * kDetMaxCells + d] = cntf;
-                Lg[DC_PHASE * kDetMaxCells + d] = (cntf * (c.es & rm)) & rm; Lg[DC_PINC * kDetMaxCells + d] = c.es & rm;
-                Lg[DC_INACT * kDetMaxCells + d] = streak; Lg[DC_PART * kDetMaxCells + d] = c.part0 + npart;
-                Lg[DC_OWNER * kDetMaxCells + d] = c.own; Lg[DC_TAIL * kDetMaxCells + d] = 0;
-                Lg[DC_TIME_LO * kDetMaxCells + d] = c.tlo; Lg[DC_TIME_HI * kDetMaxCells + d] = c.thi;
+                pl[p] = r;
+            } else {                                             // still alive: an entry of the list the next call starts from (placed below)
+                int d = atomicAdd(&cnt[4], 1);
+                if (d >= kDetMaxCells) d = kDetMaxCells - 1;     // cannot happen: live channels are disjoint, at most one per cell
+                SV[d] = c.own;
+                L2[DC_ID * kDetMaxCells + d] = c.id; L2[DC_DSTART * kDetMaxCells + d] = c.ds; L2[DC_DSTOP * kDetMaxCells + d] = c.de;
+                L2[DC_ESTART * kDetMaxCells + d] = c.es; L2[DC_CLS * kDetMaxCells + d] = c.cls; L2[DC_COUNT * kDetMaxCells + d] = cntf;
+                L2[DC_PHASE * kDetMaxCells + d] = (cntf * (c.es & rm)) & rm; L2[DC_PINC * kDetMaxCells + d] = c.es & rm;
+                L2[DC_INACT * kDetMaxCells + d] = streak; L2[DC_PART * kDetMaxCells + d] = c.part0 + npart;
+                L2[DC_OWNER * kDetMaxCells + d] = c.own; L2[DC_TAIL * kDetMaxCells + d] = 0;
+                L2[DC_TIME_LO * kDetMaxCells + d] = c.tlo; L2[DC_TIME_HI * kDetMaxCells + d] = c.thi;
             }
         }
-        if (end >= 0) pcur += 1; else nout += 1;
     };
-
-    // ---- the channels alive before the call, in list order
-    for (int i = 0; i < nlive0; i++) {
+    FDC_DT(6);
+    for (int t = wv; t < nown; t += kDetWaves) {
+        const DetCh h = chs[t];
         DetChanRegs c;
-        c.id = Lg[DC_ID * kDetMaxCells + i]; c.ds = Lg[DC_DSTART * kDetMaxCells + i]; c.de = Lg[DC_DSTOP * kDetMaxCells + i];
-        c.es = Lg[DC_ESTART * kDetMaxCells + i]; c.cls = Lg[DC_CLS * kDetMaxCells + i]; c.cnt0 = Lg[DC_COUNT * kDetMaxCells + i];
-        c.inact0 = Lg[DC_INACT * kDetMaxCells + i]; c.part0 = Lg[DC_PART * kDetMaxCells + i]; c.buf0 = Lg[DC_TAIL * kDetMaxCells + i];
-        c.phase0 = Lg[DC_PHASE * kDetMaxCells + i]; c.tlo = Lg[DC_TIME_LO * kDetMaxCells + i]; c.thi = Lg[DC_TIME_HI * kDetMaxCells + i];
-        c.prev_off = Og[i]; c.a = -1; c.own = i;
-        handle(c);
+        if (t < nlive0) {
+            c.id = Lg[DC_ID * kDetMaxCells + t]; c.ds = Lg[DC_DSTART * kDetMaxCells + t]; c.de = Lg[DC_DSTOP * kDetMaxCells + t];
+            c.es = Lg[DC_ESTART * kDetMaxCells + t]; c.cls = Lg[DC_CLS * kDetMaxCells + t]; c.cnt0 = Lg[DC_COUNT * kDetMaxCells + t];
+            c.inact0 = Lg[DC_INACT * kDetMaxCells + t]; c.part0 = Lg[DC_PART * kDetMaxCells + t]; c.buf0 = Lg[DC_TAIL * kDetMaxCells + t];
+            c.phase0 = Lg[DC_PHASE * kDetMaxCells + t]; c.tlo = Lg[DC_TIME_LO * kDetMaxCells + t]; c.thi = Lg[DC_TIME_HI * kDetMaxCells + t];
+            c.prev_off = Og[t]; c.a = -1; c.own = t;
+        } else {
+            int rk = NB[h.a];
+            for (int w = 0; w < (h.j >> 6); w++) rk += __popcll(NM[(size_t)h.a * words + w]);
+            rk += __popcll(NM[(size_t)h.a * words + (h.j >> 6)] & ((1ull << (h.j & 63)) - 1ull));
+            c.id = counter0 + rk; c.ds = h.ds; c.de = h.de; c.es = h.es; c.cls = h.cls; c.cnt0 = 0; c.inact0 = 0; c.part0 = 0; c.buf0 = 0;
+            c.phase0 = 0; c.tlo = (int)(unsigned)(now & 0xFFFFFFFFll); c.thi = (int)(now >> 32); c.prev_off = 0; c.a = h.a; c.own = nlive0 + rk;
+        }
+        emit(c, h.end, h.streak);
     }
-    // ---- candidates nobody took become channels (:785-841), block after block
-    for (int ms = 0; ms < nb;) {
-        int found = -1;
-        for (int m0 = ms; m0 < nb && found < 0; m0 += 64) {
-            const int m = m0 + lane;
-            bool un = false;
-            if (m < nb) {
-                const int k = KM[m];
-                for (int w = 0; w < words; w++) {
-                    const int kk = k - 64 * w;
-                    const unsigned long long vm = kk >= 64 ? ~0ull : (kk > 0 ? (1ull << kk) - 1ull : 0ull);
-                    un = un || (vm & ~CL[(size_t)m * words + w]) != 0;
-                }
-            }
-            const unsigned long long U = __ballot(un);
-            if (U) found = m0 + __builtin_ctzll(U);
-        }
-        if (found < 0) break;
-        const int m = found, k = KM[m];
-        int nq = 0;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int j = j0 + lane;
-            bool ok = false;
-            int es = 0, cls = 0;
-            int2 pc = make_int2(0, 0);
-            if (j < k && !((CL[(size_t)m * words + (j >> 6)] >> (j & 63)) & 1ull)) {
-                pc = j < staged ? CS[(size_t)m * staged + j] : cbase[(size_t)m * g.cand_cap + j];
-                const int dw = pc.y - pc.x, mid = pc.x + dw / 2;
-                const int ew = pow2ceil_dev((int)ceil((double)dw * (1.0 + 2.0 * dp.puffer)));
-                if (ew <= dp.N) {                                // wider than the block: logged and skipped in the reference
-                    cls = 31 - __clz(ew);
-                    if (wofs[cls] >= 0) {
-                        ok = true;
-                        es = mid - ew / 2;
-                        int ee = mid + ew / 2;
-                        if (es < 0) { es = 0; ee = ew; }
-                        if (ee > dp.N) { ee = dp.N; es = dp.N - ew; }
-                    }
-                }
-            }
-            const unsigned long long bo = __ballot(ok);
-            if (ok) QU[nq + __popcll(bo & ltm)] = make_int4(pc.x, pc.y, es, cls);
-            nq += __popcll(bo);
-        }
-        for (int w = lane; w < words; w += 64) CL[(size_t)m * words + w] = ~0ull;   // taken or skipped: nothing of this block is looked at again
-        lds_sync();
-        for (int i = 0; i < nq; i++) {
-            const int4 qv = QU[i];
-            DetChanRegs c;
-            c.id = counter + i; c.ds = qv.x; c.de = qv.y; c.es = qv.z; c.cls = qv.w; c.cnt0 = 0; c.inact0 = 0; c.part0 = 0; c.buf0 = 0;
-            c.phase0 = 0; c.tlo = (int)(unsigned)(now & 0xFFFFFFFFll); c.thi = (int)(now >> 32); c.prev_off = 0; c.a = m; c.own = nown + i;
-            handle(c);
-        }
-        counter += nq; nown += nq;
-        lds_sync();
-        ms = m + 1;
+    __syncthreads();
+    // ---- the list of the next call: the survivors in sequence order (old ones first, in their old order, then by activation)
+    const int nsv = cnt[4] < kDetMaxCells ? cnt[4] : kDetMaxCells;
+    if (tid < nsv) {
+        const int me = SV[tid];
+        int d = 0;
+        for (int u = 0; u < nsv; u++) d += SV[u] < me ? 1 : 0;
+        SVS[tid] = d;
     }
-    if (lane == 0) {
-        sst[sg].nlive = nout; sst[sg].counter = counter;
-        npdu[lst] = pcur; nowner[sg] = nown;
+    __syncthreads();
+    for (int e = tid; e < nsv * kDetFields; e += 64 * kDetWaves) {
+        const int f = e / nsv, u = e - f * nsv;
+        Lg[f * kDetMaxCells + SVS[u]] = L2[f * kDetMaxCells + u];
+    }
+    if (tid == 0) {
+        sst[sg].nlive = nsv; sst[sg].counter = counter0 + nnew;
+        npdu[lst] = cnt[3]; nowner[sg] = nown;
+#ifdef FDC_DET_STATS
+        FDC_DT(7);
+        printf("[det] seg %d: %d cells, %d live before, %d new, %d survive, %d records, %d regions in all slabs; kcycles wave 0: tables %llu cover %llu regions %llu work %llu wait %llu "
+               "rebuild %llu prefix %llu emit+rest %llu\n", sg, g.ncell, nlive0, nnew, nsv, cnt[3], nregsum, tacc[0] / 1000, tacc[1] / 1000, tacc[2] / 1000,
+               tacc[3] / 1000, tacc[4] / 1000, tacc[5] / 1000, tacc[6] / 1000, tacc[7] / 1000);
+#endif
     }
 }
 
@@ -581,26 +787,27 @@ hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const
 }
 
 hipError_t init_sink_kernels();
-// candidates staged in LDS per block: as many as fit beside the taken-masks (8, 4, 2 or none)
+// do the tracker's tables (per block of a call: activation masks and their prefix) fit the LDS?  >= 0: yes
 int det_track_staged(int nbmax, int max_cand_cap)
 {
     const int w0 = (max_cand_cap + 63) / 64, words = w0 <= 2 ? w0 : 8;      // the kernel exists for 1, 2 and 8 words
     if (w0 > 8) return -1;
-    for (int st : {8, 4, 2, 0}) if (det_lds_bytes(nbmax, words, st) <= (size_t)150 * 1024) return st;
-    return -1;                                          // does not fit: the bank takes the host engine
+    return det_lds_bytes(nbmax, words) <= (size_t)150 * 1024 ? kDetStaged : -1;   // does not fit: the bank takes the host engine
 }
 hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, DetSegState *sst, int32_t *live, int64_t *live_off,
-                            const int2 *cand, const int64_t *cand_base, const int32_t *ncand, const int32_t *win_off,
-                            long long bc0, long long now, SinkTask *tasks, SinkPdu *pdus, const int64_t *task_base,
-                            const int64_t *pdu_base, int32_t *ntask, int32_t *npdu, SinkOwner *owners, const int64_t *owner_base,
-                            int32_t *nowner, int32_t *error, hipStream_t s)
+                            const int2 *cand, const int64_t *cand_base, const int32_t *ncand, const int32_t *win_off, long long now,
+                            SinkPdu *pdus, const int64_t *pdu_base, int32_t *npdu, SinkOwner *owners, const int64_t *owner_base,
+                            int32_t *nowner, DetCh *chs, int32_t *live2, hipStream_t s)
 {
     if (dp.nseg <= 0) return hipSuccess;
-    const int words = (dp.max_cand_cap + 63) / 64, staged = det_track_staged(dp.nbmax, dp.max_cand_cap);
-    if (staged < 0 || words > 8) return hipErrorInvalidValue;
+    const int words = (dp.max_cand_cap + 63) / 64;
+    if (det_track_staged(dp.nbmax, dp.max_cand_cap) < 0 || words > 8) return hipErrorInvalidValue;
+    DetParams dq = dp;
+    // n / dec by a multiply-high: exact while n * dec < 2^32 (n <= N); otherwise the kernel divides
+    dq.dec_magic = (dp.dec > 1 && (unsigned long long)dp.N * (unsigned long long)dp.dec < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)dp.dec) + 1u : 0u;
 #define FDC_LT(W) \
-    hipLaunchKernelGGL(k_det_track<W>, dim3((unsigned)dp.nseg), dim3(64), det_lds_bytes(nb, W, staged), s, dp, nb, geom, sst, live, live_off, cand, \
-                       cand_base, ncand, win_off, bc0, now, tasks, pdus, task_base, pdu_base, ntask, npdu, owners, owner_base, nowner, error, staged)
+    hipLaunchKernelGGL(k_det_track<W>, dim3((unsigned)dp.nseg), dim3(64 * kDetWaves), det_lds_bytes(nb, W), s, dq, nb, geom, sst, live, live_off, \
+                       cand, cand_base, ncand, win_off, now, pdus, pdu_base, npdu, owners, owner_base, nowner, chs, live2)
     if (words == 1) FDC_LT(1); else if (words == 2) FDC_LT(2); else FDC_LT(8);
 #undef FDC_LT
     return hipGetLastError();
