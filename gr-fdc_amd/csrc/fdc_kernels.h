@@ -128,6 +128,12 @@ hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStr
 // sinks
 hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
                              hipStream_t s);
+// several width classes (w <= 4096 each) in one launch: class k = tasks [first[k], first[k] + cnt[k]) of width w[k]
+constexpr int kMaxExtractClasses = 12;
+struct ExtractClass { int32_t tile0, task0, ntasks, log2w, log2TC, ld, skip, pad; };
+struct ExtractClasses { ExtractClass c[kMaxExtractClasses]; int32_t n; };
+hipError_t launch_extract_multi(const float2 *spec, int N, const ExtractTask *tasks, const int *w, const size_t *first, const size_t *cnt,
+                                int nclass, int R, const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip,
                           const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 

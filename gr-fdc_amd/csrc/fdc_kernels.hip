@@ -448,15 +448,15 @@ __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restric
 // Extraction of one width class: out = IFFT_w( halfswap( X[slot][start .. start+w) * win ) )[skip .. w)
 //   lib/PowerActivationChannel_impl.cc:260-284, lib/activity_detection_channelizer_vcm_impl.cc:373-397
 template <int NB>
-__global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, int N,
-                                                      const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
-                                                      int log2TC, int ld, int skip, const float2 *__restrict__ wins,
-                                                      float2 *__restrict__ out, const float2 *__restrict__ tw,
-                                                      int twstride)
+__device__ __forceinline__ void extract_tile(const int tile, const float2 *__restrict__ spec, int N,
+                                             const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
+                                             int log2TC, int ld, int skip, const float2 *__restrict__ wins,
+                                             float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                             int twstride)
 {
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
     const int w = 1 << log2w, TC = 1 << log2TC;
-    const int t0 = blockIdx.x * TC;
+    const int t0 = tile * TC;
     constexpr int PT = 16 * NB;
     __shared__ ColInfo col[32];
     const int total = w << log2TC;
@@ -497,6 +497,29 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec
         const ColInfo ci = col[tl];
         if (e < total && ci.valid && i >= skip) out[ci.dst + i] = lds[i * ld + tl];
     }
+}
+
+template <int NB>
+__global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, int N,
+                                                      const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
+                                                      int log2TC, int ld, int skip, const float2 *__restrict__ wins,
+                                                      float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                                      int twstride)
+{
+    extract_tile<NB>((int)blockIdx.x, spec, N, tasks, ntasks, log2w, log2TC, ld, skip, wins, out, tw, twstride);
+}
+
+// Several width classes (each up to 4096 points: the one-transform-per-workgroup tiling) in ONE launch: a bank of detected channels
+// has a handful of classes with a few hundred to a few thousand extractions each, none of which fills the device on its own.
+// A workgroup finds its class from the tile ranges.
+__global__ FDC_GENERIC_BOUNDS(1) void k_extract_multi(const float2 *__restrict__ spec, int N, const ExtractTask *__restrict__ tasks,
+                                                      const ExtractClasses cls, const float2 *__restrict__ wins, float2 *__restrict__ out,
+                                                      const float2 *__restrict__ tw, int ntab)
+{
+    int c = 0;
+    while (c + 1 < cls.n && (int)blockIdx.x >= cls.c[c + 1].tile0) c++;
+    const ExtractClass ec = cls.c[c];
+    extract_tile<1>((int)blockIdx.x - ec.tile0, spec, N, tasks + ec.task0, ec.ntasks, ec.log2w, ec.log2TC, ec.ld, ec.skip, wins, out, tw, ntab >> ec.log2w);
 }
 
 // multiply_const_cc(1/N, N) on spectrum items that arrive already transformed (hier block with inpveclen > 1,
@@ -591,7 +614,7 @@ hipError_t init_kernels()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds); \
     if (e != hipSuccess) return e;
     FDC_SETLDS((k_fft_small<false, 2>)) FDC_SETLDS((k_fft_small<true, 2>))
-    FDC_SETLDS(k_channels<2>) FDC_SETLDS(k_extract<2>)
+    FDC_SETLDS(k_channels<2>) FDC_SETLDS(k_extract<2>) FDC_SETLDS(k_extract_multi)
 #undef FDC_SETLDS
     if ((e = init_sink_kernels()) != hipSuccess) return e;
     return init_fast_kernels();
@@ -749,6 +772,26 @@ hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, i
     else
         hipLaunchKernelGGL(k_extract<1>, dim3((ntasks + g.TC - 1) / g.TC), dim3(kThreads), g.lds_bytes(), s, spec, N, tasks, ntasks,
                            g.log2L, g.log2TC, g.ld, skip, wins, out, tw, ntab / w);
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_multi(const float2 *spec, int N, const ExtractTask *tasks, const int *w, const size_t *first, const size_t *cnt,
+                                int nclass, int R, const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s)
+{
+    ExtractClasses cls{};
+    size_t lds = 0;
+    int tiles = 0;
+    for (int k = 0; k < nclass && cls.n < kMaxExtractClasses; k++) {
+        if (!cnt[k]) continue;
+        const TileGeom g = tile_geom(w[k]);
+        if (g.NB != 1) return hipErrorInvalidValue;
+        const int nt = (int)((cnt[k] + (size_t)g.TC - 1) / (size_t)g.TC);
+        cls.c[cls.n++] = ExtractClass{tiles, (int)first[k], (int)cnt[k], g.log2L, g.log2TC, g.ld, w[k] / R, 0};
+        tiles += nt;
+        lds = std::max(lds, g.lds_bytes());
+    }
+    if (!tiles) return hipSuccess;
+    hipLaunchKernelGGL(k_extract_multi, dim3((unsigned)tiles), dim3(kThreads), lds, s, spec, N, tasks, cls, wins, out, tw, ntab);
     return hipGetLastError();
 }
 

@@ -211,6 +211,8 @@ struct fdc_sinks {
         float2 *d_land[2] = {nullptr, nullptr}; size_t cap_land[2] = {0, 0};      // landing buffers (emitted runs, then buffered rests)
         cfl *h_land[2] = {nullptr, nullptr}; size_t cap_hland[2] = {0, 0};        // pinned copies of the emitted runs
         hipStream_t s_copy = nullptr;
+        int carry_width = 0;                 // streams that can hold blocks from the call before: every PowerActivationChannel, or a
+                                             // segment's live channels (disjoint detect ranges: at most one per power cell)
         hipEvent_t ev_decide = nullptr, ev_extract[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
         std::vector<fdc::SinkPdu> recs[2];
         fdc::SinkSummary sum[2];
@@ -487,6 +489,8 @@ int dev_setup(fdc_sinks *s)
         if (nseg && (capmax > 512 || fdc::det_track_staged(cfg.max_blocks, capmax) < 0)) return FDC_OK;   // the tracker's tables would not fit
     }
     const int64_t nbmax = cfg.max_blocks;
+    d.carry_width = npac;
+    for (const Segment &g : s->segs) d.carry_width = std::max(d.carry_width, std::min(g.ncell, fdc::kDetMaxCells));
     d.npw = npac;                                                              // one list per PowerActivationChannel (one wave each)
     d.nlist = d.npw + nseg;
     d.task_base.assign((size_t)d.nlist + 1, 0); d.pdu_base.assign((size_t)d.nlist + 1, 0);
@@ -842,11 +846,22 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
 static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const size_t *first, const size_t *cnt, float2 *d_out, bool trace)
 {
     const int N = s->N;
+    // the classes that fit one workgroup's transform at 16 points per lane (w <= 4096; 256 has a kernel of its own) are independent and
+    // each fills a part of the device only: two or more of them go out as ONE launch
+    int mw[32], nm = 0;
+    size_t mfirst[32], mcnt[32];
+    for (int k = 0; k < 32; k++) {
+        const int w = 1 << k;
+        if (cnt[k] && w <= 4096 && !(w == 256 && s->d_tw256)) { mw[nm] = w; mfirst[nm] = first[k]; mcnt[nm] = cnt[k]; nm++; }
+    }
+    const bool multi = nm >= 2 && nm <= fdc::kMaxExtractClasses;
+    if (multi) HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
     for (int k = 0; k < 32; k++) {
         if (!cnt[k]) continue;
         const int w = 1 << k, skip = w / s->R;
         const size_t i = first[k], j = first[k] + cnt[k];
         if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
+        if (multi && w <= 4096 && !(w == 256 && s->d_tw256)) continue;
         if (w == 256 && s->d_tw256) {
             HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, s->stream));
         } else if (w <= fdc::kMaxLdsFft) {
@@ -1214,7 +1229,7 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         HIPCHK(fdc::launch_task_scatter(d.nlist, d.d_task_base, d.d_ntask, d.max_list, d.d_tasks, d.d_owners, d.d_sum, d.d_class_fill,
                                         d.d_sorted, s->stream));
     if (d.any)
-        HIPCHK(fdc::launch_carry_copy(d.d_owners, std::max(npac, fdc::kDetMaxCells), d.d_owner_base, d.d_nowner, npac, nseg, d.d_sum,
+        HIPCHK(fdc::launch_carry_copy(d.d_owners, d.carry_width, d.d_owner_base, d.d_nowner, npac, nseg, d.d_sum,
                                       d.d_land[d.cur], d.d_land[b], s->stream));
     if (sum.ntask) {
         size_t first[32], cnt[32];

@@ -986,7 +986,7 @@ hipError_t launch_task_scatter(int nlist, const int64_t *task_base, const int32_
 }
 
 // blocks buffered across the call boundary: from the previous landing buffer to their place in this one
-constexpr int kCarrySplit = 16;     // workgroups per stream (a wide carrier buffers megabytes)
+constexpr int kCarrySplit = 64;     // workgroups per stream (a wide carrier buffers megabytes)
 __global__ __launch_bounds__(256) void k_carry_copy(const SinkOwner *__restrict__ owners, const int64_t *__restrict__ owner_base,
                                                     const int32_t *__restrict__ nowner, int npac, const float2 *__restrict__ prev,
                                                     float2 *__restrict__ cur)
@@ -1000,15 +1000,24 @@ __global__ __launch_bounds__(256) void k_carry_copy(const SinkOwner *__restrict_
     const float2 *src = prev + o.prev_off;
     float2 *da = cur + o.a_off, *db = cur + o.b_off - (long long)ne * o.len;
     const long long nA = (long long)ne * o.len, n = (long long)o.carried * o.len;
-    for (long long i = (long long)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * kCarrySplit) (i < nA ? da : db)[i] = src[i];
+    // a few streams carry everything (a wide channel: megabytes): many workgroups per stream, 16 bytes per lane and trip
+    if (!((o.len | o.prev_off | o.a_off | o.b_off) & 1)) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *a4 = reinterpret_cast<float4 *>(da), *b4 = reinterpret_cast<float4 *>(db);
+        const long long n4 = n >> 1, nA4 = nA >> 1;
+        for (long long i = (long long)blockIdx.z * 256 + threadIdx.x; i < n4; i += 256 * kCarrySplit) (i < nA4 ? a4 : b4)[i] = s4[i];
+    } else {
+        for (long long i = (long long)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * kCarrySplit) (i < nA ? da : db)[i] = src[i];
+    }
 }
 
-hipError_t launch_carry_copy(const SinkOwner *owners, int nowner_cap, const int64_t *owner_base, const int32_t *nowner, int npac, int nseg,
+// nowner_max: the largest number of streams one region of the owner table holds in this call (the grid's width)
+hipError_t launch_carry_copy(const SinkOwner *owners, int nowner_max, const int64_t *owner_base, const int32_t *nowner, int npac, int nseg,
                              const SinkSummary *sum, const float2 *prev, float2 *cur, hipStream_t s)
 {
     (void)sum;
-    if (nowner_cap <= 0 || !prev) return hipSuccess;
-    hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)nowner_cap, (unsigned)(nseg + 1), kCarrySplit), dim3(256), 0, s, owners, owner_base,
+    if (nowner_max <= 0 || !prev) return hipSuccess;
+    hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)nowner_max, (unsigned)(nseg + 1), kCarrySplit), dim3(256), 0, s, owners, owner_base,
                        nowner, npac, prev, cur);
     return hipGetLastError();
 }
