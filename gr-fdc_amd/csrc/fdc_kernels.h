@@ -128,6 +128,10 @@ hipError_t launch_scale(const float2 *in, float2 *out, size_t n, float k, hipStr
 // sinks
 hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, int ncells, int nblocks, float *out,
                              hipStream_t s);
+// one width class above 4096 points (two passes through `tmp`, ntasks * w points; slice * window read by pass A, kept samples
+// written to their places by pass B)
+hipError_t launch_extract_wide(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip, const float2 *wins,
+                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s);
 // several width classes (w <= 4096 each) in one launch: class k = tasks [first[k], first[k] + cnt[k]) of width w[k]
 constexpr int kMaxExtractClasses = 12;
 struct ExtractClass { int32_t tile0, task0, ntasks, log2w, log2TC, ld, skip, pad; };
@@ -140,13 +144,6 @@ hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, i
 // width 256 on the register kernel of the l = 256 channels (fdc_fast256.hip); tw256: exp(-2 pi i j/256)
 hipError_t launch_extract256(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int skip, const float2 *wins, float2 *out,
                              const float2 *tw256, hipStream_t s);
-
-// extractions wider than kMaxLdsFft, a whole width class at once: gather (slice * window) into [ntasks][w], batched two-pass
-// inverse transform (launch_fft), scatter of [skip, w) to the tasks' landing offsets
-hipError_t launch_extract_gather(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, const float2 *wins,
-                                 float2 *dst, hipStream_t s);
-hipError_t launch_extract_scatter(const float2 *src, const ExtractTask *tasks, int ntasks, int w, int skip, float2 *out,
-                                  hipStream_t s);
 
 // single-block faces
 hipError_t launch_overlap_save(const unsigned char *ring, unsigned char *out, size_t in_item_bytes,

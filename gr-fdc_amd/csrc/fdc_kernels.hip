@@ -206,12 +206,15 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_small(const float2 *__restrict__ in
 // ---- two-pass transform N = N1*N2, n = n1 + N1*n2, k = N2*k1 + k2 -----------------------------------
 // Pass A: TC columns n1, length-N2 transforms over n2 (row stride N1 in memory), times W_N^(n1*k2),
 //         stored transposed-by-construction as T[k2][n1] (n1 contiguous).
-template <bool INV, int NB>
+// TASK: item m is extraction m of a width class (fdc_sinks): its input is the slice of the spectrum the task names, times the task's
+// window (read where the transform reads it: no gathered copy), and pass B writes the kept part [skip, N) to the task's place.
+template <bool INV, int NB, bool TASK = false>
 __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
                                                     float2 *__restrict__ tmp, int log2N, int log2N1,
                                                     int log2TC, int ld, int in_rot,
                                                     const float2 *__restrict__ tw, int ntab,
-                                                    const float2 *__restrict__ twf)
+                                                    const float2 *__restrict__ twf, const ExtractTask *__restrict__ tasks = nullptr,
+                                                    const float2 *__restrict__ wins = nullptr)
 {
     constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
@@ -219,14 +222,19 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ i
     const int TC = 1 << log2TC, total = N2 << log2TC;
     const int c0 = blockIdx.x * TC;
     const size_t m = blockIdx.y;
-    const float2 *src = in + m * in_stride;
+    const float2 *src = in + m * in_stride, *win = nullptr;
+    if (TASK) { const ExtractTask tk = tasks[m]; src = in + (size_t)tk.slot * in_stride + tk.start; win = wins + tk.win_off; }
     float2 v[PT];
 #pragma unroll
     for (int u = 0; u < PT; u++) {
         const int e = threadIdx.x + u * kThreads;
         const int r = e >> log2TC, c = e & (TC - 1);
         v[u] = make_float2(0.f, 0.f);
-        if (e < total) v[u] = src[(c0 + c + (r << log2N1) + in_rot) & (N - 1)];
+        if (e < total) {
+            const int idx = (c0 + c + (r << log2N1) + in_rot) & (N - 1);
+            v[u] = src[idx];
+            if (TASK) v[u] = cmulf(v[u], win[idx]);
+        }
     }
 #pragma unroll
     for (int u = 0; u < PT; u++) {
@@ -258,10 +266,11 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ i
 
 // Pass B: TR rows k2 of T, length-N1 transforms over n1 (contiguous in memory), result bin
 //         k = N2*k1 + k2 stored at (k + out_rot) mod N, scaled.
-template <bool INV, int NB>
+template <bool INV, int NB, bool TASK = false>
 __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ tmp, float2 *__restrict__ out,
                                                     int log2N, int log2N1, int log2TR, int ld, int out_rot,
-                                                    float scale, const float2 *__restrict__ tw, int ntab)
+                                                    float scale, const float2 *__restrict__ tw, int ntab,
+                                                    const ExtractTask *__restrict__ tasks = nullptr, int skip = 0)
 {
     constexpr int PT = 16 * NB;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
@@ -284,7 +293,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ t
     }
     __syncthreads();
     fft_cols<INV, NB>(lds, log2N1, log2TR, ld, tw, ntab >> log2N1);
-    float2 *dst = out + m * (size_t)N;
+    float2 *dst = TASK ? out + tasks[m].out_off - skip : out + m * (size_t)N;
 #pragma unroll
     for (int u = 0; u < PT; u++) {
         const int e = threadIdx.x + u * kThreads;
@@ -292,7 +301,8 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ t
         if (e < total) {
             const int k = (k1 << log2N2) + r0 + r;
             const float2 y = lds[k1 * ld + r];
-            dst[(k + out_rot) & (N - 1)] = make_float2(y.x * scale, y.y * scale);
+            const int kk = (k + out_rot) & (N - 1);
+            if (!TASK || kk >= skip) dst[kk] = make_float2(y.x * scale, y.y * scale);
         }
     }
 }
@@ -563,24 +573,6 @@ __global__ void k_phase_window(const float2 *__restrict__ in, float2 *__restrict
         out[(size_t)m * l + i] = cmulf(in[(size_t)m * l + i], w[i]);
 }
 
-__global__ __launch_bounds__(256) void k_extract_gather(const float2 *__restrict__ spec, int N, const ExtractTask *__restrict__ tasks,
-                                                        int w, const float2 *__restrict__ wins, float2 *__restrict__ dst)
-{
-    const ExtractTask tk = tasks[blockIdx.y];
-    const float2 *src = spec + (size_t)tk.slot * N + tk.start, *win = wins + tk.win_off;
-    float2 *d = dst + (size_t)blockIdx.y * w;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < w; i += gridDim.x * 256) d[i] = cmulf(src[i], win[i]);
-}
-
-__global__ __launch_bounds__(256) void k_extract_scatter(const float2 *__restrict__ src, const ExtractTask *__restrict__ tasks, int w,
-                                                         int skip, float2 *__restrict__ out)
-{
-    const ExtractTask tk = tasks[blockIdx.y];
-    const float2 *sp = src + (size_t)blockIdx.y * w;
-    float2 *d = out + tk.out_off - skip;
-    for (int i = skip + blockIdx.x * 256 + threadIdx.x; i < w; i += gridDim.x * 256) d[i] = sp[i];
-}
-
 // ---- host side ---------------------------------------------------------------------------------------
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 
@@ -775,6 +767,26 @@ hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, i
     return hipGetLastError();
 }
 
+// One width class above 4096 points: the two-pass inverse transform with the slice * window read in pass A and the kept samples
+// written to their landing offsets by pass B.  tmp: ntasks * w points.
+hipError_t launch_extract_wide(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip, const float2 *wins,
+                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s)
+{
+    if (ntasks <= 0) return hipSuccess;
+    const BigGeom g = big_geom(w);
+    const int lgN = ilog2(w), lgN1 = ilog2(g.N1);
+    if (g.a.NB != 1 || g.b.NB != 1) return hipErrorInvalidValue;
+    for (int m0 = 0; m0 < ntasks; m0 += 32768) {       // gridDim.y limit is 65535
+        const int nb = ntasks - m0 < 32768 ? ntasks - m0 : 32768;
+        dim3 ga(g.N1 / g.a.TC, nb), gb(g.N2 / g.b.TC, nb);
+        hipLaunchKernelGGL((k_fft_pass_a<true, 1, true>), ga, dim3(kThreads), g.a.lds_bytes(), s, spec, (size_t)N, tmp, lgN, lgN1, g.a.log2TC,
+                           g.a.ld, w / 2, tw, ntab, static_cast<const float2 *>(nullptr), tasks + m0, wins);
+        hipLaunchKernelGGL((k_fft_pass_b<true, 1, true>), gb, dim3(kThreads), g.b.lds_bytes(), s, tmp, out, lgN, lgN1, g.b.log2TC, g.b.ld, 0,
+                           1.0f, tw, ntab, tasks + m0, skip);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_extract_multi(const float2 *spec, int N, const ExtractTask *tasks, const int *w, const size_t *first, const size_t *cnt,
                                 int nclass, int R, const float2 *wins, float2 *out, const float2 *tw, int ntab, hipStream_t s)
 {
@@ -837,19 +849,5 @@ hipError_t launch_phase_window(const float2 *in, float2 *out, const float2 *win,
     return hipGetLastError();
 }
 
-hipError_t launch_extract_gather(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, const float2 *wins,
-                                 float2 *dst, hipStream_t s)
-{
-    if (ntasks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_extract_gather, dim3((unsigned)((w + 1023) / 1024), (unsigned)ntasks), dim3(256), 0, s, spec, N, tasks, w, wins, dst);
-    return hipGetLastError();
-}
-
-hipError_t launch_extract_scatter(const float2 *src, const ExtractTask *tasks, int ntasks, int w, int skip, float2 *out, hipStream_t s)
-{
-    if (ntasks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_extract_scatter, dim3((unsigned)((w + 1023) / 1024), (unsigned)ntasks), dim3(256), 0, s, src, tasks, w, skip, out);
-    return hipGetLastError();
-}
 
 }  // namespace fdc

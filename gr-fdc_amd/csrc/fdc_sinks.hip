@@ -177,7 +177,7 @@ struct fdc_sinks {
     float *d_power = nullptr;
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
     float2 *d_ext = nullptr; size_t cap_ext = 0;
-    float2 *d_wide = nullptr; size_t wide_cap = 0;  // scratch of extractions wider than kMaxLdsFft: 3 x wide_cap points
+    float2 *d_wide = nullptr; size_t wide_cap = 0;  // scratch of extractions wider than 4096 points (between the two passes): wide_cap points
     std::vector<fdc::ExtractTask> sorted;          // tasks grouped by width class
     cfl *h_ext = nullptr; size_t cap_hext = 0;      // pinned landing buffer of the extractions
     std::vector<float> h_power;
@@ -864,27 +864,26 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
         if (multi && w <= 4096 && !(w == 256 && s->d_tw256)) continue;
         if (w == 256 && s->d_tw256) {
             HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, s->stream));
-        } else if (w <= fdc::kMaxLdsFft) {
+        } else if (w <= 4096) {
             HIPCHK(fdc::launch_extract(s->d_spec, N, d_tasks + i, (int)(j - i), w, skip, s->d_wins, d_out, s->d_tw, N, s->stream));
         } else {
-            // wider than one workgroup's transform (a carrier, or a run of merged carriers, over 1/8 of a 65536-bin band):
-            // the whole class in batches of up to 64 Mi points — gather (slice * window), batched two-pass inverse transform
-            // with the half swap as input rotation, scatter of [skip, w) to the landing offsets.  The scratch follows the
-            // demand (3 x batch x w points, grown geometrically), not the 64 Mi ceiling.
+            // above 4096 points (a carrier, or a run of merged carriers, over 1/16 of a 65536-bin band): the two-pass inverse transform,
+            // the whole class in batches of up to 64 Mi points — pass A reads slice * window straight from the spectrum (the half swap is
+            // its input rotation), pass B writes [skip, w) to the landing offsets.  The scratch between the passes follows the demand
+            // (batch x w points, grown geometrically), not the 64 Mi ceiling.  (One workgroup per 8192-point transform — 32 points per
+            // lane, two workgroups per compute unit — was slower than the two passes: 98 us for the 536 extractions of a configs[4] step;
+            // that class and the two above it took 271 us with a gathered copy and a scatter around the transform, 212 us this way.)
             const size_t per = std::min(std::max<size_t>(1, ((size_t)64 << 20) / (size_t)w), j - i);
             if (s->wide_cap < per * (size_t)w) {
                 const size_t want = std::min(std::max(per * (size_t)w, s->wide_cap * 2), std::max<size_t>((size_t)64 << 20, (size_t)w));
                 (void)hipFree(s->d_wide); s->d_wide = nullptr; s->wide_cap = 0;
-                HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * 3 * want));
+                HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * want));
                 s->wide_cap = want;
             }
             const size_t fit = std::max<size_t>(1, s->wide_cap / (size_t)w);
-            float2 *A = s->d_wide, *B = A + s->wide_cap, *T = B + s->wide_cap;
             for (size_t k0 = i; k0 < j; k0 += fit) {
                 const int n = (int)std::min(fit, j - k0);
-                HIPCHK(fdc::launch_extract_gather(s->d_spec, N, d_tasks + k0, n, w, s->d_wins, A, s->stream));
-                HIPCHK(fdc::launch_fft(A, (size_t)w, B, T, w, n, true, w / 2, 0, 1.0f, s->d_tw, N, s->stream, nullptr));
-                HIPCHK(fdc::launch_extract_scatter(B, d_tasks + k0, n, w, skip, d_out, s->stream));
+                HIPCHK(fdc::launch_extract_wide(s->d_spec, N, d_tasks + k0, n, w, skip, s->d_wins, s->d_wide, d_out, s->d_tw, N, s->stream));
             }
         }
     }
