@@ -229,6 +229,34 @@ def test_sinks_wider_than_one_workgroup_transform(oracle):
     compare([g for g in got if g[0]["kind"] != rp[0]["kind"]], rd)
 
 
+def test_sinks_every_width_class_in_one_call(oracle):
+    """PowerActivationChannels of extraction widths 128 ... 32768 in one bank and one call: the 256 kernel, the one launch for the
+    other classes up to 4096 points, the task-addressed two-pass transform above that (8192, 16384, 32768) — every PDU against the
+    oracle, on both engines."""
+    N, R, nb = 65536, 2, 10
+    widths = [128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
+    plan, bursts, pos = [], [], 0.004
+    for k, w in enumerate(widths):
+        bw = 0.8 * w / N
+        cf = pos + bw / 2
+        plan.append((cf, bw, 10 + k))
+        bursts.append((int(round((cf - bw / 2) * N)), int(round((cf + bw / 2) * N)), 1 + k % 3, 5 + k % 4, 1.0))
+        pos += bw + 0.02
+    assert pos < 1.0
+    spec = burst_spectrum(N, nb, bursts, 77)
+    for host in (False, True):
+        bank = G.Sinks(N, R, pac=plan, pac_thresh=6.0, pac_maxblocks=3, max_blocks=16, host_decisions=host)
+        assert [bank.pac_params(i)["extract_width"] for i in range(len(widths))] == widths
+        got = bank.work(spec.reshape(-1))
+        ref = []
+        for (cf, bw, ident) in plan:
+            ref.append(oracle.PowerActivationChannel(N, cf, bw, R, 6.0, 3, 0, ident).work(spec))
+        assert all(len(r) >= 1 for r in ref)
+        for k, (cf, bw, ident) in enumerate(plan):
+            mine = [g for g in got if g[0]["source"] == ident]
+            compare(mine, ref[k], vec=False)
+
+
 def test_pipeline_refuses_sinks_of_other_size():
     """fdc_pipeline_work_sinks writes the spectrum into the sinks' device buffer: a bank made for fewer blocks per call or
     another block length is refused before anything is written."""
