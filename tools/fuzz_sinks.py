@@ -4,7 +4,7 @@
 deactivation delay, flank puffer, a spectrum of carriers keyed on and off at random — including carriers that touch, merge and
 split, zero-power stretches and carriers wider than a block after the puffer — and a pattern of calls, and runs it on the device
 engine and on the host engine.  Everything must agree exactly: order, metadata, payload.
-Usage: python tools/fuzz_sinks.py [cases] [seed]"""
+Usage: python tools/fuzz_sinks.py [cases] [seed] [max blocks per case, default 90]"""
 import os
 import sys
 
@@ -37,11 +37,11 @@ def spectrum(rng, N, nb, carriers, floor, zero_prob):
     return s.astype(np.complex64)
 
 
-def draw(rng):
+def draw(rng, nbmax=90):
     N = int(2 ** rng.integers(10, 15))
     R = int(2 ** rng.integers(1, 3))
-    nb = int(rng.integers(8, 90))
-    kw = dict(max_blocks=int(rng.integers(3, 40)))
+    nb = int(rng.integers(8, nbmax))
+    kw = dict(max_blocks=int(rng.integers(3, 40)) if nbmax <= 90 or rng.random() < 0.3 else int(rng.integers(40, nbmax + 1)))
     carriers = []
     what = int(rng.integers(0, 3))                     # 0 PAC only, 1 detection only, 2 both
     if what in (0, 2):
@@ -89,13 +89,14 @@ def run(bank, spec, cuts, max_blocks):
     return out
 
 
-def main(cases=None, seed=None):
+def main(cases=None, seed=None, nbmax=None):
     cases = cases if cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 60)
     seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    nbmax = nbmax if nbmax is not None else (int(sys.argv[3]) if len(sys.argv) > 3 else 90)
     rng = np.random.default_rng(seed)
     npdu = ndev = 0
     for case in range(cases):
-        N, R, kw, spec, cuts = draw(rng)
+        N, R, kw, spec, cuts = draw(rng, nbmax)
         try:
             dev, host = G.Sinks(N, R, **kw), G.Sinks(N, R, host_decisions=True, **kw)
         except ValueError:
