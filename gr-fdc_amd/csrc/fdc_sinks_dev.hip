@@ -293,6 +293,12 @@ __host__ __device__ constexpr size_t det_lds_bytes(int nb, int words)
     return (size_t)nb * (size_t)words * 8 + (size_t)nb * 4 + 64 * (4 + kDetStaged * 8) + (size_t)(kDetMaxCells / 2 + 1) * 8 +
            (size_t)kDetMaxCells * 40 + 16 * 8 + 16 * 8 + 32 * 4 + 64;
 }
+// value of a lane the whole wave agrees on (v_readlane: no trip through the LDS crossbar as for __shfl)
+__device__ __forceinline__ int lane_val(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned long long lane_val(unsigned long long v, int l)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+}
 __device__ __forceinline__ int pow2ceil_dev(int k)
 {
     if (k > (1 << 30)) return 0x7FFFFFFF;               // absurd flank puffer: wider than any block, the caller skips it
@@ -386,8 +392,12 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
 #ifdef FDC_DET_STATS
     unsigned long long tacc[8] = {}, tlast = __builtin_readcyclecounter();
     int nregsum = 0;
+    unsigned long long wacc[3] = {};                                 // this wave: region set-up, passes of alive channels, activations
+    int wcnt[3] = {};                                                // regions, passes of alive channels, activations
+#define FDC_WT(i, n) do { const unsigned long long tn = __builtin_readcyclecounter(); wacc[i] += tn - wlast; wlast = tn; wcnt[i] += (n); } while (0)
 #define FDC_DT(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tlast; tlast = tn; } while (0)
 #else
+#define FDC_WT(i, n) do { } while (0)
 #define FDC_DT(i) do { } while (0)
 #endif
     for (m0 = 0; m0 < nb; m0 += 64) {
@@ -447,6 +457,9 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
             // This wave is the only one that looks at the region's candidates in this slab, and lane = block: what a block's
             // candidates are, which of them are the region's (RM), taken (cl) or have become channels (nm) stays in the lane's
             // registers for the whole region — a channel's pass over the slab is compares and ballots, no memory round trip.
+#ifdef FDC_DET_STATS
+            unsigned long long wlast = __builtin_readcyclecounter();
+#endif
             const int m = m0 + lane;
             const int k = KM[lane];
             int2 cs[staged];
@@ -505,8 +518,9 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                 }
                 const int lastv = (nb - m0 < 64 ? nb - m0 : 64) - 1;
                 end_out = F ? m0 + endlane : -1;
-                streak_out = lastv >= f ? __shfl(st, lastv, 64) : inact0;
+                streak_out = lastv >= f ? lane_val(st, lastv) : inact0;
             };
+            FDC_WT(0, 1);
             // the channels alive at the start of the slab, in list order
             for (int i0 = 0; i0 < nal; i0 += 64) {
                 const int i = i0 + lane;
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                     int end, streak;
                     scan(ds, de, m0, AL[A_STK + ii], end, streak);
                     settle(AL[A_T + ii], AL[A_KEY + ii], ds, de, end, streak);
+                    FDC_WT(1, 1);
                 }
             }
             // candidates of the region nobody took become channels (:785-841), block after block
@@ -529,13 +544,13 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                 }
                 const unsigned long long U = __ballot(un);
                 if (!U) break;
-                const int fl = __builtin_ctzll(U), mf = m0 + fl, kf = __shfl(k, fl, 64);
+                const int fl = __builtin_ctzll(U), mf = m0 + fl, kf = lane_val(k, fl);
                 // the activating candidates of block mf; everything of the region in this block is now settled
 #pragma unroll
                 for (int w = 0; w < WORDS; w++) {
                     const int j = 64 * w + lane;
                     bool ok = false;
-                    const unsigned long long rmw = __shfl(RM[w], fl, 64), clw = __shfl(cl[w], fl, 64);
+                    const unsigned long long rmw = lane_val(RM[w], fl), clw = lane_val(cl[w], fl);
                     int2 pc = make_int2(0, 0);
                     int es = 0, cls = 0;
                     if (j < kf && ((rmw >> lane) & 1ull) && !((clw >> lane) & 1ull)) {
@@ -562,13 +577,14 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                     while (q) {
                         const int jl = __builtin_ctzll(q);
                         q &= q - 1;
-                        const int cx = __shfl(pc.x, jl, 64), cy = __shfl(pc.y, jl, 64), ces = __shfl(es, jl, 64), ccls = __shfl(cls, jl, 64);
+                        const int cx = lane_val(pc.x, jl), cy = lane_val(pc.y, jl), ces = lane_val(es, jl), ccls = lane_val(cls, jl);
                         int end, streak;
                         scan(cx, cy, mf + 1, 0, end, streak);
                         const int t = nlive0 + t0;
                         t0++;
                         if (lane == 0) chs[t] = DetCh{cx, cy, ces, ccls, mf, 64 * w + jl, -1, 0};
                         settle(t, nlive0 + mf * g.cand_cap + 64 * w + jl, cx, cy, end, streak);
+                        FDC_WT(2, 1);
                     }
                 }
                 ms = mf + 1;
@@ -738,6 +754,8 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
         sst[sg].nlive = nsv; sst[sg].counter = counter0 + nnew;
         npdu[lst] = cnt[3]; nowner[sg] = nown;
 #ifdef FDC_DET_STATS
+        printf("[det]   wave 0 of seg %d: %d regions set up in %llu kcycles, %d passes of alive channels in %llu, %d activations in %llu\n", sg, wcnt[0],
+               wacc[0] / 1000, wcnt[1], wacc[1] / 1000, wcnt[2], wacc[2] / 1000);
         FDC_DT(7);
         printf("[det] seg %d: %d cells, %d live before, %d new, %d survive, %d records, %d regions in all slabs; kcycles wave 0: tables %llu cover %llu regions %llu work %llu wait %llu "
                "rebuild %llu prefix %llu emit+rest %llu\n", sg, g.ncell, nlive0, nnew, nsv, cnt[3], nregsum, tacc[0] / 1000, tacc[1] / 1000, tacc[2] / 1000,

@@ -89,10 +89,7 @@ def run(bank, spec, cuts, max_blocks):
     return out
 
 
-def main(cases=None, seed=None, nbmax=None):
-    cases = cases if cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 60)
-    seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    nbmax = nbmax if nbmax is not None else (int(sys.argv[3]) if len(sys.argv) > 3 else 90)
+def main(cases=60, seed=1, nbmax=90):
     rng = np.random.default_rng(seed)
     npdu = ndev = 0
     for case in range(cases):
@@ -118,4 +115,4 @@ def main(cases=None, seed=None, nbmax=None):
 
 
 if __name__ == "__main__":
-    main()
+    main(*[int(v) for v in sys.argv[1:4]])
