@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
                                                              "dropped): a tiling that does not start at bin 0")
-    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic"), default=None,
+    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum"), default=None,
                     help="diagnostics: fdc_pipeline_cfg.flags FDC_PIPE_NO_BLOCK / NO_POLY / FORCE_GENERIC (the slower forms of the path)")
     ap.add_argument("--input-rings", type=int, default=3,
                     help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 x 268 MB no input byte of "
@@ -78,7 +78,11 @@ def parse():
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
+    ap.add_argument("--sparse", type=int, default=0, metavar="K", help="diagnostics (config 2): K channels (widths 256 ... 2048 in turn) spread "
+                                                                       "over the band instead of a plan that tiles it (spectrum path)")
     a = ap.parse_args()
+    if a.sparse and a.config != 2:
+        ap.error("--sparse applies to --config 2 only")
     if a.offset and a.config not in (2, 4):
         ap.error("--offset applies to --config 2 and 4 only")
     if a.mixed and a.config != 2:
@@ -345,7 +349,8 @@ def main():
         return
     import gr_fdc_amd as G
     if a.force_path:
-        G.defaults[{"no-block": "FDC_NO_BLOCK", "no-poly": "FDC_NO_POLY", "generic": "FDC_FORCE_GENERIC"}[a.force_path]] = "1"
+        G.defaults[{"no-block": "FDC_NO_BLOCK", "no-poly": "FDC_NO_POLY", "generic": "FDC_FORCE_GENERIC",
+                    "full-spectrum": "FDC_FULL_SPECTRUM"}[a.force_path]] = "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -372,6 +377,9 @@ def main():
         if a.config == 1:    # examples/FDC_example.grc: [[0.12,0.05],[0.22,0.1],[-0.14,0.12],[0,0.081]]
             params = [G.get_opt_channelparams(N, R, (u + 0.5) % 1.0, bw) for (u, bw) in
                       ((0.12, 0.05), (0.22, 0.1), (-0.14, 0.12), (0.0, 0.081))]
+        elif a.sparse:
+            wid = (256, 512, 1024, 2048)
+            params = [G.get_opt_channelparams(N, R, ((c + 0.37) / a.sparse) % 1.0, 0.8 * wid[c % 4] / N) for c in range(a.sparse)]
         else:
             bws = (0.8, 0.4, 0.8, 1.6) if a.mixed else (0.8,)
             params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
@@ -390,7 +398,9 @@ def main():
             "configs[1]" if (N, R, C) == (65536, 2, 256) else "configs[3] per-GPU shape" if (N, R, C) == (262144, 2, 1024)
             else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "") + \
             (", %d input rings in rotation (cache-cold input)" % len(rings) if len(rings) > 1 else ", ONE input ring (stays in the memory-side cache)") + \
-            (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "")
+            (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "") + \
+            (", SPARSE plan: %d channels, l = %s, %d of %d bins read" % (len(plan), sorted(set(p_[1] for p_ in params)), sum(p_[1] for p_ in params), N)
+             if a.sparse else "")
     else:
         # the stateful sinks run on a spectrum in device memory: forward transform into the bank's buffer, then the bank
         plan, params, sum_lout = [], [], 0
@@ -575,7 +585,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or R != 2):
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
                              "not counters of this process"

@@ -157,6 +157,10 @@ struct fdc_pipeline {
     float2 *d_fscr = nullptr;    // 256 KiB per compute unit: the half of T the block kernel puts aside between its two stage-2 runs
     fdc::ChanDev *d_chans = nullptr;
     int32_t *d_groups = nullptr;
+    // plans that read part of the band only: 64-bin groups of the shifted spectrum some channel reads (the forward kernels that store
+    // whole 64-bin runs per wave leave the other groups of the handle's internal spectrum unwritten)
+    unsigned long long keep4096 = ~0ull;   // N = 4096
+    unsigned *d_keep = nullptr;            // N = 65536, block forward transform: [klo][k2 / 64] words, bit = register index of the slot
     float2 *d_big = nullptr;     // channels wider than one workgroup's transform: 3 x chunk x (widest l) scratch
     int big_l = 0;
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
@@ -285,7 +289,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
     for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
-    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups);
+    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -536,6 +540,28 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if (p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
+        std::vector<char> g64((size_t)N / 64, 0);
+        bool all = true;
+        for (const auto &ch : p->chans) for (int b = ch.f / 64; b <= (ch.f + ch.l - 1) / 64 && b < N / 64; b++) g64[(size_t)b] = 1;
+        for (char v : g64) all = all && v;
+        if (!all && N == 4096) {
+            p->keep4096 = 0;
+            for (int b = 0; b < 64; b++) if (g64[(size_t)b]) p->keep4096 |= 1ull << b;
+        } else if (!all) {
+            // the block kernel's wave klo stores, per 64-row chunk q, the bins 256 c + 64 q .. + 63 of the slots c = klo + 8 khi; slot khi =
+            // k0 + 2 k1 sits in register 16 k0 + rev16(k1) (fdc_block256.hip, soff)
+            std::vector<unsigned> kw(32, 0u);
+            for (int klo = 0; klo < 8; klo++)
+                for (int q = 0; q < 4; q++)
+                    for (int r = 0; r < 32; r++) {
+                        const int k0 = r >> 4, k1 = 4 * (r & 3) + ((r & 15) >> 2), c = klo + 8 * (k0 + 2 * k1);
+                        if (g64[(size_t)(4 * c + q)]) kw[(size_t)(klo * 4 + q)] |= 1u << r;
+                    }
+            CHK_OR_FREE(hipMalloc(&p->d_keep, sizeof(unsigned) * 32));
+            CHK_OR_FREE(hipMemcpy(p->d_keep, kw.data(), sizeof(unsigned) * 32, hipMemcpyHostToDevice));
+        }
+    }
     if (p->poly_block) {
         if (const char *dg = fdc::debug_env("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
             CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
@@ -718,13 +744,13 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
         if (p->fwd_block && !few)
             HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
-                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, evp));
+                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
         else if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
         else
             HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
-                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic));
+                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
         for (size_t g = 0; g < p->groups.size(); g++) {
             const int l = p->groups[g].first;
             if (l > fdc::kMaxLdsFft) {

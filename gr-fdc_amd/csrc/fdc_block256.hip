@@ -89,7 +89,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                                                 const long long *__restrict__ slot_off, long long out_base,
                                                 long long nb_call, unsigned out_bytes, int nb, int hints,
                                                 unsigned long long *__restrict__ dbg, int roff, long long first_block,
-                                                float2 *__restrict__ fwd_scratch)
+                                                float2 *__restrict__ fwd_scratch, const unsigned *__restrict__ keep)
 {
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: G chunk
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrow);      // [b][p] = W256^(b p), rows of 18
@@ -103,6 +103,14 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     // stage-1 roles
     const int w = tid >> 6, lane = tid & 63, col = lane & 3, b = lane >> 2, c5 = 4 * w + col;
     // stage-2 roles: writer = the stage-1 role (column c5, rows b + 16 j); reader: row = lane, klo = wave
+    // FWD with a plan that reads part of the spectrum only: which of this wave's 64-bin stores some channel reads at all
+    // ([klo = wave][k2 / 64], bit = register index of the slot); the others are dropped (offset beyond the descriptor's extent)
+    unsigned mqs[4] = {~0u, ~0u, ~0u, ~0u};
+    if (FWD && keep) {
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+        for (int q = 0; q < 4; q++) mqs[q] = keep[wu * 4 + q];
+    }
 
     // block order: round rho, XCD x = workgroup mod 8 (round-robin dispatch), slot = workgroup / 8:
     // block = rho*grid + x*(grid/8) + slot, i.e. one XCD works on grid/8 consecutive blocks at a time
@@ -396,13 +404,18 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                     }
                 }
 #else
+                unsigned mq = FWD ? mqs[((rowbase >> 6) + ch) & 3] : ~0u;
+                if constexpr (FWD) asm volatile("" : "+s"(mq));       // the 32 scalar terms below are worked out here, not held from block to block
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint4 t = sow[q];
                     const unsigned so[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+                    for (int e = 0; e < 4; e++) {
+                        // FWD: a store nobody reads gets the offset of an unused slot (all ones: a scalar term, one OR per store)
+                        const unsigned o = FWD ? (so[e] | (((mq >> (4 * q + e)) & 1u) - 1u)) : so[e];
+                        bst2t<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb), v[4 * q + e]);
+                    }
                 }
 #endif
                 FDC_STAMP(14 + 5 * ch);
@@ -461,7 +474,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 #define FDC_LB4(A) \
         hipExtLaunchKernelGGL((k_blk256<A, false, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
                               tw256, twq, cbt, shn, slot_off, (long long)mbase * 192, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, 0, first_block, \
-                              scratch)
+                              scratch, (const unsigned *)nullptr)
         if (hints & 1) FDC_LB4(true); else FDC_LB4(false);
 #undef FDC_LB4
         return hipGetLastError();
@@ -474,7 +487,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 #define FDC_LB(A, B) \
     hipExtLaunchKernelGGL((k_blk256<A, B, false>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
                           tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block, \
-                          (float2 *)nullptr)
+                          (float2 *)nullptr, (const unsigned *)nullptr)
     if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
     else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
 #undef FDC_LB
@@ -487,7 +500,8 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 // of the two-pass transform: its second interval is empty here).
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
                                  const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
-                                 float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev)
+                                 float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev,
+                                 const unsigned *keep)
 {
     for (int m0 = 0; m0 < nitems; m0 += 4096) {            // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum
         const int nb = nitems - m0 < 4096 ? nitems - m0 : 4096;
@@ -497,7 +511,7 @@ hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out
 #define FDC_LF(A) \
         hipExtLaunchKernelGGL((k_blk256<A, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
                               in_stride, out + (size_t)m0 * 65536, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
-                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch)
+                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep)
         if (hints & 1) FDC_LF(true); else FDC_LF(false);
 #undef FDC_LF
     }

@@ -168,7 +168,8 @@ constexpr int kF4096Tile = 16 * 272 * 8;                       // 34816 >= 16 * 
 template <bool INV>
 __global__ __launch_bounds__(256, 4) void k_fft4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                     int nitems, int in_rot, int out_rot, float scale,
-                                                    const float2 *__restrict__ tw, int twstride /* ntab / 4096 */)
+                                                    const float2 *__restrict__ tw, int twstride /* ntab / 4096 */,
+                                                    unsigned long long keep /* 64-bin groups of the output that are wanted */)
 {
     float2 *tile = reinterpret_cast<float2 *>(fdc_smem_wide);
     float2 *t256 = reinterpret_cast<float2 *>(fdc_smem_wide + kF4096Tile);               // [x][y] = W_256^(x y), 16 x 18
@@ -218,23 +219,26 @@ __global__ __launch_bounds__(256, 4) void k_fft4096(const float2 *__restrict__ i
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = ld2(&tile[hi * 257 + lo * 16 + (a ^ lo)]);
     dft16<INV>(v);                                               // layer 3 over a: k2 in v[rev16(k2)]
+    // a wave's store is 64 consecutive bins (out_rot is a multiple of 64 whenever `keep` is not all ones): groups nobody reads stay unwritten
+    const int g0 = __builtin_amdgcn_readfirstlane(((tid & ~63) + out_rot) >> 6);
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++)
-        st2(out + m * 4096 + ((tid + 256 * k2 + out_rot) & 4095), v[rev16(k2)] * scale);
+        if ((keep >> ((g0 + 4 * k2) & 63)) & 1ull) st2(out + m * 4096 + ((tid + 256 * k2 + out_rot) & 4095), v[rev16(k2)] * scale);
     (void)nitems;
 }
 
 hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int nitems, bool inverse, int in_rot, int out_rot,
-                          float scale, const float2 *tw, int ntab, hipStream_t s)
+                          float scale, const float2 *tw, int ntab, hipStream_t s, unsigned long long keep)
 {
+    if (out_rot & 63) keep = ~0ull;
     if (nitems <= 0) return hipSuccess;
     const int lds = kF4096Tile + 2 * 16 * 18 * 8;
     if (inverse)
         hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)nitems), dim3(256), lds, s, in, in_stride, out, nitems, in_rot, out_rot,
-                           scale, tw, ntab / 4096);
+                           scale, tw, ntab / 4096, keep);
     else
         hipLaunchKernelGGL(k_fft4096<false>, dim3((unsigned)nitems), dim3(256), lds, s, in, in_stride, out, nitems, in_rot, out_rot,
-                           scale, tw, ntab / 4096);
+                           scale, tw, ntab / 4096, keep);
     return hipGetLastError();
 }
 

@@ -51,7 +51,8 @@ hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *t
                       bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
                       hipStream_t s, hipEvent_t *ev /* null or 3 events: start, after pass A, end */,
                       const float2 *twf = nullptr /* two-pass sizes: [k2][n1] = exp(-2 pi i n1*k2/N), N entries, optional */,
-                      bool generic_only = false /* no size-specific register kernels (FDC_FORCE_GENERIC handles) */);
+                      bool generic_only = false /* no size-specific register kernels (FDC_FORCE_GENERIC handles) */,
+                      unsigned long long keep4096 = ~0ull /* N = 4096: 64-bin groups of the output that are wanted (others may stay unwritten) */);
 
 // Fused slice + phase + window + ifftshift + IFFT(l) + overlap discard + *l for one group of channels of
 // equal l (<= kMaxLdsFft).  spec holds nb_chunk spectra; block m of the chunk is block mbase+m of the call.
@@ -78,7 +79,8 @@ hipError_t launch_channels_wide(const float2 *spec, float2 *out, const ChanDev *
 
 // 4096-point transforms in registers (fdc_chanwide.hip), same meaning of the arguments as launch_fft
 hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int nitems, bool inverse, int in_rot, int out_rot,
-                          float scale, const float2 *tw, int ntab, hipStream_t s);
+                          float scale, const float2 *tw, int ntab, hipStream_t s,
+                          unsigned long long keep = ~0ull /* 64-bin groups of the output some reader wants */);
 
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
@@ -118,7 +120,8 @@ hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out
                                  const float2 *twq, const float2 *cbt0 /* r = 0 */, const float *shn1 /* 256 x 1/N */,
                                  const long long *slot_off /* [256]: 256 c */, float2 *scratch /* ncu x 32768 points */,
                                  int ncu, int hints, hipStream_t s,
-                                 hipEvent_t *ev /* null or 3: start, end, end */);
+                                 hipEvent_t *ev /* null or 3: start, end, end */,
+                                 const unsigned *keep = nullptr /* [8][4] words: 64-bin stores some channel reads (fdc_api.hip), or all */);
 
 // real samples -> complex samples with zero imaginary part (the real-input front end)
 hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s);

@@ -614,13 +614,13 @@ hipError_t init_kernels()
 
 hipError_t launch_fft(const float2 *in, size_t in_stride, float2 *out, float2 *tmp, int N, int nitems,
                       bool inverse, int in_rot, int out_rot, float scale, const float2 *tw, int ntab,
-                      hipStream_t s, hipEvent_t *ev, const float2 *twf, bool generic_only)
+                      hipStream_t s, hipEvent_t *ev, const float2 *twf, bool generic_only, unsigned long long keep4096)
 {
     if (nitems <= 0) return hipSuccess;
     hipError_t e;
     if (ev && (e = hipEventRecord(ev[0], s)) != hipSuccess) return e;
     if (N == 4096 && ntab % 4096 == 0 && !generic_only) {
-        if ((e = launch_fft4096(in, in_stride, out, nitems, inverse, in_rot, out_rot, scale, tw, ntab, s)) != hipSuccess) return e;
+        if ((e = launch_fft4096(in, in_stride, out, nitems, inverse, in_rot, out_rot, scale, tw, ntab, s, keep4096)) != hipSuccess) return e;
         if (ev && (e = hipEventRecord(ev[1], s)) != hipSuccess) return e;
     } else if (N <= kMaxLdsFft) {
         const TileGeom g = tile_geom(N);

@@ -90,7 +90,8 @@ enum {
     FDC_PIPE_NO_POLY = 2,         /* no uniform-plan commutation: forward transform to a spectrum in memory + channel kernels */
     FDC_PIPE_NO_BLOCK = 4,        /* no one-block-per-compute-unit kernels (two-launch uniform path / two-pass transform)   */
     FDC_PIPE_PLAIN_STORES = 8,    /* block kernels: ordinary instead of streamed (nt) output stores                 */
-    FDC_PIPE_NT_LOADS = 16        /* block kernels: streamed (nt) input loads                                       */
+    FDC_PIPE_NT_LOADS = 16,       /* block kernels: streamed (nt) input loads                                       */
+    FDC_PIPE_FULL_SPECTRUM = 32   /* the handle's internal spectrum is written in full (default: only the 64-bin groups some channel reads) */
 };
 
 int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out);

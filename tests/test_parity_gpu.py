@@ -557,6 +557,33 @@ def test_spectrum_path_block_forward_kernel_vs_two_pass(oracle, R):
     assert_close(res[None][1].reshape(-1), res["FDC_NO_BLOCK"][1].reshape(-1), "block kernel vs two-pass spectrum")
 
 
+@pytest.mark.parametrize("N", [4096, 65536])
+def test_plans_that_read_part_of_the_band_leave_the_rest_unwritten(oracle, N):
+    """A few channels in a wide band: the forward kernels whose waves store whole 64-bin runs (k_fft4096, the block kernel as a
+    forward transform) write only the groups some channel reads into the handle's internal spectrum (FDC_PIPE_FULL_SPECTRUM switches
+    that off).  Channels that start / end inside a 64-bin group, at bin 0 and at the top of the band, wider than a slot; outputs
+    against the oracle and bit for bit against the full-spectrum form; a spectrum asked for by the caller is still complete."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    R, nb = 2, 6
+    if N == 4096:
+        chans = [(0, 64, 0.88, 1.0), (100, 256, 0.9, 1.0), (1023, 128, 0.88, 1.0), (2048 + 63, 512, 0.8, 0.95), (4096 - 32, 32, 0.88, 1.0)]
+    else:
+        chans = [(0, 256, 0.88, 1.0), (37, 256, 0.88, 1.0), (300, 512, 0.9, 1.0), (16384 + 191, 2048, 0.88, 1.0), (40000, 64, 0.8, 0.95),
+                 (65536 - 1024, 1024, 0.88, 1.0)]
+    x = noise(nb * (N - N // R), 91)
+    ref, sref = oracle.channelizer(N, R, 1, chans, x, want_spectrum=True, nthreads=4)
+    part = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb).work(x)
+    full = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_FULL_SPECTRUM).work(x)
+    for c in range(len(chans)):
+        assert_close(part[c], ref[c], "channel %d" % c)
+        assert (part[c] == full[c]).all(), c
+    outs, spec = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, keep_spectrum=True).work(x, want_spectrum=True)
+    assert_close(spec.reshape(-1), sref.reshape(-1), "spectrum handed to the caller")
+    for c in range(len(chans)):
+        assert (outs[c] == full[c]).all(), c
+
+
 def test_plan_classes_one_kernel_path(oracle):
     """A plan that is the union of a few 256-bin tilings stays on the one-kernel path, one launch per class (fdc_api.hip,
     PolyClass): (a) a 2x oversampled bank (tilings at offsets 0 and 128, 200 + 200 channels, interleaved in plan order),
