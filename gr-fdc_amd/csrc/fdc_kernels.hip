@@ -28,6 +28,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem[];
 // thread owns PT = 16*NB of them in each pass and while a tile is loaded or stored (all PT global loads are issued
 // before the first is used).
 #define FDC_GENERIC_BOUNDS(NB) __launch_bounds__(kThreads, (NB) == 1 ? 4 : 2)
+// the kernels that hold a tile's samples AND its window (or twiddle) values in flight: at four workgroups per compute unit (128 VGPRs)
+// they spill 25 registers into the loops; three (168 VGPRs) hold everything
+#define FDC_TILE_BOUNDS(NB) __launch_bounds__(kThreads, (NB) == 1 ? 3 : 2)
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
@@ -209,7 +212,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_small(const float2 *__restrict__ in
 // TASK: item m is extraction m of a width class (fdc_sinks): its input is the slice of the spectrum the task names, times the task's
 // window (read where the transform reads it: no gathered copy), and pass B writes the kept part [skip, N) to the task's place.
 template <bool INV, int NB, bool TASK = false>
-__global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
+__global__ FDC_TILE_BOUNDS(NB) void k_fft_pass_a(const float2 *__restrict__ in, size_t in_stride,
                                                     float2 *__restrict__ tmp, int log2N, int log2N1,
                                                     int log2TC, int ld, int in_rot,
                                                     const float2 *__restrict__ tw, int ntab,
@@ -356,7 +359,7 @@ __global__ FDC_GENERIC_BOUNDS(1) void k_p2g(const float2 *__restrict__ g, float2
 struct ColInfo { long long src; long long dst; int win; int valid; };
 
 template <int NB>
-__global__ FDC_GENERIC_BOUNDS(NB) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
+__global__ FDC_TILE_BOUNDS(NB) void k_channels(const float2 *__restrict__ spec, float2 *__restrict__ out,
                                                   const ChanDev *__restrict__ chans,
                                                   const int32_t *__restrict__ group, int ngroup, int log2l,
                                                   int log2TC, int ld, int N, int R, int nb_chunk, int mbase,
@@ -510,7 +513,7 @@ __device__ __forceinline__ void extract_tile(const int tile, const float2 *__res
 }
 
 template <int NB>
-__global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, int N,
+__global__ FDC_TILE_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, int N,
                                                       const ExtractTask *__restrict__ tasks, int ntasks, int log2w,
                                                       int log2TC, int ld, int skip, const float2 *__restrict__ wins,
                                                       float2 *__restrict__ out, const float2 *__restrict__ tw,
@@ -522,7 +525,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec
 // Several width classes (each up to 4096 points: the one-transform-per-workgroup tiling) in ONE launch: a bank of detected channels
 // has a handful of classes with a few hundred to a few thousand extractions each, none of which fills the device on its own.
 // A workgroup finds its class from the tile ranges.
-__global__ FDC_GENERIC_BOUNDS(1) void k_extract_multi(const float2 *__restrict__ spec, int N, const ExtractTask *__restrict__ tasks,
+__global__ FDC_TILE_BOUNDS(1) void k_extract_multi(const float2 *__restrict__ spec, int N, const ExtractTask *__restrict__ tasks,
                                                       const ExtractClasses cls, const float2 *__restrict__ wins, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw, int ntab)
 {
