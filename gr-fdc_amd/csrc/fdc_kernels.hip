@@ -427,35 +427,59 @@ __global__ FDC_TILE_BOUNDS(NB) void k_channels(const float2 *__restrict__ spec, 
 // ---- sinks: power cells + task-list extraction (PowerActivationChannel / activity_detection_channelizer_vcm) ----
 // One wave per (block, cell): sum |X|^2 over [start, start+len), times scale.
 //   lib/PowerActivationChannel_impl.cc:289-291 (scale 1), lib/activity_detection_channelizer_vcm_impl.cc:641-648 (1/dec)
+// A cell of a detector or a channel is a few hundred bins: one or two 16-byte loads per lane.  A wave takes its cell in kCellBlocks
+// consecutive blocks at once (their loads are in flight together); every block's sum is formed exactly as before.
+constexpr int kCellBlocks = 4;
 __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restrict__ spec, int N,
-                                                         const PowerCell *__restrict__ cells, int ncells,
+                                                         const PowerCell *__restrict__ cells, int ncells, int nblocks,
                                                          float *__restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cell = blockIdx.x * (kThreads / 64) + wave;
-    const size_t m = blockIdx.y;
+    const int mb = blockIdx.y * kCellBlocks;
     if (cell >= ncells) return;
     const PowerCell pc = cells[cell];
-    const float2 *x = spec + m * (size_t)N + pc.start;
-    // two bins per 16-byte load from the first even bin on (the spectrum and N are 16-byte aligned), two loads in flight per lane
+    // two bins per 16-byte load from the first even bin on (the spectrum and N are 16-byte aligned), two loads in flight per lane and block
     const int head = (pc.start & 1) && pc.len > 0 ? 1 : 0, n2 = (pc.len - head) >> 1;
-    float acc = 0.f, acc2 = 0.f;
-    if (lane == 0) {
-        if (head) { const float2 v = x[0]; acc += v.x * v.x + v.y * v.y; }
-        if ((pc.len - head) & 1) { const float2 v = x[pc.len - 1]; acc += v.x * v.x + v.y * v.y; }
+    const bool tail = (pc.len - head) & 1;
+    float acc[kCellBlocks], acc2[kCellBlocks];
+    const float4 *x4[kCellBlocks];
+#pragma unroll
+    for (int j = 0; j < kCellBlocks; j++) {
+        const int m = mb + j < nblocks ? mb + j : nblocks - 1;     // the surplus blocks of the last group repeat the last one (not stored)
+        const float2 *x = spec + (size_t)m * N + pc.start;
+        acc[j] = 0.f; acc2[j] = 0.f;
+        if (lane == 0) {
+            if (head) { const float2 v = x[0]; acc[j] += v.x * v.x + v.y * v.y; }
+            if (tail) { const float2 v = x[pc.len - 1]; acc[j] += v.x * v.x + v.y * v.y; }
+        }
+        x4[j] = reinterpret_cast<const float4 *>(x + head);
     }
-    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
     int i = lane;
     for (; i + 64 < n2; i += 128) {
-        const float4 a = x4[i], b = x4[i + 64];
-        acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-        acc2 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-    }
-    if (i < n2) { const float4 a = x4[i]; acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
-    acc += acc2;
+        float4 a[kCellBlocks], b[kCellBlocks];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) out[m * (size_t)ncells + cell] = acc * pc.scale;
+        for (int j = 0; j < kCellBlocks; j++) { a[j] = x4[j][i]; b[j] = x4[j][i + 64]; }
+#pragma unroll
+        for (int j = 0; j < kCellBlocks; j++) {
+            acc[j] += a[j].x * a[j].x + a[j].y * a[j].y + a[j].z * a[j].z + a[j].w * a[j].w;
+            acc2[j] += b[j].x * b[j].x + b[j].y * b[j].y + b[j].z * b[j].z + b[j].w * b[j].w;
+        }
+    }
+    if (i < n2) {
+        float4 a[kCellBlocks];
+#pragma unroll
+        for (int j = 0; j < kCellBlocks; j++) a[j] = x4[j][i];
+#pragma unroll
+        for (int j = 0; j < kCellBlocks; j++) acc[j] += a[j].x * a[j].x + a[j].y * a[j].y + a[j].z * a[j].z + a[j].w * a[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < kCellBlocks; j++) {
+        float t = acc[j] + acc2[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0 && mb + j < nblocks) out[(size_t)(mb + j) * ncells + cell] = t * pc.scale;
+    }
 }
 
 // Extraction of one width class: out = IFFT_w( halfswap( X[slot][start .. start+w) * win ) )[skip .. w)
@@ -750,8 +774,8 @@ hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, 
     if (ncells <= 0 || nblocks <= 0) return hipSuccess;
     for (int m0 = 0; m0 < nblocks; m0 += 32768) {
         const int nb = nblocks - m0 < 32768 ? nblocks - m0 : 32768;
-        hipLaunchKernelGGL(k_cell_power, dim3((ncells + 3) / 4, nb), dim3(kThreads), 0, s, spec + (size_t)m0 * N, N, cells,
-                           ncells, out + (size_t)m0 * ncells);
+        hipLaunchKernelGGL(k_cell_power, dim3((ncells + 3) / 4, (nb + kCellBlocks - 1) / kCellBlocks), dim3(kThreads), 0, s, spec + (size_t)m0 * N, N, cells,
+                           ncells, nb, out + (size_t)m0 * ncells);
     }
     return hipGetLastError();
 }
