@@ -6,8 +6,9 @@
 //
 // These loops are sequential over the blocks of a stream and tiny per block; what makes them worth a kernel is that nothing has to
 // leave the device between the power sums and the extractions.  The parts that do not depend on the state run in parallel over
-// the blocks (power ratios of a PowerActivationChannel; edge detection, sort and candidate selection of a segment), the rest is a
-// loop over the blocks with one lane per PowerActivationChannel / one wave per segment (lanes = live channels).
+// the blocks (power ratios of a PowerActivationChannel; edge detection, sort and candidate selection of a segment); the state machines
+// themselves are turned so that lanes are BLOCKS: one wave per PowerActivationChannel (toggles found by walking the changes), and the
+// detector channel by channel, slab by slab, independent frequency regions in parallel waves (k_det_track).
 // Output of a call: extraction tasks and emission records that name blocks of per-channel streams (fdc_sinks_dev.h); the layout
 // kernel places the streams in the landing buffer so that every PDU is one contiguous run and only emitted runs cross PCIe.
 #include <climits>
