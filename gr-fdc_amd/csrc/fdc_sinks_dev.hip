@@ -905,16 +905,17 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
         (void)block_exscan((long long)(l < nlist ? ntask[l] : 0), &tt, sh);
         nt += (int)tt;
         __syncthreads();
-        const int wv = tid >> 6, ln = tid & 63, lim = nlist - l0 < 1024 ? nlist - l0 : 1024;
-        for (int ll = wv; ll < lim; ll += 16) {
-            const int nn = npdu[l0 + ll], b0 = lbase[ll];
-            const SinkPdu *p = pdus + pdu_base[l0 + ll];
-            for (int k = ln; k < nn; k += 64) {
-                SinkPdu r = p[k];
-                const SinkOwner o = owners[r.owner];
-                r.off = o.a_off + (long long)r.q0 * o.len;
-                pdus_out[b0 + k] = r;
-            }
+        // a thread per record (a bank of 256 channels has 256 short lists: a wave per list would walk them sixteen deep, two dependent
+        // loads each); the list of a record by bisection of the bases
+        const int lim = nlist - l0 < 1024 ? nlist - l0 : 1024;
+        for (int idx = tid; idx < (int)tot; idx += 1024) {
+            const int g = np + idx;
+            int lo = 0, hi = lim - 1;                           // last list whose base is <= g
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (lbase[mid] <= g) lo = mid; else hi = mid - 1; }
+            SinkPdu r = pdus[pdu_base[l0 + lo] + (g - lbase[lo])];
+            const SinkOwner o = owners[r.owner];
+            r.off = o.a_off + (long long)r.q0 * o.len;
+            pdus_out[g] = r;
         }
         np += (int)tot;
         __syncthreads();
