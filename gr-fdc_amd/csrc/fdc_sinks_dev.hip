@@ -287,6 +287,12 @@ __device__ long long block_exscan(long long v, long long *tot, long long *sh /* 
 // pass of their own, :359-362), position of the channel in the list (its sequence number: the list is ordered by activation).
 constexpr int kDetWaves = 16;
 constexpr int kDetStaged = 8;                        // candidates per block held in LDS (more than that: read from memory)
+#ifndef FDC_DET_SLAB
+#define FDC_DET_SLAB 64
+#endif
+constexpr int kDetSlab = FDC_DET_SLAB;               // blocks per slab (<= 64: lanes = blocks).  Measured on configs[4], payloads in HBM:
+                                                     // 64 -> 1.00 ms per step, 32 -> 1.06, 16 -> 1.18 (shorter slabs split the regions
+                                                     // further but pay the per-slab set-up more often)
 __host__ __device__ constexpr size_t det_lds_bytes(int nb, int words)
 {
     // activation masks + activation prefix per block of the call; per slab: candidate counts, staged candidates;
@@ -401,18 +407,18 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
 #define FDC_WT(i, n) do { } while (0)
 #define FDC_DT(i) do { } while (0)
 #endif
-    for (m0 = 0; m0 < nb; m0 += 64) {
+    for (m0 = 0; m0 < nb; m0 += kDetSlab) {
         // ---- the slab's tables; cells covered by one of its candidates or by a channel alive at its start
-        if (tid < 64) KM[tid] = m0 + tid < nb ? kc[m0 + tid] : 0;
+        if (tid < 64) KM[tid] = (tid < kDetSlab && m0 + tid < nb) ? kc[m0 + tid] : 0;
         for (int e = tid; e < 64 * staged; e += 64 * kDetWaves) {
             const int m = m0 + e / staged, j = e % staged;
-            CS[e] = (m < nb && j < g.cand_cap) ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
+            CS[e] = (m < nb && m < m0 + kDetSlab && j < g.cand_cap) ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
         }
         if (tid < 16) COV[tid] = 0;
         if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[5] = 0; }
         __syncthreads();
         FDC_DT(0);
-        for (int q = wv; q < 64 && m0 + q < nb; q += kDetWaves) {
+        for (int q = wv; q < kDetSlab && m0 + q < nb; q += kDetWaves) {
             const int k = KM[q];
             for (int j = lane; j < k; j += 64) { const int2 pc = cand_of(m0 + q, j); cover(cell_of(pc.x), cell_of(pc.y)); }
         }
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
             // (-1: it lives on), its misses in a row after the last block
             auto scan = [&](int ds, int de, int first, int inact0, int &end_out, int &streak_out) {
                 const int f = first > m0 ? first - m0 : 0;     // first lane that takes part
-                const bool valid = lane >= f && m < nb;
+                const bool valid = lane >= f && lane < kDetSlab && m < nb;
                 unsigned long long ov[WORDS];
 #pragma unroll
                 for (int w = 0; w < WORDS; w++) ov[w] = 0;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
 #pragma unroll
                     for (int w = 0; w < WORDS; w++) cl[w] |= ov[w];
                 }
-                const int lastv = (nb - m0 < 64 ? nb - m0 : 64) - 1;
+                const int lastv = (nb - m0 < kDetSlab ? nb - m0 : kDetSlab) - 1;
                 end_out = F ? m0 + endlane : -1;
                 streak_out = lastv >= f ? lane_val(st, lastv) : inact0;
             };
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
             // candidates of the region nobody took become channels (:785-841), block after block
             for (int ms = m0;;) {
                 bool un = false;
-                if (m < nb && m >= ms) {
+                if (m < nb && m >= ms && lane < kDetSlab) {
 #pragma unroll
                     for (int w = 0; w < WORDS; w++) un = un || (RM[w] & ~cl[w]) != 0;
                 }
