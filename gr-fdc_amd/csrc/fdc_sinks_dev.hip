@@ -407,20 +407,32 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
 #define FDC_WT(i, n) do { } while (0)
 #define FDC_DT(i) do { } while (0)
 #endif
+    // the tables of a slab (candidate counts of its blocks, the first `staged` candidates of each) are requested a slab ahead, one entry
+    // per thread (64 x staged = 512 <= the workgroup's threads), and only written to LDS here: their latency lies behind the slab before
+    auto want_km = [&](int mb) { return (tid < kDetSlab && mb + tid < nb) ? kc[mb + tid] : 0; };
+    auto want_cs = [&](int mb) {
+        const int m = mb + tid / staged, j = tid % staged;
+        return (tid < 64 * staged && m < nb && m < mb + kDetSlab && j < g.cand_cap) ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
+    };
+    static_assert(64 * kDetStaged <= 64 * kDetWaves, "one staged candidate per thread");
+    int nkm = want_km(0);
+    int2 ncs = want_cs(0);
     for (m0 = 0; m0 < nb; m0 += kDetSlab) {
         // ---- the slab's tables; cells covered by one of its candidates or by a channel alive at its start
-        if (tid < 64) KM[tid] = (tid < kDetSlab && m0 + tid < nb) ? kc[m0 + tid] : 0;
-        for (int e = tid; e < 64 * staged; e += 64 * kDetWaves) {
-            const int m = m0 + e / staged, j = e % staged;
-            CS[e] = (m < nb && m < m0 + kDetSlab && j < g.cand_cap) ? cbase[(size_t)m * g.cand_cap + j] : make_int2(0, 0);
-        }
+        if (tid < 64) KM[tid] = nkm;
+        if (tid < 64 * staged) CS[tid] = ncs;
+        nkm = want_km(m0 + kDetSlab); ncs = want_cs(m0 + kDetSlab);
         if (tid < 16) COV[tid] = 0;
         if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[5] = 0; }
         __syncthreads();
         FDC_DT(0);
-        for (int q = wv; q < kDetSlab && m0 + q < nb; q += kDetWaves) {
-            const int k = KM[q];
-            for (int j = lane; j < k; j += 64) { const int2 pc = cand_of(m0 + q, j); cover(cell_of(pc.x), cell_of(pc.y)); }
+        {   // the staged candidates: a thread each; what a block has beyond them (rare): a wave per block
+            const int q = tid / staged, j = tid % staged;
+            if (tid < 64 * staged && j < KM[q]) { const int2 pc = CS[tid]; cover(cell_of(pc.x), cell_of(pc.y)); }
+            for (int qq = wv; qq < kDetSlab && m0 + qq < nb; qq += kDetWaves) {
+                const int k = KM[qq];
+                for (int jj = staged + lane; jj < k; jj += 64) { const int2 pc = cbase[(size_t)(m0 + qq) * g.cand_cap + jj]; cover(cell_of(pc.x), cell_of(pc.y)); }
+            }
         }
         for (int i = tid; i < nal; i += 64 * kDetWaves) cover(cell_of(AL[A_DS + i]), cell_of(AL[A_DE + i]));
         __syncthreads();
