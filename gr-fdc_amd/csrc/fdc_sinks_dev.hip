@@ -567,6 +567,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                 // the activating candidates of block mf; everything of the region in this block is now settled
 #pragma unroll
                 for (int w = 0; w < WORDS; w++) {
+                    if (kf <= 64 * w) continue;                   // the block has no candidates in this word (wave-uniform)
                     const int j = 64 * w + lane;
                     bool ok = false;
                     const unsigned long long rmw = lane_val(RM[w], fl), clw = lane_val(cl[w], fl);
