@@ -80,6 +80,7 @@ def parse():
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
     ap.add_argument("--sparse", type=int, default=0, metavar="K", help="diagnostics (config 2): K channels (widths 256 ... 2048 in turn) spread "
                                                                        "over the band instead of a plan that tiles it (spectrum path)")
+    ap.add_argument("--sparse-widths", default="256,512,1024,2048", help="--sparse: the channel widths in turn (bins, powers of two)")
     a = ap.parse_args()
     if a.sparse and a.config != 2:
         ap.error("--sparse applies to --config 2 only")
@@ -378,8 +379,8 @@ def main():
             params = [G.get_opt_channelparams(N, R, (u + 0.5) % 1.0, bw) for (u, bw) in
                       ((0.12, 0.05), (0.22, 0.1), (-0.14, 0.12), (0.0, 0.081))]
         elif a.sparse:
-            wid = (256, 512, 1024, 2048)
-            params = [G.get_opt_channelparams(N, R, ((c + 0.37) / a.sparse) % 1.0, 0.8 * wid[c % 4] / N) for c in range(a.sparse)]
+            wid = tuple(int(v) for v in a.sparse_widths.split(","))
+            params = [G.get_opt_channelparams(N, R, ((c + 0.37) / a.sparse) % 1.0, 0.8 * wid[c % len(wid)] / N) for c in range(a.sparse)]
         else:
             bws = (0.8, 0.4, 0.8, 1.6) if a.mixed else (0.8,)
             params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]

@@ -161,7 +161,9 @@ struct fdc_pipeline {
     // whole 64-bin runs per wave leave the other groups of the handle's internal spectrum unwritten)
     unsigned long long keep4096 = ~0ull;   // N = 4096
     unsigned *d_keep = nullptr;            // N = 65536, block forward transform: [klo][k2 / 64] words, bit = register index of the slot
-    float2 *d_big = nullptr;     // channels wider than one workgroup's transform: 3 x chunk x (widest l) scratch
+    float2 *d_big = nullptr;     // channels wider than 4096 bins: scratch between the two passes of their inverse transform (big_pts points)
+    fdc::ExtractTask *d_wtasks = nullptr;   // ... and their (channel, block) tasks of one piece
+    size_t big_pts = 0;
     int big_l = 0;
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
     float2 *d_spec = nullptr;    // spectrum, chunk*N (or max_blocks*N with keep_spectrum)
@@ -290,7 +292,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_keep);
-    (void)hipFree(p->d_big); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
+    (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -577,8 +579,16 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (two_launch)
             CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
     }
-    for (int c = 0; c < p->C; c++) if (p->chans[c].l > fdc::kMaxLdsFft) p->big_l = std::max(p->big_l, (int)p->chans[c].l);
-    if (p->big_l) CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * 3 * (size_t)chunk * p->big_l));
+    {
+        // widest "channels x width" of a group above 4096 bins: a piece of the launch group is as many blocks as fit 32 Mi points
+        size_t widest = 0;
+        for (const auto &gr : p->groups) if (gr.first > 4096) { widest = std::max(widest, gr.second.size() * (size_t)gr.first); p->big_l = std::max(p->big_l, gr.first); }
+        if (widest) {
+            p->big_pts = std::max<size_t>(widest, std::min<size_t>((size_t)32 << 20, widest * (size_t)chunk));
+            CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * p->big_pts));
+            CHK_OR_FREE(hipMalloc(&p->d_wtasks, sizeof(fdc::ExtractTask) * (p->big_pts / 8192 + (size_t)p->C + 1)));   // a piece: at most big_pts / l tasks, l >= 8192
+        }
+    }
     // two-pass scratch; with the block kernel only launch groups shorter than kBlockMinBlocks take the two-pass kernels
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)(p->fwd_block ? std::min(chunk, p->block_min) : chunk) * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
@@ -652,26 +662,20 @@ static int get_event(fdc_pipeline *p, size_t *idx)
     return FDC_OK;
 }
 
-// Channels wider than one workgroup's transform (l > kMaxLdsFft): the reference's block chain one step at a time on
-// scratch — vector_cut_vxx, phase_shifting_windowing_vcc, fft_vcc(l, inverse, shift) as the two-pass transform with the
-// ifftshift as input rotation and the *l in its store, vector_cut_vxx(l, l - lout, lout) — in pieces of `chunk` blocks.
-static int channels_wide(fdc_pipeline *p, const float2 *spec, float2 *d_out, const std::vector<int32_t> &ids, int l, int nb,
+// Channels wider than 4096 bins: all channels of one width and all blocks of the launch group as ONE batch of the task-addressed two-pass
+// inverse transform (fdc_kernels.hip: pass A reads slice * window straight from the spectrum, the ifftshift is its input rotation; pass B
+// writes the kept samples, times l, into the channel streams) — in pieces of up to 32 Mi points of scratch between the passes.
+// gids: the group's channel ids in the device list p->d_groups.
+static int channels_wide(fdc_pipeline *p, const float2 *spec, float2 *d_out, const int32_t *d_gids, int ngroup, int l, int nb,
                          int mbase, int nb_call, int64_t first_block, hipStream_t s)
 {
-    for (int c : ids) {
-        const fdc::ChanDev &ch = p->chans[(size_t)c];
-        for (int m0 = 0; m0 < nb; m0 += p->chunk) {
-            const int n = std::min(p->chunk, nb - m0);
-            float2 *A = p->d_big, *B = A + (size_t)p->chunk * p->big_l, *T = B + (size_t)p->chunk * p->big_l;
-            HIPCHK(fdc::launch_vector_cut(reinterpret_cast<const unsigned char *>(spec + (size_t)m0 * p->N), reinterpret_cast<unsigned char *>(A),
-                                          sizeof(float2) * (size_t)p->N, sizeof(float2) * (size_t)ch.f, sizeof(float2) * (size_t)l, n, s));
-            const int c0 = (int)((((first_block + mbase + m0) % p->R) * ch.shift) % p->R);
-            HIPCHK(fdc::launch_phase_window(A, A, p->d_wins + ch.win_off, l, p->R, ch.shift, c0, n, s));
-            HIPCHK(fdc::launch_fft(A, (size_t)l, B, T, l, n, true, l / 2, 0, (float)l, p->d_tw, p->ntab, s, nullptr));
-            HIPCHK(fdc::launch_vector_cut(reinterpret_cast<const unsigned char *>(B),
-                                          reinterpret_cast<unsigned char *>(d_out + (size_t)nb_call * ch.out_off + (size_t)(mbase + m0) * ch.lout),
-                                          sizeof(float2) * (size_t)l, sizeof(float2) * (size_t)(l - ch.lout), sizeof(float2) * (size_t)ch.lout, n, s));
-        }
+    const int per = (int)std::max<long long>(1, std::min<long long>(nb, (long long)p->big_pts / ((long long)ngroup * l)));   // blocks per piece
+    const int lout = l - l / p->R;
+    for (int m0 = 0; m0 < nb; m0 += per) {
+        const int n = std::min(per, nb - m0);
+        HIPCHK(fdc::launch_wide_tasks(p->d_wtasks, p->d_chans, d_gids, ngroup, p->R, n, mbase + m0, nb_call, first_block, s));
+        HIPCHK(fdc::launch_extract_wide(spec + (size_t)m0 * p->N, p->N, p->d_wtasks, n * ngroup, l, l - lout, p->d_wins, p->d_big, d_out, p->d_tw, p->ntab, s,
+                                        (float)l));
     }
     return FDC_OK;
 }
@@ -753,8 +757,9 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                    1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
         for (size_t g = 0; g < p->groups.size(); g++) {
             const int l = p->groups[g].first;
-            if (l > fdc::kMaxLdsFft) {
-                const int rcw = channels_wide(p, spec, static_cast<float2 *>(d_out), p->groups[g].second, l, nb, m0, nblocks, first_block, s);
+            if (l > 4096) {
+                const int rcw = channels_wide(p, spec, static_cast<float2 *>(d_out), p->d_groups + p->group_off[g], (int)p->groups[g].second.size(), l, nb, m0,
+                                              nblocks, first_block, s);
                 if (rcw != FDC_OK) return rcw;
             } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
                 HIPCHK(fdc::launch_channels256(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
@@ -1045,8 +1050,9 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
     HIPCHK(fdc::launch_scale(d_full, d_full, n, 1.0f / (float)p->N, s));
     for (size_t g = 0; g < p->groups.size(); g++) {
         const int l = p->groups[g].first;
-        if (l > fdc::kMaxLdsFft) {
-            const int rcw = channels_wide(p, d_full, p->d_out, p->groups[g].second, l, nblocks, 0, nblocks, p->blockcount, s);
+        if (l > 4096) {
+            const int rcw = channels_wide(p, d_full, p->d_out, p->d_groups + p->group_off[g], (int)p->groups[g].second.size(), l, nblocks, 0, nblocks,
+                                          p->blockcount, s);
             if (rcw != FDC_OK) { if (d_owned) (void)hipFree(d_owned); return rcw; }
         } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
             HIPCHK(fdc::launch_channels256(d_full, p->d_out, p->d_chans, p->d_groups + p->group_off[g],

@@ -134,7 +134,10 @@ hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, 
 // one width class above 4096 points (two passes through `tmp`, ntasks * w points; slice * window read by pass A, kept samples
 // written to their places by pass B)
 hipError_t launch_extract_wide(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip, const float2 *wins,
-                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s);
+                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s, float scale = 1.0f);
+// the channels of one width above 4096 bins of a pipeline as such tasks: task m * ngroup + gi = channel group[gi] in block m of the launch group
+hipError_t launch_wide_tasks(ExtractTask *tasks, const ChanDev *chans, const int32_t *group, int ngroup, int R, int nb_chunk, int mbase, int nb_call,
+                             int64_t first_block, hipStream_t s);
 // several width classes (w <= 4096 each) in one launch: class k = tasks [first[k], first[k] + cnt[k]) of width w[k]
 constexpr int kMaxExtractClasses = 12;
 struct ExtractClass { int32_t tile0, task0, ntasks, log2w, log2TC, ld, skip, pad; };

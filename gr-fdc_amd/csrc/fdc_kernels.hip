@@ -546,6 +546,33 @@ __global__ FDC_TILE_BOUNDS(NB) void k_extract(const float2 *__restrict__ spec, i
     extract_tile<NB>((int)blockIdx.x, spec, N, tasks, ntasks, log2w, log2TC, ld, skip, wins, out, tw, twstride);
 }
 
+// Channels wider than 4096 bins of a pipeline as extraction tasks (one per channel and block of the launch group), so that they take the
+// task-addressed two-pass transform of the sinks: slice = bins [f, f + l) of block m's spectrum, window = the channel's table at the
+// block's phase (phase_shifting_windowing_vcc's counter in closed form), output = the channel's stream at block mbase + m.
+__global__ __launch_bounds__(256) void k_wide_tasks(ExtractTask *__restrict__ tasks, const ChanDev *__restrict__ chans, const int32_t *__restrict__ group,
+                                                    int ngroup, int R, int nb_chunk, int mbase, int nb_call, long long first_block)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)nb_chunk * ngroup) return;
+    const int m = (int)(t / ngroup), gi = (int)(t - (long long)m * ngroup);
+    const ChanDev ch = chans[group[gi]];
+    const int cnt = (int)((((first_block + mbase + m) % R) * ch.shift) % R);
+    ExtractTask e{};
+    e.slot = m; e.start = ch.f; e.win_off = ch.win_off + cnt * ch.l;
+    e.out_off = (long long)nb_call * ch.out_off + (long long)(mbase + m) * ch.lout;
+    tasks[t] = e;
+}
+
+hipError_t launch_wide_tasks(ExtractTask *tasks, const ChanDev *chans, const int32_t *group, int ngroup, int R, int nb_chunk, int mbase, int nb_call,
+                             int64_t first_block, hipStream_t s)
+{
+    const long long n = (long long)nb_chunk * ngroup;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wide_tasks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tasks, chans, group, ngroup, R, nb_chunk, mbase, nb_call,
+                       (long long)first_block);
+    return hipGetLastError();
+}
+
 // Several width classes (each up to 4096 points: the one-transform-per-workgroup tiling) in ONE launch: a bank of detected channels
 // has a handful of classes with a few hundred to a few thousand extractions each, none of which fills the device on its own.
 // A workgroup finds its class from the tile ranges.
@@ -797,7 +824,7 @@ hipError_t launch_extract(const float2 *spec, int N, const ExtractTask *tasks, i
 // One width class above 4096 points: the two-pass inverse transform with the slice * window read in pass A and the kept samples
 // written to their landing offsets by pass B.  tmp: ntasks * w points.
 hipError_t launch_extract_wide(const float2 *spec, int N, const ExtractTask *tasks, int ntasks, int w, int skip, const float2 *wins,
-                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s)
+                               float2 *tmp, float2 *out, const float2 *tw, int ntab, hipStream_t s, float scale)
 {
     if (ntasks <= 0) return hipSuccess;
     const BigGeom g = big_geom(w);
@@ -809,7 +836,7 @@ hipError_t launch_extract_wide(const float2 *spec, int N, const ExtractTask *tas
         hipLaunchKernelGGL((k_fft_pass_a<true, 1, true>), ga, dim3(kThreads), g.a.lds_bytes(), s, spec, (size_t)N, tmp, lgN, lgN1, g.a.log2TC,
                            g.a.ld, w / 2, tw, ntab, static_cast<const float2 *>(nullptr), tasks + m0, wins);
         hipLaunchKernelGGL((k_fft_pass_b<true, 1, true>), gb, dim3(kThreads), g.b.lds_bytes(), s, tmp, out, lgN, lgN1, g.b.log2TC, g.b.ld, 0,
-                           1.0f, tw, ntab, tasks + m0, skip);
+                           scale, tw, ntab, tasks + m0, skip);
     }
     return hipGetLastError();
 }

@@ -406,8 +406,8 @@ def test_host_path_sub_batches_staged_and_pinned(oracle, sub):
 
 
 def test_widest_channels_and_no_channels(oracle):
-    """Every channel width up to the whole band: l = 8192 takes the two-tile form of the generic kernels, wider ones the
-    block-by-block form with a two-pass inverse transform; a plan without any channel (spectrum only); an empty call."""
+    """Every channel width up to the whole band: above 4096 bins the channels of one width and all blocks of a launch group are one
+    batch of the task-addressed two-pass inverse transform; a plan without any channel (spectrum only); an empty call."""
     N, R, nb = 32768, 4, 3
     H = N - N // R
     chans = [(100, 8192, 0.7, 0.9), (12000, 4096, 0.5, 0.8), (20000, 2048, 0.9, 1.0), (30000, 8, 0.5, 1.0),
@@ -429,6 +429,20 @@ def test_widest_channels_and_no_channels(oracle):
         p.work(np.zeros(H + 1, np.complex64))                 # not a whole number of items
     with pytest.raises(ValueError):
         G.Pipeline(N, R, [(0, 3, 0.5, 1.0)], max_blocks=1)   # l not a power of two
+
+
+def test_wide_channels_in_pieces(oracle):
+    """Channels above 4096 bins, several of one width, over more blocks than one 32 Mi-point piece of the scratch between the two
+    passes holds (the 32768-wide channel: 1030 blocks = two pieces); every sample of every channel against the oracle."""
+    if G.defaults.get("FDC_FORCE_GENERIC"):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 2, 1030
+    chans = [(0, 32768, 0.8, 0.95), (32768, 8192, 0.88, 1.0), (41060, 8192, 0.7, 0.9), (49152, 16384, 0.88, 1.0), (5000, 1024, 0.88, 1.0)]
+    x = noise(nb * (N - N // R), 123)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
+    out = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb).work(x)
+    for c in range(len(chans)):
+        assert_close(out[c], ref[c], "l=%d" % chans[c][1])
 
 
 def test_fft_vcc_largest_supported_size(oracle):
