@@ -64,9 +64,12 @@ def parse():
     ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum"), default=None,
                     help="diagnostics: fdc_pipeline_cfg.flags FDC_PIPE_NO_BLOCK / NO_POLY / FORCE_GENERIC (the slower forms of the path)")
     ap.add_argument("--input-rings", type=int, default=3,
-                    help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 x 268 MB no input byte of "
-                         "a step can still sit in the 256 MiB memory-side cache when its ring comes round again (1 = the round-1/2 "
-                         "form, where it can)")
+                    help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 rings of 537 MB (2048 blocks of "
+                         "262144 B) no input byte of a step can still sit in the 256 MiB memory-side cache when its ring comes round again "
+                         "(1 = the round-1/2 form with 1024 blocks, where it can)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed launch's output (the `verified` object)")
+    ap.add_argument("--verify-blocks", type=int, default=8, help="blocks of the last timed launch checked against the oracle (first, last, random)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer legs (end_to_end_h2d, end_to_end_h2d_group)")
     ap.add_argument("--one-ring-leg", action="store_true",
                     help="config 2: after the timed region, the same steps on ONE 268 MB ring (the round-1/2 workload, whose input stays in "
                          "the memory-side cache) reported as roofline.one_ring; off by default so that the rocprofv3 average of the dominant "
@@ -314,6 +317,75 @@ def cpu_baseline_sinks(a, N, R, C, x, nb, segments):
             "host": {"cpu_model": model, "nproc": nproc, "cpu_share_of_this_process": share}}
 
 
+def verify_last_launch(torch, np, a, pipe, ring, out, plan, params, N, R, nb, first_block, rank):
+    """Blocks of the output buffer the last timed launch wrote, against the oracle run on the input that launch read."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O          # the checker, after the timed region
+    H = N - N // R
+    k = max(2, min(a.verify_blocks, nb))
+    rng = np.random.default_rng(4242 + rank)
+    blocks = sorted(set([0, nb - 1] + [int(v) for v in rng.integers(0, nb, size=max(0, k - 2))]))
+    chans = list(range(0, len(plan), 16)) or [0]
+    if len(plan) - 1 not in chans:
+        chans.append(len(plan) - 1)
+    sub = [plan[c] for c in chans]
+    worst_l2, worst_mx = 0.0, 0.0
+    for m in blocks:
+        xs = ring[m * H:m * H + N].cpu().numpy()                     # the block as overlap-save forms it: N/R old + H new samples
+        ref, _ = O.channelizer(N, R, 1, sub, xs[N // R:], prefix=xs[:N // R], first_block=first_block + m, nthreads=4)
+        for c, r in zip(chans, ref):
+            lo = params[c][2]
+            o0 = pipe.channel_offset(c, nb) + m * lo
+            got = out[o0:o0 + lo].cpu().numpy()
+            den = float(np.abs(r).max()) or 1.0
+            worst_mx = max(worst_mx, float(np.abs(got - r).max()) / den)
+            worst_l2 = max(worst_l2, float(np.linalg.norm(got - r) / (np.linalg.norm(r) or 1.0)))
+    err = max(worst_l2, worst_mx)
+    return {"blocks": len(blocks), "block_indices": blocks, "channels": len(chans), "max_rel_err": err, "tolerance": 1e-5,
+            "what": "output of the last timed launch vs the oracle on the ring it read (max over rel. L2 and max-abs/max per block and channel)"}
+
+
+def host_entry_leg(G, np, N, R, plan, sum_lout, devices, blocks_per_member):
+    """fdc_pipeline_work (one device) or fdc_pipeline_group_work (several) on pinned caller buffers: Msamples/s in, PCIe included."""
+    import ctypes as ct
+    H = N - N // R
+    k = len(devices)
+    nbh = blocks_per_member * k
+    if k == 1:
+        ph = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nbh, device_id=devices[0])
+    else:
+        ph = G.PipelineGroup(N, R, plan, devices, windowtype=1, max_blocks=nbh)
+    rng_h = np.random.default_rng(7)
+    xh = np.empty(nbh * H, np.complex64)
+    for b0 in range(0, nbh, 64):                                        # generated in pieces: the complex128 temporaries stay small
+        n = min(64, nbh - b0) * H
+        xh[b0 * H:b0 * H + n] = (rng_h.standard_normal(n) + 1j * rng_h.standard_normal(n)).astype(np.complex64)
+    pool = np.zeros(nbh * sum_lout, np.complex64)
+    ptrs, off = (ct.c_void_p * len(plan))(), 0
+    for c, lo in enumerate(ph.lout):
+        ptrs[c] = pool.ctypes.data + 8 * off
+        off += nbh * lo
+    G.register_host(xh); G.register_host(pool)
+    try:
+        for _ in range(2):
+            ph.work_raw(xh.ctypes.data, nbh, ptrs)
+        th = time.perf_counter()
+        reps_h = 8
+        for _ in range(reps_h):
+            ph.work_raw(xh.ctypes.data, nbh, ptrs)
+        dth = (time.perf_counter() - th) / reps_h
+        res = {"value": round(nbh * H / dth / 1e6, 3), "unit": "Msamples/s", "blocks_per_call": nbh, "ms_per_call": round(dth * 1e3, 3),
+               "devices": list(devices),
+               "entry": ("fdc_pipeline_work" if k == 1 else "fdc_pipeline_group_work: one call cut into %d spans, one per member" % k) +
+                        " (H2D of the input + kernels + D2H of every channel output per call; buffers pinned with fdc_host_register)"}
+        if k > 1:
+            res["spans_of_a_call"] = ph.last_spans()
+    finally:
+        G.unregister_host(xh); G.unregister_host(pool)
+        ph.close()
+    return res
+
+
 def main():
     a = parse()
     dry = os.environ.get("FDC_BENCH_DRYRUN") == "1"      # launcher rehearsal on a CPU box: ranks, barrier, MAX — no GPU work
@@ -522,6 +594,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # The line certifies itself: blocks of the LAST timed launch's output (first, last and random ones; every 16th channel) and the
+    # matching piece of the input ring it read go to the host and through the oracle (the checker; nothing of it is timed).
+    verified = None
+    if sinks is None and not a.no_verify:
+        verified = verify_last_launch(torch, np, a, pipe, rings[(turn[0] - 1) % len(rings)], out, plan, params, N, R, nb, first_block, rank)
+        if dist is not None:
+            t = torch.tensor([verified["max_rel_err"]], device="cpu" if rehearse else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            verified["max_rel_err"] = float(t.item())
+            verified["ranks"] = world
+    elif sinks is not None:
+        verified = {"blocks": 0, "note": "sink configurations are not re-checked inside bench.py: tests/test_fullsize_gpu.py compares every PDU "
+                                         "of this workload at this size with the oracle"}
+
     # configs[1] only: the same steps again on ONE ring (rounds 1-2 measured this: the ring then stays in the 256 MiB memory-side
     # cache from step to step) — reported beside the headline for continuity, never as `value`
     one_ring = None
@@ -547,34 +633,25 @@ def main():
                     "note": "input re-read from the memory-side cache (268 MB ring, 256 MiB cache): the round-1/2 default"}
     # "also report an end-to-end number with H2D": the host-buffer entry sync_block::work() calls
     # (fdc_pipeline_work: input H2D, kernels, outputs D2H), 256 blocks per call, caller buffers pinned once with
-    # fdc_host_register.  PCIe-bound; never `value`.
-    end_to_end = None
-    if sinks is None and a.config == 2 and world == 1 and not a.no_kernel_timing:
-        import ctypes as ct
-        nbh = 256
-        ph = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nbh, device_id=local)
-        rng_h = np.random.default_rng(7)
-        xh = (rng_h.standard_normal(nbh * H) + 1j * rng_h.standard_normal(nbh * H)).astype(np.complex64)
-        pool = np.zeros(nbh * sum_lout, np.complex64)
-        ptrs, off = (ct.c_void_p * len(plan))(), 0
-        for c, lo in enumerate(ph.lout):
-            ptrs[c] = pool.ctypes.data + 8 * off
-            off += nbh * lo
-        G.register_host(xh); G.register_host(pool)
-        try:
-            for _ in range(2):
-                ph.work_raw(xh.ctypes.data, nbh, ptrs)
-            th = time.perf_counter()
-            reps_h = 8
-            for _ in range(reps_h):
-                ph.work_raw(xh.ctypes.data, nbh, ptrs)
-            dth = (time.perf_counter() - th) / reps_h
-            end_to_end = {"value": round(nbh * H / dth / 1e6, 3), "unit": "Msamples/s", "blocks_per_call": nbh, "ms_per_call": round(dth * 1e3, 3),
-                          "entry": "fdc_pipeline_work (H2D of the input + kernels + D2H of every channel output per call; buffers "
-                                   "pinned with fdc_host_register)"}
-        finally:
-            G.unregister_host(xh); G.unregister_host(pool)
-            del ph
+    # fdc_host_register.  PCIe-bound; never `value`.  Every rank runs it on its own device at the same time (N ranks = N PCIe
+    # links); with one rank the same call also goes through the multi-device handle over every visible device.
+    # (Its sub-batches of 32 blocks take the tiled kernels, not the block kernel: the rocprofv3 average of the dominant kernel over
+    # this command is still the average of the settle / warm-up / timed launches.)
+    end_to_end, end_to_end_group = None, None
+    if sinks is None and a.config == 2 and not a.no_end_to_end and not a.no_kernel_timing:
+        fence()
+        end_to_end = host_entry_leg(G, np, N, R, plan, sum_lout, [local], 256)
+        if dist is not None:
+            t = torch.tensor([end_to_end["value"]], device="cpu" if rehearse else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            end_to_end["per_rank_value_rank0"] = end_to_end["value"]
+            end_to_end["value"] = round(float(t.item()), 3)
+            end_to_end["ranks"] = world
+        elif not rehearse:
+            devs = list(range(ndev)) if ndev > 1 else [0, 0]
+            end_to_end_group = host_entry_leg(G, np, N, R, plan, sum_lout, devs, 256)
+            if ndev == 1:
+                end_to_end_group["note"] = "one GPU visible: two VIRTUAL members on device 0 share its one PCIe link (dispatcher exercised, no gain expected)"
     msps = world * nb * H * a.steps / dt / 1e6
     chunk = pipe.chunk_blocks()
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
@@ -613,6 +690,13 @@ def main():
                    "blocklen": N, "relinvovl": R, "channels": C, "blocks_per_step_per_gpu": nb,
                    "input_rings": len(rings) if sinks is None else 1,
                    "settle_ms": a.settle_ms, "settle_steps": nsettle,
+                   # what ran untimed in front of the K timed steps: the running-in (the device leaves its idle clocks only under load)
+                   # plus the W warm-up steps the command line names
+                   "effective_warmup_steps": nsettle + a.warmup,
+                   # revision of the headline workload: 1 = rounds 1-2 (1024 blocks per step on ONE 268 MB ring, input re-read from the
+                   # memory-side cache), 2 = round 3 on (2048 blocks per step, three 537 MB rings in rotation: cache-cold input, 150 ms
+                   # running-in).  Lines of different revisions are not comparable.
+                   "workload_rev": 2,
                    "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
         # frac: the contract's definition (all algorithmic bytes of a launch over the dominant kernel's launch time);
         # pipeline_frac: SURVEY.md §8d's headline, algorithmic bytes over the WHOLE step.  With the one-kernel path (3) the
@@ -630,8 +714,12 @@ def main():
                      "frac_of_achievable_6300": round(achieved / 6300.0, 4),
                      "pipeline_frac_of_achievable_6300": round(pipe_gbs / 6300.0, 4)},
     }
+    if verified is not None:
+        res["verified"] = verified
     if end_to_end is not None:
         res["end_to_end_h2d"] = end_to_end
+    if end_to_end_group is not None:
+        res["end_to_end_h2d_group"] = end_to_end_group
     if sinks is not None:
         res["config"]["pdus_per_step"] = round(extracted[1] / max(1, extracted[2]), 1)
         res["config"]["extracted_samples_per_step"] = round(extracted[0] / max(1, extracted[2]), 1)
@@ -649,6 +737,8 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+    if verified is not None and verified.get("blocks", 0) > 0 and not verified["max_rel_err"] <= 1e-5:
+        raise SystemExit("bench.py: the last timed launch's output differs from the oracle: max rel err %.3g" % verified["max_rel_err"])
 
 
 if __name__ == "__main__":

@@ -79,6 +79,18 @@ SYMBOLS = {
     "fdc_pipeline_channel_lout": (C.c_int32, [_vp, C.c_int]),
     "fdc_pipeline_work": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
     "fdc_pipeline_work_real": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_work_span": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_work_span_real": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_group_create": (C.c_int, [C.POINTER(fdc_pipeline_cfg), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fdc_pipeline_group_destroy": (None, [_vp]),
+    "fdc_pipeline_group_work": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_group_work_real": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdc_pipeline_group_reset": (None, [_vp]),
+    "fdc_pipeline_group_size": (C.c_int32, [_vp]),
+    "fdc_pipeline_group_member": (_vp, [_vp, C.c_int]),
+    "fdc_pipeline_group_device": (C.c_int32, [_vp, C.c_int]),
+    "fdc_pipeline_group_member_max_blocks": (C.c_int32, [_vp]),
+    "fdc_pipeline_group_last_spans": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int]),
     "fdc_host_register": (C.c_int, [_vp, C.c_size_t]),
     "fdc_host_unregister": (C.c_int, [_vp]),
     "fdc_pipeline_reset": (None, [_vp]),

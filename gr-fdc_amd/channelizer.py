@@ -252,6 +252,94 @@ class Pipeline:
             pass
 
 
+class PipelineGroup:
+    """fdc_pipeline_group handle: one work() spread over several devices (contiguous spans of the call's blocks, one per
+    member, run concurrently).  devices: HIP ordinals, repeats allowed (virtual members on one GPU).  Same work() / work_real()
+    as Pipeline; state (overlap history, block counter) is kept once, by the group."""
+
+    def __init__(self, blocklen, relinvovl, channels, devices, windowtype=WINDOWTYPES.HANN, max_blocks=64, min_span_blocks=0,
+                 chunk_blocks=0, keep_spectrum=False, flags=None, min_block_launch=None, host_sub_blocks=None):
+        self._h = C.c_void_p()
+        self.N, self.R = int(blocklen), int(relinvovl)
+        self.channels = [(int(f), int(l), float(p), float(s)) for (f, l, p, s) in channels]
+        self.devices = [int(d) for d in devices]
+        arr = (_lib.fdc_channel * max(1, len(self.channels)))()
+        for i, (f, l, p, s) in enumerate(self.channels):
+            arr[i].f, arr[i].l, arr[i].passbw, arr[i].stopbw = f, l, p, s
+        dflags, dmin, dsub = _default_cfg_fields()
+        cfg = _lib.fdc_pipeline_cfg(0, self.N, self.R, int(windowtype), len(self.channels), arr,
+                                    int(max_blocks), int(chunk_blocks), int(bool(keep_spectrum)),
+                                    dflags if flags is None else int(flags), dmin if min_block_launch is None else int(min_block_launch),
+                                    dsub if host_sub_blocks is None else int(host_sub_blocks))
+        devs = (C.c_int32 * max(1, len(self.devices)))(*self.devices)
+        rc = _lib.lib().fdc_pipeline_group_create(C.byref(cfg), devs, len(self.devices), int(min_span_blocks), C.byref(self._h))
+        if rc == -1:
+            raise ValueError(_lib.lib().fdc_last_error().decode())
+        _lib.check(rc)
+        self.max_blocks = int(max_blocks)
+        self.keep_spectrum = bool(keep_spectrum)
+        self.ovl = self.N // self.R if self.N >= self.R else 0
+        self.H = self.N - self.ovl
+        m0 = _lib.lib().fdc_pipeline_group_member(self._h, 0)
+        self.lout = [_lib.lib().fdc_pipeline_channel_lout(m0, c) for c in range(len(self.channels))]
+
+    def _run(self, fn, x, nb, want_spectrum, outs):
+        if outs is None:
+            outs = [np.empty(nb * lo, dtype=np.complex64) for lo in self.lout]
+        ptrs = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data for o in outs])
+        spec = np.empty(nb * self.N, dtype=np.complex64) if want_spectrum else None
+        _lib.check(fn(self._h, x.ctypes.data, nb, ptrs, spec.ctypes.data if spec is not None else None))
+        return (outs, spec) if want_spectrum else outs
+
+    def work(self, x, want_spectrum=False, outs=None):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if x.size % self.H:
+            raise ValueError("input must be a whole number of (N - N/R)-sample items")
+        return self._run(_lib.lib().fdc_pipeline_group_work, x, x.size // self.H, want_spectrum, outs)
+
+    def work_real(self, x, want_spectrum=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.size % self.H:
+            raise ValueError("input must be a whole number of (N - N/R)-sample items")
+        return self._run(_lib.lib().fdc_pipeline_group_work_real, x, x.size // self.H, want_spectrum, None)
+
+    def work_raw(self, in_ptr, nblocks, out_ptrs):
+        return _lib.check(_lib.lib().fdc_pipeline_group_work(self._h, in_ptr, int(nblocks), out_ptrs, None))
+
+    def reset(self):
+        _lib.lib().fdc_pipeline_group_reset(self._h)
+
+    def size(self):
+        return int(_lib.lib().fdc_pipeline_group_size(self._h))
+
+    def member_path(self, i=0):
+        return int(_lib.lib().fdc_pipeline_path(_lib.lib().fdc_pipeline_group_member(self._h, i)))
+
+    def path(self):
+        return self.member_path(0)
+
+    def member_max_blocks(self):
+        return int(_lib.lib().fdc_pipeline_group_member_max_blocks(self._h))
+
+    def last_spans(self):
+        """[(first_block, nblocks)] per member for the last call (nblocks 0 = the member was idle)."""
+        n = self.size()
+        fb, nb = (C.c_int64 * n)(), (C.c_int32 * n)()
+        _lib.check(_lib.lib().fdc_pipeline_group_last_spans(self._h, fb, nb, n))
+        return [(int(fb[i]), int(nb[i])) for i in range(n)]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().fdc_pipeline_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrequencyDomainChannelizer:
     """Same constructor as FDC.FrequencyDomainChannelizer (python/FrequencyDomainChannelizer.py:46-60).
 
@@ -272,7 +360,7 @@ class FrequencyDomainChannelizer:
                  act_det_deactivation_delay, minchanflankpuffer, verbose,
                  pow_act_deactivation_delay,
                  pow_act_maxblocks, act_det_maxblocks,
-                 debug, device_id=0, max_blocks=64):
+                 debug, device_id=0, max_blocks=64, devices=None):
         self.verbose = int(verbose)
         self.itemsize = inptype
         self.debug = bool(debug)
@@ -340,10 +428,18 @@ class FrequencyDomainChannelizer:
                                det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id,
                                det_variant=1,      # the hier block instantiates SegmentDetection (:25, :261-278)
                                verbose=self.verbose)
-        self.pipeline = Pipeline(self.blocksize, self.relinvovl,
-                                 [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
-                                 windowtype=int(windowtype), max_blocks=max_blocks, device_id=device_id,
-                                 keep_spectrum=self.debug or self.sinks is not None)
+        # devices = [ordinals]: the throughput chain of one work() call spread over several GPUs (fdc_pipeline_group); the sink
+        # blocks stay on ONE device's spectrum, so a hier block with sinks keeps the single-device handle
+        if devices is not None and len(devices) > 1 and self.sinks is None and self.inpveclen == 1:
+            self.pipeline = PipelineGroup(self.blocksize, self.relinvovl,
+                                          [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params], devices,
+                                          windowtype=int(windowtype), max_blocks=max_blocks, keep_spectrum=self.debug)
+        else:
+            self.pipeline = Pipeline(self.blocksize, self.relinvovl,
+                                     [(f, l, p, s) for (f, l, _lo, p, s) in self.channel_params],
+                                     windowtype=int(windowtype), max_blocks=max_blocks,
+                                     device_id=devices[0] if devices else device_id,
+                                     keep_spectrum=self.debug or self.sinks is not None)
         self.N_throughput_channelizers = len(self.channel_params)
         self.messages = []          # PDUs published on "msgout" by the last work() call
 
@@ -393,6 +489,8 @@ class FrequencyDomainChannelizer:
             if self.sinks is not None:
                 raise ValueError("real input with sink blocks is not supported")
             res = self.pipeline.work_real(samples, want_spectrum=self.debug)
+        elif self.inpveclen == 1 and self.sinks is None:
+            res = self.pipeline.work(samples, want_spectrum=self.debug)
         elif self.inpveclen == 1:
             res = self.pipeline.work(samples, want_spectrum=self.debug, sinks=self.sinks)
         else:       # the front end (stream_to_vector, overlap_save, fft_vcc) is the caller's: :201, :284-290

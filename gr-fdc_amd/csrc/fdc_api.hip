@@ -3,6 +3,7 @@
 #include "../../include/fdc_amd.h"
 #include "fdc_kernels.h"
 #include "fdc_window.hpp"
+#include "fdc_guard.hpp"
 
 #include <algorithm>
 #include <array>
@@ -38,6 +39,10 @@ int fail(int code, const char *fmt, ...)
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) return fail(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// body of an extern "C" entry: nothing thrown inside crosses the C boundary (fdc_guard.hpp)
+#define FDC_ENTRY(name) return fdc::guarded(name, [&]() -> int {
+#define FDC_ENTRY_END });
 
 bool ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -201,6 +206,7 @@ int fdc_device_count(void)
 
 int fdc_selftest_devices(void)
 {
+    FDC_ENTRY("fdc_selftest_devices")
     const int ndev = fdc_device_count();
     if (ndev <= 0) return fail(FDC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     constexpr int N = 65536, R = 2, C = 256, NB = 96, H = N - N / R, LOUT = 128;
@@ -213,10 +219,22 @@ int fdc_selftest_devices(void)
     std::vector<void *> outs((size_t)C);
     for (int c = 0; c < C; c++) outs[(size_t)c] = out[(size_t)c].data();
     uint64_t ref = 0;
+    auto checksum = [&](double *energy) {                          // FNV-1a over every output byte
+        uint64_t h = 1469598103934665603ull;
+        *energy = 0.0;
+        for (int c = 0; c < C; c++) {
+            const unsigned char *b = reinterpret_cast<const unsigned char *>(out[(size_t)c].data());
+            for (size_t i = 0; i < out[(size_t)c].size() * sizeof(float); i++) { h ^= b[i]; h *= 1099511628211ull; }
+            for (float v : out[(size_t)c]) *energy += (double)v * v;
+        }
+        return h;
+    };
+    fdc_pipeline_cfg cfg{};
+    cfg.blocklen = N; cfg.relinvovl = R; cfg.windowtype = FDC_WIN_HANN; cfg.nchannels = C; cfg.channels = ch.data();
+    cfg.max_blocks = NB; cfg.host_sub_blocks = NB;
+    cfg.min_block_launch = 1;          // the one-kernel form whatever the launch length: the group's members get NB / ndev blocks each
     for (int d = 0; d < ndev; d++) {
-        fdc_pipeline_cfg cfg{};
-        cfg.device_id = d; cfg.blocklen = N; cfg.relinvovl = R; cfg.windowtype = FDC_WIN_HANN; cfg.nchannels = C; cfg.channels = ch.data();
-        cfg.max_blocks = NB; cfg.host_sub_blocks = NB;
+        cfg.device_id = d;
         fdc_pipeline *p = nullptr;
         int rc = fdc_pipeline_create(&cfg, &p);
         if (rc != FDC_OK) return fail(rc, "selftest: device %d: create failed: %s", d, std::string(g_err).c_str());
@@ -224,32 +242,53 @@ int fdc_selftest_devices(void)
         rc = fdc_pipeline_work(p, x.data(), NB, outs.data(), nullptr);
         fdc_pipeline_destroy(p);
         if (rc != NB) return fail(rc < 0 ? rc : FDC_ERR_HIP, "selftest: device %d: work failed: %s", d, std::string(g_err).c_str());
-        uint64_t h = 1469598103934665603ull;                    // FNV-1a over every output byte
         double energy = 0.0;
-        for (int c = 0; c < C; c++) {
-            const unsigned char *b = reinterpret_cast<const unsigned char *>(out[(size_t)c].data());
-            for (size_t i = 0; i < out[(size_t)c].size() * sizeof(float); i++) { h ^= b[i]; h *= 1099511628211ull; }
-            for (float v : out[(size_t)c]) energy += (double)v * v;
-        }
+        const uint64_t h = checksum(&energy);
         if (!(energy > 0.0)) return fail(FDC_ERR_HIP, "selftest: device %d produced no output", d);
         if (d == 0) ref = h;
         else if (h != ref) return fail(FDC_ERR_HIP, "selftest: device %d differs from device 0 (checksum %016llx vs %016llx)", d,
                                        (unsigned long long)h, (unsigned long long)ref);
     }
+    // the multi-device handle over ALL visible devices (one device: two virtual members on it), the same call in two pieces so
+    // that the second piece's first span takes its halo from the group's history: one work() spread over the node must give
+    // device 0's bytes
+    {
+        std::vector<int32_t> devs;
+        for (int d = 0; d < std::max(ndev, 2); d++) devs.push_back(d % ndev);
+        fdc_pipeline_group *g = nullptr;
+        int rc = fdc_pipeline_group_create(&cfg, devs.data(), (int)devs.size(), 4, &g);
+        if (rc != FDC_OK) return fail(rc, "selftest: group over %d device(s): create failed: %s", ndev, std::string(g_err).c_str());
+        for (auto &o : out) std::fill(o.begin(), o.end(), 0.0f);
+        const int n1 = NB / 3, n2 = NB - n1;
+        std::vector<void *> outs2((size_t)C);
+        for (int c = 0; c < C; c++) outs2[(size_t)c] = out[(size_t)c].data() + (size_t)2 * n1 * LOUT;
+        rc = fdc_pipeline_group_work(g, x.data(), n1, outs.data(), nullptr);
+        if (rc == n1) rc = fdc_pipeline_group_work(g, x.data() + (size_t)2 * n1 * H, n2, outs2.data(), nullptr);
+        fdc_pipeline_group_destroy(g);
+        if (rc != n2) return fail(rc < 0 ? rc : FDC_ERR_HIP, "selftest: group over %d device(s): work failed: %s", ndev, std::string(g_err).c_str());
+        double energy = 0.0;
+        const uint64_t h = checksum(&energy);
+        if (h != ref) return fail(FDC_ERR_HIP, "selftest: the group over %d device(s) differs from device 0 (checksum %016llx vs %016llx)", ndev,
+                                  (unsigned long long)h, (unsigned long long)ref);
+    }
     return ndev;
+    FDC_ENTRY_END
 }
 
 int fdc_window_table(int windowtype, int blocklen, float passbw, float stopbw, int numphasestates, int step,
                      int normalize, float *w)
 {
+    FDC_ENTRY("fdc_window_table")
     if (blocklen < 1 || numphasestates < 1 || !w) return fail(FDC_ERR_INVALID_ARGUMENT, "bad window table arguments");
     fdc::window_table(windowtype, blocklen, passbw, stopbw, numphasestates, step, normalize != 0,
                       reinterpret_cast<std::complex<float> *>(w));
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_host_register(void *ptr, size_t bytes)
 {
+    FDC_ENTRY("fdc_host_register")
     if (!ptr || !bytes) return fail(FDC_ERR_INVALID_ARGUMENT, "fdc_host_register: empty range");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FDC_ERR_NO_DEVICE, "no HIP device visible");
@@ -261,10 +300,12 @@ int fdc_host_register(void *ptr, size_t bytes)
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_reg.push_back(HostRange{a, a + bytes, reinterpret_cast<uintptr_t>(dev)});
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_host_unregister(void *ptr)
 {
+    FDC_ENTRY("fdc_host_unregister")
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -274,6 +315,7 @@ int fdc_host_unregister(void *ptr)
     }
     HIPCHK(hipHostUnregister(ptr));
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 void fdc_pipeline_destroy(fdc_pipeline *p)
@@ -299,6 +341,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
 
 int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
 {
+    FDC_ENTRY("fdc_pipeline_create")
     if (!cfg || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     const int N = cfg->blocklen, R = cfg->relinvovl;
@@ -320,6 +363,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     if (rc != FDC_OK) return rc;
 
     fdc_pipeline *p = new fdc_pipeline();
+    struct Owner { fdc_pipeline *p; ~Owner() { if (p) fdc_pipeline_destroy(p); } } owner{p};   // error returns and exceptions free the handle
     p->cfg = *cfg; p->cfg.channels = nullptr;
     p->N = N; p->R = R; p->ovl = N / R; p->H = N - p->ovl; p->C = cfg->nchannels;
 
@@ -429,9 +473,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
         if (_e != hipSuccess) {                                                                 \
-            int _rc = fail(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-            fdc_pipeline_destroy(p);                                                            \
-            return _rc;                                                                         \
+            return fail(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
         }                                                                                       \
     } while (0)
 
@@ -593,8 +635,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)(p->fwd_block ? std::min(chunk, p->block_min) : chunk) * N));
     CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
 #undef CHK_OR_FREE
+    owner.p = nullptr;
     *out = p;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int64_t fdc_pipeline_input_samples(const fdc_pipeline *p, int nblocks) { return p ? (int64_t)nblocks * p->H : 0; }
@@ -622,6 +666,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 
 int fdc_pipeline_synchronize(fdc_pipeline *p)
 {
+    FDC_ENTRY("fdc_pipeline_synchronize")
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     HIPCHK(hipSetDevice(p->cfg.device_id));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -639,16 +684,19 @@ int fdc_pipeline_synchronize(fdc_pipeline *p)
             }
     }
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable)
 {
+    FDC_ENTRY("fdc_pipeline_enable_timing")
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     p->timing = enable != 0;
     p->timing_stride = enable > 1 ? enable : 1;
     p->timing_seq = 0;
     p->ev_used = 0; p->ev_spans.clear();
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 static int get_event(fdc_pipeline *p, size_t *idx)
@@ -683,6 +731,7 @@ static int channels_wide(fdc_pipeline *p, const float2 *spec, float2 *d_out, con
 int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
                                 void *d_out, void *d_spectrum, void *stream)
 {
+    FDC_ENTRY("fdc_pipeline_process_device")
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0 || first_block < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative block count/index");
     if (nblocks == 0) return FDC_OK;
@@ -781,10 +830,12 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
     }
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
 {
+    FDC_ENTRY("fdc_pipeline_last_kernel_ms")
     if (!p || !ms || n < 4) return fail(FDC_ERR_INVALID_ARGUMENT, "need room for 4 values");
     ms[0] = ms[1] = ms[2] = 0.f;
     ms[3] = (float)p->ev_spans.size();
@@ -800,6 +851,7 @@ int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
     }
     p->ev_used = 0; p->ev_spans.clear();
     return 4;
+    FDC_ENTRY_END
 }
 
 void fdc_pipeline_reset(fdc_pipeline *p)
@@ -846,8 +898,10 @@ static int work_io_setup(fdc_pipeline *p)
 // place (input: one async copy; outputs: one scatter kernel storing straight into the caller's per-channel buffers).
 // Pageable input is copied by the runtime's pin-on-the-fly path from a feeder thread; pageable outputs come back
 // through two pinned staging slots and a CPU copy on this thread.
+// span: the call is one contiguous span of a longer stream handed over by a dispatcher (fdc_pipeline_work_span): the history comes
+// from `halo` (N/R samples, NULL = zeros) and the block counter from `first_block` instead of from the handle.
 static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
-                              float2 *d_spec_dst)
+                              float2 *d_spec_dst, bool span = false, const void *halo = nullptr, int64_t first_block = 0)
 {
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
@@ -861,6 +915,12 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
     hipStream_t s = p->stream;
     const size_t nin = (size_t)nblocks * p->H;
     const float2 *hin = static_cast<const float2 *>(in);
+    if (span) {
+        // every kernel of the call is enqueued on s behind this copy; the previous call ended with s drained
+        if (halo) HIPCHK(hipMemcpyAsync(p->d_ring, halo, sizeof(float2) * (size_t)p->ovl, hipMemcpyHostToDevice, s));
+        else HIPCHK(hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, s));
+        p->blockcount = first_block;
+    }
 
     // spectrum wanted (debug port / sinks): every sub-batch writes its part of one whole-call buffer
     float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
@@ -976,12 +1036,24 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
 
 int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
 {
+    FDC_ENTRY("fdc_pipeline_work")
     return pipeline_work_impl(p, in, nblocks, outs, spectrum, nullptr);
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_work_span(fdc_pipeline *p, const void *halo, const void *in, int64_t first_block, int nblocks, void *const *outs,
+                           void *spectrum)
+{
+    FDC_ENTRY("fdc_pipeline_work_span")
+    if (first_block < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative block index");
+    return pipeline_work_impl(p, in, nblocks, outs, spectrum, nullptr, true, halo, first_block);
+    FDC_ENTRY_END
 }
 
 // Real input: the float items are copied to the device and widened there into the complex ring (imaginary part 0); the
 // rest of the call is the one-stream form of the complex entry.
-int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+static int pipeline_work_real_impl(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum, bool span,
+                                   const void *halo, int64_t first_block)
 {
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
@@ -994,12 +1066,20 @@ int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *c
     if (rc != FDC_OK) return rc;
     hipStream_t s = p->stream;
     const size_t nin = (size_t)nblocks * p->H;
-    if (!p->d_real) HIPCHK(hipMalloc(&p->d_real, sizeof(float) * (size_t)p->cfg.max_blocks * p->H));
+    // d_real: [N/R history samples of a span call][max_blocks*H new samples]
+    if (!p->d_real) HIPCHK(hipMalloc(&p->d_real, sizeof(float) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
     float2 *d_specfull = nullptr;
     if (spectrum) HIPCHK(hipMalloc(&d_specfull, sizeof(float2) * (size_t)nblocks * p->N));
     struct Guard { float2 *p; ~Guard() { if (p) (void)hipFree(p); } } guard{d_specfull};
-    HIPCHK(hipMemcpyAsync(p->d_real, in, sizeof(float) * nin, hipMemcpyHostToDevice, s));
-    HIPCHK(fdc::launch_real_to_complex(p->d_real, p->d_ring + p->ovl, nin, s));
+    HIPCHK(hipMemcpyAsync(p->d_real + p->ovl, in, sizeof(float) * nin, hipMemcpyHostToDevice, s));
+    if (span) {
+        if (halo) HIPCHK(hipMemcpyAsync(p->d_real, halo, sizeof(float) * (size_t)p->ovl, hipMemcpyHostToDevice, s));
+        else HIPCHK(hipMemsetAsync(p->d_real, 0, sizeof(float) * (size_t)p->ovl, s));
+        HIPCHK(fdc::launch_real_to_complex(p->d_real, p->d_ring, (size_t)p->ovl + nin, s));
+        p->blockcount = first_block;
+    } else {
+        HIPCHK(fdc::launch_real_to_complex(p->d_real + p->ovl, p->d_ring + p->ovl, nin, s));
+    }
     rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, d_specfull, s);
     if (rc != FDC_OK) return rc;
     for (int c = 0; c < p->C; c++)
@@ -1013,9 +1093,26 @@ int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *c
     return nblocks;
 }
 
+int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    FDC_ENTRY("fdc_pipeline_work_real")
+    return pipeline_work_real_impl(p, in, nblocks, outs, spectrum, false, nullptr, 0);
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_work_span_real(fdc_pipeline *p, const void *halo, const void *in, int64_t first_block, int nblocks, void *const *outs,
+                                void *spectrum)
+{
+    FDC_ENTRY("fdc_pipeline_work_span_real")
+    if (first_block < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative block index");
+    return pipeline_work_real_impl(p, in, nblocks, outs, spectrum, true, halo, first_block);
+    FDC_ENTRY_END
+}
+
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                             fdc_sinks *sinks)
 {
+    FDC_ENTRY("fdc_pipeline_work_sinks")
     if (!sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null sinks handle");
     if (p && (fdc_sinks_blocklen(sinks) != p->N || nblocks > fdc_sinks_max_blocks(sinks)))
         return fail(FDC_ERR_INVALID_ARGUMENT, "sinks were created for blocklen %d / %d blocks per call, pipeline call has %d / %d",
@@ -1025,11 +1122,13 @@ int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *
     if (rc < 0) return rc;
     const int rs = fdc_sinks_work_device(sinks, nblocks);
     return rs < 0 ? rs : rc;
+    FDC_ENTRY_END
 }
 
 int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                                fdc_sinks *sinks)
 {
+    FDC_ENTRY("fdc_pipeline_work_spectrum")
     // hier block with inpveclen > 1 (py:284-290): items are spectra already; only multiply_const(1/N) and the channel /
     // sink branches remain.  The front-end state (overlap history) is untouched; the block counter advances.
     if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
@@ -1077,6 +1176,7 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
         if (rs < 0) return rs;
     }
     return nblocks;
+    FDC_ENTRY_END
 }
 
 /* ---------------- single-block faces ---------------- */
@@ -1086,6 +1186,7 @@ struct fdc_overlap_save {
 
 int fdc_overlap_save_create(int device_id, int itemsize, int outputlen, int overlaplen, fdc_overlap_save **out)
 {
+    FDC_ENTRY("fdc_overlap_save_create")
     if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (itemsize < 1 || outputlen < 1 || overlaplen < 0 || overlaplen >= outputlen)
@@ -1097,10 +1198,12 @@ int fdc_overlap_save_create(int device_id, int itemsize, int outputlen, int over
     HIPCHK(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
     *out = b;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_overlap_save_work(fdc_overlap_save *b, const void *in, int nitems, void *out)
 {
+    FDC_ENTRY("fdc_overlap_save_work")
     if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     HIPCHK(hipSetDevice(b->dev));
@@ -1120,6 +1223,7 @@ int fdc_overlap_save_work(fdc_overlap_save *b, const void *in, int nitems, void 
     if (ovb) HIPCHK(hipMemcpyAsync(b->d_ring, b->d_ring + inb * nitems, ovb, hipMemcpyDeviceToDevice, b->s));
     HIPCHK(hipStreamSynchronize(b->s));
     return nitems;
+    FDC_ENTRY_END
 }
 
 void fdc_overlap_save_destroy(fdc_overlap_save *b)
@@ -1136,6 +1240,7 @@ struct fdc_vector_cut {
 
 int fdc_vector_cut_create(int device_id, int itemsize, int veclen, int offset, int blocklen, fdc_vector_cut **out)
 {
+    FDC_ENTRY("fdc_vector_cut_create")
     if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (itemsize < 1 || veclen < 1 || blocklen < 1 || offset < 0 || offset + blocklen > veclen)
@@ -1145,10 +1250,12 @@ int fdc_vector_cut_create(int device_id, int itemsize, int veclen, int offset, i
     HIPCHK(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
     *out = b;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_vector_cut_work(fdc_vector_cut *b, const void *in, int nitems, void *out)
 {
+    FDC_ENTRY("fdc_vector_cut_work")
     if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     HIPCHK(hipSetDevice(b->dev));
@@ -1164,6 +1271,7 @@ int fdc_vector_cut_work(fdc_vector_cut *b, const void *in, int nitems, void *out
     HIPCHK(hipMemcpyAsync(out, b->d_out, outb * nitems, hipMemcpyDeviceToHost, b->s));
     HIPCHK(hipStreamSynchronize(b->s));
     return nitems;
+    FDC_ENTRY_END
 }
 
 void fdc_vector_cut_destroy(fdc_vector_cut *b)
@@ -1181,6 +1289,7 @@ struct fdc_phase_window {
 int fdc_phase_window_create(int device_id, int blocklen, int numphasestates, int shifts, float passbw, float stopbw,
                             int windowtype, fdc_phase_window **out)
 {
+    FDC_ENTRY("fdc_phase_window_create")
     if (!out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     // lib/phase_shifting_windowing_vcc_impl.cc:46-53
@@ -1198,10 +1307,12 @@ int fdc_phase_window_create(int device_id, int blocklen, int numphasestates, int
     HIPCHK(hipMemcpy(b->d_win, w.data(), sizeof(float2) * w.size(), hipMemcpyHostToDevice));
     *out = b;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_phase_window_work(fdc_phase_window *b, const void *in, int nitems, void *out)
 {
+    FDC_ENTRY("fdc_phase_window_work")
     if (!b) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     HIPCHK(hipSetDevice(b->dev));
@@ -1218,6 +1329,7 @@ int fdc_phase_window_work(fdc_phase_window *b, const void *in, int nitems, void 
     HIPCHK(hipStreamSynchronize(b->s));
     b->counter = (int)(((long long)b->counter + (long long)(nitems % b->R) * b->shift) % b->R);
     return nitems;
+    FDC_ENTRY_END
 }
 
 void fdc_phase_window_destroy(fdc_phase_window *b)
@@ -1230,6 +1342,7 @@ void fdc_phase_window_destroy(fdc_phase_window *b)
 
 int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, int nitems, void *out)
 {
+    FDC_ENTRY("fdc_fft_vcc")
     if (!ispow2(n) || n < 2 || n > (1 << 24)) return fail(FDC_ERR_INVALID_ARGUMENT, "fft size %d must be a power of two in [2, 2^24]", n);
     if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     if (!in || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null buffer");
@@ -1253,6 +1366,7 @@ int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, in
 #undef CHK2
     cleanup();
     return nitems;
+    FDC_ENTRY_END
 }
 
 }  // extern "C"

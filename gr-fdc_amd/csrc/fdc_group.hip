@@ -1,0 +1,296 @@
+// Multi-device handle of the throughput chain (include/fdc_amd.h, fdc_pipeline_group_*): ONE work() call of the hier block
+// (python/FrequencyDomainChannelizer.py:283-315 — one flowgraph block, one scheduler thread) is cut into contiguous spans of
+// blocks, one per member device, and the members run their spans concurrently: H2D of the span's samples over that device's
+// own PCIe link, the kernels, D2H of the results straight into the caller's per-channel buffers at the span's block offset.
+//
+// Why spans are independent: the chain's only state is the N/R-sample overlap history
+// (lib/overlap_save_impl.h:33) and the window counter, which is (block index * shift) mod R in closed form
+// (lib/phase_shifting_windowing_vcc_impl.cc:82).  A span is therefore fully described by its halo — the N/R samples in front
+// of it, which lie in the caller's own input buffer for every span but the first — and the global index of its first block.
+// The group keeps the stream's history (for the first span of the next call) and the block counter ONCE, on the host.
+// No collective, no device-to-device traffic.
+//
+// The reference's own parallelism inside one work() for comparison: four FFTW threads (python/…:206) and one std::thread per
+// segment / per detected channel (lib/activity_detection_channelizer_vcm_impl.cc:293-304, :339-371).
+//
+// Members may name the same device more than once ("virtual members"): the spans then share one GPU — that is how the
+// arithmetic of the dispatcher is tested bit for bit on a one-GPU box (tests/test_group_gpu.py).
+#include "../../include/fdc_amd.h"
+#include "fdc_guard.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+#define FDC_ENTRY(name) return fdc::guarded(name, [&]() -> int {
+#define FDC_ENTRY_END });
+
+struct SpanJob {
+    const void *halo = nullptr, *in = nullptr;
+    int64_t first = 0;
+    int n = 0;
+    void *const *outs = nullptr;
+    void *spectrum = nullptr;
+    bool real = false;
+};
+
+// one worker thread per member beyond the first (the first member's span runs on the calling thread)
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int state = 0;               // 0 idle, 1 job posted, 2 job done, 3 quit
+    SpanJob job;
+    fdc_pipeline *pipe = nullptr;
+    int rc = 0;
+    std::string err;
+};
+
+int run_span(fdc_pipeline *p, const SpanJob &j)
+{
+    return j.real ? fdc_pipeline_work_span_real(p, j.halo, j.in, j.first, j.n, j.outs, j.spectrum)
+                  : fdc_pipeline_work_span(p, j.halo, j.in, j.first, j.n, j.outs, j.spectrum);
+}
+
+void worker_main(Worker *w)
+{
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [w] { return w->state == 1 || w->state == 3; });
+        if (w->state == 3) return;
+        const SpanJob j = w->job;
+        lk.unlock();
+        int rc = run_span(w->pipe, j);
+        std::string err;
+        if (rc < 0) {
+            try { err = fdc_last_error(); } catch (...) { rc = FDC_ERR_NOMEM; }     // this thread's text: handed to the caller
+        }
+        lk.lock();
+        w->rc = rc; w->err.swap(err);
+        w->state = 2;
+        w->cv.notify_all();
+    }
+}
+
+}  // namespace
+
+struct fdc_pipeline_group {
+    std::vector<fdc_pipeline *> mem;
+    std::vector<int32_t> dev;
+    std::vector<std::unique_ptr<Worker>> workers;          // workers[i - 1] serves member i
+    int N = 0, R = 0, ovl = 0, H = 0, C = 0;
+    int max_blocks = 0, min_span = 0, member_max = 0;
+    std::vector<int32_t> lout;
+    std::vector<unsigned char> hist;                        // the last N/R samples of the stream so far (zeros at start, overlap_save_impl.cc:52)
+    size_t hist_item = 0;                                   // bytes per history sample: 8 (complex) until a real-input call makes it 4
+    int64_t blockcount = 0;
+    std::vector<std::vector<void *>> outs;                  // per member: the caller's output pointers moved to its span
+    std::vector<int64_t> last_first;
+    std::vector<int32_t> last_n;
+    bool dead = false;                                      // a member failed mid-call: the stream state is no longer defined
+};
+
+namespace {
+
+// members that take part in a call of n blocks: every span at least min_span blocks (one member below 2 * min_span)
+int members_for(const fdc_pipeline_group *g, int n)
+{
+    const int k = n / g->min_span;
+    return std::max(1, std::min<int>(k, (int)g->mem.size()));
+}
+
+void span_of(int n, int k, int i, int *first, int *cnt)      // balanced contiguous spans (gr-fdc_amd/sharding.py:span_for_rank)
+{
+    const int base = n / k, extra = n % k;
+    *cnt = base + (i < extra ? 1 : 0);
+    *first = i * base + std::min(i, extra);
+}
+
+int group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *outs, void *spectrum, bool real)
+{
+    if (!g) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null group handle");
+    if (g->dead) return fdc::set_error(FDC_ERR_HIP, "the group failed in an earlier call: reset or destroy it");
+    if (nblocks < 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (nblocks == 0) return 0;
+    if (nblocks > g->max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, g->max_blocks);
+    if (!in || (g->C > 0 && !outs)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    const size_t item = real ? sizeof(float) : 2 * sizeof(float);
+    if (g->blockcount == 0) g->hist_item = item;
+    if (item != g->hist_item)
+        return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "complex and real input calls must not be mixed on one group (reset it first)");
+    const unsigned char *hin = static_cast<const unsigned char *>(in);
+    const int k = members_for(g, nblocks);
+    g->last_first.assign(g->mem.size(), 0);
+    g->last_n.assign(g->mem.size(), 0);
+    SpanJob job0;
+    // whatever happens on this thread, no posted span is left running with the caller's pointers when the call returns
+    struct Join {
+        fdc_pipeline_group *g; int posted = 0;
+        void wait() { for (; posted > 0; posted--) { Worker *w = g->workers[(size_t)posted - 1].get(); std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [w] { return w->state == 2; }); } }
+        ~Join() { wait(); for (auto &w : g->workers) { std::lock_guard<std::mutex> lk(w->mu); if (w->state == 2) w->state = 0; } }
+    } join{g};
+    for (int i = 0; i < k; i++) {
+        int b0, nb;
+        span_of(nblocks, k, i, &b0, &nb);
+        SpanJob j;
+        // halo: the N/R samples in front of the span.  Span 0: the stream's history; every other span starts at block b0 >= 1 and
+        // H >= N/R (R >= 2), so its halo is inside the caller's buffer.
+        j.halo = i == 0 ? g->hist.data() : hin + ((size_t)b0 * g->H - (size_t)g->ovl) * item;
+        j.in = hin + (size_t)b0 * g->H * item;
+        j.first = g->blockcount + b0;
+        j.n = nb;
+        for (int c = 0; c < g->C; c++)
+            g->outs[(size_t)i][(size_t)c] = outs[c] ? static_cast<unsigned char *>(outs[c]) + (size_t)b0 * (size_t)g->lout[(size_t)c] * 8 : nullptr;
+        j.outs = g->outs[(size_t)i].data();
+        j.spectrum = spectrum ? static_cast<unsigned char *>(spectrum) + (size_t)b0 * (size_t)g->N * 8 : nullptr;
+        j.real = real;
+        g->last_first[(size_t)i] = j.first; g->last_n[(size_t)i] = nb;
+        if (i == 0) { job0 = j; continue; }
+        Worker *w = g->workers[(size_t)i - 1].get();
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->job = j; w->state = 1;
+        w->cv.notify_all();
+        join.posted = i;
+    }
+    int rc = run_span(g->mem[0], job0);
+    std::string err;
+    if (rc < 0) err = fdc_last_error();
+    join.wait();                                           // every posted span is waited for, whatever the others returned
+    for (int i = 1; i < k; i++) {
+        Worker *w = g->workers[(size_t)i - 1].get();
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (w->rc < 0 && rc >= 0) { rc = w->rc; err = "member " + std::to_string(i) + " (device " + std::to_string(g->dev[(size_t)i]) + "): " + w->err; }
+    }
+    if (rc < 0) {
+        g->dead = true;                                     // some spans of the call were written, others not
+        return fdc::set_error(rc, "%s", err.c_str());
+    }
+    // history <- the last N/R samples of the stream (lib/overlap_save_impl.cc:78); nblocks * H >= N/R
+    std::memcpy(g->hist.data(), hin + ((size_t)nblocks * g->H - (size_t)g->ovl) * item, (size_t)g->ovl * item);
+    g->blockcount += nblocks;
+    return nblocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fdc_pipeline_group_destroy(fdc_pipeline_group *g)
+{
+    if (!g) return;
+    for (auto &w : g->workers) {
+        if (!w) continue;
+        { std::lock_guard<std::mutex> lk(w->mu); w->state = 3; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+    }
+    for (fdc_pipeline *p : g->mem) fdc_pipeline_destroy(p);
+    delete g;
+}
+
+int fdc_pipeline_group_create(const fdc_pipeline_cfg *cfg, const int32_t *devices, int ndevices, int min_span_blocks,
+                              fdc_pipeline_group **out)
+{
+    FDC_ENTRY("fdc_pipeline_group_create")
+    if (!cfg || !out) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!devices || ndevices < 1 || ndevices > 64) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a group has 1 to 64 members");
+    if (cfg->max_blocks < 1) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "max_blocks must be >= 1");
+    if (min_span_blocks < 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "negative min_span_blocks");
+    std::unique_ptr<fdc_pipeline_group, void (*)(fdc_pipeline_group *)> g(new fdc_pipeline_group(), fdc_pipeline_group_destroy);
+    g->max_blocks = cfg->max_blocks;
+    g->min_span = min_span_blocks > 0 ? min_span_blocks : 8;
+    g->mem.assign((size_t)ndevices, nullptr);
+    g->dev.assign(devices, devices + ndevices);
+    // the longest span a member can be given: max over call lengths of ceil(n / members_for(n))
+    {
+        int worst = 1;
+        for (int k = 1; k <= ndevices; k++) {
+            // call lengths that use k members: [k * min_span, (k + 1) * min_span) (k = ndevices: up to max_blocks; k = 1: from 1)
+            const long long hi = k == ndevices ? cfg->max_blocks : std::min<long long>(cfg->max_blocks, (long long)(k + 1) * g->min_span - 1);
+            const long long lo = k == 1 ? 1 : (long long)k * g->min_span;
+            if (hi >= lo) worst = std::max<int>(worst, (int)((hi + k - 1) / k));
+        }
+        g->member_max = worst;
+    }
+    for (int i = 0; i < ndevices; i++) {
+        fdc_pipeline_cfg c = *cfg;
+        c.device_id = devices[i];
+        c.max_blocks = g->member_max;
+        const int rc = fdc_pipeline_create(&c, &g->mem[(size_t)i]);
+        if (rc != FDC_OK) {
+            const std::string why = fdc_last_error();
+            return fdc::set_error(rc, "member %d (device %d): %s", i, devices[i], why.c_str());
+        }
+    }
+    fdc_pipeline *p0 = g->mem[0];
+    g->N = cfg->blocklen; g->R = cfg->relinvovl; g->ovl = g->N / g->R; g->H = g->N - g->ovl; g->C = cfg->nchannels;
+    for (int c = 0; c < g->C; c++) g->lout.push_back(fdc_pipeline_channel_lout(p0, c));
+    g->hist.assign((size_t)g->ovl * 8, 0);
+    g->hist_item = 8;
+    g->outs.assign((size_t)ndevices, std::vector<void *>((size_t)std::max(1, g->C), nullptr));
+    for (int i = 1; i < ndevices; i++) {
+        g->workers.emplace_back(new Worker());
+        Worker *w = g->workers.back().get();
+        w->pipe = g->mem[(size_t)i];
+        w->th = std::thread(worker_main, w);
+    }
+    *out = g.release();
+    return FDC_OK;
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    FDC_ENTRY("fdc_pipeline_group_work")
+    return group_work(g, in, nblocks, outs, spectrum, false);
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_group_work_real(fdc_pipeline_group *g, const void *in, int nblocks, void *const *outs, void *spectrum)
+{
+    FDC_ENTRY("fdc_pipeline_group_work_real")
+    return group_work(g, in, nblocks, outs, spectrum, true);
+    FDC_ENTRY_END
+}
+
+void fdc_pipeline_group_reset(fdc_pipeline_group *g)
+{
+    if (!g) return;
+    std::fill(g->hist.begin(), g->hist.end(), 0);
+    g->blockcount = 0;
+    g->hist_item = 8;
+    g->dead = false;
+}
+
+int32_t fdc_pipeline_group_size(const fdc_pipeline_group *g) { return g ? (int32_t)g->mem.size() : -1; }
+fdc_pipeline *fdc_pipeline_group_member(fdc_pipeline_group *g, int i)
+{
+    return g && i >= 0 && i < (int)g->mem.size() ? g->mem[(size_t)i] : nullptr;
+}
+int32_t fdc_pipeline_group_device(const fdc_pipeline_group *g, int i)
+{
+    return g && i >= 0 && i < (int)g->dev.size() ? g->dev[(size_t)i] : -1;
+}
+int32_t fdc_pipeline_group_member_max_blocks(const fdc_pipeline_group *g) { return g ? g->member_max : -1; }
+
+int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_block, int32_t *nblocks, int cap)
+{
+    if (!g) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null group handle");
+    const int n = (int)g->last_n.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        if (first_block) first_block[i] = g->last_first[(size_t)i];
+        if (nblocks) nblocks[i] = g->last_n[(size_t)i];
+    }
+    return n;
+}
+
+}  // extern "C"

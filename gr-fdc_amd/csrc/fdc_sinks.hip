@@ -14,6 +14,7 @@
 #include "../../include/fdc_amd.h"
 #include "fdc_kernels.h"
 #include "fdc_sinks_dev.h"
+#include "fdc_guard.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -44,6 +45,10 @@ using cfl = std::complex<float>;
         hipError_t _e = (expr);                                                                                   \
         if (_e != hipSuccess) return fdc::set_error(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// body of an extern "C" entry: nothing thrown inside crosses the C boundary (fdc_guard.hpp)
+#define FDC_ENTRY(name) return fdc::guarded(name, [&]() -> int {
+#define FDC_ENTRY_END });
 
 int pow2ceil(int k) { return (int)std::pow(2.0, std::ceil(std::log2((double)k))); }
 bool ispow2i(int k) { return k > 0 && (k & (k - 1)) == 0; }
@@ -600,6 +605,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
 
 int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
 {
+    FDC_ENTRY("fdc_sinks_create")
     if (!cfg || !out) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     const int N = cfg->blocklen, R = cfg->relinvovl;
@@ -818,6 +824,7 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
     }
     *out = raw;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 void *fdc_sinks_spectrum(fdc_sinks *s) { return s ? (void *)(s->d_spec + s->N) : nullptr; }
@@ -827,19 +834,23 @@ int32_t fdc_sinks_max_blocks(const fdc_sinks *s) { return s ? s->cfg.max_blocks 
 
 int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v)
 {
+    FDC_ENTRY("fdc_sinks_pac_params")
     if (!s || i < 0 || i >= (int)s->pacs.size() || !v) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad index");
     const Pac &p = s->pacs[i];
     v[0] = p.extract_start; v[1] = p.extract_stop; v[2] = p.extract_width; v[3] = p.measure_start; v[4] = p.measure_stop;
     v[5] = p.output_len; v[6] = p.ovl_offset; v[7] = p.deltaphase;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
 {
+    FDC_ENTRY("fdc_sinks_segment_params")
     if (!s || i < 0 || i >= (int)s->segs.size() || !v) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad index");
     const Segment &g = s->segs[i];
     v[0] = g.start; v[1] = g.stop; v[2] = g.width; v[3] = s->dec; v[4] = g.ncell;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 // Extractions of one call, one launch (or one gather / batched transform / scatter sequence) per width class.
@@ -1346,6 +1357,7 @@ static int dev_complete(fdc_sinks *s, int b)
 
 int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
 {
+    FDC_ENTRY("fdc_sinks_submit_device")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
     if (!s->dev.on) {                                          // host engine: the batch is done when the call returns
@@ -1372,20 +1384,24 @@ int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
     rc = dev_launch_extractions(s, nblocks);
     if (rc != FDC_OK) return rc;
     return had ? dev_wait(s, before) : 0;
+    FDC_ENTRY_END
 }
 
 int fdc_sinks_flush(fdc_sinks *s)
 {
+    FDC_ENTRY("fdc_sinks_flush")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (!s->dev.on || !s->dev.inflight) return 0;
     HIPCHK(hipSetDevice(s->cfg.device_id));
     return dev_complete(s, s->dev.cur);
+    FDC_ENTRY_END
 }
 
 int32_t fdc_sinks_engine(const fdc_sinks *s) { return s ? (s->dev.on ? 1 : 0) : -1; }
 
 int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
 {
+    FDC_ENTRY("fdc_sinks_work_device")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
@@ -1396,10 +1412,12 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
     if (rc < 0) return rc;
     rc = dev_complete(s, s->dev.cur);
     return rc < 0 ? rc : nblocks;
+    FDC_ENTRY_END
 }
 
 int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
 {
+    FDC_ENTRY("fdc_sinks_work")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
@@ -1408,6 +1426,7 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     HIPCHK(hipSetDevice(s->cfg.device_id));
     HIPCHK(hipMemcpyAsync(s->d_spec + s->N, spectrum, sizeof(float2) * (size_t)nitems * s->N, hipMemcpyHostToDevice, s->stream));
     return fdc_sinks_work_device(s, nitems);
+    FDC_ENTRY_END
 }
 
 void fdc_set_log_callback(fdc_log_fn fn, void *user) { std::lock_guard<std::mutex> g(g_log_mu); g_log_fn = fn; g_log_user = user; }
@@ -1416,17 +1435,21 @@ int fdc_sinks_pdu_count(const fdc_sinks *s) { return s ? (int)s->pdus.size() : 0
 
 int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out)
 {
+    FDC_ENTRY("fdc_sinks_pdu")
     if (!s || !out || i < 0 || i >= (int)s->pdus.size()) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad PDU index");
     *out = s->pdus[(size_t)i].meta;
     return FDC_OK;
+    FDC_ENTRY_END
 }
 
 int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap)
 {
+    FDC_ENTRY("fdc_sinks_pdus")
     if (!s || (cap > 0 && !out)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad PDU array");
     const int n = (int)s->pdus.size();
     for (int i = 0; i < n && i < cap; i++) out[i] = s->pdus[(size_t)i].meta;
     return n;
+    FDC_ENTRY_END
 }
 
 }  // extern "C"

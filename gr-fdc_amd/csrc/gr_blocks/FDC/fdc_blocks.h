@@ -15,65 +15,73 @@
 #define FDC_API __attribute__((visibility("default")))
 #endif
 
-// The smart pointer of the block API follows the GNU Radio it is built against: boost::shared_ptr up to 3.8 (what the
+// The smart pointer of the block API is the one of the GNU Radio it is built against: boost::shared_ptr up to 3.8 (what the
 // reference targets, include/FDC/overlap_save.h:39 `typedef boost::shared_ptr<overlap_save> sptr`, GNU Radio >= 3.7.2 per
-// its CMakeLists.txt:148), std::shared_ptr from 3.9 on and in the stand-alone build.  FDC_SPTR_BOOST=0/1 overrides the
-// detection.
-#if !defined(FDC_SPTR_BOOST)
-#if defined(FDC_HAVE_GNURADIO) && __has_include(<gnuradio/api.h>)
-#include <gnuradio/api.h>
+// its CMakeLists.txt:148), std::shared_ptr from 3.9 on.  It is taken from GNU Radio's own gr::basic_block_sptr (no version
+// macro exists in its headers): whatever template that is, rebound to the block class.  Stand-alone build: std::shared_ptr.
+#ifdef FDC_HAVE_GNURADIO
+#include <gnuradio/basic_block.h>
 #endif
-#if defined(FDC_HAVE_GNURADIO) && defined(GR_VERSION_MAJOR)
-#define FDC_SPTR_BOOST ((GR_VERSION_MAJOR * 100 + GR_VERSION_API) < 309)
-#elif defined(FDC_HAVE_GNURADIO) && !__has_include(<gnuradio/buffer_type.h>) && __has_include(<boost/shared_ptr.hpp>)
-#define FDC_SPTR_BOOST 1      /* no version macros: 3.7 / 3.8 headers (buffer_type.h came with 3.10) and boost at hand */
+namespace gr {
+namespace FDC {
+namespace detail {
+template <class Ptr, class T> struct rebind_sptr;
+template <template <class...> class SP, class U, class T> struct rebind_sptr<SP<U>, T> { typedef SP<T> type; };
+}  // namespace detail
+#ifdef FDC_HAVE_GNURADIO
+template <class T> using block_sptr = typename detail::rebind_sptr<gr::basic_block_sptr, T>::type;
 #else
-#define FDC_SPTR_BOOST 0
+template <class T> using block_sptr = std::shared_ptr<T>;
 #endif
-#endif
-#if FDC_SPTR_BOOST
-#include <boost/shared_ptr.hpp>
-#include <boost/make_shared.hpp>
-#define FDC_SHARED_PTR boost::shared_ptr
-#else
-#define FDC_SHARED_PTR std::shared_ptr
-#endif
+}  // namespace FDC
+}  // namespace gr
+#define FDC_SHARED_PTR gr::FDC::block_sptr
 
 namespace gr {
 namespace FDC {
 
-// What the reference's make() signatures have no room for: the HIP device the blocks made from now on run on, and the
-// largest number of items one device batch takes (sinks: spectrum items per fdc_sinks_work; fdc_pipeline_vcc: its max_items
-// argument when that is 0).  Set before make(); process-wide.
-struct amd_options { int device_id = 0; int max_items = 64; };
-FDC_API amd_options &options();
+// What the reference's make() signatures have no room for lives on the BLOCK, not in the process (two flowgraphs of one
+// process may want different devices): which HIP device(s) the block runs on and how many items one device batch takes.
+// A block is made on device 0 with batches of 64 items; call these after make() and before the flowgraph starts (they
+// rebuild the device handle, so the stream state is that of a fresh block).  They throw what make() throws.
+//   set_devices({d})        the block's handle lives on device d
+//   set_devices({d0, d1…})  fdc_pipeline_vcc only: ONE work() call is cut into contiguous spans of items, one per device, run
+//                           concurrently (fdc_pipeline_group, include/fdc_amd.h); the other blocks take the first entry
+class FDC_API amd_device_config {
+public:
+    virtual ~amd_device_config() {}
+    virtual void set_devices(const std::vector<int> &devices) = 0;
+    virtual void set_max_items(int max_items) = 0;
+    virtual std::vector<int> devices() const = 0;
+    virtual int max_items() const = 0;
+};
 
-class FDC_API overlap_save : virtual public gr::sync_block {
+class FDC_API overlap_save : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<overlap_save> sptr;
     static sptr make(int itemsize, int outputlen, int overlaplen);
 };
 
-class FDC_API vector_cut_vxx : virtual public gr::sync_block {
+class FDC_API vector_cut_vxx : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<vector_cut_vxx> sptr;
     static sptr make(int itemsize, int veclen, int offset, int blocklen);
 };
 
-class FDC_API phase_shifting_windowing_vcc : virtual public gr::sync_block {
+class FDC_API phase_shifting_windowing_vcc : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<phase_shifting_windowing_vcc> sptr;
     static sptr make(int blocklen, int numphasestates, int shifts, float passbw, float stopbw, int windowtype);
 };
 
-class FDC_API PowerActivationChannel : virtual public gr::sync_block {
+class FDC_API PowerActivationChannel : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<PowerActivationChannel> sptr;
     static sptr make(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
                      int deactivation_delay, bool msg, bool fileoutput, std::string path, int verbose, int ID);
 };
 
-class FDC_API activity_detection_channelizer_vcm : virtual public gr::sync_block {
+class FDC_API activity_detection_channelizer_vcm : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<activity_detection_channelizer_vcm> sptr;
     static sptr make(int blocklen, std::vector<std::vector<float>> segments, float thresh, int relinvovl, int maxblocks,
@@ -81,7 +89,7 @@ public:
                      int channel_deactivation_delay, double window_flank_puffer, int verbose);
 };
 
-class FDC_API SegmentDetection : virtual public gr::sync_block {
+class FDC_API SegmentDetection : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<SegmentDetection> sptr;
     static sptr make(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh, float minchandist,
@@ -95,10 +103,11 @@ public:
 // (blocklen - blocklen/relinvovl) new samples, output port c carries items of lout_c = l_c - l_c/relinvovl samples.
 // Not a class of the reference: it is the block a maintainer adds so that the fused device path is reachable from a
 // flowgraph.
-class FDC_API fdc_pipeline_vcc : virtual public gr::sync_block {
+class FDC_API fdc_pipeline_vcc : virtual public gr::sync_block, public amd_device_config {
 public:
     typedef FDC_SHARED_PTR<fdc_pipeline_vcc> sptr;
     // channels: rows (f, l, passbw, stopbw) as produced by get_opt_channelparams (py:322-345)
+    // max_items: items per device batch (0 = 64; set_max_items() changes it)
     static sptr make(int blocklen, int relinvovl, std::vector<std::vector<float>> channels, int windowtype, int max_items);
     // optional: pin the scheduler's buffers of this block's ports once the flowgraph has allocated them (start()), so
     // that work() DMAs in place (fdc_host_register); call unpin_buffers() before they are freed (stop()).

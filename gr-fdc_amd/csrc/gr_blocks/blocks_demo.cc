@@ -92,9 +92,23 @@ int main(int argc, char **argv)
                     if (std::memcmp(so[c].data(), po[c].data(), so[c].size() * sizeof(gr_complex)) != 0)
                         throw std::runtime_error("fdc_pipeline_vcc: chunked work() differs from the whole call");
             }
-            // the device and the batch size of the blocks made from here on (what make() has no argument for)
-            gr::FDC::options().device_id = 0;
-            gr::FDC::options().max_items = 5;
+            // what make() has no argument for is per-block state: two virtual members on device 0 = one work() call cut into two
+            // spans (fdc_pipeline_group); the output must not change by a bit
+            {
+                auto two = fdc_pipeline_vcc::make(N, R, chans, 1, nb);
+                two->set_devices({0, 0});       // calls of 16 items and more are cut in two (a member's span is at least 8 items)
+                if (two->devices().size() != 2 || two->max_items() != nb) throw std::runtime_error("fdc_pipeline_vcc: device state not kept");
+                std::vector<std::vector<gr_complex>> so(chans.size());
+                gr_vector_void_star sv;
+                for (size_t c = 0; c < chans.size(); c++) { so[c].resize((size_t)nb * two->output_item_len((int)c)); sv.push_back(so[c].data()); }
+                if (two->work(nb, pi, sv) != nb) throw std::runtime_error("fdc_pipeline_vcc: work() on a device group failed");
+                for (size_t c = 0; c < chans.size(); c++)
+                    if (std::memcmp(so[c].data(), po[c].data(), so[c].size() * sizeof(gr_complex)) != 0)
+                        throw std::runtime_error("fdc_pipeline_vcc: a two-member group differs from the single handle");
+                bool threw3 = false;
+                try { two->set_devices({0, 77}); } catch (const std::exception &) { threw3 = true; }
+                if (!threw3 || two->devices().size() != 2) throw std::runtime_error("fdc_pipeline_vcc: bad device list accepted");
+            }
             bool threw2 = false;
             try { fdc_pipeline_vcc::make(N, R, {{0.f, 64.f, 0.9f, 0.5f}}, 1, 4); } catch (const std::invalid_argument &) { threw2 = true; }
             if (!threw2) throw std::runtime_error("fdc_pipeline_vcc: bad channel did not throw");
@@ -105,6 +119,8 @@ int main(int argc, char **argv)
         gr_vector_const_void_star si{spec.data()};
         gr_vector_void_star none;
         auto pac = PowerActivationChannel::make(N, 320.0f / N, 40.0f / N, R, 6.0f, -1, 0, true, false, "", 0, 5);
+        pac->set_max_items(5);          // batches of 5 spectrum items per fdc_sinks_work: channel state carries across batches
+        pac->set_devices({0});
         pac->work(ns, si, none);
         std::vector<gr_complex> all;
         FILE *meta = std::fopen((dir + "/pdus.txt").c_str(), "w");
@@ -113,6 +129,7 @@ int main(int argc, char **argv)
             all.insert(all.end(), m.samples.begin(), m.samples.end());
         }
         auto det = activity_detection_channelizer_vcm::make(N, {{0.5f, 0.9f}}, 10.0f, R, -1, true, false, "", false, 0.01f, 1, 0.2, 0);
+        det->set_max_items(5);
         det->work(ns, si, none);
         for (auto &m : det->published()) {
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
@@ -120,6 +137,7 @@ int main(int argc, char **argv)
         }
         // verbose = 2: log file gr-FDC.ActDetChan.ID_2.log in the working directory; fileoutput: <dir>/<ID>.fin
         auto sd = SegmentDetection::make(2, N, R, 0.5f, 0.9f, 10.0f, 0.01f, 0.2f, -1, 1, true, true, dir, false, 2);
+        sd->set_max_items(5);
         sd->work(ns, si, none);
         for (auto &m : sd->published()) {
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());

@@ -13,12 +13,6 @@
 namespace gr {
 namespace FDC {
 
-amd_options &options()
-{
-    static amd_options o;
-    return o;
-}
-
 namespace {
 
 void check_create(int rc)
@@ -35,14 +29,50 @@ int report(const char *who, int n)
     return n;
 }
 
-class overlap_save_impl : public overlap_save {
+// per-block device state (amd_device_config): the setters rebuild the handle through the block's own create()
+class device_state {
+protected:
+    std::vector<int> d_devices{0};
+    int d_max_items = 64;
+    virtual ~device_state() {}
+    virtual void rebuild() = 0;            // destroy the handle(s), create them again from d_devices / d_max_items; throws like make()
+    void assign_devices(const std::vector<int> &devices)
+    {
+        if (devices.empty()) throw std::invalid_argument("set_devices: empty device list");
+        const std::vector<int> before = d_devices;
+        d_devices = devices;
+        try { rebuild(); } catch (...) { d_devices = before; try { rebuild(); } catch (...) {} throw; }
+    }
+    void assign_max_items(int n)
+    {
+        if (n < 1) throw std::invalid_argument("set_max_items: must be >= 1");
+        const int before = d_max_items;
+        d_max_items = n;
+        try { rebuild(); } catch (...) { d_max_items = before; try { rebuild(); } catch (...) {} throw; }
+    }
+};
+#define FDC_DEVICE_CONFIG                                                                       \
+    void set_devices(const std::vector<int> &devices) override { assign_devices(devices); }      \
+    void set_max_items(int n) override { assign_max_items(n); }                                   \
+    std::vector<int> devices() const override { return d_devices; }                               \
+    int max_items() const override { return d_max_items; }
+
+class overlap_save_impl : public overlap_save, device_state {
     fdc_overlap_save *d_h = nullptr;
+    int d_itemsize, d_outputlen, d_overlaplen;
+    void rebuild() override
+    {
+        fdc_overlap_save_destroy(d_h); d_h = nullptr;
+        check_create(fdc_overlap_save_create(d_devices[0], d_itemsize, d_outputlen, d_overlaplen, &d_h));
+    }
 public:
+    FDC_DEVICE_CONFIG
     overlap_save_impl(int itemsize, int outputlen, int overlaplen)
         : gr::sync_block("overlap_save", gr::io_signature::make(1, 1, itemsize * (outputlen - overlaplen)),
-                         gr::io_signature::make(1, 1, itemsize * outputlen))
+                         gr::io_signature::make(1, 1, itemsize * outputlen)),
+          d_itemsize(itemsize), d_outputlen(outputlen), d_overlaplen(overlaplen)
     {
-        check_create(fdc_overlap_save_create(options().device_id, itemsize, outputlen, overlaplen, &d_h));
+        rebuild();
     }
     ~overlap_save_impl() override { fdc_overlap_save_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -51,14 +81,22 @@ public:
     }
 };
 
-class vector_cut_vxx_impl : public vector_cut_vxx {
+class vector_cut_vxx_impl : public vector_cut_vxx, device_state {
     fdc_vector_cut *d_h = nullptr;
+    int d_itemsize, d_veclen, d_offset, d_blocklen;
+    void rebuild() override
+    {
+        fdc_vector_cut_destroy(d_h); d_h = nullptr;
+        check_create(fdc_vector_cut_create(d_devices[0], d_itemsize, d_veclen, d_offset, d_blocklen, &d_h));
+    }
 public:
+    FDC_DEVICE_CONFIG
     vector_cut_vxx_impl(int itemsize, int veclen, int offset, int blocklen)
         : gr::sync_block("vector_cut_vxx", gr::io_signature::make(1, 1, itemsize * veclen),
-                         gr::io_signature::make(1, 1, itemsize * blocklen))
+                         gr::io_signature::make(1, 1, itemsize * blocklen)),
+          d_itemsize(itemsize), d_veclen(veclen), d_offset(offset), d_blocklen(blocklen)
     {
-        check_create(fdc_vector_cut_create(options().device_id, itemsize, veclen, offset, blocklen, &d_h));
+        rebuild();
     }
     ~vector_cut_vxx_impl() override { fdc_vector_cut_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -67,14 +105,23 @@ public:
     }
 };
 
-class phase_shifting_windowing_vcc_impl : public phase_shifting_windowing_vcc {
+class phase_shifting_windowing_vcc_impl : public phase_shifting_windowing_vcc, device_state {
     fdc_phase_window *d_h = nullptr;
+    int d_blocklen, d_states, d_shifts, d_windowtype;
+    float d_passbw, d_stopbw;
+    void rebuild() override
+    {
+        fdc_phase_window_destroy(d_h); d_h = nullptr;
+        check_create(fdc_phase_window_create(d_devices[0], d_blocklen, d_states, d_shifts, d_passbw, d_stopbw, d_windowtype, &d_h));
+    }
 public:
+    FDC_DEVICE_CONFIG
     phase_shifting_windowing_vcc_impl(int blocklen, int numphasestates, int shifts, float passbw, float stopbw, int windowtype)
         : gr::sync_block("phase_shifting_windowing_vcc", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
-                         gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen))
+                         gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen)),
+          d_blocklen(blocklen), d_states(numphasestates), d_shifts(shifts), d_windowtype(windowtype), d_passbw(passbw), d_stopbw(stopbw)
     {
-        check_create(fdc_phase_window_create(options().device_id, blocklen, numphasestates, shifts, passbw, stopbw, windowtype, &d_h));
+        rebuild();
     }
     ~phase_shifting_windowing_vcc_impl() override { fdc_phase_window_destroy(d_h); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
@@ -83,9 +130,11 @@ public:
     }
 };
 
-class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc {
-    fdc_pipeline *d_p = nullptr;
-    int d_max = 64;
+class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
+    fdc_pipeline *d_p = nullptr;               // one device
+    fdc_pipeline_group *d_g = nullptr;         // several devices: one work() call cut into spans (include/fdc_amd.h)
+    int d_blocklen, d_relinvovl, d_windowtype;
+    std::vector<fdc_channel> d_ch;
     size_t d_in_item = 0;
     std::vector<int> d_lout;
     std::vector<void *> d_pinned;
@@ -99,35 +148,51 @@ class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc {
         }
         return v;
     }
+    void rebuild() override
+    {
+        fdc_pipeline_destroy(d_p); d_p = nullptr;
+        fdc_pipeline_group_destroy(d_g); d_g = nullptr;
+        fdc_pipeline_cfg cfg{d_devices[0], d_blocklen, d_relinvovl, d_windowtype, (int32_t)d_ch.size(), d_ch.data(), d_max_items, 0, 0};
+        if (d_devices.size() > 1) {
+            std::vector<int32_t> dv(d_devices.begin(), d_devices.end());
+            check_create(fdc_pipeline_group_create(&cfg, dv.data(), (int)dv.size(), 0, &d_g));
+        } else {
+            check_create(fdc_pipeline_create(&cfg, &d_p));
+        }
+        fdc_pipeline *p0 = d_g ? fdc_pipeline_group_member(d_g, 0) : d_p;
+        d_lout.clear();
+        for (size_t i = 0; i < d_ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(p0, (int)i));
+#ifdef FDC_HAVE_GNURADIO
+        set_max_noutput_items(d_max_items);           // the scheduler then never offers more than one device batch
+#endif
+    }
 public:
+    FDC_DEVICE_CONFIG
     fdc_pipeline_vcc_impl(int blocklen, int relinvovl, const std::vector<std::vector<float>> &channels, int windowtype, int max_items)
         : gr::sync_block("fdc_pipeline_vcc",
                          gr::io_signature::make(1, 1, (int)sizeof(gr_complex) * (blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1))),
-                         gr::io_signature::makev((int)channels.size(), (int)channels.size(), out_sizes(relinvovl, channels)))
+                         gr::io_signature::makev((int)channels.size(), (int)channels.size(), out_sizes(relinvovl, channels))),
+          d_blocklen(blocklen), d_relinvovl(relinvovl), d_windowtype(windowtype)
     {
-        std::vector<fdc_channel> ch(channels.size());
+        d_ch.resize(channels.size());
         for (size_t i = 0; i < channels.size(); i++)
-            ch[i] = fdc_channel{(int32_t)channels[i][0], (int32_t)channels[i][1], channels[i][2], channels[i][3]};
-        d_max = max_items > 0 ? max_items : options().max_items;
-        fdc_pipeline_cfg cfg{options().device_id, blocklen, relinvovl, windowtype, (int32_t)ch.size(), ch.data(), d_max, 0, 0};
-        check_create(fdc_pipeline_create(&cfg, &d_p));
-        for (size_t i = 0; i < ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(d_p, (int)i));
+            d_ch[i] = fdc_channel{(int32_t)channels[i][0], (int32_t)channels[i][1], channels[i][2], channels[i][3]};
+        if (max_items > 0) d_max_items = max_items;
         d_in_item = sizeof(gr_complex) * (size_t)(blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1));
-#ifdef FDC_HAVE_GNURADIO
-        set_max_noutput_items(d_max);                 // the scheduler then never offers more than one device batch
-#endif
+        rebuild();
     }
-    ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); }
+    ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); fdc_pipeline_group_destroy(d_g); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
         // noutput_items may exceed the handle's batch size: pieces of at most max_items, every port advanced by its item length
         std::vector<void *> o(out.size());
-        for (int a = 0; a < n; a += d_max) {
-            const int k = n - a < d_max ? n - a : d_max;
+        for (int a = 0; a < n; a += d_max_items) {
+            const int k = n - a < d_max_items ? n - a : d_max_items;
             for (size_t c = 0; c < out.size(); c++)
                 o[c] = static_cast<char *>(out[c]) + (size_t)a * (size_t)d_lout[c] * sizeof(gr_complex);
-            const int r = report("fdc_pipeline_vcc", fdc_pipeline_work(d_p, static_cast<const char *>(in[0]) + (size_t)a * d_in_item, k,
-                                                                      o.data(), nullptr));
+            const char *src = static_cast<const char *>(in[0]) + (size_t)a * d_in_item;
+            const int r = report("fdc_pipeline_vcc", d_g ? fdc_pipeline_group_work(d_g, src, k, o.data(), nullptr)
+                                                         : fdc_pipeline_work(d_p, src, k, o.data(), nullptr));
             if (r != k) return a > 0 ? a : r;
         }
         return n;
@@ -147,11 +212,25 @@ public:
 };
 
 // shared by the two sink faces: PDU records -> messages on "msgout" and raw files
-class sink_base {
+class sink_base : protected device_state {
 protected:
     fdc_sinks *d_s = nullptr;
     bool d_msg = false, d_file = false;
     std::string d_path;
+    // the bank's configuration, kept so that set_devices() / set_max_items() can build it again
+    fdc_sinks_cfg d_cfg{};
+    std::vector<fdc_pac_cfg> d_pacs;
+    std::vector<fdc_segment_cfg> d_segs;
+    void rebuild() override
+    {
+        fdc_sinks_destroy(d_s); d_s = nullptr;
+        d_cfg.pac = d_pacs.data(); d_cfg.npac = (int32_t)d_pacs.size();
+        d_cfg.seg = d_segs.data(); d_cfg.nseg = (int32_t)d_segs.size();
+        d_cfg.device_id = d_devices[0];
+        d_cfg.max_blocks = d_max_items;
+        check_create(fdc_sinks_create(&d_cfg, &d_s));
+    }
+    ~sink_base() override { fdc_sinks_destroy(d_s); }
     void publish(gr::sync_block *blk, bool pac)
     {
         fdc_pdu p;
@@ -209,33 +288,31 @@ protected:
         blk->message_port_register_out("msgout");
 #endif
     }
-    // items per fdc_sinks_work call (the bank's device batch)
-    int d_batch = 64;
 };
 
 class PowerActivationChannel_impl : public PowerActivationChannel, sink_base {
 public:
+    FDC_DEVICE_CONFIG
     PowerActivationChannel_impl(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
                                 int deactivation_delay, bool msg, bool fileoutput, std::string path, int verbose, int ID)
         : gr::sync_block("PowerActivationChannel", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
-        fdc_pac_cfg pc{cfreq, bw, ID};
-        fdc_sinks_cfg c{};
-        c.blocklen = blocklen; c.relinvovl = relinvovl; c.npac = 1; c.pac = &pc; c.pac_thresh_db = thresh;
+        d_pacs.push_back(fdc_pac_cfg{cfreq, bw, ID});
+        fdc_sinks_cfg &c = d_cfg;
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.pac_thresh_db = thresh;
         c.pac_maxblocks = maxblocks; c.pac_deactivation_delay = deactivation_delay;
-        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = -1;
-        check_create(fdc_sinks_create(&c, &d_s));
+        c.verbose = verbose; c.det_id = -1;
+        rebuild();
         d_msg = msg; d_file = fileoutput; d_path = path;
         if (msg) register_port(this);
     }
-    ~PowerActivationChannel_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = sizeof(gr_complex) * (size_t)input_signature()->sizeof_stream_item / sizeof(gr_complex);
-        for (int a = 0; a < n; a += d_batch) {
-            const int k = n - a < d_batch ? n - a : d_batch;
+        for (int a = 0; a < n; a += d_max_items) {
+            const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("PowerActivationChannel", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, true);
         }
@@ -245,6 +322,7 @@ public:
 
 class activity_detection_channelizer_vcm_impl : public activity_detection_channelizer_vcm, sink_base {
 public:
+    FDC_DEVICE_CONFIG
     activity_detection_channelizer_vcm_impl(int blocklen, std::vector<std::vector<float>> segments, float thresh,
                                             int relinvovl, int maxblocks, bool message, bool fileoutput, std::string path,
                                             bool /*threads: GPU batching replaces the per-channel std::thread fan-out*/,
@@ -252,27 +330,25 @@ public:
         : gr::sync_block("activity_detection_channelizer_vcm", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
-        std::vector<fdc_segment_cfg> sg;
         for (auto &v : segments) {
             if (v.size() != 2) throw std::invalid_argument("Segment is incorrect. must be of size 2");
-            sg.push_back({v[0], v[1]});
+            d_segs.push_back({v[0], v[1]});
         }
-        fdc_sinks_cfg c{};
-        c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = (int)sg.size(); c.seg = sg.data(); c.det_thresh_db = thresh;
+        fdc_sinks_cfg &c = d_cfg;
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.det_thresh_db = thresh;
         c.det_maxblocks = maxblocks; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
         c.window_flank_puffer = window_flank_puffer;
-        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = -1;
-        check_create(fdc_sinks_create(&c, &d_s));
+        c.verbose = verbose; c.det_id = -1;
+        rebuild();
         d_msg = message; d_file = fileoutput; d_path = path;
         if (message) register_port(this);
     }
-    ~activity_detection_channelizer_vcm_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
-        for (int a = 0; a < n; a += d_batch) {
-            const int k = n - a < d_batch ? n - a : d_batch;
+        for (int a = 0; a < n; a += d_max_items) {
+            const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("activity_detection_channelizer_vcm", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }
@@ -282,29 +358,29 @@ public:
 
 class SegmentDetection_impl : public SegmentDetection, sink_base {
 public:
+    FDC_DEVICE_CONFIG
     SegmentDetection_impl(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh,
                           float minchandist, float window_flank_puffer, int maxblocks_to_emit,
                           int channel_deactivation_delay, bool messageoutput, bool fileoutput, std::string path, bool, int verbose)
         : gr::sync_block("SegmentDetection", gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen),
                          gr::io_signature::make(0, 0, 0))
     {
-        fdc_segment_cfg sg{seg_start, seg_stop};
-        fdc_sinks_cfg c{};
-        c.blocklen = blocklen; c.relinvovl = relinvovl; c.nseg = 1; c.seg = &sg; c.det_thresh_db = thresh;
+        d_segs.push_back(fdc_segment_cfg{seg_start, seg_stop});
+        fdc_sinks_cfg &c = d_cfg;
+        c.blocklen = blocklen; c.relinvovl = relinvovl; c.det_thresh_db = thresh;
         c.det_maxblocks = maxblocks_to_emit; c.minchandist = minchandist; c.det_deactivation_delay = channel_deactivation_delay;
         c.window_flank_puffer = window_flank_puffer; c.det_variant = 1;
-        c.device_id = options().device_id; c.max_blocks = d_batch = options().max_items; c.verbose = verbose; c.det_id = ID;
-        check_create(fdc_sinks_create(&c, &d_s));
+        c.verbose = verbose; c.det_id = ID;
+        rebuild();
         d_msg = messageoutput; d_file = fileoutput; d_path = path;
         if (messageoutput) register_port(this);
     }
-    ~SegmentDetection_impl() override { fdc_sinks_destroy(d_s); }
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
-        for (int a = 0; a < n; a += d_batch) {
-            const int k = n - a < d_batch ? n - a : d_batch;
+        for (int a = 0; a < n; a += d_max_items) {
+            const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("SegmentDetection", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }

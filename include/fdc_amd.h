@@ -117,6 +117,20 @@ int fdc_pipeline_work(fdc_pipeline *p, const void *in, int nblocks, void *const 
  * fdc_pipeline_work; do not mix the two on one handle. */
 int fdc_pipeline_work_real(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum);
 
+/* One contiguous SPAN of a longer stream, handed over by a dispatcher that cuts a work() call over several handles (the
+ * members of an fdc_pipeline_group below; a user-written scheduler may call it directly).  Same as fdc_pipeline_work() except
+ * that the two pieces of stream state come from the caller instead of from the handle:
+ *   halo         the N/R samples in front of the span (the tail of the previous span; lib/overlap_save_impl.cc:62-81), or NULL
+ *                for zeros (stream start, :52)
+ *   first_block  global index of the span's first block (window phase = first_block*shift mod R,
+ *                lib/phase_shifting_windowing_vcc_impl.cc:82)
+ * Afterwards the handle's own state is that of a stream that ended with this span (a following fdc_pipeline_work() continues it).
+ * _real: float32 samples, halo included (see fdc_pipeline_work_real). */
+int fdc_pipeline_work_span(fdc_pipeline *p, const void *halo, const void *in, int64_t first_block, int nblocks, void *const *outs,
+                           void *spectrum);
+int fdc_pipeline_work_span_real(fdc_pipeline *p, const void *halo, const void *in, int64_t first_block, int nblocks, void *const *outs,
+                                void *spectrum);
+
 /* Optional: pin a host range that will be handed to fdc_pipeline_work() again and again (GNU Radio's circular buffers
  * live as long as the flowgraph: register them in start(), unregister in stop()).  A call whose `in` lies in a
  * registered range is DMA'd from it in place, and when every outs[c] does, the results are stored straight into
@@ -158,6 +172,38 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p);
  * kernels cost 7-17 us per group on MI355X, enough to show in the throughput of the region they time) */
 int fdc_pipeline_enable_timing(fdc_pipeline *p, int enable);
 int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-device handle: the same chain behind ONE work() — what the FrequencyDomainChannelizer hier block is to the scheduler
+ * (python/FrequencyDomainChannelizer.py:283-315: one block, one work() thread) — spread over several GPUs of the node.  A call
+ * of nblocks items is cut into contiguous spans, one per member device; every member copies its span's samples over its own
+ * PCIe link (the halo of a span is the N/R samples in front of it in the caller's buffer; the first span's halo is the history
+ * the group keeps), runs the kernels with the span's global first-block index and writes its results into the caller's
+ * per-channel buffers at the span's block offset, all members concurrently.  No collective and no device-to-device traffic:
+ * spans are independent given halo and block index.  Results are those of one handle fed the same stream
+ * (bit for bit when the members run the kernels one handle would run: tests/test_group_gpu.py).
+ * The reference's own parallelism inside one work(): 4 FFTW threads (python/...:206), one std::thread per segment / per
+ * detected channel (lib/activity_detection_channelizer_vcm_impl.cc:293-304, :339-371).
+ *   cfg              as for fdc_pipeline_create; device_id is ignored, max_blocks is the largest nblocks of a GROUP call
+ *   devices[n]       HIP device ordinal of each member; an ordinal may appear more than once (virtual members on one GPU)
+ *   min_span_blocks  a member is not given fewer blocks than this, so short calls use fewer members (0 = default 8)
+ * One thread at a time per group, like every handle.  A call that fails on some member leaves the group unusable until
+ * fdc_pipeline_group_reset() (the other members' spans of that call were written).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fdc_pipeline_group fdc_pipeline_group;
+int fdc_pipeline_group_create(const fdc_pipeline_cfg *cfg, const int32_t *devices, int ndevices, int min_span_blocks,
+                              fdc_pipeline_group **out);
+void fdc_pipeline_group_destroy(fdc_pipeline_group *g);
+/* work()-shaped, same arguments and state semantics as fdc_pipeline_work() / fdc_pipeline_work_real() */
+int fdc_pipeline_group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *outs, void *spectrum);
+int fdc_pipeline_group_work_real(fdc_pipeline_group *g, const void *in, int nblocks, void *const *outs, void *spectrum);
+void fdc_pipeline_group_reset(fdc_pipeline_group *g);           /* history <- zeros, block counter <- 0, error state cleared */
+int32_t fdc_pipeline_group_size(const fdc_pipeline_group *g);
+fdc_pipeline *fdc_pipeline_group_member(fdc_pipeline_group *g, int i);   /* owned by the group (fdc_pipeline_path, sizes, timing) */
+int32_t fdc_pipeline_group_device(const fdc_pipeline_group *g, int i);
+int32_t fdc_pipeline_group_member_max_blocks(const fdc_pipeline_group *g);   /* the longest span a member can be given */
+/* the spans of the last call: first_block[i] (global index) and nblocks[i] (0 = member idle) for i < min(size, cap); returns size */
+int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_block, int32_t *nblocks, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Stateful sinks fed with the normalised spectrum (what the hier block connects to normalize_input,

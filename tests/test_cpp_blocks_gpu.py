@@ -17,7 +17,7 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     N, R = 1024, 4
     H = N - N // R
     rng = np.random.default_rng(21)
-    x = (rng.standard_normal(6 * H) + 1j * rng.standard_normal(6 * H)).astype(np.complex64)
+    x = (rng.standard_normal(20 * H) + 1j * rng.standard_normal(20 * H)).astype(np.complex64)     # 20 items: a two-member group cuts them into 10 + 10
     spec = (1e-3 * (rng.standard_normal((14, N)) + 1j * rng.standard_normal((14, N)))).astype(np.complex64)
     spec[3:8, 300:340] += (rng.standard_normal((5, 40)) + 1j * rng.standard_normal((5, 40))).astype(np.complex64)
     spec[5:11, 700:760] += (rng.standard_normal((6, 60)) + 1j * rng.standard_normal((6, 60))).astype(np.complex64)

@@ -81,6 +81,31 @@ def test_full_size_batch_vs_oracle_and_launch_grouping(oracle, N, C, nb):
             assert np.linalg.norm(d) <= TOL * np.linalg.norm(ref[c]) and np.abs(d).max() <= TOL * np.abs(ref[c]).max(), (force, c)
 
 
+def test_bench_launch_size_one_group_of_2048_blocks(oracle):
+    """bench.py's default step: 2048 blocks of configs[1] in ONE launch group of the one-kernel path (the library cuts calls into
+    groups of chunk_blocks; at this size the group is the whole call).  Every output sample against the oracle, and bit for bit
+    against the same stream run in sub-batches."""
+    N, R, C, nb = 65536, 2, 256, 2048
+    H = N - N // R
+    plan = plan_for(N, R, C)
+    x = noise(nb * H, 77)
+    whole = run(N, R, plan, x, nb, sub=nb)
+    p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+    assert p.chunk_blocks() >= nb and (FORCED or p.path() == 3)
+    p.close()
+    pieces = run(N, R, plan, x, nb)
+    for c in range(C):
+        assert np.array_equal(bits(pieces[c]), bits(whole[c])), "launch grouping changed channel %d" % c
+    del pieces
+    ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=min(16, os.cpu_count() or 1))
+    worst_l2 = worst_mx = 0.0
+    for c in range(C):
+        d = whole[c].astype(np.complex128) - ref[c].astype(np.complex128)
+        worst_l2 = max(worst_l2, float(np.linalg.norm(d) / np.linalg.norm(ref[c])))
+        worst_mx = max(worst_mx, float(np.abs(d).max() / np.abs(ref[c]).max()))
+    assert worst_l2 <= TOL and worst_mx <= TOL, (worst_l2, worst_mx)
+
+
 def test_full_size_linearity_and_block_shift():
     N, R, C, nb = 65536, 2, 256, 1024
     H = N - N // R
