@@ -71,6 +71,7 @@ SYMBOLS = {
     "fdc_version": (C.c_char_p, []),
     "fdc_device_count": (C.c_int, []),
     "fdc_selftest_devices": (C.c_int, []),
+    "fdc_selftest_exception_barrier": (C.c_int, []),
     "fdc_pipeline_create": (C.c_int, [C.POINTER(fdc_pipeline_cfg), C.POINTER(_vp)]),
     "fdc_pipeline_destroy": (None, [_vp]),
     "fdc_pipeline_input_samples": (C.c_int64, [_vp, C.c_int]),

@@ -14,7 +14,9 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -202,6 +204,26 @@ int fdc_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int fdc_selftest_exception_barrier(void)
+{
+    struct Case { int kind, want; };
+    const Case cases[] = {{0, FDC_ERR_NOMEM}, {1, FDC_ERR_NOMEM}, {2, FDC_ERR_HIP}, {3, FDC_ERR_HIP}, {4, 7}};
+    for (const Case &c : cases) {
+        const int got = fdc::guarded("fdc_selftest_exception_barrier", [&]() -> int {
+            switch (c.kind) {
+            case 0: throw std::bad_alloc();
+            case 1: throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread");
+            case 2: throw std::runtime_error("runtime");
+            case 3: throw 42;
+            default: return 7;                                     // nothing thrown: the body's own status passes through
+            }
+        });
+        if (got != c.want) return fail(FDC_ERR_HIP, "exception barrier: kind %d came back as %d, expected %d", c.kind, got, c.want);
+        if (c.want < 0 && g_err.empty()) return fail(FDC_ERR_HIP, "exception barrier: kind %d left no text", c.kind);
+    }
+    return FDC_OK;
 }
 
 int fdc_selftest_devices(void)

@@ -50,6 +50,13 @@ using cfl = std::complex<float>;
 #define FDC_ENTRY(name) return fdc::guarded(name, [&]() -> int {
 #define FDC_ENTRY_END });
 
+// the bank failed mid-call: remember why, refuse everything that follows
+#define FDC_DEAD_CHECK(s)                                                                                                     \
+    do {                                                                                                                      \
+        if ((s)->poisoned)                                                                                                    \
+            return fdc::set_error(FDC_ERR_HIP, "the bank failed in an earlier call and must be destroyed (%s)", (s)->poison_why.c_str()); \
+    } while (0)
+
 int pow2ceil(int k) { return (int)std::pow(2.0, std::ceil(std::log2((double)k))); }
 bool ispow2i(int k) { return k > 0 && (k & (k - 1)) == 0; }
 
@@ -175,6 +182,11 @@ struct fdc_sinks {
     std::vector<int> det_win_off;            // per width class
     std::vector<fdc::PowerCell> cells;
     int64_t blockcount = 1;                  // both reference blocks start counting at 1 (hist is block 0)
+    // A work / submit / flush call that fails after it has begun to advance the bank's state (block counter, channel state on the
+    // device, buffered blocks, the two-deep pipeline) cannot be undone or repeated: the handle is dead from then on and every
+    // later call says so (include/fdc_amd.h, "Failure").
+    bool poisoned = false;
+    std::string poison_why;
     hipStream_t stream = nullptr;
     float2 *d_spec = nullptr;                // (max_blocks + 1) * N: slot 0 = history block
     float2 *d_wins = nullptr, *d_tw = nullptr, *d_tw256 = nullptr;    // window pool, exp(-2 pi i k/N), exp(-2 pi i j/256)
@@ -1188,7 +1200,7 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
         dp.segname0 = s->cfg.det_id;
         HIPCHK(fdc::launch_det_track(dp, nblocks, d.d_dgeom, d.d_sst, d.d_live, d.d_live_off, d.d_cand, d.d_cand_base, d.d_ncand, d.d_winoff,
                                      now, d.d_pdus, d.d_pdu_base, d.d_npdu, d.d_owners, d.d_owner_base, d.d_nowner, d.d_detch, d.d_live2,
-                                     s->stream));
+                                     d.d_error, s->stream));
         HIPCHK(fdc::launch_det_expand(nseg, npac, s->R, d.d_owners, d.d_owner_base, d.d_nowner, d.d_tasks, d.d_task_base, d.d_ntask, s->stream));
     }
     HIPCHK(fdc::launch_sink_layout(d.nlist, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_tasks, d.d_pdus, d.d_pdus_out, d.d_owners,
@@ -1349,6 +1361,16 @@ static int dev_build(fdc_sinks *s, int b)
     return d.nb_of[b];
 }
 
+// rc < 0 from a step that may have advanced the bank's state: the handle is dead (see fdc_sinks::poisoned)
+static int poison(fdc_sinks *s, int rc)
+{
+    if (rc < 0 && !s->poisoned) {
+        s->poisoned = true;
+        try { s->poison_why = fdc_last_error(); } catch (...) {}
+    }
+    return rc;
+}
+
 static int dev_complete(fdc_sinks *s, int b)
 {
     const int rc = dev_build(s, b);
@@ -1359,31 +1381,35 @@ int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
 {
     FDC_ENTRY("fdc_sinks_submit_device")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
     if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
     if (!s->dev.on) {                                          // host engine: the batch is done when the call returns
         if (nblocks == 0) { s->pdus.clear(); return 0; }
         HIPCHK(hipSetDevice(s->cfg.device_id));
-        return host_work_device(s, nblocks);
+        return poison(s, host_work_device(s, nblocks));
     }
     HIPCHK(hipSetDevice(s->cfg.device_id));
     auto &d = s->dev;
     if (nblocks == 0) {
-        const int done = dev_complete(s, d.cur);
+        const int done = poison(s, dev_complete(s, d.cur));
         if (done == 0) s->pdus.clear();
         return done;
     }
     // This batch's decision kernels are enqueued; while the device runs them the PDUs of the batch before are built (host work);
     // then the one wait for the layout summary, the extractions of this batch, and last the wait for the payload of the batch
     // before — its copy has been running beside all of that.
-    int rc = dev_enqueue(s, nblocks);
+    // From the first launch of dev_enqueue on, the channel state on the device, the block counter and the layout of this batch's
+    // landing buffer have moved on: a failure anywhere below leaves them ahead of the host's bookkeeping (d.cur, d.pend), so it
+    // poisons the handle instead of returning an error that invites a retry.
+    int rc = poison(s, dev_enqueue(s, nblocks));
     if (rc != FDC_OK) return rc;
     const int before = d.cur;
     const bool had = d.pend[before];
-    if (had) { rc = dev_build(s, before); if (rc < 0) return rc; }
+    if (had) { rc = poison(s, dev_build(s, before)); if (rc < 0) return rc; }
     else s->pdus.clear();
-    rc = dev_launch_extractions(s, nblocks);
+    rc = poison(s, dev_launch_extractions(s, nblocks));
     if (rc != FDC_OK) return rc;
-    return had ? dev_wait(s, before) : 0;
+    return had ? poison(s, dev_wait(s, before)) : 0;
     FDC_ENTRY_END
 }
 
@@ -1391,9 +1417,10 @@ int fdc_sinks_flush(fdc_sinks *s)
 {
     FDC_ENTRY("fdc_sinks_flush")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
     if (!s->dev.on || !s->dev.inflight) return 0;
     HIPCHK(hipSetDevice(s->cfg.device_id));
-    return dev_complete(s, s->dev.cur);
+    return poison(s, dev_complete(s, s->dev.cur));
     FDC_ENTRY_END
 }
 
@@ -1403,14 +1430,15 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks)
 {
     FDC_ENTRY("fdc_sinks_work_device")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
     if (nblocks < 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [0, max_blocks]", nblocks);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
     if (nblocks == 0) { s->pdus.clear(); return 0; }
     HIPCHK(hipSetDevice(s->cfg.device_id));
-    if (!s->dev.on) return host_work_device(s, nblocks);
+    if (!s->dev.on) return poison(s, host_work_device(s, nblocks));
     int rc = fdc_sinks_submit_device(s, nblocks);
     if (rc < 0) return rc;
-    rc = dev_complete(s, s->dev.cur);
+    rc = poison(s, dev_complete(s, s->dev.cur));
     return rc < 0 ? rc : nblocks;
     FDC_ENTRY_END
 }
@@ -1419,6 +1447,7 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
 {
     FDC_ENTRY("fdc_sinks_work")
     if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
     if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
     if (nitems == 0) { s->pdus.clear(); return 0; }

@@ -98,7 +98,8 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
                             int64_t *live_off /* [nseg][kDetMaxCells] */, const int2 *cand, const int64_t *cand_base,
                             const int32_t *ncand, const int32_t *win_off /* [log2 N + 1] */, long long now, SinkPdu *pdus,
                             const int64_t *pdu_base, int32_t *npdu, SinkOwner *owners, const int64_t *owner_base /* [nseg + 1], first = npac */,
-                            int32_t *nowner /* [nseg] */, DetCh *chs, int32_t *live2, hipStream_t s);
+                            int32_t *nowner /* [nseg] */, DetCh *chs, int32_t *live2,
+                            int32_t *error /* set to 1 when a segment has more live channels than kDetMaxCells (read by k_sink_layout) */, hipStream_t s);
 
 // extraction tasks of the detected channels of a call, from their stream records (one workgroup per segment)
 hipError_t launch_det_expand(int nseg, int npac, int R, SinkOwner *owners, const int64_t *owner_base, const int32_t *nowner, SinkTask *tasks,

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                                                   long long now, SinkPdu *__restrict__ pdus, const int64_t *__restrict__ pdu_base,
                                                   int32_t *__restrict__ npdu, SinkOwner *__restrict__ owners,
                                                   const int64_t *__restrict__ owner_base, int32_t *__restrict__ nowner,
-                                                  DetCh *__restrict__ chs_g, int32_t *__restrict__ live2_g)
+                                                  DetCh *__restrict__ chs_g, int32_t *__restrict__ live2_g, int32_t *__restrict__ error)
 {
     constexpr int words = WORDS, staged = kDetStaged;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdc_det_smem[];
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
             else {
                 const int d = atomicAdd(&cnt[5], 1);
                 if (d < kDetMaxCells) { TL[A_T + d] = t; TL[A_KEY + d] = key; TL[A_DS + d] = ds; TL[A_DE + d] = de; TL[A_STK + d] = streak; }
+                else atomicExch(error, 1);                       // more live channels than power cells: the host refuses the batch (SinkSummary.error)
             }
         }
     };
@@ -726,7 +727,8 @@ __global__ __launch_bounds__(64 * kDetWaves) void k_det_track(DetParams dp, int 
                 pl[p] = r;
             } else {                                             // still alive: an entry of the list the next call starts from (placed below)
                 int d = atomicAdd(&cnt[4], 1);
-                if (d >= kDetMaxCells) d = kDetMaxCells - 1;     // cannot happen: live channels are disjoint, at most one per cell
+                if (d >= kDetMaxCells) { d = kDetMaxCells - 1; atomicExch(error, 1); }   // live channels are disjoint, at most one per cell — unless
+                                                                                          // a threshold below 0 dB lets one-cell candidates through
                 SV[d] = c.own;
                 L2[DC_ID * kDetMaxCells + d] = c.id; L2[DC_DSTART * kDetMaxCells + d] = c.ds; L2[DC_DSTOP * kDetMaxCells + d] = c.de;
                 L2[DC_ESTART * kDetMaxCells + d] = c.es; L2[DC_CLS * kDetMaxCells + d] = c.cls; L2[DC_COUNT * kDetMaxCells + d] = cntf;
@@ -835,7 +837,7 @@ int det_track_staged(int nbmax, int max_cand_cap)
 hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, DetSegState *sst, int32_t *live, int64_t *live_off,
                             const int2 *cand, const int64_t *cand_base, const int32_t *ncand, const int32_t *win_off, long long now,
                             SinkPdu *pdus, const int64_t *pdu_base, int32_t *npdu, SinkOwner *owners, const int64_t *owner_base,
-                            int32_t *nowner, DetCh *chs, int32_t *live2, hipStream_t s)
+                            int32_t *nowner, DetCh *chs, int32_t *live2, int32_t *error, hipStream_t s)
 {
     if (dp.nseg <= 0) return hipSuccess;
     const int words = (dp.max_cand_cap + 63) / 64;
@@ -845,7 +847,7 @@ hipError_t launch_det_track(const DetParams &dp, int nb, const DetGeom *geom, De
     dq.dec_magic = (dp.dec > 1 && (unsigned long long)dp.N * (unsigned long long)dp.dec < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)dp.dec) + 1u : 0u;
 #define FDC_LT(W) \
     hipLaunchKernelGGL(k_det_track<W>, dim3((unsigned)dp.nseg), dim3(64 * kDetWaves), det_lds_bytes(nb, W), s, dq, nb, geom, sst, live, live_off, \
-                       cand, cand_base, ncand, win_off, now, pdus, pdu_base, npdu, owners, owner_base, nowner, chs, live2)
+                       cand, cand_base, ncand, win_off, now, pdus, pdu_base, npdu, owners, owner_base, nowner, chs, live2, error)
     if (words == 1) FDC_LT(1); else if (words == 2) FDC_LT(2); else FDC_LT(8);
 #undef FDC_LT
     return hipGetLastError();

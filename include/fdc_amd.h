@@ -37,13 +37,20 @@ typedef enum {
 enum { FDC_WIN_RECTANGULAR = 0, FDC_WIN_HANN = 1, FDC_WIN_RAMP = 2 };
 
 const char *fdc_last_error(void);            /* thread-local text of the last failure */
+/* No C++ exception leaves the library: every entry that can allocate on the host (std::vector, std::thread, new) runs behind one
+ * barrier that turns std::bad_alloc / std::system_error into FDC_ERR_NOMEM and anything else into FDC_ERR_HIP (csrc/fdc_guard.hpp).
+ * This entry throws each kind through that same barrier and returns FDC_OK when every one came back as the status it should
+ * (needs no device; tests/test_abi_cpu.py). */
+int fdc_selftest_exception_barrier(void);
 const char *fdc_version(void);
 int fdc_device_count(void);                  /* number of visible HIP devices (0 if none) */
 /* Runs the headline geometry (65536-point blocks, R = 2, 256 channels of 256 bins, 96 blocks: the one-kernel path) through
  * fdc_pipeline_work() on EVERY visible device and compares a checksum of all output samples with device 0's (same kernels,
- * same input: the bytes must be identical).  Returns the number of devices verified, or a negative fdc_status with the
- * device and the mismatch in fdc_last_error().  A multi-GPU launcher calls it once before sharding block spans over the
- * devices (the kernel attributes are set per device: this is what exercises device_id > 0). */
+ * same input: the bytes must be identical), then once more through ONE multi-device handle over all visible devices
+ * (fdc_pipeline_group below; with one device: two virtual members on it), the call cut in two so that the group's history is
+ * used: again device 0's bytes.  Returns the number of devices verified, or a negative fdc_status with the device and the
+ * mismatch in fdc_last_error().  A multi-GPU launcher calls it once before sharding block spans over the devices (the kernel
+ * attributes are set per device: this is what exercises device_id > 0, and the group's worker threads on real peers). */
 int fdc_selftest_devices(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -220,6 +227,12 @@ int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_bl
  * (dict + c32vector, …vcm_impl.cc:415-430, PowerActivationChannel_impl.cc:222-233) comes back as POD records that the
  * C++ face turns into pmt; `msg`, `fileoutput`, `path`, `verbose` and `threads` stay with that face.
  * create() fails with FDC_ERR_INVALID_ARGUMENT exactly where the reference constructors throw.
+ * Failure: the blocks are stateful and a batch advances that state on the device as it goes (block counter, channel state
+ * machines, buffered blocks, the two-deep submission).  A work / submit / flush call that fails after it has started to do so
+ * (a HIP error, out of memory while growing a landing buffer) cannot be rolled back or repeated: the handle is DEAD from then
+ * on — every later work / submit / flush returns FDC_ERR_HIP naming the first failure, PDUs of the failed call are not handed
+ * out (none twice, none with a wrong payload) — and must be destroyed.  Argument errors (a count out of range, a null buffer,
+ * work_device while a batch is in flight) are refused before anything moves and leave the handle usable.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fdc_sinks fdc_sinks;
 typedef struct { float cfreq, bw; int32_t id; } fdc_pac_cfg;           /* INTERNAL frequency units, [0,1) */

@@ -150,3 +150,32 @@ def test_round_half_away_is_c_round_on_the_edges():
     for x in (0.49999999999999994, -0.49999999999999994, 0.5, -0.5, 1.5, 2.5, -2.5, 4503599627370497.0, -4503599627370497.0,
               4503599627370495.5, 1e300, 0.0, 123.49999999999999, 123.5):
         assert _round_half_away(x) == m.round(x), x
+
+
+def test_exception_barrier_of_the_c_abi():
+    """No C++ exception crosses the extern "C" boundary: the barrier every entry runs behind turns bad_alloc /
+    system_error into FDC_ERR_NOMEM and anything else into FDC_ERR_HIP; and every int-returning entry that has a body of its
+    own in the three ABI sources goes through that barrier (one-line accessors cannot throw)."""
+    assert G.lib().fdc_selftest_exception_barrier() == 0, G.lib().fdc_last_error()
+    csrc = os.path.join(ROOT, "gr-fdc_amd", "csrc")
+    for fn in ("fdc_api.hip", "fdc_sinks.hip", "fdc_group.hip"):
+        txt = open(os.path.join(csrc, fn)).read()
+        ext = txt[txt.index('extern "C" {'):]
+        for m in re.finditer(r"^int (fdc_\w+)\([^;{]*\)\n\{\n(.*?)^\}", ext, flags=re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            if name == "fdc_selftest_exception_barrier" or body.count("\n") <= 8 and "std::" not in body and "new " not in body:
+                continue
+            assert "FDC_ENTRY(" in body, "%s: %s has no exception barrier" % (fn, name)
+
+
+def test_group_entry_points_validate_without_a_device():
+    """The multi-device handle refuses bad member lists before any device is touched."""
+    import ctypes as C
+    cfg = _lib.fdc_pipeline_cfg(0, 4096, 2, 1, 0, None, 8, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert G.lib().fdc_pipeline_group_create(C.byref(cfg), None, 2, 0, C.byref(h)) == -1
+    devs = (C.c_int32 * 2)(0, 0)
+    assert G.lib().fdc_pipeline_group_create(C.byref(cfg), devs, 0, 0, C.byref(h)) == -1
+    assert G.lib().fdc_pipeline_group_create(C.byref(cfg), devs, 65, 0, C.byref(h)) == -1
+    assert G.lib().fdc_pipeline_group_size(None) == -1 and not G.lib().fdc_pipeline_group_member(None, 0)
+    G.lib().fdc_pipeline_group_destroy(None)
