@@ -447,7 +447,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
         // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
         // classes: same offset r = f mod 256, same window, every slot at most once
-        const bool block_form = N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);
+        const bool block_form = fdc::poly_block_supports(N) && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);
         constexpr size_t kMaxPolyClasses = 3;
         std::vector<std::vector<char>> used;
         for (int c = 0; ok && c < p->C; c++) {
@@ -474,7 +474,8 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (ok && block_form && R == 4) for (const auto &pc : p->classes) if (pc.r != 0) ok = false;
         // one launch per class (0.16 ms per 1024 blocks each, measured) against the spectrum path (0.25 ms forward transform +
         // 0.16 ms per 256 channels): several classes only where that is the faster of the two
-        if (ok && p->classes.size() > 1 && 0.16 * (double)p->classes.size() >= 0.25 + 0.16 * (double)p->C / 256.0) ok = false;
+        // (N = 65536; at N = 16384 / 32768 the alternative is the generic three-kernel path at 3-4x the cost of one class: always classes)
+        if (ok && N == 65536 && p->classes.size() > 1 && 0.16 * (double)p->classes.size() >= 0.25 + 0.16 * (double)p->C / 256.0) ok = false;
         p->poly_block = ok && block_form;
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
@@ -605,7 +606,8 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    if (p->fwd_block) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizer's rows 64..127
+    if (p->fwd_block || (p->poly_block && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
         std::vector<char> g64((size_t)N / 64, 0);
         bool all = true;
@@ -790,7 +792,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                               p->d_tw256, p->d_twq, pc.d_cbt, pc.d_shn, pc.d_slot_off,
                                               (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
                                               pc.r, first_block + m0, tg && k == 0 ? p->events[span[0]] : nullptr,
-                                              tg && k + 1 == p->classes.size() ? p->events[span[1]] : nullptr, p->R, p->d_fscr));
+                                              tg && k + 1 == p->classes.size() ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->N));
             }
             if (tg) {
                 span[2] = span[3] = span[1];

@@ -50,39 +50,69 @@ __device__ __forceinline__ cf unpack_cf(unsigned long long u) { return mk(__uint
 #define FDC_PLAIN_DS
 #endif
 
+// The block length is a template parameter: N = 256 rows x (32 P) columns with P = 2, 4, 8 passes of 32 columns, i.e. N = 16384,
+// 32768, 65536; the number of channel slots is the number of columns N1 = 32 P.  Stage 1 does not depend on P except through the row
+// pitch and the table sizes (a pass is a pass); G is 16 P registers per lane; stage 2 is a DFT-P over the pass index in registers, one
+// trip through LDS and the same DFT-32 over c5.  With P < 8 a trip holds all 128 rows of a run (P = 8: 64) and a wave reads
+// (klo = wave mod P, row half = wave div P).
+//
 // LDS map (bytes).  Stage-1 scratch: per wave 68*15 + 64 = 1084 points (element (p; lane) at lane + 68 p).
 constexpr int kBlkScrPts = 1084;
-// stage-2 chunk: [64 rows][262] (8 klo x 32 c5 + 6).  Row stride 524 dwords = 12 mod 64: the 16-lane groups of ds_read_b128
-// (lanes {0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS table) then cover all 64 banks, and the 16 contiguous lanes of a
-// ds_write_b64 group (4 rows x 4 columns) all 32 (a stride of 8 mod 64 is conflict-free for the stores only: 1.46 M conflict cycles)
-constexpr int kBlkGbufLd = 262;
-constexpr int kBlkOffCt = 64 * kBlkGbufLd * 8;                    // 133120: stage-2 twiddles [32][8]
-constexpr int kBlkXbufPts = 8448;                                 // upper part of the stage-2 chunk (free during stage 1)
 constexpr int kBlkOffX = 8 * kBlkScrPts * 8;                      // 69376: end of the stage-1 strips
-constexpr int kBlkOffWrow = kBlkOffX + kBlkXbufPts * 8;           // 136960
-constexpr int kBlkOffB = kBlkOffWrow + 16 * 18 * 8;               // 139264
-constexpr int kBlkOffSA = kBlkOffB + 32 * 18 * 8;                 // 143872
-constexpr int kBlkOffSoff = kBlkOffSA + 128 * 18 * 8;             // 162304
-constexpr int kBlkLds = kBlkOffSoff + 256 * 4;                    // 163328 <= 163840
-constexpr int kBlkOffSoffOff = kBlkOffSA + 128 * 16 * 8;          // offset plans: unpadded SA rows, then soff, then wrowF
-constexpr int kBlkOffWrowF = kBlkOffSoffOff + 256 * 4;
-constexpr int kBlkLdsOff = kBlkOffWrowF + 16 * 18 * 8;           // 163584 <= 163840
-static_assert(kBlkLdsOff <= 160 * 1024, "LDS budget of the offset-plan variant");
-static_assert(kBlkLds <= 160 * 1024, "LDS budget");
-static_assert(kBlkOffCt >= kBlkOffX && kBlkOffCt + 32 * 8 * 8 <= kBlkOffWrow, "stage-2 chunk and twiddles below the tables");
+template <int P>
+struct BlkGeom {
+    static_assert(P == 2 || P == 4 || P == 8, "passes of 32 columns: N = 16384, 32768 or 65536");
+    static constexpr int kN1 = 32 * P;                            // columns = channel slots
+    static constexpr int kN = 256 * kN1;
+    static constexpr int kJT = P == 8 ? 4 : 8;                    // 16-row groups per stage-2 trip (64 or 128 rows)
+    static constexpr int kJB = P == 8 ? 2 : P == 4 ? 4 : 8;       // 16-row groups within reach of one ds base register (16-bit byte offset)
+    // stage-2 trip: [rows][32 P + 6] (P klo x 32 c5 + 6).  The row stride in dwords is 12 mod 64 for every P: the 16-lane groups of
+    // ds_read_b128 (lanes {0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS table) then cover all 64 banks, and the 16 contiguous lanes
+    // of a ds_write_b64 group (4 rows x 4 columns) all 32 (a stride of 8 mod 64 is conflict-free for the stores only: 1.46 M conflict
+    // cycles at P = 8)
+    static constexpr int kLd = 32 * P + 6;
+    static constexpr int kTripBytes = 16 * kJT * kLd * 8;         // P = 8: 134144
+    static constexpr int kOffCt = kTripBytes;                     // stage-2 twiddles [32][P], behind the trip buffer
+    static constexpr int kOffWrow = P == 8 ? 136960 : kOffCt + 32 * P * 8;   // tables: above the strips and the trip buffer
+    static constexpr int kOffB = kOffWrow + 16 * 18 * 8;
+    static constexpr int kOffSA = kOffB + 32 * 18 * 8;
+    static constexpr int kOffSoff = kOffSA + 16 * P * 18 * 8;
+    static constexpr int kLds = kOffSoff + kN1 * 4;               // P = 8: 163328 <= 163840
+    static constexpr int kOffSoffOff = kOffSA + 16 * P * 16 * 8;  // offset plans: unpadded SA rows, then soff, then wrowF
+    static constexpr int kOffWrowF = kOffSoffOff + kN1 * 4;
+    static constexpr int kLdsOff = kOffWrowF + 16 * 18 * 8;       // P = 8: 163584 <= 163840
+    static_assert(kLdsOff <= 160 * 1024 && kLds <= 160 * 1024, "LDS budget");
+    static_assert(kOffCt >= kBlkOffX && kOffCt + 32 * P * 8 <= kOffWrow, "stage-2 trip buffer and twiddles below the tables, tables above the strips");
+    static_assert((16 * (kJB - 1) * kLd + 32 * (P - 1)) * 8 < 65536, "ds offsets of a base register");
+};
 
 // FWD = false: the channelizer (above).  FWD = true: the same machinery as a plain forward transform of the block (no window,
-// no inverse transform).  Stage 1 stops after the forward FFT-256 of a column: T[k2][n1] = A[k2] W_N^(n1 k2) / N.  The half
+// no inverse transform; P = 8 only).  Stage 1 stops after the forward FFT-256 of a column: T[k2][n1] = A[k2] W_N^(n1 k2) / N.  The half
 // k2 < 128 stays in the G registers, the other half goes to 256 KiB of per-workgroup scratch (it stays in the L2 / the
 // memory-side cache) and is read back into the G registers after the first run of stage 2; stage 2 is unchanged and runs
 // twice, its "slots" are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 =
 // fftshift), 64 consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans,
 // the sinks, the debug port) use instead of two passes through a scratch buffer of the whole batch.
 // R4 = true: the channelizer at relinvovl = 4 (the reference's default overlap, grc/FDC_FrequencyDomainChannelizer.xml:61): three
-// quarters of every inverse transform are kept, G is 192 rows x 256 columns = 384 KiB.  The rows t >= 128 stay in the G registers
-// as for R = 2; the rows 64 <= t < 128 take the route of the forward-transform variant: 128 KiB of per-workgroup scratch (L2),
-// read back for a third 64-row run of stage 2.  On-grid plans only (f = 256 slot: the window phase stays 0).
-template <bool NT, bool OFF, bool FWD, bool R4 = false>
+// quarters of every inverse transform are kept, G is 192 rows x N1 columns.  The rows t >= 128 stay in the G registers
+// as for R = 2; the rows 64 <= t < 128 take the route of the forward-transform variant: per-workgroup scratch (L2),
+// read back for a third, 64-row run of stage 2.  On-grid plans only (f = 256 slot: the window phase stays 0).
+
+// DFT over the pass index (the register index of G): P points in place; the result X[k] is read through blk_pass_idx<P>(k)
+template <int P> __device__ __forceinline__ constexpr int blk_pass_idx(int k) { return P == 8 ? 4 * (k & 1) + (k >> 1) : k; }
+template <int P>
+__device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
+{
+    if constexpr (P == 8) dft8<false>(a);                          // klo = k0 + 2 k1 in a[4 k0 + k1]
+    else if constexpr (P == 4) {                                   // natural order
+        dft4<false>(a[0], a[1], a[2], a[3]);
+    } else {
+        const cf s0 = a[0] + a[1], d0 = a[0] - a[1];
+        a[0] = s0; a[1] = d0;
+    }
+}
+
+template <int P, bool NT, bool OFF, bool FWD, bool R4 = false>
 __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -91,18 +121,21 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                                                 unsigned long long *__restrict__ dbg, int roff, long long first_block,
                                                 float2 *__restrict__ fwd_scratch, const unsigned *__restrict__ keep)
 {
-    float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: G chunk
-    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrow);      // [b][p] = W256^(b p), rows of 18
-    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffB);           // [c5][q] = W_N^(16 c5 q)
-    float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffSA);          // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
+    typedef BlkGeom<P> GM;
+    static_assert(!FWD || P == 8, "the forward-transform variant exists for N = 65536 only");
+    constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
+    float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: the trip buffer
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffWrow);     // [b][p] = W256^(b p), rows of 18
+    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffB);          // [c5][q] = W_N^(16 c5 q)
+    float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffSA);         // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
     // offset plans need a second twiddle table: the SA rows give up their padding for it (2-way conflicts on 8 reads per pass)
     constexpr int kSaLd = OFF ? 16 : 18;
-    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (OFF ? kBlkOffSoffOff : kBlkOffSoff));
-    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffCt);      // [c5][klo] = W_256^(c5 klo): stage 2, after the DFT-8
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (OFF ? GM::kOffSoffOff : GM::kOffSoff));
+    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffCt);       // [c5][klo] = W_N1^(c5 klo): stage 2, after the DFT-P
     const int tid = threadIdx.x;
     // stage-1 roles
     const int w = tid >> 6, lane = tid & 63, col = lane & 3, b = lane >> 2, c5 = 4 * w + col;
-    // stage-2 roles: writer = the stage-1 role (column c5, rows b + 16 j); reader: row = lane, klo = wave
+    // stage-2 roles: writer = the stage-1 role (column c5, rows b + 16 j); reader: row = lane (+ 64 row half), klo = wave mod P
     // FWD with a plan that reads part of the spectrum only: which of this wave's 64-bin stores some channel reads at all
     // ([klo = wave][k2 / 64], bit = register index of the slot); the others are dropped (offset beyond the descriptor's extent)
     unsigned mqs[4] = {~0u, ~0u, ~0u, ~0u};
@@ -124,35 +157,38 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     if ((blockIdx.x >> 3) & 1) for (int i = 0; i < FDC_BLK_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
 #endif
 
-    const unsigned inbytes = 65536u * 8u;
-    const unsigned voff = (unsigned)(b * 256 + c5) * 8u;          // row b, column c5 of pass 0; pass adds 256 B, row group a 32 KiB
+    constexpr unsigned inbytes = (unsigned)GM::kN * 8u;
+    constexpr unsigned kRowGrp = (unsigned)kN1 * 128u;            // 16 rows of kN1 columns, bytes (P = 8: 32 KiB)
+    const unsigned voff = (unsigned)(b * kN1 + c5) * 8u;          // row b, column c5 of pass 0; pass adds 256 B, row group a 16 rows
     // the first block's rows are requested before the tables are built: their latency hides behind the table set-up
-    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 256u * 16u * 8u);      // cbt[n1][b], n1 = 32 pass + c5
+    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, (unsigned)kN1 * 16u * 8u);      // cbt[n1][b], n1 = 32 pass + c5
     const unsigned voffc = (unsigned)(c5 * 16 + b) * 8u;
     cf L[16], cbn;
     {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * kRowGrp);
         cbn = bld2(rcb, voffc, 0);
     }
     // ---- tables (once per workgroup; the workgroup is persistent)
-    // Offset plans (every channel at f = 256*slot + r, OFF): the block is modulated by exp(-2 pi i r n / N), n = n1 + 256 (16a + b),
+    // Offset plans (every channel at f = 256*slot + r, OFF): the block is modulated by exp(-2 pi i r n / N), n = n1 + N1 (16a + b),
     // without a single extra multiplication.  W_16^(r a) rotates the outputs of the first DFT-16 (index p reads Z[(p + r) mod 16]:
     // the exchange slot of register Z[p] becomes (p - r) mod 16), W_256^(r b) joins the forward twiddle (table wrowF), W_N^(r n1)
     // sits in cbt (host), and for odd r the window phase (-1)^block (phase_shifting_windowing_vcc_impl.cc:82, R = 2) in cb.
-    float2 *wrowF = OFF ? reinterpret_cast<float2 *>(fdc_smem_blk + kBlkOffWrowF) : wrow;
+    float2 *wrowF = OFF ? reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffWrowF) : wrow;
     const int r16 = roff & 15;
     for (int i = tid; i < 256; i += 512) {
         wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
         if (OFF)     // entry [b][p]: the twiddle of register Z[p], whose true index is pt = (p - r) mod 16: W_256^(b (pt + r))
             wrowF[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * ((((i & 15) - r16) & 15) + roff)) & 255];
-        const long long o = slot_off[i];                  // slot i = klo + 8 khi, khi = k0 + 2 k1, is entry [klo][16 k0 + rev16(k1)]
-        soff[(i & 7) * 32 + ((i >> 3) & 1) * 16 + rev16(i >> 4)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
-        ctab[i] = tw256[((i >> 3) * (i & 7)) & 255];      // [c5][klo] = W_256^(c5 klo)
     }
+    for (int i = tid; i < kN1; i += 512) {
+        const long long o = slot_off[i];                  // slot i = klo + P khi, khi = k0 + 2 k1, is entry [klo][16 k0 + rev16(k1)]
+        soff[(i % P) * 32 + ((i / P) & 1) * 16 + rev16((i / P) >> 1)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+    }
+    for (int i = tid; i < 32 * P; i += 512) ctab[i] = tw256[((i / P) * (i % P) * (8 / P)) & 255];     // [c5][klo] = W_N1^(c5 klo)
     Bt[(tid >> 4) * 18 + (tid & 15)] = twq[tid];                                // c5 = tid >> 4 < 32, q = tid & 15
-    for (int i = tid; i < 2048; i += 512) {
+    for (int i = tid; i < 256 * P; i += 512) {
         const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15;
         const float2 t = twq[(size_t)(32 * ps) * 16 + q];                        // W_N^(16 * 32 ps * q)
         const float s = shn[bb + 16 * q];
@@ -166,7 +202,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     const float2 *const wrf = wrowF + b * 18;
     const float2 *const btr = Bt + c5 * 18;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
-    // FWD: this workgroup's scratch for the second half of k2, [pass][j][thread]
+    // FWD / R4: this workgroup's scratch, [pass][j][thread]
     const __amdgpu_buffer_rsrc_t rscr = make_rsrc((FWD || R4) ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, (FWD || R4) ? 32768u * 8u : 0u);
 
     // Two waves share a SIMD (waves w and w + 4).  The older one wins the issue arbitration and finishes stage 1 ~10 k cycles
@@ -195,7 +231,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // into an integer): the element index is the pass number at run time, and with 64-bit elements the compiler brackets
         // all sixteen moves of a pass with ONE s_set_gpr_idx_on / off pair (a pair per dword with 32-bit elements).  Integer,
         // not double, elements: bit-casting an extracted double to two floats read element 0 for every pass (seen in the ISA).
-        u8v G[8];
+        typedef unsigned long long gvec __attribute__((ext_vector_type(P)));
+        gvec G[8];
 #define FDC_GGET(j, ps) unpack_cf(G[j][ps])
 #define FDC_GPUT(j, ps, val) G[j][ps] = pack_cf(val)
         // ---------------- stage 1 ----------------
@@ -203,15 +240,15 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // pass (of this block, or pass 0 of this workgroup's next block; after the last block: the same rows again, unused)
         // are requested first, unconditionally (a conditional request costs a second set of register copies).
 #pragma nounroll
-        for (int ps = 0; ps < 8; ps++) {
+        for (int ps = 0; ps < P; ps++) {
 #ifdef FDC_BLK_L2PF
             // experiment: touch every 128-byte line of the pass after next (this block's, or the next block's) once, two passes ahead
             {
                 asm volatile("" :: "v"(pfd));
-                const int p2 = (ps + 2) & 7;
-                const int mb2 = ps < 6 ? m : mnext;
+                const int p2 = (ps + 2) & (P - 1);
+                const int mb2 = ps < P - 2 ? m : mnext;
                 const __amdgpu_buffer_rsrc_t rpf = make_rsrc(in + (size_t)mb2 * in_stride + 32 * p2, inbytes);
-                pfd = __builtin_amdgcn_raw_buffer_load_b32(rpf, (unsigned)((tid >> 1) * 2048 + (tid & 1) * 128), 0u, 0);
+                pfd = __builtin_amdgcn_raw_buffer_load_b32(rpf, (unsigned)((tid >> 1) * (kN1 * 8) + (tid & 1) * 128), 0u, 0);
             }
 #endif
             const cf cb = OFF ? cbn * sgn : cbn;
@@ -219,21 +256,21 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
 #pragma unroll
             for (int a = 0; a < 16; a++) cur[a] = L[a];
             {
-                const int pn = ps < 7 ? ps + 1 : 0;
-                const int mb = ps < 7 ? m : mnext;
+                const int pn = ps < P - 1 ? ps + 1 : 0;
+                const int mb = ps < P - 1 ? m : mnext;
                 // the pass offset (32 columns) sits in the descriptor's base: every pass uses the same per-lane offset and the
                 // same 16 scalar row offsets
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 32 * pn, inbytes);
                 if (hints & 2) {
 #pragma unroll
 #ifdef FDC_BLK_SC1LOADS
-                    for (int a = 0; a < 16; a++) L[a] = bld2_sc1(rin, voff, (unsigned)a * 32768u);
+                    for (int a = 0; a < 16; a++) L[a] = bld2_sc1(rin, voff, (unsigned)a * kRowGrp);
 #else
-                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * 32768u);
+                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * kRowGrp);
 #endif
                 } else {
 #pragma unroll
-                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * kRowGrp);
                 }
                 cbn = bld2(rcb, voffc, (unsigned)pn * 4096u);
             }
@@ -311,15 +348,17 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             FDC_STAMP(1 + ps);
         }
         // ---------------- stage 2 ----------------
-        // FFT-256 over n1 = 32 pass + c5 of every row t' = b + 16 j.  The 8 passes of a column sit in ONE lane: a DFT-8 over
-        // the pass index needs no exchange at all (k1 = klo + 8 khi: W_256^(n1 k1) = W_8^(pass klo) W_256^(c5 klo) W_32^(c5 khi)).
+        // FFT-N1 over n1 = 32 pass + c5 of every row t' = b + 16 j.  The P passes of a column sit in ONE lane: a DFT-P over
+        // the pass index needs no exchange at all (k1 = klo + P khi: W_N1^(n1 k1) = W_P^(pass klo) W_N1^(c5 klo) W_32^(c5 khi)).
         // What is left is a DFT-32 over c5 = 4 wave + col, i.e. across the whole workgroup: ONE trip through LDS per value
-        // (two chunks of 64 rows: [row][klo][c5], rows 262 apart), read back as whole 32-point runs by lane = row, wave = klo,
-        // transformed in registers.  A wave's store is 64 consecutive samples of one channel (512 B).
+        // (trips of 16 kJT rows: [row][klo][c5], rows kLd apart), read back as whole 32-point runs by lane = row (+ 64 for the
+        // upper row half when P < 8), klo = wave mod P, transformed in registers.  A wave's store is 64 consecutive samples of one
+        // channel (512 B).
         // rowbase: first output row (sample index inside the block's lout rows, or bin offset 128 h of a forward transform) of the
-        // run; nchc: its number of 64-row chunks
-        auto stage2 = [&](auto get, const int rowbase, auto nchc) __attribute__((always_inline)) {
-            constexpr int kNch = decltype(nchc)::value;
+        // run; njc: its number of 16-row groups (8 = the 128 rows in the G registers, 4 = a 64-row run from the scratch)
+        auto stage2 = [&](auto get, const int rowbase, auto njc) __attribute__((always_inline)) {
+            constexpr int kNJ = decltype(njc)::value;
+            constexpr int kNTrip = (kNJ + kJT - 1) / kJT;
             __syncthreads();                                          // every wave is done with its stage-1 scratch
             FDC_STAMP(9);
             // the stage-2 roles are worked out here, from a thread index the compiler cannot trace back: loop-invariant address
@@ -327,113 +366,98 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6), b_2 = lane2 >> 2, c5_2 = 4 * w2 + (lane2 & 3);
-            float2 *const gw0 = scr + b_2 * kBlkGbufLd + c5_2;        // element (row b + 16 jj, klo) at + 16 jj * 262 + 32 klo
-            // rows 32.. are out of reach of the 16-bit ds offset from gw0: a second base, opaque to the constant folder (it would
-            // otherwise materialise one address register per write)
-            int row32 = 32 * kBlkGbufLd;
-            asm volatile("" : "+v"(row32));
-            float2 *const gw1 = gw0 + row32;
-            const float2 *const gr = scr + lane2 * kBlkGbufLd + 32 * w2;   // row = lane, klo = wave: 32 consecutive points
-            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * w2);
+            const int klo2 = w2 % P, rh2 = w2 / P;                    // reader: klo, row half (0 for P = 8)
+            float2 *const gw0 = scr + b_2 * kLd + c5_2;               // element (row b + 16 jj, klo) at + 16 jj * kLd + 32 klo
+            // rows beyond 16 kJB are out of reach of the 16-bit ds offset from gw0: a second base, opaque to the constant folder (it
+            // would otherwise materialise one address register per write)
+            int rowjb = 16 * kJB * kLd;
+            asm volatile("" : "+v"(rowjb));
+            float2 *const gw1 = gw0 + rowjb;
+            const float2 *const gr = scr + (64 * rh2 + lane2) * kLd + 32 * klo2;   // 32 consecutive points of one row
+            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 32 * klo2);
 #pragma unroll
-            for (int ch = 0; ch < kNch; ch++) {
-                cf ct[8];                                             // W_256^(c5 klo): read per chunk, not held across the DFT-32 phase
+            for (int tr = 0; tr < kNTrip; tr++) {
+                const int ja = kNJ - kJT * tr < kJT ? kNJ - kJT * tr : kJT;   // 16-row groups of this trip (compile time after unrolling)
+                cf ct[P];                                             // W_N1^(c5 klo): read per trip, not held across the DFT-32 phase
                 {
-                    const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + kBlkOffCt) + c5_2 * 8;
+                    const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_blk + GM::kOffCt) + c5_2 * P;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < P / 2; i++) {
                         const float4 t = ld4(&ctr[2 * i]);
                         ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
                     }
                 }
-                // the 32 values of this chunk: register reads, or (second half of a forward transform) 32 loads in flight at once
-                cf src[4][8];
+                // the values of this trip: register reads, or (runs that come back from the scratch) all loads in flight at once
+                cf src[kJT][P];
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++)
+                for (int jj = 0; jj < kJT; jj++)
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(4 * ch + jj, ps);
+                    for (int ps = 0; ps < P; ps++) if (jj < ja) src[jj][ps] = get(kJT * tr + jj, ps);
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    cf a[8];
+                for (int jj = 0; jj < kJT; jj++) {
+                    if (jj >= ja) continue;
+                    cf a[P];
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
-                    dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
-                    float2 *const gw = (jj < 2 ? gw0 : gw1) + (jj & 1) * 16 * kBlkGbufLd;
+                    for (int ps = 0; ps < P; ps++) a[ps] = src[jj][ps];
+                    blk_pass_dft<P>(a);
+                    float2 *const gw = (jj < kJB ? gw0 : gw1) + (jj % kJB) * 16 * kLd;
                     st2(&gw[0], a[0]);
 #pragma unroll
-                    for (int k = 1; k < 8; k++) st2(&gw[32 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+                    for (int k = 1; k < P; k++) st2(&gw[32 * k], cmul(a[blk_pass_idx<P>(k)], ct[k]));
                 }
-                FDC_STAMP(10 + 5 * ch);
+                FDC_STAMP(10 + 5 * tr);
                 __builtin_amdgcn_sched_barrier(0);                    // keep the next phase's arithmetic (and its registers) behind
-                __syncthreads();                                      // the chunk is in LDS
-                FDC_STAMP(11 + 5 * ch);
+                __syncthreads();                                      // the trip is in LDS
+                FDC_STAMP(11 + 5 * tr);
+                const bool reads = P == 8 || 4 * rh2 < ja;            // P < 8: waves whose row half the trip does not have sit the phase out
                 cf v[32];
+                if (reads) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float4 t = ld4(&gr[2 * i]);
-                    v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                    for (int i = 0; i < 16; i++) {
+                        const float4 t = ld4(&gr[2 * i]);
+                        v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                    }
                 }
-                __syncthreads();                                      // every read of the chunk is done: the region may be rewritten
+                __syncthreads();                                      // every read of the trip is done: the region may be rewritten
                 __builtin_amdgcn_sched_barrier(0);
-                FDC_STAMP(12 + 5 * ch);
-                dft32<false>(v);                                      // khi = k0 + 2 k1 in v[16 k0 + rev16(k1)]
-                FDC_STAMP(13 + 5 * ch);
-                // Stores: slot klo + 8 khi of row t' = 64 ch + lane.  The 32 stream offsets are the same for the whole wave (table
-                // laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the store is
-                // dropped by the range check of the descriptor (no branch per store).
-                const unsigned rb = (unsigned)(m * (FWD ? 65536 : (R4 ? 192 : 128)) + rowbase + 64 * ch + lane2) * 8u;   // FWD: [block][65536 bins]
-#ifdef FDC_BLK_ST16
-                // 16-byte stores: the lanes of a pair (rows 2i, 2i + 1) trade half of their slots (DPP), so that each lane holds two
-                // consecutive rows of 16 slots: half the store instructions, 1-KiB runs per wave (8-byte accesses move at 0.54-0.70x
-                // the 16-byte rate, MI355X_MICROARCH.md)
-                {
-                    const bool odd = lane2 & 1;
-                    const unsigned rb2 = rb - (odd ? 8u : 0u);                  // row 2i of the pair
+                FDC_STAMP(12 + 5 * tr);
+                if (reads) {
+                    dft32<false>(v);                                  // khi = k0 + 2 k1 in v[16 k0 + rev16(k1)]
+                    FDC_STAMP(13 + 5 * tr);
+                    // Stores: slot klo + P khi of row t' = 16 kJT tr + 64 rh + lane.  The 32 stream offsets are the same for the whole
+                    // wave (table laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the
+                    // store is dropped by the range check of the descriptor (no branch per store).
+                    const unsigned rb = (unsigned)(m * (FWD ? 65536 : (R4 ? 192 : 128)) + rowbase + 16 * kJT * tr + 64 * rh2 + lane2) * 8u;   // FWD: [block][65536 bins]
+                    unsigned mq = FWD ? mqs[((rowbase >> 6) + tr) & 3] : ~0u;
+                    if constexpr (FWD) asm volatile("" : "+s"(mq));   // the 32 scalar terms below are worked out here, not held from block to block
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         const uint4 t = sow[q];
                         const unsigned so[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const cf a = v[4 * q + e], b2 = v[4 * q + e + 1];
-                            const cf give = odd ? a : b2;                          // what the partner stores
-                            const cf got = mk(swap_pair(give.x), swap_pair(give.y));
-                            const unsigned o = odd ? so[e + 1] : so[e];
-                            bst4<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb2), odd ? got : a, odd ? b2 : got);
+                        for (int e = 0; e < 4; e++) {
+                            // FWD: a store nobody reads gets the offset of an unused slot (all ones: a scalar term, one OR per store)
+                            const unsigned o = FWD ? (so[e] | (((mq >> (4 * q + e)) & 1u) - 1u)) : so[e];
+                            bst2t<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb), v[4 * q + e]);
                         }
                     }
                 }
-#else
-                unsigned mq = FWD ? mqs[((rowbase >> 6) + ch) & 3] : ~0u;
-                if constexpr (FWD) asm volatile("" : "+s"(mq));       // the 32 scalar terms below are worked out here, not held from block to block
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint4 t = sow[q];
-                    const unsigned so[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        // FWD: a store nobody reads gets the offset of an unused slot (all ones: a scalar term, one OR per store)
-                        const unsigned o = FWD ? (so[e] | (((mq >> (4 * q + e)) & 1u) - 1u)) : so[e];
-                        bst2t<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb), v[4 * q + e]);
-                    }
-                }
-#endif
-                FDC_STAMP(14 + 5 * ch);
+                FDC_STAMP(14 + 5 * tr);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, R4 ? 64 : 0, std::integral_constant<int, 2>{});
+        stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, R4 ? 64 : 0, std::integral_constant<int, 8>{});
         if constexpr (FWD) {
             // second half of k2: the values stage 1 put aside are this lane's own stores; sc1 loads are served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 32768), 0u); }, 128,
-                   std::integral_constant<int, 2>{});
+                   std::integral_constant<int, 8>{});
         }
         if constexpr (R4) {
             // rows 64..127 of the inverse transforms = output rows 0..63: this lane's own stores, served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
-                   std::integral_constant<int, 1>{});
+                   std::integral_constant<int, 4>{});
         }
         FDC_STAMP(30);
 #ifdef FDC_BLK_STAMPS
@@ -441,55 +465,55 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
             for (int i = 0; i < 32; i++) dbg[(w * 4 + dbgk) * 32 + i] = st[i];
 #endif
         dbgk++;
-        // the chunk region (= stage-1 scratch) was last read before the barrier above: the next block starts without one
+        // the trip region (= stage-1 scratch) was last read before the barrier above: the next block starts without one
     }
 }
 
 hipError_t init_block_kernels()
 {
     hipError_t e;
-#define FDC_SETB(A, B, F) \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<A, B, F>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kBlkLdsOff : kBlkLds); \
+#define FDC_SETB(P, A, B, F, R4) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<P, A, B, F, R4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            B ? BlkGeom<P>::kLdsOff : BlkGeom<P>::kLds); \
     if (e != hipSuccess) return e;
-    FDC_SETB(true, false, false) FDC_SETB(false, false, false) FDC_SETB(true, true, false) FDC_SETB(false, true, false)
-    FDC_SETB(true, false, true) FDC_SETB(false, false, true)
+#define FDC_SETP(P) \
+    FDC_SETB(P, true, false, false, false) FDC_SETB(P, false, false, false, false) FDC_SETB(P, true, true, false, false) \
+    FDC_SETB(P, false, true, false, false) FDC_SETB(P, true, false, false, true) FDC_SETB(P, false, false, false, true)
+    FDC_SETP(2) FDC_SETP(4) FDC_SETP(8)
+    FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false)
+#undef FDC_SETP
 #undef FDC_SETB
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLds);
-    if (e != hipSuccess) return e;
     return hipSuccess;
 }
+
+bool poly_block_supports(int N) { return N == 16384 || N == 32768 || N == 65536; }
 
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
                              const float2 *tw256, const float2 *twq, const float2 *cbt, const float *shn,
                              const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
                              unsigned long long *dbg, int r, long long first_block, hipEvent_t ev_start, hipEvent_t ev_stop, int R,
-                             float2 *scratch)
+                             float2 *scratch, int N)
 {
     if (nb_chunk <= 0) return hipSuccess;
-    if (R == 4) {                                           // three quarters of every inverse transform kept: 192 rows, 64 of them via the scratch
-        int grid = ncu > 0 ? ncu : 256;
-        if (grid > nb_chunk) grid = nb_chunk;
-#define FDC_LB4(A) \
-        hipExtLaunchKernelGGL((k_blk256<A, false, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
-                              tw256, twq, cbt, shn, slot_off, (long long)mbase * 192, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, 0, first_block, \
-                              scratch, (const unsigned *)nullptr)
-        if (hints & 1) FDC_LB4(true); else FDC_LB4(false);
-#undef FDC_LB4
-        return hipGetLastError();
-    }
-    int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: 159.5 KiB each)
+    if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && ((r & 255) || !scratch))) return hipErrorInvalidValue;
+    int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: up to 159.5 KiB each)
     if (grid > nb_chunk) grid = nb_chunk;
     // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)
     // ev_start / ev_stop (timing): the dispatch packet's own begin / end time stamps (hipExtLaunchKernel) — no barrier packet
     // in front of or behind the kernel, unlike hipEventRecord (measured 7-17 us per bracketed launch)
-#define FDC_LB(A, B) \
-    hipExtLaunchKernelGGL((k_blk256<A, B, false>), dim3((unsigned)grid), dim3(512), B ? kBlkLdsOff : kBlkLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
-                          tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, r & 255, first_block, \
-                          (float2 *)nullptr, (const unsigned *)nullptr)
-    if (r & 255) { if (hints & 1) FDC_LB(true, true); else FDC_LB(false, true); }
-    else { if (hints & 1) FDC_LB(true, false); else FDC_LB(false, false); }
+    // R = 4: three quarters of every inverse transform kept: 192 rows per block, 64 of them via the scratch
+#define FDC_LB(P, A, B, R4) \
+    hipExtLaunchKernelGGL((k_blk256<P, A, B, false, R4>), dim3((unsigned)grid), dim3(512), B ? BlkGeom<P>::kLdsOff : BlkGeom<P>::kLds, s, ev_start, \
+                          ev_stop, 0u, in, in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * (R4 ? 192 : 128), (long long)nb_call, \
+                          out_bytes, nb_chunk, hints, dbg, r & 255, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr)
+#define FDC_LP(P) \
+    do { \
+        if (R == 4) { if (hints & 1) FDC_LB(P, true, false, true); else FDC_LB(P, false, false, true); } \
+        else if (r & 255) { if (hints & 1) FDC_LB(P, true, true, false); else FDC_LB(P, false, true, false); } \
+        else { if (hints & 1) FDC_LB(P, true, false, false); else FDC_LB(P, false, false, false); } \
+    } while (0)
+    if (N == 65536) FDC_LP(8); else if (N == 32768) FDC_LP(4); else FDC_LP(2);
+#undef FDC_LP
 #undef FDC_LB
     return hipGetLastError();
 }
@@ -509,7 +533,7 @@ hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out
         if (grid > nb) grid = nb;
         hipEvent_t e0 = ev && m0 == 0 ? ev[0] : nullptr, e2 = ev && m0 + nb >= nitems ? ev[1] : nullptr;
 #define FDC_LF(A) \
-        hipExtLaunchKernelGGL((k_blk256<A, false, true>), dim3((unsigned)grid), dim3(512), kBlkLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
+        hipExtLaunchKernelGGL((k_blk256<8, A, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<8>::kLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
                               in_stride, out + (size_t)m0 * 65536, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
                               (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep)
         if (hints & 1) FDC_LF(true); else FDC_LF(false);

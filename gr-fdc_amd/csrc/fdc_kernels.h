@@ -103,7 +103,7 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 102
 hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
                                       const long long *slot_off, const float2 *tw, int ntab, hipStream_t s);
 
-// uniform plan, N = 65536, R = 2 or 4: the whole path in one kernel, one block per CU, G kept in registers (fdc_block256.hip).
+// uniform plan, N = 16384 / 32768 / 65536, R = 2 or 4: the whole path in one kernel, one block per CU, G kept in registers (fdc_block256.hip).
 // hints: 1 = nt output stores, 2 = nt input loads.  ncu: compute units of the device (grid size).
 hipError_t init_block_kernels();
 hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call,
@@ -113,7 +113,9 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              int r = 0 /* common offset f mod 256 of the channels; cbt must then hold (-1)^n1 W_N^(n1 (b + r)) */,
                              long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* timing: stamped by the dispatch itself */,
-                             int R = 2 /* 2 or 4 (4: r = 0 only) */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */);
+                             int R = 2 /* 2 or 4 (4: r = 0 only) */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
+                             int N = 65536 /* block length: 16384, 32768 or 65536 (poly_block_supports) */);
+bool poly_block_supports(int N);
 
 // forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,

@@ -211,7 +211,7 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
     forced = any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
-    assert forced or p.path() == (3 if N == 65536 and R in (2, 4) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 65536, R = 2 or 4: the one-kernel form
+    assert forced or p.path() == (3 if N in (16384, 32768, 65536) and R in (2, 4) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 16384 / 32768 / 65536, R = 2 or 4: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
     for c in range(len(chans)):
@@ -738,3 +738,78 @@ def test_one_kernel_form_at_relinvovl_4(oracle, wt):
     # an offset tiling at R = 4 keeps the spectrum path (the window phase would rotate from block to block)
     off = G.Pipeline(N, R, [(256 * c + 37, 256, 0.88, 1.0) for c in range(8)], windowtype=1, max_blocks=2)
     assert off.path() == 1
+
+
+@pytest.mark.parametrize("N,R,nb", [(16384, 2, 7), (16384, 2, 600), (32768, 2, 5), (32768, 2, 530), (16384, 4, 9), (32768, 4, 300)])
+def test_one_kernel_path_other_block_lengths(oracle, N, R, nb):
+    """The one-kernel form is a template on the number of 32-column passes: N = 16384 (64 slots, 2 passes) and N = 32768 (128
+    slots, 4 passes) beside 65536 (l is data, python/FrequencyDomainChannelizer.py:323-327, and so is the
+    block length).  All slots and a scattered subset; block counts below and above one round of workgroups; against the oracle
+    (head and tail) and against the two-launch form on every sample; ragged calls bit for bit."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    H, n1, lout = N - N // R, N // 256, 256 - 256 // R
+    x = noise(nb * H, N // 256 + R + nb)
+    rng = np.random.default_rng(N + nb)
+    for slots in (list(range(n1)), [int(v) for v in rng.permutation(n1)[:9]]):
+        chans = [(256 * c, 256, 0.88, 1.0) for c in slots]
+        G.defaults["FDC_HOST_SUB"] = str(nb)
+        try:
+            p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+            assert p.path() == 3
+            outs = p.work(x)
+        finally:
+            G.defaults.pop("FDC_HOST_SUB", None)
+        k = min(nb, 3)
+        ref, _ = oracle.channelizer(N, R, 1, chans, x[:k * H], nthreads=8)
+        for c in range(len(chans)):
+            assert outs[c].size == nb * lout
+            assert_close(outs[c][:k * lout], ref[c], "N %d slot %d head" % (N, slots[c]))
+        if nb > k:
+            t0 = nb - k
+            ref2, _ = oracle.channelizer(N, R, 1, chans, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+            for c in range(len(chans)):
+                assert_close(outs[c][t0 * lout:], ref2[c], "N %d slot %d tail" % (N, slots[c]))
+        q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+        assert q.path() == 2
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "N %d slot %d vs two launches" % (N, slots[c]))
+        p.reset()
+        cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("N", [16384, 32768])
+def test_one_kernel_path_other_block_lengths_offsets_and_classes(oracle, N):
+    """Offset tilings (f = 256 slot + r, odd r: the window phase follows the global block index) and plan classes at the other two
+    block lengths of the one-kernel form."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    R, nb = 2, 6
+    H, n1 = N - N // R, N // 256
+    x = noise(nb * H, 5 + n1)
+    rng = np.random.default_rng(n1)
+    for r in (1, 16, 37, 128, 255):
+        slots = [int(v) for v in rng.permutation(n1 - 1)[:min(n1 - 1, 11)]]
+        chans = [(256 * c + r, 256, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
+        for c in range(len(chans)):
+            assert_close(outs[c], ref[c], "N %d offset %d slot %d" % (N, r, slots[c]))
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 1), (1, 4), (4, 6)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+    # a 2x oversampled bank (two tilings 128 bins apart) and the same slots under two windows: one launch per class
+    s0 = [int(v) for v in rng.permutation(n1 - 1)[:n1 // 2]]
+    plan = [(256 * c, 256, 0.88, 1.0) for c in s0] + [(256 * c + 128, 256, 0.88, 1.0) for c in s0] + [(256 * c, 256, 0.7, 0.9) for c in s0[:5]]
+    p = G.Pipeline(N, R, plan, windowtype=2, max_blocks=nb)
+    assert p.path() == 3
+    outs = p.work(x)
+    ref, _ = oracle.channelizer(N, R, 2, plan, x, nthreads=8)
+    for c in range(len(plan)):
+        assert_close(outs[c], ref[c], "N %d classes channel %d" % (N, c))
