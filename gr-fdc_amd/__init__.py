@@ -12,4 +12,4 @@ from ._lib import (FDC_PIPE_FORCE_GENERIC, FDC_PIPE_NO_POLY, FDC_PIPE_NO_BLOCK, 
                    FDC_PIPE_FULL_SPECTRUM,
                    FDC_SINKS_HOST_DECISIONS, FDC_SINKS_DEVICE_PAYLOAD)
 from .sharding import span_for_rank, ring_bounds, ring_for_span                       # noqa: F401
-from .sinks import Sinks, PowerActivationChannel, activity_detection_channelizer_vcm, SegmentDetection      # noqa: F401
+from .sinks import Sinks, SinksGroup, PowerActivationChannel, activity_detection_channelizer_vcm, SegmentDetection      # noqa: F401

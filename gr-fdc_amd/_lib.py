@@ -50,7 +50,7 @@ class fdc_sinks_cfg(C.Structure):
                 ("det_thresh_db", C.c_float), ("det_maxblocks", C.c_int32), ("minchandist", C.c_float),
                 ("det_deactivation_delay", C.c_int32), ("window_flank_puffer", C.c_double), ("max_blocks", C.c_int32),
                 ("det_variant", C.c_int32), ("verbose", C.c_int32), ("det_id", C.c_int32), ("flags", C.c_int32),
-                ("threads", C.c_int32)]
+                ("threads", C.c_int32), ("seg_id_base", C.c_int32)]
 
 
 FDC_SINKS_HOST_DECISIONS = 1
@@ -107,6 +107,17 @@ SYMBOLS = {
     "fdc_pipeline_work_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_pipeline_work_sinks": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),
+    "fdc_sinks_work_band": (C.c_int, [_vp, _vp, C.c_int, C.c_int32, C.c_int32]),
+    "fdc_sinks_read_band": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "fdc_sinks_pdu_emit_items": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
+    "fdc_sinks_group_create": (C.c_int, [C.POINTER(fdc_sinks_cfg), C.POINTER(C.c_int32), C.c_int, C.POINTER(_vp)]),
+    "fdc_sinks_group_destroy": (None, [_vp]),
+    "fdc_sinks_group_work": (C.c_int, [_vp, _vp, C.c_int]),
+    "fdc_sinks_group_pdu_count": (C.c_int, [_vp]),
+    "fdc_sinks_group_pdus": (C.c_int, [_vp, C.POINTER(fdc_pdu), C.c_int]),
+    "fdc_sinks_group_size": (C.c_int32, [_vp]),
+    "fdc_sinks_group_member": (_vp, [_vp, C.c_int]),
+    "fdc_sinks_group_member_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int32)] * 5),
     "fdc_sinks_spectrum": (_vp, [_vp]),
     "fdc_sinks_stream": (_vp, [_vp]),
     "fdc_sinks_blocklen": (C.c_int32, [_vp]),

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -43,14 +44,13 @@ struct SpanJob {
     bool real = false;
 };
 
-// one worker thread per member beyond the first (the first member's span runs on the calling thread)
+// one worker thread per member beyond the first (the first member's share runs on the calling thread)
 struct Worker {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
     int state = 0;               // 0 idle, 1 job posted, 2 job done, 3 quit
-    SpanJob job;
-    fdc_pipeline *pipe = nullptr;
+    std::function<int()> job;    // a C-ABI call on the member's handle: returns its status, never throws
     int rc = 0;
     std::string err;
 };
@@ -67,9 +67,9 @@ void worker_main(Worker *w)
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [w] { return w->state == 1 || w->state == 3; });
         if (w->state == 3) return;
-        const SpanJob j = w->job;
+        const std::function<int()> j = w->job;
         lk.unlock();
-        int rc = run_span(w->pipe, j);
+        int rc = j();
         std::string err;
         if (rc < 0) {
             try { err = fdc_last_error(); } catch (...) { rc = FDC_ERR_NOMEM; }     // this thread's text: handed to the caller
@@ -78,6 +78,44 @@ void worker_main(Worker *w)
         w->rc = rc; w->err.swap(err);
         w->state = 2;
         w->cv.notify_all();
+    }
+}
+
+// whatever happens on the calling thread, no posted job is left running with the caller's pointers when the call returns
+struct Join {
+    std::vector<std::unique_ptr<Worker>> &ws;
+    std::vector<int> posted;                                 // indices into ws
+    explicit Join(std::vector<std::unique_ptr<Worker>> &w) : ws(w) {}
+    void post(int wi, std::function<int()> job)
+    {
+        posted.reserve(ws.size());
+        Worker *w = ws[(size_t)wi].get();
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->job = std::move(job); w->state = 1;
+        w->cv.notify_all();
+        posted.push_back(wi);
+    }
+    void wait()
+    {
+        for (int wi : posted) {
+            Worker *w = ws[(size_t)wi].get();
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return w->state == 2; });
+        }
+    }
+    ~Join()
+    {
+        wait();
+        for (int wi : posted) { Worker *w = ws[(size_t)wi].get(); std::lock_guard<std::mutex> lk(w->mu); w->state = 0; }
+    }
+};
+
+void stop_workers(std::vector<std::unique_ptr<Worker>> &ws)
+{
+    for (auto &w : ws) {
+        if (!w) continue;
+        { std::lock_guard<std::mutex> lk(w->mu); w->state = 3; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
     }
 }
 
@@ -132,12 +170,7 @@ int group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *
     g->last_first.assign(g->mem.size(), 0);
     g->last_n.assign(g->mem.size(), 0);
     SpanJob job0;
-    // whatever happens on this thread, no posted span is left running with the caller's pointers when the call returns
-    struct Join {
-        fdc_pipeline_group *g; int posted = 0;
-        void wait() { for (; posted > 0; posted--) { Worker *w = g->workers[(size_t)posted - 1].get(); std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [w] { return w->state == 2; }); } }
-        ~Join() { wait(); for (auto &w : g->workers) { std::lock_guard<std::mutex> lk(w->mu); if (w->state == 2) w->state = 0; } }
-    } join{g};
+    Join join(g->workers);
     for (int i = 0; i < k; i++) {
         int b0, nb;
         span_of(nblocks, k, i, &b0, &nb);
@@ -155,11 +188,8 @@ int group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *
         j.real = real;
         g->last_first[(size_t)i] = j.first; g->last_n[(size_t)i] = nb;
         if (i == 0) { job0 = j; continue; }
-        Worker *w = g->workers[(size_t)i - 1].get();
-        std::lock_guard<std::mutex> lk(w->mu);
-        w->job = j; w->state = 1;
-        w->cv.notify_all();
-        join.posted = i;
+        fdc_pipeline *pm = g->mem[(size_t)i];
+        join.post(i - 1, [pm, j] { return run_span(pm, j); });
     }
     int rc = run_span(g->mem[0], job0);
     std::string err;
@@ -187,11 +217,7 @@ extern "C" {
 void fdc_pipeline_group_destroy(fdc_pipeline_group *g)
 {
     if (!g) return;
-    for (auto &w : g->workers) {
-        if (!w) continue;
-        { std::lock_guard<std::mutex> lk(w->mu); w->state = 3; w->cv.notify_all(); }
-        if (w->th.joinable()) w->th.join();
-    }
+    stop_workers(g->workers);
     for (fdc_pipeline *p : g->mem) fdc_pipeline_destroy(p);
     delete g;
 }
@@ -240,7 +266,6 @@ int fdc_pipeline_group_create(const fdc_pipeline_cfg *cfg, const int32_t *device
     for (int i = 1; i < ndevices; i++) {
         g->workers.emplace_back(new Worker());
         Worker *w = g->workers.back().get();
-        w->pipe = g->mem[(size_t)i];
         w->th = std::thread(worker_main, w);
     }
     *out = g.release();
@@ -291,6 +316,171 @@ int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_bl
         if (nblocks) nblocks[i] = g->last_n[(size_t)i];
     }
     return n;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * The sink blocks over several devices: the bank cut BY FREQUENCY BAND (include/fdc_amd.h, fdc_sinks_group_*).  Member i holds a run
+ * of the bank's PowerActivationChannels and a run of its segments (runs of the bank order, equal counts), copies only the bins that
+ * run reads, and is an ordinary fdc_sinks bank on its device: no state is shared between members.
+ * ------------------------------------------------------------------------------------------------------------------------------- */
+}  // extern "C"
+
+struct fdc_sinks_group {
+    struct Member { fdc_sinks *s = nullptr; int32_t dev = 0, lo = 0, hi = 0, npac = 0, nseg = 0; };
+    std::vector<Member> mem;
+    std::vector<std::unique_ptr<Worker>> workers;          // workers[i] serves member i (member 0 runs on the calling thread)
+    int N = 0, max_blocks = 0;
+    std::vector<fdc_pdu> pdus;                              // of the last call, merged into one bank's emission order
+    bool dead = false;
+};
+
+extern "C" {
+
+void fdc_sinks_group_destroy(fdc_sinks_group *g)
+{
+    if (!g) return;
+    stop_workers(g->workers);
+    for (auto &m : g->mem) fdc_sinks_destroy(m.s);
+    delete g;
+}
+
+int fdc_sinks_group_create(const fdc_sinks_cfg *cfg, const int32_t *devices, int ndevices, fdc_sinks_group **out)
+{
+    FDC_ENTRY("fdc_sinks_group_create")
+    if (!cfg || !out) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!devices || ndevices < 1 || ndevices > 64) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a group has 1 to 64 members");
+    if (cfg->npac < 0 || cfg->nseg < 0 || (cfg->npac && !cfg->pac) || (cfg->nseg && !cfg->seg)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "bad sink lists");
+    if (cfg->npac + cfg->nseg == 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "an empty bank");
+    std::unique_ptr<fdc_sinks_group, void (*)(fdc_sinks_group *)> g(new fdc_sinks_group(), fdc_sinks_group_destroy);
+    g->N = cfg->blocklen; g->max_blocks = cfg->max_blocks;
+    g->mem.resize((size_t)ndevices);
+    auto run_of = [ndevices](int n, int i, int *first, int *cnt) {       // balanced runs of the bank order
+        const int base = n / ndevices, extra = n % ndevices;
+        *cnt = base + (i < extra ? 1 : 0);
+        *first = i * base + std::min(i, extra);
+    };
+    for (int i = 0; i < ndevices; i++) {
+        auto &m = g->mem[(size_t)i];
+        m.dev = devices[i];
+        int p0, pn, s0, sn;
+        run_of(cfg->npac, i, &p0, &pn);
+        run_of(cfg->nseg, i, &s0, &sn);
+        m.npac = pn; m.nseg = sn;
+        if (pn + sn == 0) continue;                          // more devices than channels and segments: the member stays idle
+        fdc_sinks_cfg c = *cfg;
+        c.device_id = devices[i];
+        c.npac = pn; c.pac = pn ? cfg->pac + p0 : nullptr;
+        c.nseg = sn; c.seg = sn ? cfg->seg + s0 : nullptr;
+        c.seg_id_base = cfg->seg_id_base + s0;
+        const int rc = fdc_sinks_create(&c, &m.s);
+        if (rc != FDC_OK) {
+            const std::string why = fdc_last_error();
+            return fdc::set_error(rc, "member %d (device %d): %s", i, devices[i], why.c_str());
+        }
+        fdc_sinks_read_band(m.s, &m.lo, &m.hi);
+    }
+    for (int i = 0; i < ndevices; i++) {
+        g->workers.emplace_back(new Worker());
+        if (i > 0 && g->mem[(size_t)i].s) g->workers.back()->th = std::thread(worker_main, g->workers.back().get());
+    }
+    *out = g.release();
+    return FDC_OK;
+    FDC_ENTRY_END
+}
+
+int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
+{
+    FDC_ENTRY("fdc_sinks_group_work")
+    if (!g) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null group handle");
+    if (g->dead) return fdc::set_error(FDC_ERR_HIP, "the group failed in an earlier call and must be destroyed");
+    if (nitems < 0 || nitems > g->max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
+    g->pdus.clear();
+    if (nitems == 0) return 0;
+    if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
+    int rc = nitems;
+    std::string err;
+    {
+        Join join(g->workers);
+        int first = -1;
+        for (int i = 0; i < (int)g->mem.size(); i++) {
+            auto &m = g->mem[(size_t)i];
+            if (!m.s) continue;
+            if (first < 0) { first = i; continue; }         // the first member with work runs on this thread
+            fdc_sinks *sm = m.s;
+            const int32_t lo = m.lo, hi = m.hi;
+            if (!g->workers[(size_t)i]->th.joinable()) g->workers[(size_t)i]->th = std::thread(worker_main, g->workers[(size_t)i].get());
+            join.post(i, [sm, spectrum, nitems, lo, hi] { return fdc_sinks_work_band(sm, spectrum, nitems, lo, hi); });
+        }
+        if (first >= 0) {
+            auto &m = g->mem[(size_t)first];
+            const int r0 = fdc_sinks_work_band(m.s, spectrum, nitems, m.lo, m.hi);
+            if (r0 < 0) { rc = r0; err = "member " + std::to_string(first) + " (device " + std::to_string(m.dev) + "): " + fdc_last_error(); }
+        }
+        join.wait();
+        for (int wi : join.posted) {
+            Worker *w = g->workers[(size_t)wi].get();
+            std::lock_guard<std::mutex> lk(w->mu);
+            if (w->rc < 0 && rc >= 0) { rc = w->rc; err = "member " + std::to_string(wi) + " (device " + std::to_string(g->mem[(size_t)wi].dev) + "): " + w->err; }
+        }
+    }
+    if (rc < 0) {
+        g->dead = true;                                      // the members' state machines are no longer at the same item
+        return fdc::set_error(rc, "%s", err.c_str());
+    }
+    // Merge: one bank emits, item by item, the PowerActivationChannels in bank order and then the segments in order; the members hold
+    // runs of that order, so for every item it is member 0's PowerActivationChannel PDUs, member 1's, ..., then the detections likewise.
+    // Inside a member the PDUs are in its own (= the bank's) order already: the sort is stable on (item, kind, member).
+    struct Key { int32_t item, kind, member; uint32_t seq; };
+    std::vector<Key> keys;
+    std::vector<std::vector<fdc_pdu>> got(g->mem.size());
+    std::vector<int32_t> items;
+    for (int i = 0; i < (int)g->mem.size(); i++) {
+        fdc_sinks *sm = g->mem[(size_t)i].s;
+        if (!sm) continue;
+        const int n = fdc_sinks_pdu_count(sm);
+        if (n <= 0) continue;
+        got[(size_t)i].resize((size_t)n);
+        items.resize((size_t)n);
+        fdc_sinks_pdus(sm, got[(size_t)i].data(), n);
+        fdc_sinks_pdu_emit_items(sm, items.data(), n);
+        for (int k = 0; k < n; k++) keys.push_back(Key{items[(size_t)k], got[(size_t)i][(size_t)k].kind, i, (uint32_t)k});
+    }
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.item != b.item) return a.item < b.item;
+        if (a.kind != b.kind) return a.kind < b.kind;
+        return a.member < b.member;
+    });
+    g->pdus.reserve(keys.size());
+    for (const Key &k : keys) g->pdus.push_back(got[(size_t)k.member][k.seq]);
+    return nitems;
+    FDC_ENTRY_END
+}
+
+int fdc_sinks_group_pdu_count(const fdc_sinks_group *g) { return g ? (int)g->pdus.size() : 0; }
+
+int fdc_sinks_group_pdus(const fdc_sinks_group *g, fdc_pdu *out, int cap)
+{
+    if (!g || (!out && cap > 0)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    const int n = (int)g->pdus.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = g->pdus[(size_t)i];
+    return n;
+}
+
+int32_t fdc_sinks_group_size(const fdc_sinks_group *g) { return g ? (int32_t)g->mem.size() : -1; }
+fdc_sinks *fdc_sinks_group_member(fdc_sinks_group *g, int i) { return g && i >= 0 && i < (int)g->mem.size() ? g->mem[(size_t)i].s : nullptr; }
+
+int fdc_sinks_group_member_info(const fdc_sinks_group *g, int i, int32_t *device, int32_t *lo, int32_t *hi, int32_t *npac, int32_t *nseg)
+{
+    if (!g || i < 0 || i >= (int)g->mem.size()) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "no such member");
+    const auto &m = g->mem[(size_t)i];
+    if (device) *device = m.dev;
+    if (lo) *lo = m.lo;
+    if (hi) *hi = m.hi;
+    if (npac) *npac = m.npac;
+    if (nseg) *nseg = m.nseg;
+    return FDC_OK;
 }
 
 }  // extern "C"

@@ -697,7 +697,7 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
             if (sp > (size_t)N) { sp = (size_t)N; st = sp - (size_t)N; }                 // reference clamp (App. B.2)
             if (st + width > (size_t)N) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "segment %d: the reference reads past the block here", i);
             Segment g;
-            g.ID = i; g.start = (int)st; g.stop = (int)sp; g.width = (int)width;
+            g.ID = cfg->seg_id_base + i; g.start = (int)st; g.stop = (int)sp; g.width = (int)width;
             g.ncell = (int)width / s->dec; g.cell0 = (int)s->cells.size();
             for (int c = 0; c < g.ncell; c++) s->cells.push_back({g.start + c * s->dec, s->dec, 1.0f, 0});   // raw sums (:185-190)
             s->segs.push_back(std::move(g));
@@ -723,7 +723,7 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
                 width = N - N % s->dec;
             }
             Segment g;
-            g.ID = i;
+            g.ID = cfg->seg_id_base + i;
             g.start = mid - width / 2 <= 0 ? 0 : mid - width / 2;
             g.stop = g.start + width;
             if (g.stop > N) { g.stop = N; g.start = N - width; }
@@ -1456,6 +1456,62 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     HIPCHK(hipMemcpyAsync(s->d_spec + s->N, spectrum, sizeof(float2) * (size_t)nitems * s->N, hipMemcpyHostToDevice, s->stream));
     return fdc_sinks_work_device(s, nitems);
     FDC_ENTRY_END
+}
+
+int fdc_sinks_read_band(const fdc_sinks *s, int32_t *lo, int32_t *hi)
+{
+    FDC_ENTRY("fdc_sinks_read_band")
+    if (!s || !lo || !hi) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    int a = s->N, b = 0;
+    for (const Pac &p : s->pacs) {
+        a = std::min(a, std::min(p.extract_start, p.measure_start));
+        b = std::max(b, std::max(std::max(p.extract_stop, p.extract_start + p.extract_width), p.measure_stop));
+    }
+    for (const Segment &g : s->segs) {
+        // a detected channel is at most the segment wide; its extraction is the next power of two above width * (1 + 2 puffer),
+        // centred on the channel and clamped to the block (seg_detect): it can reach half that width beyond either end
+        const int ew = pow2ceil((int)std::ceil((double)g.width * (1.0 + 2.0 * s->cfg.window_flank_puffer)));
+        a = std::min(a, g.start - ew);
+        b = std::max(b, g.stop + ew);
+    }
+    if (b <= a) { a = 0; b = 0; }
+    *lo = std::max(0, a); *hi = std::min(s->N, b);
+    return FDC_OK;
+    FDC_ENTRY_END
+}
+
+int fdc_sinks_work_band(fdc_sinks *s, const void *spectrum, int nitems, int32_t bin_lo, int32_t bin_hi)
+{
+    FDC_ENTRY("fdc_sinks_work_band")
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
+    if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
+    if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
+    if (bin_lo < 0 || bin_hi > s->N || bin_lo > bin_hi) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "band [%d, %d) outside the block", bin_lo, bin_hi);
+    int32_t need_lo = 0, need_hi = 0;
+    fdc_sinks_read_band(s, &need_lo, &need_hi);
+    if (need_hi > need_lo && (bin_lo > need_lo || bin_hi < need_hi))
+        return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "band [%d, %d) does not cover what the bank reads, [%d, %d)", bin_lo, bin_hi, need_lo, need_hi);
+    if (nitems == 0) { s->pdus.clear(); return 0; }
+    if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    if (bin_hi > bin_lo) {
+        const size_t pitch = sizeof(float2) * (size_t)s->N;
+        HIPCHK(hipMemcpy2DAsync(s->d_spec + s->N + bin_lo, pitch, static_cast<const float2 *>(spectrum) + bin_lo, pitch,
+                                sizeof(float2) * (size_t)(bin_hi - bin_lo), (size_t)nitems, hipMemcpyHostToDevice, s->stream));
+    }
+    return fdc_sinks_work_device(s, nitems);
+    FDC_ENTRY_END
+}
+
+int fdc_sinks_pdu_emit_items(const fdc_sinks *s, int32_t *item, int cap)
+{
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    const int n = (int)s->pdus.size();
+    // the order key of a PDU starts with the index of the item that emitted it: bits 24.. on the host engine, 40.. on the device engine
+    const int sh = s->dev.on ? 40 : 24;
+    for (int i = 0; i < n && i < cap; i++) item[i] = (int32_t)(s->pdus[(size_t)i].key >> sh);
+    return n;
 }
 
 void fdc_set_log_callback(fdc_log_fn fn, void *user) { std::lock_guard<std::mutex> g(g_log_mu); g_log_fn = fn; g_log_user = user; }

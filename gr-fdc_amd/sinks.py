@@ -142,6 +142,89 @@ class Sinks:
             pass
 
 
+class SinksGroup(Sinks):
+    """fdc_sinks_group: the bank cut by frequency band over several devices (devices: HIP ordinals, repeats allowed).  Member i holds
+    a run of the PowerActivationChannels and a run of the segments (bank order, equal counts) and copies only the bins that run reads;
+    the PDUs come back merged into the order one bank emits them in.  work() as for Sinks."""
+
+    def __init__(self, blocklen, relinvovl, devices, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
+                 segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
+                 max_blocks=64, det_variant=0, verbose=0, det_id=-1, host_decisions=False, threads=0):
+        self._h = C.c_void_p()
+        self._g = C.c_void_p()
+        self.N = int(blocklen)
+        pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
+        for i, (cf, bw, ident) in enumerate(pac):
+            pa[i].cfreq, pa[i].bw, pa[i].id = float(cf), float(bw), int(ident)
+        sg = (_lib.fdc_segment_cfg * max(1, len(segments)))()
+        for i, (a, b) in enumerate(segments):
+            sg[i].start, sg[i].stop = float(a), float(b)
+        cfg = _lib.fdc_sinks_cfg(0, self.N, int(relinvovl), len(pac), pa, float(pac_thresh), int(pac_maxblocks),
+                                 int(pac_delay), len(segments), sg, float(det_thresh), int(det_maxblocks),
+                                 float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant),
+                                 int(verbose), int(det_id), _lib.FDC_SINKS_HOST_DECISIONS if host_decisions else 0, int(threads), 0)
+        devs = (C.c_int32 * max(1, len(devices)))(*[int(d) for d in devices])
+        rc = _lib.lib().fdc_sinks_group_create(C.byref(cfg), devs, len(devices), C.byref(self._g))
+        if rc == -1:
+            raise ValueError(_lib.lib().fdc_last_error().decode())
+        _lib.check(rc)
+        self.device_payload = False
+        self.max_blocks = int(max_blocks)
+        self.npac, self.nseg = len(pac), len(segments)
+
+    def engine(self):
+        return 1
+
+    def size(self):
+        return int(_lib.lib().fdc_sinks_group_size(self._g))
+
+    def members(self):
+        """[(device, band_lo, band_hi, npac, nseg)] per member"""
+        out = []
+        for i in range(self.size()):
+            v = [C.c_int32() for _ in range(5)]
+            _lib.check(_lib.lib().fdc_sinks_group_member_info(self._g, i, *[C.byref(x) for x in v]))
+            out.append(tuple(int(x.value) for x in v))
+        return out
+
+    def _pdu_array(self):
+        n = _lib.lib().fdc_sinks_group_pdu_count(self._g)
+        if n <= 0:
+            return None, 0
+        arr = (_lib.fdc_pdu * n)()
+        _lib.check(_lib.lib().fdc_sinks_group_pdus(self._g, arr, n))
+        return arr, n
+
+    def _collect(self):
+        arr, n = self._pdu_array()
+        out = []
+        for k in range(n):
+            p = arr[k]
+            data = np.frombuffer((C.c_float * (2 * p.nsamples)).from_address(p.samples), dtype=np.complex64).copy() if p.nsamples > 0 \
+                else np.zeros(0, np.complex64)
+            out.append((dict(id=p.id.decode(), kind=p.kind, source=p.source, chan_id=p.chan_id, finalized=bool(p.finalized), part=p.part,
+                             has_part=bool(p.has_part), rel_bw=p.rel_bw, rel_cfreq=p.rel_cfreq, blockstart=p.blockstart,
+                             blockend=p.blockend, vectorstart=p.vectorstart, vectorend=p.vectorend), data))
+        return out
+
+    def work(self, spectrum):
+        spectrum = np.ascontiguousarray(spectrum, dtype=np.complex64).reshape(-1)
+        if spectrum.size % self.N:
+            raise ValueError("input is not a whole number of spectrum items")
+        n = spectrum.size // self.N
+        out = []
+        for a in range(0, n, self.max_blocks):
+            b = min(n, a + self.max_blocks)
+            _lib.check(_lib.lib().fdc_sinks_group_work(self._g, spectrum[a * self.N:].ctypes.data, b - a))
+            out += self._collect()
+        return out
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            _lib.lib().fdc_sinks_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+
 def _pac_pdu(meta, data):
     """dict keys of PowerActivationChannel_impl.cc:222-230"""
     d = {"ID": meta["id"] + (".fin" if meta["finalized"] else ".part"),

@@ -260,6 +260,9 @@ typedef struct {
                               segment in the message IDs); < 0 = the segment index */
     int32_t flags;         /* FDC_SINKS_* bits, 0 = defaults */
     int32_t threads;       /* host engine only: worker threads of the decision phase (0 = chosen from the bank's size) */
+    int32_t seg_id_base;   /* segment i of this bank is segment seg_id_base + i of the block it belongs to (the number in the message
+                              IDs, fdc_pdu.source and the log lines): a bank that holds part of a block's segments — a member of an
+                              fdc_sinks_group — still names them as the reference does; 0 for a whole block */
 } fdc_sinks_cfg;
 /* fdc_sinks_cfg.flags.  A bank runs on one of two engines.  DEVICE (default): the work() loops of the blocks
  * (lib/PowerActivationChannel_impl.cc:146-170, lib/activity_detection_channelizer_vcm_impl.cc:551-568) are device kernels —
@@ -307,6 +310,14 @@ int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *
 void fdc_sinks_destroy(fdc_sinks *s);
 /* work()-shaped: nitems normalised-spectrum items of blocklen samples each on the host; returns nitems */
 int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems);
+/* the same when only the bins [bin_lo, bin_hi) of every item are needed by this bank's channels and segments: only those columns
+ * cross PCIe (one strided copy), the rest of the device-side items keeps whatever it held.  The caller answers for the band covering
+ * every bin the bank reads (fdc_sinks_read_band gives it); what an fdc_sinks_group member is fed with. */
+int fdc_sinks_work_band(fdc_sinks *s, const void *spectrum, int nitems, int32_t bin_lo, int32_t bin_hi);
+/* [lo, hi): every bin this bank can ever read — the measure and extract ranges of its PowerActivationChannels, its segments widened by
+ * the widest extraction a detected channel can get (lib/activity_detection_channelizer_vcm_impl.cc:575-607: the next power of two above
+ * width * (1 + 2 * window_flank_puffer), centred on the channel, clamped to the block) */
+int fdc_sinks_read_band(const fdc_sinks *s, int32_t *lo, int32_t *hi);
 /* device-resident: the producer (fdc_pipeline_process_device with d_spectrum = fdc_sinks_spectrum(s)) has written
  * nblocks spectra there on a stream it has synchronised; no PCIe traffic for the spectrum */
 void *fdc_sinks_spectrum(fdc_sinks *s);
@@ -330,10 +341,38 @@ int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);
 /* all of them at once: fills out[0 .. min(count, cap)) and returns the count.  Every payload is one contiguous run of a pinned
  * buffer of the handle (device engine: always; host engine: when all blocks of the PDU come from the last call). */
 int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap);
+/* for every PDU of the last call, the index (inside that call) of the item at which the block emitted it: what orders the PDUs of
+ * several banks that saw the same items (fdc_sinks_group) the way one bank orders its own; returns the PDU count */
+int fdc_sinks_pdu_emit_items(const fdc_sinks *s, int32_t *item, int cap);
 /* derived geometry (for logs and tests): v[8] = extract_start, extract_stop, extract_width, measure_start,
  * measure_stop, output_len, output_ovl_offset, deltaphase;  v[5] = start, stop, width, decimation, power cells */
 int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v8);
 int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v5);
+
+/* ------------------------------------------------------------------------------------------------
+ * The sink blocks over several devices ("shard by channel / by segment").  A sink block's input is the
+ * stream of normalised spectrum items (512 KiB each at N = 65536): fed from host memory, ONE device is bound by its PCIe link
+ * long before its kernels matter (1024 items: 9.6 ms of copy, 0.5 ms of kernels).  The group cuts the bank BY FREQUENCY: the
+ * PowerActivationChannels sorted by centre frequency and the segments, in runs of equal load, one run per member device; every
+ * member copies only the band of bins its run reads (fdc_sinks_work_band) over its own link and runs its state machines and
+ * extractions on it, all members concurrently; their PDUs are merged into the order ONE bank emits them in (item by item:
+ * PowerActivationChannels in bank order, then the segments in order).  Every channel / segment lives on exactly one member, so
+ * no state is shared and nothing is exchanged between devices.  Same PDUs as one bank on one device, payload bits included
+ * (tests/test_group_gpu.py).  The reference's counterpart: one std::thread per segment and per detected channel
+ * (lib/activity_detection_channelizer_vcm_impl.cc:293-304, :339-371), one scheduler thread per PowerActivationChannel block.
+ *   cfg       as for fdc_sinks_create; device_id is ignored; max_blocks = items per call, for every member
+ *   devices   HIP ordinals, repeats allowed (virtual members)
+ * One thread at a time per group.  PDUs (and payload pointers) stay valid until the next work call on the group. */
+typedef struct fdc_sinks_group fdc_sinks_group;
+int fdc_sinks_group_create(const fdc_sinks_cfg *cfg, const int32_t *devices, int ndevices, fdc_sinks_group **out);
+void fdc_sinks_group_destroy(fdc_sinks_group *g);
+int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems);      /* like fdc_sinks_work */
+int fdc_sinks_group_pdu_count(const fdc_sinks_group *g);
+int fdc_sinks_group_pdus(const fdc_sinks_group *g, fdc_pdu *out, int cap);           /* like fdc_sinks_pdus */
+int32_t fdc_sinks_group_size(const fdc_sinks_group *g);
+fdc_sinks *fdc_sinks_group_member(fdc_sinks_group *g, int i);                        /* owned by the group; NULL for a member without work */
+/* member i: its device, the band [lo, hi) of bins it copies, how many PowerActivationChannels and segments it holds */
+int fdc_sinks_group_member_info(const fdc_sinks_group *g, int i, int32_t *device, int32_t *lo, int32_t *hi, int32_t *npac, int32_t *nseg);
 
 /* ------------------------------------------------------------------------------------------------
  * Single-block faces (same arithmetic as the fused pipeline, one reference block each).

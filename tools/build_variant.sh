@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../gr-fdc_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall "$@" -c fdc_block256.hip -o /tmp/fdc_block256_$TAG.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall "$@" -c fdc_kernels.hip -o /tmp/fdc_kernels_$TAG.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall "$@" -c fdc_sinks_dev.hip -o /tmp/fdc_sinks_dev_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libfdc_amd_$TAG.so fdc_api.o /tmp/fdc_kernels_$TAG.o fdc_fast256.o /tmp/fdc_block256_$TAG.o fdc_chanwide.o fdc_sinks.o /tmp/fdc_sinks_dev_$TAG.o -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libfdc_amd_$TAG.so fdc_api.o /tmp/fdc_kernels_$TAG.o fdc_fast256.o /tmp/fdc_block256_$TAG.o fdc_chanwide.o fdc_sinks.o /tmp/fdc_sinks_dev_$TAG.o fdc_group.o -Wl,-rpath,/opt/rocm/lib
 echo built ../libfdc_amd_$TAG.so
