@@ -130,6 +130,7 @@ int main(int argc, char **argv)
         }
         auto det = activity_detection_channelizer_vcm::make(N, {{0.5f, 0.9f}}, 10.0f, R, -1, true, false, "", false, 0.01f, 1, 0.2, 0);
         det->set_max_items(5);
+        det->set_devices({0, 0});       // one segment over two members: the second stays idle, the PDUs are the single bank's
         det->work(ns, si, none);
         for (auto &m : det->published()) {
             std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());

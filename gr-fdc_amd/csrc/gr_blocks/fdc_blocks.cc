@@ -214,7 +214,8 @@ public:
 // shared by the two sink faces: PDU records -> messages on "msgout" and raw files
 class sink_base : protected device_state {
 protected:
-    fdc_sinks *d_s = nullptr;
+    fdc_sinks *d_s = nullptr;                  // one device
+    fdc_sinks_group *d_sg = nullptr;           // several: the bank cut by frequency band over the devices (include/fdc_amd.h)
     bool d_msg = false, d_file = false;
     std::string d_path;
     // the bank's configuration, kept so that set_devices() / set_max_items() can build it again
@@ -224,18 +225,25 @@ protected:
     void rebuild() override
     {
         fdc_sinks_destroy(d_s); d_s = nullptr;
+        fdc_sinks_group_destroy(d_sg); d_sg = nullptr;
         d_cfg.pac = d_pacs.data(); d_cfg.npac = (int32_t)d_pacs.size();
         d_cfg.seg = d_segs.data(); d_cfg.nseg = (int32_t)d_segs.size();
         d_cfg.device_id = d_devices[0];
         d_cfg.max_blocks = d_max_items;
-        check_create(fdc_sinks_create(&d_cfg, &d_s));
+        if (d_devices.size() > 1) {
+            std::vector<int32_t> dv(d_devices.begin(), d_devices.end());
+            check_create(fdc_sinks_group_create(&d_cfg, dv.data(), (int)dv.size(), &d_sg));
+        } else {
+            check_create(fdc_sinks_create(&d_cfg, &d_s));
+        }
     }
-    ~sink_base() override { fdc_sinks_destroy(d_s); }
+    ~sink_base() override { fdc_sinks_destroy(d_s); fdc_sinks_group_destroy(d_sg); }
+    int sink_work(const void *items, int n) { return d_sg ? fdc_sinks_group_work(d_sg, items, n) : fdc_sinks_work(d_s, items, n); }
     void publish(gr::sync_block *blk, bool pac)
     {
-        fdc_pdu p;
-        for (int i = 0; i < fdc_sinks_pdu_count(d_s); i++) {
-            if (fdc_sinks_pdu(d_s, i, &p) != FDC_OK) continue;
+        std::vector<fdc_pdu> all((size_t)(d_sg ? fdc_sinks_group_pdu_count(d_sg) : fdc_sinks_pdu_count(d_s)));
+        if (d_sg) fdc_sinks_group_pdus(d_sg, all.data(), (int)all.size()); else fdc_sinks_pdus(d_s, all.data(), (int)all.size());
+        for (const fdc_pdu &p : all) {
             const std::string id(p.id);          // "<time>.PowActChan.<ID>.<n>" / "<time>.DETECTED.<seg>.<n>", fixed at activation
             const gr_complex *d = static_cast<const gr_complex *>(p.samples);
             if (d_msg) {
@@ -313,7 +321,7 @@ public:
         const size_t item = sizeof(gr_complex) * (size_t)input_signature()->sizeof_stream_item / sizeof(gr_complex);
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
-            if (report("PowerActivationChannel", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
+            if (report("PowerActivationChannel", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, true);
         }
         return n;
@@ -349,7 +357,7 @@ public:
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
-            if (report("activity_detection_channelizer_vcm", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
+            if (report("activity_detection_channelizer_vcm", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }
         return n;
@@ -381,7 +389,7 @@ public:
         const size_t item = (size_t)input_signature()->sizeof_stream_item;
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
-            if (report("SegmentDetection", fdc_sinks_work(d_s, p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
+            if (report("SegmentDetection", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
             publish(this, false);
         }
         return n;
