@@ -147,6 +147,17 @@ struct fdc_pipeline {
     // two window shapes.  One launch per class; class 0 is what poly_r / d_cbt / d_shn / d_slot_off name.
     struct PolyClass { int r = 0; float passbw = 0, stopbw = 0; std::vector<int> chan; float2 *d_cbt = nullptr; float *d_shn = nullptr; long long *d_slot_off = nullptr; };
     std::vector<PolyClass> classes;
+    // Split plans (round 4; N = 65536, one-kernel form): the channels that fit no class — other widths, a fourth tiling — are the
+    // REMAINDER: the classes take one block-kernel launch each, the remainder takes the spectrum path on a PARTIAL spectrum (the
+    // forward kernel writes only the 64-bin groups a remainder channel reads) and channel kernels over the remainder's groups.
+    // Taken where its estimated cost is below the whole plan on the spectrum path (fdc_pipeline_create).
+    bool split = false;
+    std::vector<int> rem;                                        // channel ids of the remainder
+    std::vector<std::pair<int, std::vector<int32_t>>> rgroups;   // the remainder by width, like `groups`
+    std::vector<size_t> rgroup_off;
+    std::vector<char> rg_aligned, rg_out_aligned;
+    int32_t *d_rgroups = nullptr;
+    bool last_was_split = false;
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
     int block_min = kBlockMinBlocks;   // FDC_BLOCK_MIN_BLOCKS (tests: 1 = the block kernels at any size)
@@ -355,7 +366,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
     for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
-    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_keep);
+    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -450,16 +461,25 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const bool block_form = fdc::poly_block_supports(N) && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);
         constexpr size_t kMaxPolyClasses = 3;
         std::vector<std::vector<char>> used;
+        const bool may_split = block_form && N == 65536;
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != 256) { ok = false; break; }
+            if (ch.l != 256 || (block_form && R == 4 && (ch.f & 255))) {       // another width; R = 4: off the grid (the window phase would rotate)
+                if (!may_split) { ok = false; break; }
+                p->rem.push_back(c);
+                continue;
+            }
             size_t k = 0;
             for (; k < p->classes.size(); k++) {
                 const auto &pc = p->classes[k];
                 if (pc.r == (ch.f & 255) && pc.passbw == ch.passbw && pc.stopbw == ch.stopbw && !used[k][ch.f >> 8]) break;
             }
             if (k == p->classes.size()) {
-                if (k == (block_form ? kMaxPolyClasses : 1)) { ok = false; break; }
+                if (k == (block_form ? kMaxPolyClasses : 1)) {
+                    if (!may_split) { ok = false; break; }
+                    p->rem.push_back(c);
+                    continue;
+                }
                 fdc_pipeline::PolyClass pc;
                 pc.r = ch.f & 255; pc.passbw = ch.passbw; pc.stopbw = ch.stopbw;
                 p->classes.push_back(pc);
@@ -468,14 +488,39 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             used[k][ch.f >> 8] = 1;
             p->classes[k].chan.push_back(c);
         }
+        if (ok && p->classes.empty()) ok = false;
         // the two-launch form knows one class on the grid (r = 0) only
         if (ok && !block_form && p->classes[0].r != 0) ok = false;
-        // R = 4 on the one-kernel form: on-grid tilings only (an offset would rotate the window phase from block to block)
-        if (ok && block_form && R == 4) for (const auto &pc : p->classes) if (pc.r != 0) ok = false;
-        // one launch per class (0.16 ms per 1024 blocks each, measured) against the spectrum path (0.25 ms forward transform +
-        // 0.16 ms per 256 channels): several classes only where that is the faster of the two
-        // (N = 65536; at N = 16384 / 32768 the alternative is the generic three-kernel path at 3-4x the cost of one class: always classes)
-        if (ok && N == 65536 && p->classes.size() > 1 && 0.16 * (double)p->classes.size() >= 0.25 + 0.16 * (double)p->C / 256.0) ok = false;
+        // Cost per 1024 blocks, ms, measured on MI355X (profiles/r02-r04): a class launch 0.16 whatever it holds; the spectrum path:
+        // forward transform 0.20 (nothing written) ... 0.25 (everything written), channel kernels 0.19 per 65536 bins read.
+        if (ok && N == 65536) {
+            auto bins = [&](const std::vector<int> *ids) {
+                double b = 0;
+                if (ids) for (int c : *ids) b += cfg->channels[c].l; else for (int c = 0; c < p->C; c++) b += cfg->channels[c].l;
+                return b / 65536.0;
+            };
+            // a tiling of few channels costs a whole launch: once there is a remainder anyway, a small class is cheaper as part of it
+            if (may_split) {
+                for (bool moved = true; moved && p->classes.size() > 1;) {
+                    moved = false;
+                    size_t k = 0;
+                    for (size_t i = 1; i < p->classes.size(); i++) if (p->classes[i].chan.size() < p->classes[k].chan.size()) k = i;
+                    const double bk = (double)p->classes[k].chan.size() * 256.0 / 65536.0;
+                    if ((p->rem.empty() ? 0.20 : 0.0) + 0.24 * bk < 0.16) {
+                        p->rem.insert(p->rem.end(), p->classes[k].chan.begin(), p->classes[k].chan.end());
+                        p->classes.erase(p->classes.begin() + (long)k);
+                        moved = true;
+                    }
+                }
+                std::sort(p->rem.begin(), p->rem.end());
+            }
+            const double all = bins(nullptr), rb = bins(&p->rem);
+            const double cost_spec = 0.20 + 0.05 * std::min(1.0, all) + 0.19 * all;
+            const double cost_split = 0.16 * (double)p->classes.size() + (p->rem.empty() ? 0.0 : 0.20 + 0.05 * std::min(1.0, rb) + 0.19 * rb);
+            if ((p->classes.size() > 1 || !p->rem.empty()) && cost_split >= cost_spec) ok = false;
+        }
+        p->split = ok && !p->rem.empty();
+        if (!ok) p->rem.clear();
         p->poly_block = ok && block_form;
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
@@ -483,6 +528,22 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
         if (cfg->min_block_launch >= 1) p->block_min = cfg->min_block_launch;
         if (const char *bm = fdc::debug_env("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
+    }
+    std::vector<int32_t> rflat;
+    if (p->split) {
+        std::map<int, std::vector<int32_t>> rbylen;
+        for (int c : p->rem) rbylen[p->chans[c].l].push_back(c);
+        for (auto &kv : rbylen) {
+            bool al = true, oal = true;
+            for (int c : kv.second) {
+                if (p->chans[c].f & 1) al = false;
+                if ((p->chans[c].out_off & 1) || (p->chans[c].lout & 1)) oal = false;
+            }
+            p->rg_aligned.push_back(al); p->rg_out_aligned.push_back(oal);
+            p->rgroup_off.push_back(rflat.size());
+            p->rgroups.emplace_back(kv.first, kv.second);
+            rflat.insert(rflat.end(), kv.second.begin(), kv.second.end());
+        }
     }
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
@@ -512,6 +573,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMemcpy(p->d_chans, p->chans.data(), sizeof(fdc::ChanDev) * p->chans.size(), hipMemcpyHostToDevice));
         CHK_OR_FREE(hipMalloc(&p->d_groups, sizeof(int32_t) * flat.size()));
         CHK_OR_FREE(hipMemcpy(p->d_groups, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+        if (!rflat.empty()) {
+            CHK_OR_FREE(hipMalloc(&p->d_rgroups, sizeof(int32_t) * rflat.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_rgroups, rflat.data(), sizeof(int32_t) * rflat.size(), hipMemcpyHostToDevice));
+        }
     }
     {
         std::vector<float2> t256(256);
@@ -611,7 +676,12 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
         std::vector<char> g64((size_t)N / 64, 0);
         bool all = true;
-        for (const auto &ch : p->chans) for (int b = ch.f / 64; b <= (ch.f + ch.l - 1) / 64 && b < N / 64; b++) g64[(size_t)b] = 1;
+        // (a split plan's internal spectrum serves its remainder only)
+        for (int c = 0; c < p->C; c++) {
+            if (p->split && std::find(p->rem.begin(), p->rem.end(), c) == p->rem.end()) continue;
+            const auto &ch = p->chans[(size_t)c];
+            for (int b = ch.f / 64; b <= (ch.f + ch.l - 1) / 64 && b < N / 64; b++) g64[(size_t)b] = 1;
+        }
         for (char v : g64) all = all && v;
         if (!all && N == 4096) {
             p->keep4096 = 0;
@@ -682,6 +752,7 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk :
 int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
+    if (p->poly_block && p->split) return 4;
     if (p->poly_block) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
@@ -752,6 +823,51 @@ static int channels_wide(fdc_pipeline *p, const float2 *spec, float2 *d_out, con
     return FDC_OK;
 }
 
+// The channel kernels of one launch group over the plan's channels by width (rem: over the remainder of a split plan only)
+static int run_channel_groups(fdc_pipeline *p, bool rem, const float2 *spec, float2 *d_out, int nb, int m0, int nblocks, int64_t first_block,
+                              hipStream_t s)
+{
+    const auto &groups = rem ? p->rgroups : p->groups;
+    const auto &off = rem ? p->rgroup_off : p->group_off;
+    const auto &al = rem ? p->rg_aligned : p->g_aligned;
+    const auto &oal = rem ? p->rg_out_aligned : p->g_out_aligned;
+    const int32_t *ids = rem ? p->d_rgroups : p->d_groups;
+    for (size_t g = 0; g < groups.size(); g++) {
+        const int l = groups[g].first, ng = (int)groups[g].second.size();
+        if (l > 4096) {
+            const int rcw = channels_wide(p, spec, d_out, ids + off[g], ng, l, nb, m0, nblocks, first_block, s);
+            if (rcw != FDC_OK) return rcw;
+        } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
+            HIPCHK(fdc::launch_channels256(spec, d_out, p->d_chans, ids + off[g], ng, al[g] != 0, oal[g] != 0, p->N, p->R, nb, m0, nblocks, first_block,
+                                           p->d_wins, p->d_tw256, s));
+        else if ((l == 512 || l == 1024) && l <= p->N && !p->cfg_generic)
+            HIPCHK(fdc::launch_channels_wide(spec, d_out, p->d_chans, ids + off[g], ng, l, p->N, p->R, nb, m0, nblocks, first_block, p->d_wins, p->d_tw,
+                                             p->ntab, s));
+        else
+            HIPCHK(fdc::launch_channels(spec, d_out, p->d_chans, ids + off[g], ng, l, p->N, p->R, nb, m0, nblocks, first_block, p->d_wins, p->d_tw,
+                                        p->ntab, s));
+    }
+    return FDC_OK;
+}
+
+// The remainder of a split plan for one launch group: forward transform into the handle's internal (partial) spectrum, channel kernels
+// over the remainder's groups.  ev2 / ev3 (timing): recorded behind the forward transform and behind the channel kernels.
+static int run_remainder(fdc_pipeline *p, const float2 *ring, int m0, int nb, int nblocks, int64_t first_block, float2 *d_out, bool few,
+                         hipStream_t s, hipEvent_t ev2, hipEvent_t ev3)
+{
+    if (p->fwd_block && !few)
+        HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt, p->d_fshn,
+                                          p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, nullptr, p->d_keep));
+    else
+        HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, p->d_tmp, nb, p->N / 2, 1.0f / (float)p->N, p->d_tw256,
+                                    p->d_twf, s, nullptr));
+    if (ev2) HIPCHK(hipEventRecord(ev2, s));
+    const int rc = run_channel_groups(p, true, p->d_spec, d_out, nb, m0, nblocks, first_block, s);
+    if (rc != FDC_OK) return rc;
+    if (ev3) HIPCHK(hipEventRecord(ev3, s));
+    return FDC_OK;
+}
+
 int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
                                 void *d_out, void *d_spectrum, void *stream)
 {
@@ -766,6 +882,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
     const float2 *ring = static_cast<const float2 *>(d_ring);
     const bool use_poly = p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < 0xFFFFFF00ll;
     p->last_was_poly = use_poly;
+    p->last_was_split = use_poly && p->split && p->poly_block;
     for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
         const int nb = std::min(p->chunk, nblocks - m0);
         float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
@@ -794,7 +911,12 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                               pc.r, first_block + m0, tg && k == 0 ? p->events[span[0]] : nullptr,
                                               tg && k + 1 == p->classes.size() ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->N));
             }
-            if (tg) {
+            if (p->split) {
+                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, static_cast<float2 *>(d_out), few, s,
+                                              tg ? p->events[span[2]] : nullptr, tg ? p->events[span[3]] : nullptr);
+                if (rcr != FDC_OK) return rcr;
+                if (tg) p->ev_spans.push_back(span);
+            } else if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);
             }
@@ -813,6 +935,10 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 HIPCHK(fdc::launch_poly_stage2(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
                                                p->d_tw256, p->d_tw1024, p->d_slot_off,
                                                (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, s));
+            if (p->split) {                                     // (timing: the remainder is counted with stage 2)
+                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, static_cast<float2 *>(d_out), few, s, nullptr, nullptr);
+                if (rcr != FDC_OK) return rcr;
+            }
             if (tg) {
                 HIPCHK(hipEventRecord(p->events[span[3]], s));
                 p->ev_spans.push_back(span);
@@ -828,26 +954,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         else
             HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
                                    1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
-        for (size_t g = 0; g < p->groups.size(); g++) {
-            const int l = p->groups[g].first;
-            if (l > 4096) {
-                const int rcw = channels_wide(p, spec, static_cast<float2 *>(d_out), p->d_groups + p->group_off[g], (int)p->groups[g].second.size(), l, nb, m0,
-                                              nblocks, first_block, s);
-                if (rcw != FDC_OK) return rcw;
-            } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
-                HIPCHK(fdc::launch_channels256(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
-                                               (int)p->groups[g].second.size(), p->g_aligned[g] != 0,
-                                               p->g_out_aligned[g] != 0, p->N, p->R, nb, m0, nblocks, first_block,
-                                               p->d_wins, p->d_tw256, s));
-            else if ((l == 512 || l == 1024) && l <= p->N && !p->cfg_generic)
-                HIPCHK(fdc::launch_channels_wide(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
-                                                 (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks, first_block,
-                                                 p->d_wins, p->d_tw, p->ntab, s));
-            else
-                HIPCHK(fdc::launch_channels(spec, static_cast<float2 *>(d_out), p->d_chans, p->d_groups + p->group_off[g],
-                                            (int)p->groups[g].second.size(), l, p->N, p->R, nb, m0, nblocks,
-                                            first_block, p->d_wins, p->d_tw, p->ntab, s));
-        }
+        { const int rcc = run_channel_groups(p, false, spec, static_cast<float2 *>(d_out), nb, m0, nblocks, first_block, s); if (rcc != FDC_OK) return rcc; }
         if (tg) {
             HIPCHK(hipEventRecord(p->events[span[3]], s));
             p->ev_spans.push_back(span);
@@ -869,7 +976,8 @@ int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
         HIPCHK(hipEventElapsedTime(&a, p->events[sp[0]], p->events[sp[1]]));
         HIPCHK(hipEventElapsedTime(&b, p->events[sp[1]], p->events[sp[2]]));
         HIPCHK(hipEventElapsedTime(&c, p->events[sp[2]], p->events[sp[3]]));
-        if (p->poly_ok && p->last_was_poly) { ms[0] += a; ms[1] += c; }        // stage 1, stage 2 (b = wait between them)
+        if (p->last_was_split) { ms[0] += a; ms[1] += b; ms[2] += c; }          // class launches, remainder: forward transform, channel kernels
+        else if (p->poly_ok && p->last_was_poly) { ms[0] += a; ms[1] += c; }   // stage 1, stage 2 (b = wait between them)
         else if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; ms[2] += c; }
         else { ms[0] += a; ms[1] += b; ms[2] += c; }
     }

@@ -70,9 +70,10 @@ struct BlkGeom {
     // ds_read_b128 (lanes {0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS table) then cover all 64 banks, and the 16 contiguous lanes
     // of a ds_write_b64 group (4 rows x 4 columns) all 32 (a stride of 8 mod 64 is conflict-free for the stores only: 1.46 M conflict
     // cycles at P = 8)
-    static constexpr int kLd = 32 * P + 6;
+    // P = 2: 32 P + 2 (4 dwords mod 64: as clean for the reads), which brings the workgroup under half of the LDS: two workgroups per CU
+    static constexpr int kLd = P == 2 ? 32 * P + 2 : 32 * P + 6;
     static constexpr int kTripBytes = 16 * kJT * kLd * 8;         // P = 8: 134144
-    static constexpr int kOffCt = kTripBytes;                     // stage-2 twiddles [32][P], behind the trip buffer
+    static constexpr int kOffCt = kTripBytes > kBlkOffX ? kTripBytes : kBlkOffX;   // stage-2 twiddles [32][P], behind the trip buffer and the strips
     static constexpr int kOffWrow = P == 8 ? 136960 : kOffCt + 32 * P * 8;   // tables: above the strips and the trip buffer
     static constexpr int kOffB = kOffWrow + 16 * 18 * 8;
     static constexpr int kOffSA = kOffB + 32 * 18 * 8;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
 }
 
 template <int P, bool NT, bool OFF, bool FWD, bool R4 = false>
-__global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
+__global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
                                                 const long long *__restrict__ slot_off, long long out_base,
@@ -163,12 +164,13 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
     // the first block's rows are requested before the tables are built: their latency hides behind the table set-up
     const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, (unsigned)kN1 * 16u * 8u);      // cbt[n1][b], n1 = 32 pass + c5
     const unsigned voffc = (unsigned)(c5 * 16 + b) * 8u;
-    cf L[16], cbn;
+    // two row sets: a pass computes on one while the rows of the next pass arrive in the other (no register copies between passes)
+    cf LA[16], LB[16], cbA, cbB;
     {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * kRowGrp);
-        cbn = bld2(rcb, voffc, 0);
+        for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * kRowGrp);
+        cbA = bld2(rcb, voffc, 0);
     }
     // ---- tables (once per workgroup; the workgroup is persistent)
     // Offset plans (every channel at f = 256*slot + r, OFF): the block is modulated by exp(-2 pi i r n / N), n = n1 + N1 (16a + b),
@@ -239,8 +241,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
         // One pass per trip.  The 16 rows of this lane's column were requested a whole pass ago into L; the rows of the next
         // pass (of this block, or pass 0 of this workgroup's next block; after the last block: the same rows again, unused)
         // are requested first, unconditionally (a conditional request costs a second set of register copies).
-#pragma nounroll
-        for (int ps = 0; ps < P; ps++) {
+        auto one_pass = [&](const int ps, cf (&cur)[16], const cf cbc, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
 #ifdef FDC_BLK_L2PF
             // experiment: touch every 128-byte line of the pass after next (this block's, or the next block's) once, two passes ahead
             {
@@ -251,10 +252,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 pfd = __builtin_amdgcn_raw_buffer_load_b32(rpf, (unsigned)((tid >> 1) * (kN1 * 8) + (tid & 1) * 128), 0u, 0);
             }
 #endif
-            const cf cb = OFF ? cbn * sgn : cbn;
-            cf cur[16];
-#pragma unroll
-            for (int a = 0; a < 16; a++) cur[a] = L[a];
+            const cf cb = OFF ? cbc * sgn : cbc;
             {
                 const int pn = ps < P - 1 ? ps + 1 : 0;
                 const int mb = ps < P - 1 ? m : mnext;
@@ -346,6 +344,23 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512) void k_blk256(const float2 *__res
                 }
             }
             FDC_STAMP(1 + ps);
+        };
+        // two passes per trip: the row sets swap roles (the pass count is even for every P).  The offset-plan variant at P = 8 has no
+        // registers for the second set's live range (32 bytes of scratch): it copies the rows at the top of a pass as before.
+        if constexpr (OFF && P == 8) {
+#pragma nounroll
+            for (int ps = 0; ps < P; ps++) {
+                cf cur[16];
+#pragma unroll
+                for (int a = 0; a < 16; a++) cur[a] = LA[a];
+                one_pass(ps, cur, cbA, LA, cbA);
+            }
+        } else {
+#pragma nounroll
+            for (int pp = 0; pp < P; pp += 2) {
+                one_pass(pp, LA, cbA, LB, cbB);
+                one_pass(pp + 1, LB, cbB, LA, cbA);
+            }
         }
         // ---------------- stage 2 ----------------
         // FFT-N1 over n1 = 32 pass + c5 of every row t' = b + 16 j.  The P passes of a column sit in ONE lane: a DFT-P over
@@ -497,6 +512,9 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
     if (nb_chunk <= 0) return hipSuccess;
     if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && ((r & 255) || !scratch))) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: up to 159.5 KiB each)
+    // N = 16384 on the grid at R = 2: 126 registers and 79.75 KiB of LDS per workgroup: two workgroups per CU, one's stage 2 beside the
+    // other's stage 1
+    if (N == 16384 && R == 2 && !(r & 255)) grid *= 2;
     if (grid > nb_chunk) grid = nb_chunk;
     // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)
     // ev_start / ev_stop (timing): the dispatch packet's own begin / end time stamps (hipExtLaunchKernel) — no barrier packet

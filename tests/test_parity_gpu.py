@@ -813,3 +813,54 @@ def test_one_kernel_path_other_block_lengths_offsets_and_classes(oracle, N):
     ref, _ = oracle.channelizer(N, R, 2, plan, x, nthreads=8)
     for c in range(len(plan)):
         assert_close(outs[c], ref[c], "N %d classes channel %d" % (N, c))
+
+
+def test_split_plans_classes_plus_remainder(oracle):
+    """a plan that is ALMOST a bank — tilings of 256-bin channels plus a few channels of other widths, off every
+    tiling, or a fourth tiling — is split: the tilings on the one-kernel form (one launch each), the remainder on the spectrum path
+    over a partial spectrum that holds only what it reads (fdc_pipeline_path() = 4), where the cost rule says that beats the whole
+    plan on the spectrum path.  Every channel against the oracle and against the spectrum path; ragged calls; short launch groups."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, nb = 65536, 2, 6
+    H = N - N // R
+    x = noise(nb * H, 4711)
+    rng = np.random.default_rng(9)
+    bank = [(256 * int(c), 256, 0.88, 1.0) for c in rng.permutation(256)[:230]]
+    odd = [(12345, 512, 0.7, 0.9), (40001, 128, 0.88, 1.0), (2049, 1024, 0.6, 0.85), (60000, 64, 0.5, 0.8), (31, 256, 0.88, 1.0), (50000, 2048, 0.9, 1.0)]
+    plans = {"bank + six others": bank + odd,
+             "interleaved": [ch for pair in zip(bank[:6], odd) for ch in pair] + bank[6:],
+             "two tilings + others": bank + [(256 * int(c) + 128, 256, 0.88, 1.0) for c in rng.permutation(255)[:200]] + odd[:3]}
+    for name, plan in plans.items():
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb)
+        assert p.path() == 4, name
+        outs = p.work(x)
+        ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+        for c in range(len(plan)):
+            if plan[c][1] != 256 or c % 17 == 0 or (plan[c][0] & 255):
+                assert_close(outs[c], ref[c], "%s: channel %d %s" % (name, c, plan[c]))
+        q = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+        assert q.path() == 1
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "%s: channel %d vs the spectrum path" % (name, c))
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 1), (1, 4), (4, 6)]]
+        for c in range(len(plan)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c]), (name, c)
+        # launch groups below the block-kernel threshold: tiled kernels for the tiling (one on-grid class) and for the remainder's transform
+        t = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, min_block_launch=96)
+        assert t.path() == 4
+        for c, (a, b_) in enumerate(zip(t.work(x), outs)):
+            assert_close(a, b_, "%s: channel %d on the tiled kernels" % (name, c))
+    # the spectrum port (debug) of a split plan is the whole spectrum, and its channels are unchanged
+    p = G.Pipeline(N, R, plans["bank + six others"], windowtype=1, max_blocks=nb, keep_spectrum=True)
+    outs, spec = p.work(x, want_spectrum=True)
+    ref, rspec = oracle.channelizer(N, R, 1, plans["bank + six others"], x, nthreads=8, want_spectrum=True)
+    assert_close(spec, np.asarray(rspec).reshape(-1), "spectrum port")
+    for c in (0, 229, 230, 235):
+        assert_close(outs[c], ref[c])
+    # where the split does not pay the plan stays on the spectrum path: half the band in other widths (bench.py --mixed) ...
+    half = [(256 * c, 256, 0.88, 1.0) if c % 2 == 0 else (256 * c + 64, 128, 0.88, 1.0) for c in range(256)]
+    assert G.Pipeline(N, R, half, windowtype=1, max_blocks=2).path() == 1
+    # ... and a handful of channels
+    assert G.Pipeline(N, R, bank[:20] + odd[:1], windowtype=1, max_blocks=2).path() == 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2.  Every case draws a plan (on-grid,
-offset, two or three classes, or mixed widths), a block count, a chunk size and a call pattern, runs it on the default
+offset, two or three classes, mixed widths, or a split plan: tilings plus a remainder), a block count, a chunk size and a call pattern, runs it on the default
 dispatch and on the spectrum-in-memory path (FDC_NO_POLY=1) and compares every output sample; every fifth case is also
 compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed]"""
 import os
@@ -25,7 +25,7 @@ def rel(a, b):
 
 
 def draw_plan(rng):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 6)
     if kind == 0:                                     # on-grid subset
         slots = rng.permutation(256)[:rng.integers(1, 257)]
         return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "grid"
@@ -49,6 +49,17 @@ def draw_plan(rng):
             l = int(2 ** rng.integers(6, 12))
             plan.append((int(rng.integers(0, N - l + 1)), l, 0.88, 1.0))
         return plan, "mixed"
+    if kind == 5:                                     # split plans: one to three tilings plus a remainder of other widths / further tilings
+        plan = []
+        for k in range(int(rng.integers(1, 4))):
+            r = int(rng.integers(0, 256)) if k else 0
+            slots = rng.permutation(255)[:rng.integers(120, 256)]
+            plan += [(256 * int(c) + r, 256, 0.88, 1.0) for c in slots]
+        for _ in range(int(rng.integers(1, 9))):
+            l = int(2 ** rng.integers(6, 12))
+            plan.append((int(rng.integers(0, N - l + 1)), l, 0.7, 0.9))
+        order = rng.permutation(len(plan))
+        return [plan[int(i)] for i in order], "split"
     slots = rng.permutation(256)[:rng.integers(1, 40)]   # few channels
     return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "few"
 
