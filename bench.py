@@ -83,6 +83,9 @@ def parse():
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
+    ap.add_argument("--extra", type=int, default=0, metavar="K", help="diagnostics (config 2): K more channels of widths 512 / 128 / 1024 at odd bins beside "
+                                                                      "the 256-channel bank: an ALMOST uniform plan (split: the bank on the one-kernel "
+                                                                      "form, the K others on a partial spectrum; kernel_path 4)")
     ap.add_argument("--sparse", type=int, default=0, metavar="K", help="diagnostics (config 2): K channels (widths 256 ... 2048 in turn) spread "
                                                                        "over the band instead of a plan that tiles it (spectrum path)")
     ap.add_argument("--sparse-widths", default="256,512,1024,2048", help="--sparse: the channel widths in turn (bins, powers of two)")
@@ -460,6 +463,10 @@ def main():
             params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
         if a.offset:
             params = [(f + a.offset, l, lo, p, s) for (f, l, lo, p, s) in params[:-1]]
+        if a.extra:
+            for k in range(a.extra):
+                l = (512, 128, 1024)[k % 3]
+                params.append((int((k + 0.37) / a.extra * (N - 2048)) | 1, l, l - l // R, 0.7, 0.9))
         plan = [(f, l, p, s) for (f, l, _lo, p, s) in params]
         sum_lout = sum(lo for (_f, _l, lo, _p, _s) in params)
         pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk)
@@ -474,6 +481,7 @@ def main():
             else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "") + \
             (", %d input rings in rotation (cache-cold input)" % len(rings) if len(rings) > 1 else ", ONE input ring (stays in the memory-side cache)") + \
             (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "") + \
+            (", plus %d channels of other widths at odd bins (split plan)" % a.extra if a.extra else "") + \
             (", SPARSE plan: %d channels, l = %s, %d of %d bins read" % (len(plan), sorted(set(p_[1] for p_ in params)), sum(p_[1] for p_ in params), N)
              if a.sparse else "")
     else:
@@ -657,7 +665,8 @@ def main():
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
     nlaunch = (nb + chunk - 1) // chunk         # launch groups per step
     path = pipe.path()
-    names = ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 and sinks is None else \
+    names = ["block_kernel(the tilings of a split plan)", "block_fft(forward, partial spectrum)", "channels(remainder)"] if path == 4 and sinks is None else \
+            ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 and sinks is None else \
             ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 and sinks is None else \
             ["block_fft(forward, one kernel)", "unused", "channels"] if path == 1 and N == 65536 and a.force_path != "no-block" else \
             ["fft_pass_a", "fft_pass_b", "channels"]
@@ -674,7 +683,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or R != 2):
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
                              "not counters of this process"
