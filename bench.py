@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
                                                              "dropped): a tiling that does not start at bin 0")
-    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum"), default=None,
+    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum", "wide-uniform"), default=None,
                     help="diagnostics: fdc_pipeline_cfg.flags FDC_PIPE_NO_BLOCK / NO_POLY / FORCE_GENERIC (the slower forms of the path)")
     ap.add_argument("--input-rings", type=int, default=3,
                     help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 rings of 537 MB (2048 blocks of "
@@ -83,6 +83,8 @@ def parse():
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
+    ap.add_argument("--width", type=int, default=0, metavar="L", help="diagnostics (config 2): a uniform bank of channels L bins wide (N / L channels "
+                                                                      "on the L-bin grid) instead of 256: the generic-width two-launch path")
     ap.add_argument("--extra", type=int, default=0, metavar="K", help="diagnostics (config 2): K more channels of widths 512 / 128 / 1024 at odd bins beside "
                                                                       "the 256-channel bank: an ALMOST uniform plan (split: the bank on the one-kernel "
                                                                       "form, the K others on a partial spectrum; kernel_path 4)")
@@ -428,7 +430,7 @@ def main():
     import gr_fdc_amd as G
     if a.force_path:
         G.defaults[{"no-block": "FDC_NO_BLOCK", "no-poly": "FDC_NO_POLY", "generic": "FDC_FORCE_GENERIC",
-                    "full-spectrum": "FDC_FULL_SPECTRUM"}[a.force_path]] = "1"
+                    "full-spectrum": "FDC_FULL_SPECTRUM", "wide-uniform": "FDC_WIDE_UNIFORM"}[a.force_path]] = "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -458,6 +460,10 @@ def main():
         elif a.sparse:
             wid = tuple(int(v) for v in a.sparse_widths.split(","))
             params = [G.get_opt_channelparams(N, R, ((c + 0.37) / a.sparse) % 1.0, 0.8 * wid[c % len(wid)] / N) for c in range(a.sparse)]
+        elif a.width:
+            C = N // a.width
+            params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C) % 1.0, 0.8 / C) for c in range(C)]
+            assert all(p_[1] == a.width and p_[0] == a.width * c for c, p_ in enumerate(params)), "not a bank on the %d-bin grid" % a.width
         else:
             bws = (0.8, 0.4, 0.8, 1.6) if a.mixed else (0.8,)
             params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
@@ -665,7 +671,8 @@ def main():
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
     nlaunch = (nb + chunk - 1) // chunk         # launch groups per step
     path = pipe.path()
-    names = ["block_kernel(the tilings of a split plan)", "block_fft(forward, partial spectrum)", "channels(remainder)"] if path == 4 and sinks is None else \
+    names = ["poly_stage1_generic(colFFT+window+IFFT, any width)", "poly_stage2_generic(slotFFT)", "unused"] if path == 2 and sinks is None and a.width else \
+            ["block_kernel(the tilings of a split plan)", "block_fft(forward, partial spectrum)", "channels(remainder)"] if path == 4 and sinks is None else \
             ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 and sinks is None else \
             ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 and sinks is None else \
             ["block_fft(forward, one kernel)", "unused", "channels"] if path == 1 and N == 65536 and a.force_path != "no-block" else \
@@ -683,7 +690,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or R != 2):
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or a.width or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
                              "not counters of this process"

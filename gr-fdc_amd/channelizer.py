@@ -112,6 +112,8 @@ def _default_cfg_fields():
         flags |= _lib.FDC_PIPE_NO_BLOCK
     if defaults.get("FDC_FULL_SPECTRUM"):
         flags |= _lib.FDC_PIPE_FULL_SPECTRUM
+    if defaults.get("FDC_WIDE_UNIFORM"):
+        flags |= _lib.FDC_PIPE_WIDE_UNIFORM
     if "FDC_BLOCK_HINTS" in defaults:
         h = int(defaults["FDC_BLOCK_HINTS"])
         flags |= (0 if h & 1 else _lib.FDC_PIPE_PLAIN_STORES) | (_lib.FDC_PIPE_NT_LOADS if h & 2 else 0)

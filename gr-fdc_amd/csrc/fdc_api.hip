@@ -140,6 +140,8 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
+                                 // stage 1 on the generic LDS core, two launches; one class, no offset)
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
     bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
     // One-kernel form only: a plan may be the union of up to kMaxPolyClasses tilings (classes), each with its own offset r,
@@ -451,9 +453,24 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         flat.insert(flat.end(), kv.second.begin(), kv.second.end());
     }
 
+    // uniform plan of another width?  every channel l = L != 256 at f = L*slot, one window, every slot at most once, 16 <= N/L <= 4096
+    bool uniL = false;
+    if (p->C > 0 && !p->cfg_generic && !(flags & FDC_PIPE_NO_POLY) && N <= (1 << 20) && R <= 16) {
+        const int L = cfg->channels[0].l;
+        // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
+        // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
+        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || (flags & FDC_PIPE_WIDE_UNIFORM));
+        std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
+        for (int c = 0; uniL && c < p->C; c++) {
+            const fdc_channel &ch = cfg->channels[c];
+            if (ch.l != L || (ch.f % L) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
+            else usedL[(size_t)(ch.f / L)] = 1;
+        }
+        if (uniL) { p->poly_ok = true; p->poly_L = L; }
+    }
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
-    {
+    if (!uniL) {
         bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(flags & FDC_PIPE_NO_POLY);
         // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
         // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
@@ -599,7 +616,36 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * (size_t)N));
         CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
     }
-    if (p->poly_ok) {
+    if (p->poly_ok && p->poly_L != 256) {
+        // uniform plan of width L: the window shape (plateau 1: the chain's * l is in it) over N, the slot table; twiddles are d_tw's
+        const int L = p->poly_L, N1 = N / L;
+        fdc_pipeline::PolyClass pc;
+        pc.r = 0; pc.passbw = cfg->channels[0].passbw; pc.stopbw = cfg->channels[0].stopbw;
+        for (int c = 0; c < p->C; c++) pc.chan.push_back(c);
+        std::vector<std::complex<float>> shape((size_t)L);
+        fdc::window_table(cfg->windowtype, L, pc.passbw, pc.stopbw, 1, 0, true, shape.data());
+        std::vector<float> sn((size_t)L);
+        for (int k2 = 0; k2 < L; k2++) sn[(size_t)k2] = float(double(shape[(size_t)k2].real()) / double(N));
+        std::vector<long long> so((size_t)N1, -1);
+        for (int c = 0; c < p->C; c++) so[(size_t)(p->chans[c].f / L)] = p->chans[c].out_off;
+        p->classes.push_back(pc);
+        auto &q = p->classes.back();
+        CHK_OR_FREE(hipMalloc(&q.d_shn, sizeof(float) * (size_t)L));
+        CHK_OR_FREE(hipMemcpy(q.d_shn, sn.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&q.d_slot_off, sizeof(long long) * (size_t)N1));
+        CHK_OR_FREE(hipMemcpy(q.d_slot_off, so.data(), sizeof(long long) * (size_t)N1, hipMemcpyHostToDevice));
+        p->d_shn = q.d_shn; p->d_slot_off = q.d_slot_off;
+        // the tile-local factor of the inter-pass twiddle, in the tile's own order: t2[k2][t] = W_N^(t k2)
+        const int TCg = fdc::poly_stage1_generic_tile_columns(N, L);
+        std::vector<float2> t2v((size_t)L * TCg);
+        for (int k2 = 0; k2 < L; k2++)
+            for (int t = 0; t < TCg; t++) {
+                const double a = -2.0 * M_PI * double(((long long)t * k2) % N) / double(N);
+                t2v[(size_t)k2 * TCg + t] = make_float2(float(std::cos(a)), float(std::sin(a)));
+            }
+        CHK_OR_FREE(hipMalloc(&p->d_twq, sizeof(float2) * t2v.size()));       // (d_twq is free on this path: freed with the handle)
+        CHK_OR_FREE(hipMemcpy(p->d_twq, t2v.data(), sizeof(float2) * t2v.size(), hipMemcpyHostToDevice));
+    } else if (p->poly_ok) {
         const int N1 = N / 256;
         std::vector<float2> tq((size_t)N1 * 16);
         for (int n1 = 0; n1 < N1; n1++)
@@ -713,7 +759,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
         const int gblocks = p->poly_block ? std::min(chunk, p->block_min) : chunk;
         if (two_launch)
-            CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(256 - 256 / R) * (size_t)(N / 256)));
+            CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(p->poly_L - p->poly_L / R) * (size_t)(N / p->poly_L)));
     }
     {
         // widest "channels x width" of a group above 4096 bins: a piece of the launch group is as many blocks as fit 32 Mi points
@@ -925,10 +971,17 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         if (use_poly) {
             // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the two launches
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
-            HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N / 256, p->R, nb,
-                                           p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->ncu, s));
+            if (p->poly_L != 256)
+                HIPCHK(fdc::launch_poly_stage1_generic(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N, p->poly_L, p->R, nb, p->d_shn, p->d_tw,
+                                                       p->ntab, p->d_twq, s));
+            else
+                HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N / 256, p->R, nb,
+                                               p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->ncu, s));
             if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[1]; }   // the end of stage 1 IS the start of stage 2
-            if (p->N != 65536 && p->N != 262144)
+            if (p->poly_L != 256)
+                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, static_cast<float2 *>(d_out), p->N / p->poly_L, p->R, nb, m0, nblocks,
+                                                       p->d_slot_off, p->d_tw, p->ntab, s, p->poly_L));
+            else if (p->N != 65536 && p->N != 262144)
                 HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
                                                        p->d_slot_off, p->d_tw, p->ntab, s));
             else

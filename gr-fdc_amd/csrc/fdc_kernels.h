@@ -101,7 +101,14 @@ hipError_t launch_poly_stage2(const float2 *g, float2 *out, int N1 /* 256 or 102
 
 // stage 2 for any other slot count N1 = N/256 in [16, 4096] (generic LDS core, fdc_kernels.hip)
 hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
-                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s);
+                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s,
+                                      int L = 256 /* channel width; other than 256: G in rows of N1 columns (launch_poly_stage1_generic) */);
+// uniform plans of any power-of-two width L on the L-bin grid: stage 1 on the generic LDS core; g: nb_chunk * (L - L/R) * N/L points,
+// shn[k2] = shape[k2] / N (L entries), tw = exp(-2 pi i k / ntab) with ntab = N
+// t2[k2][t] = W_N^(t k2), t < poly_stage1_generic_tile_columns(N, L): the tile-local factor of the inter-pass twiddle
+hipError_t launch_poly_stage1_generic(const float2 *in, size_t in_stride, float2 *g, int N, int L, int R, int nb_chunk, const float *shn,
+                                      const float2 *tw, int ntab, const float2 *t2, hipStream_t s);
+int poly_stage1_generic_tile_columns(int N, int L);
 
 // uniform plan, N = 16384 / 32768 / 65536, R = 2 or 4: the whole path in one kernel, one block per CU, G kept in registers (fdc_block256.hip).
 // hints: 1 = nt output stores, 2 = nt input loads.  ncu: compute units of the device (grid size).

@@ -316,7 +316,7 @@ __global__ FDC_GENERIC_BOUNDS(NB) void k_fft_pass_b(const float2 *__restrict__ t
 // receives TR*8-byte runs.
 __global__ FDC_GENERIC_BOUNDS(1) void k_p2g(const float2 *__restrict__ g, float2 *__restrict__ out, int log2N1, int log2TR,
                                             int ld, int lout, const long long *__restrict__ slot_off, long long out_base,
-                                            long long nb_call, const float2 *__restrict__ tw, int twstride)
+                                            long long nb_call, const float2 *__restrict__ tw, int twstride, int rowmajor)
 {
     constexpr int PT = 16;
     float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
@@ -330,7 +330,8 @@ __global__ FDC_GENERIC_BOUNDS(1) void k_p2g(const float2 *__restrict__ g, float2
         const int e = threadIdx.x + u * kThreads;
         const int col = e & 15, r = (e >> 4) & (TR - 1), ct = e >> (4 + log2TR);
         v[u] = make_float2(0.f, 0.f);
-        if (e < total) v[u] = src[((size_t)ct * lout + r) * 16 + col];
+        // G of the l = 256 stage 1 is tile-major ([column tile][row][16]); the generic-width stage 1 (k_p1g) writes rows of N1 columns
+        if (e < total) v[u] = rowmajor ? g[((size_t)m * lout + t0 + r) * N1 + ct * 16 + col] : src[((size_t)ct * lout + r) * 16 + col];
     }
 #pragma unroll
     for (int u = 0; u < PT; u++) {
@@ -652,6 +653,8 @@ BigGeom big_geom(int N)
     return g;
 }
 
+static hipError_t init_p1g_kernels();      // below, behind k_p1g
+
 hipError_t init_kernels()
 {
     const int maxlds = 72 * 1024;      // largest generic tile: 8192 points (64 KiB) + static per-column records
@@ -661,6 +664,7 @@ hipError_t init_kernels()
     if (e != hipSuccess) return e;
     FDC_SETLDS((k_fft_small<false, 2>)) FDC_SETLDS((k_fft_small<true, 2>))
     FDC_SETLDS(k_channels<2>) FDC_SETLDS(k_extract<2>) FDC_SETLDS(k_extract_multi)
+    if ((e = init_p1g_kernels()) != hipSuccess) return e;
 #undef FDC_SETLDS
     if ((e = init_sink_kernels()) != hipSuccess) return e;
     return init_fast_kernels();
@@ -732,16 +736,140 @@ hipError_t launch_channels(const float2 *spec, float2 *out, const ChanDev *chans
 }
 
 hipError_t launch_poly_stage2_generic(const float2 *g, float2 *out, int N1, int R, int nb_chunk, int mbase, int nb_call,
-                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s)
+                                      const long long *slot_off, const float2 *tw, int ntab, hipStream_t s, int L)
 {
-    const int lout = 256 - 256 / R;
+    const int lout = L - L / R;
     int tr = 4096 / N1; if (tr > 32) tr = 32; if (tr < 1) tr = 1;
     while (lout % tr) tr >>= 1;                                       // tiles are whole rows of one block
     const TileGeom tg = tile_geom(N1);
     const int log2TR = ilog2(tr), ld = tr > 1 ? tr + 1 : 1;
     const long long ntiles = (long long)nb_chunk * (lout / tr);
     hipLaunchKernelGGL(k_p2g, dim3((unsigned)ntiles), dim3(kThreads), (size_t)N1 * ld * sizeof(float2), s, g, out, tg.log2L,
-                       log2TR, ld, lout, slot_off, (long long)mbase * lout, (long long)nb_call, tw, ntab / N1);
+                       log2TR, ld, lout, slot_off, (long long)mbase * lout, (long long)nb_call, tw, ntab / N1, L != 256 ? 1 : 0);
+    return hipGetLastError();
+}
+
+// ---- uniform plans of any width L (round 4): stage 1 on the generic LDS core -----------------------------------------------------
+// Every channel l = L on the L-bin grid (f = L slot), one window: the commutation of fdc_fast256.hip does not depend on L = 256 —
+//   y_c[t] = sum_n1 W_N1^(n1 k1) G[n1][t],   G[n1][t] = IFFT_L{ shape[k2]/N W_N^(n1 k2) (-1)^n1 FFT_L{ x[n1 + N1 n2] } },  N1 = N / L
+// (ifftshift = the product lands at k2 ^ L/2; the discard keeps t >= L/R).  A workgroup takes TC columns n1 of one block: gather
+// (rows of TC x 8 bytes, N1 samples apart), FFT over n2, table product, inverse FFT, kept rows to G[m][t'][n1] (rows of N1 columns:
+// k_p2g reads them with rowmajor = 1).  Two launches, G through memory: the form k_p1 + k_p2 have for L = 256, without their
+// register kernels — for uniform banks of other widths, which would otherwise take the spectrum path.
+template <int NB>
+__global__ FDC_TILE_BOUNDS(NB) void k_p1g(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ g, int log2L, int log2TC,
+                                          int ld, int log2N1, int skip, const float *__restrict__ shn, const float2 *__restrict__ tw,
+                                          int ntab, const float2 *__restrict__ t2)
+{
+    float2 *lds = reinterpret_cast<float2 *>(fdc_smem);
+    const int L = 1 << log2L, TC = 1 << log2TC, N1 = 1 << log2N1, total = L << log2TC, lout = L - skip;
+    float2 *t1 = lds + L * ld;                                            // [L]: shape[k2]/N W_N^(c0 k2), c0 = this tile's first column
+    const int c0 = blockIdx.x << log2TC;
+    const size_t m = blockIdx.y;
+    const float2 *src = in + m * in_stride + c0;
+    const int twn = ntab >> (log2L + log2N1);                             // table entries per step of W_N
+    const int nmask = (ntab / twn) - 1;                                   // N - 1
+    // gather, 16 elements per thread in flight at a time (all offsets fit 32 bits: < N)
+#pragma unroll
+    for (int h = 0; h < NB; h++) {
+        float2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = threadIdx.x + (16 * h + u) * kThreads;
+            v[u] = make_float2(0.f, 0.f);
+            if (e < total) v[u] = src[((e >> log2TC) << log2N1) + (e & (TC - 1))];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = threadIdx.x + (16 * h + u) * kThreads;
+            if (e < total) lds[(e >> log2TC) * ld + (e & (TC - 1))] = v[u];
+        }
+    }
+    // W_N^(n1 k2) = W_N^(c0 k2) W_N^(t k2): the first factor is this tile's (L values, gathered once into LDS together with the
+    // window), the second is the same for every tile and block: t2[k2][t], read in the tile's own order (coalesced)
+    for (int k2 = threadIdx.x; k2 < L; k2 += kThreads) {
+        const float2 w = tw[(int)(((long long)c0 * k2) & nmask) * twn];
+        const float sc = shn[k2];
+        t1[k2] = make_float2(w.x * sc, w.y * sc);
+    }
+    __syncthreads();
+    fft_cols<false, NB>(lds, log2L, log2TC, ld, tw, ntab >> log2L);
+    // shape[k2]/N * (-1)^n1 * W_N^(n1 k2), placed at the ifftshifted position: an element trades places with its partner k2 ^ L/2,
+    // which the SAME thread holds 8 * NB steps further on (e and e + total/2 differ by kThreads * 8 * NB exactly when total = 4096 * NB)
+    if (total == 4096 * NB) {
+#pragma unroll
+        for (int u = 0; u < 8 * NB; u++) {
+            const int e = threadIdx.x + u * kThreads, e2 = e + (total >> 1);
+            const int t = e & (TC - 1), k2 = e >> log2TC, k3 = e2 >> log2TC;
+            const float sg = ((c0 + t) & 1) ? -1.f : 1.f;
+            const float2 a = cmulf(cmulf(lds[k2 * ld + t], t1[k2]), t2[e]);
+            const float2 b = cmulf(cmulf(lds[k3 * ld + t], t1[k3]), t2[e2]);
+            lds[k3 * ld + t] = make_float2(a.x * sg, a.y * sg);
+            lds[k2 * ld + t] = make_float2(b.x * sg, b.y * sg);
+        }
+    } else {                                                              // small tiles (fewer columns than a full tile): two phases
+        float2 v[16 * NB];
+#pragma unroll
+        for (int u = 0; u < 16 * NB; u++) {
+            const int e = threadIdx.x + u * kThreads;
+            const int t = e & (TC - 1), k2 = e >> log2TC;
+            if (e < total) {
+                const float sg = ((c0 + t) & 1) ? -1.f : 1.f;
+                const float2 a = cmulf(cmulf(lds[k2 * ld + t], t1[k2]), t2[e]);
+                v[u] = make_float2(a.x * sg, a.y * sg);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16 * NB; u++) {
+            const int e = threadIdx.x + u * kThreads;
+            if (e < total) lds[((e >> log2TC) ^ (L >> 1)) * ld + (e & (TC - 1))] = v[u];
+        }
+    }
+    __syncthreads();
+    fft_cols<true, NB>(lds, log2L, log2TC, ld, tw, ntab >> log2L);
+    float2 *dst = g + m * (size_t)lout * N1 + c0;
+#pragma unroll
+    for (int u = 0; u < 16 * NB; u++) {
+        const int e = threadIdx.x + u * kThreads;
+        const int t = e & (TC - 1), tt = e >> log2TC;
+        if (e < total && tt >= skip) dst[((tt - skip) << log2N1) + t] = lds[tt * ld + t];
+    }
+}
+
+static hipError_t init_p1g_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1g<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return e;
+}
+
+// tile of the generic-width stage 1: columns per workgroup
+static TileGeom p1g_geom(int N, int L)
+{
+    TileGeom tg = tile_geom(L);
+    // (8192-point tiles for L = 512 / 1024 — 128-byte row pieces, but 256 VGPRs and two waves per SIMD — measured slower than these
+    // 4096-point ones: stage 1 0.83 against 0.73 ms per 2048 blocks at L = 512)
+    if (tg.TC > N / L) { tg.TC = N / L; tg.log2TC = ilog2(tg.TC); tg.ld = tg.TC > 1 ? tg.TC + 1 : 1; }
+    return tg;
+}
+int poly_stage1_generic_tile_columns(int N, int L) { return p1g_geom(N, L).TC; }
+
+hipError_t launch_poly_stage1_generic(const float2 *in, size_t in_stride, float2 *g, int N, int L, int R, int nb_chunk, const float *shn,
+                                      const float2 *tw, int ntab, const float2 *t2, hipStream_t s)
+{
+    if (nb_chunk <= 0) return hipSuccess;
+    const int N1 = N / L;
+    const TileGeom tg = p1g_geom(N, L);
+    for (int m0 = 0; m0 < nb_chunk; m0 += 32768) {                        // gridDim.y limit
+        const int nb = nb_chunk - m0 < 32768 ? nb_chunk - m0 : 32768;
+        dim3 grid((unsigned)(N1 / tg.TC), (unsigned)nb);
+#define FDC_L1G(B) \
+        hipLaunchKernelGGL((k_p1g<B>), grid, dim3(kThreads), tg.lds_bytes() + (size_t)L * sizeof(float2), s, in + (size_t)m0 * in_stride, in_stride, \
+                           g + (size_t)m0 * (size_t)(L - L / R) * N1, tg.log2L, tg.log2TC, tg.ld, ilog2(N1), L / R, shn, tw, ntab, t2)
+        if (tg.NB == 2) FDC_L1G(2); else FDC_L1G(1);
+#undef FDC_L1G
+    }
     return hipGetLastError();
 }
 

@@ -1249,11 +1249,12 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         d.cap_hland[b] = want;
     }
     if (sum.ntask)
-        HIPCHK(fdc::launch_task_scatter(d.nlist, d.d_task_base, d.d_ntask, d.max_list, d.d_tasks, d.d_owners, d.d_sum, d.d_class_fill,
-                                        d.d_sorted, s->stream));
-    if (d.any)
-        HIPCHK(fdc::launch_carry_copy(d.d_owners, d.carry_width, d.d_owner_base, d.d_nowner, npac, nseg, d.d_sum,
-                                      d.d_land[d.cur], d.d_land[b], s->stream));
+        // grids from what the layout found, not from the worst case the lists were allocated for
+        HIPCHK(fdc::launch_task_scatter(d.nlist, d.d_task_base, d.d_ntask, std::min<long long>(d.max_list, std::max(1, sum.max_list_tasks)), d.d_tasks,
+                                        d.d_owners, d.d_sum, d.d_class_fill, d.d_sorted, s->stream));
+    if (d.any && sum.ncarry > 0)
+        HIPCHK(fdc::launch_carry_copy(d.d_owners, std::min(d.carry_width, std::max(1, sum.max_region_owners)), d.d_owner_base, d.d_nowner, npac, nseg,
+                                      d.d_sum, d.d_land[d.cur], d.d_land[b], s->stream));
     if (sum.ntask) {
         size_t first[32], cnt[32];
         for (int k = 0; k < 32; k++) { first[k] = (size_t)sum.class_base[k]; cnt[k] = (size_t)sum.class_cnt[k]; }

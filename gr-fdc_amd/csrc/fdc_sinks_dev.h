@@ -62,6 +62,10 @@ struct SinkSummary {
     int64_t used_a, b_start, used_total;   // samples: emitted payloads [0, used_a) (copied to the host), buffered rest [b_start, used_total)
     int32_t class_cnt[32], class_base[32]; // extraction tasks per width class (log2 w), and where a class starts in the sorted array
     int32_t npdu, ntask, nowner, error;
+    // what the launches that follow the layout really need (their grids were sized for the worst case before: ADVICE r03):
+    int32_t max_list_tasks;                // the longest task list of the call (k_task_scatter's grid width)
+    int32_t ncarry, max_region_owners;     // streams that carry blocks from the call before; the widest region of the owner table
+    int32_t pad;
 };
 
 struct SinkLists {               // static partition of the task / record arrays into lists (one per wave of PACs, one per segment)

@@ -868,15 +868,18 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
 {
     __shared__ long long sh[16];
     __shared__ int hist[32];
+    __shared__ int ncar, maxlist;
     const int tid = threadIdx.x;
     if (tid < 32) hist[tid] = 0;
+    if (tid == 0) { ncar = 0; maxlist = 0; }
     __syncthreads();
     long long accA = 0, accB = 0;
-    int total_owner = 0;
+    int total_owner = 0, max_region = 0;
     for (int rg = 0; rg <= nseg; rg++) {
         const long long o0 = rg == 0 ? 0 : owner_base[rg - 1];
         const int cnt = rg == 0 ? npac : nowner[rg - 1];
         total_owner += cnt;
+        max_region = cnt > max_region ? cnt : max_region;
         for (int c0 = 0; c0 < cnt; c0 += 1024) {
             const int c = c0 + tid;
             long long a = 0, b = 0;
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
                 const SinkOwner o = owners[o0 + c];
                 a = (long long)o.emitted * o.len; b = (long long)(o.total - o.emitted) * o.len;
                 if (o.total > o.carried) atomicAdd(&hist[o.cls & 31], o.total - o.carried);     // extractions of the call, per width class
+                if (o.carried > 0) atomicAdd(&ncar, 1);
             }
             long long ta, tb;
             const long long ea = block_exscan(a, &ta, sh);
@@ -925,6 +929,7 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
         long long tt;
         (void)block_exscan((long long)(l < nlist ? ntask[l] : 0), &tt, sh);
         nt += (int)tt;
+        if (l < nlist && ntask[l] > 0) atomicMax(&maxlist, ntask[l]);
         __syncthreads();
         // a thread per record (a bank of 256 channels has 256 short lists: a wave per list would walk them sixteen deep, two dependent
         // loads each); the list of a record by bisection of the bases
@@ -948,6 +953,7 @@ __global__ __launch_bounds__(1024) void k_sink_layout(int nlist, const int64_t *
         for (int k = 0; k < 32; k++) { sum->class_base[k] = acc; acc += hist[k]; }
         sum->used_a = accA; sum->b_start = bstart; sum->used_total = bstart + accB;
         sum->npdu = np; sum->ntask = nt; sum->nowner = total_owner; sum->error = *error;
+        sum->max_list_tasks = maxlist; sum->ncarry = ncar; sum->max_region_owners = max_region; sum->pad = 0;
     }
 }
 

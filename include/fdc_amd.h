@@ -98,7 +98,10 @@ enum {
     FDC_PIPE_NO_BLOCK = 4,        /* no one-block-per-compute-unit kernels (two-launch uniform path / two-pass transform)   */
     FDC_PIPE_PLAIN_STORES = 8,    /* block kernels: ordinary instead of streamed (nt) output stores                 */
     FDC_PIPE_NT_LOADS = 16,       /* block kernels: streamed (nt) input loads                                       */
-    FDC_PIPE_FULL_SPECTRUM = 32   /* the handle's internal spectrum is written in full (default: only the 64-bin groups some channel reads) */
+    FDC_PIPE_FULL_SPECTRUM = 32,  /* the handle's internal spectrum is written in full (default: only the 64-bin groups some channel reads) */
+    FDC_PIPE_WIDE_UNIFORM = 64    /* uniform banks of ANY channel width (every channel l = L on the L-bin grid, one window) take the two-launch
+                                     form without a spectrum; default: only the widths for which it measured faster than the spectrum path
+                                     (l = 256: always, register kernels; l = 128: generic LDS kernels) */
 };
 
 int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out);

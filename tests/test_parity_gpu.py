@@ -864,3 +864,40 @@ def test_split_plans_classes_plus_remainder(oracle):
     assert G.Pipeline(N, R, half, windowtype=1, max_blocks=2).path() == 1
     # ... and a handful of channels
     assert G.Pipeline(N, R, bank[:20] + odd[:1], windowtype=1, max_blocks=2).path() == 1
+
+
+@pytest.mark.parametrize("N,L,R,wt", [(65536, 512, 2, 1), (65536, 128, 2, 1), (65536, 1024, 4, 2), (65536, 64, 2, 0), (65536, 2048, 2, 1),
+                                      (16384, 512, 2, 1), (4096, 128, 4, 1), (262144, 1024, 2, 1), (32768, 2048, 8, 2)])
+def test_uniform_banks_of_other_widths(oracle, N, L, R, wt):
+    """Uniform banks whose channels are not 256 bins wide (every channel l = L on the L-bin grid, one window): the commutation of the
+    l = 256 path does not depend on the width — stage 1 on the generic LDS core (k_p1g), stage 2 on k_p2g, G through memory, no spectrum
+    (fdc_pipeline_path() = 2).  All slots and a scattered subset against the oracle and against the spectrum path; ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY")):
+        pytest.skip("suite run under a forced path")
+    nb = 5
+    H, n1 = N - N // R, N // L
+    x = noise(nb * H, L + R)
+    rng = np.random.default_rng(N // L + R)
+    for slots in ([int(v) for v in rng.permutation(n1)[:7]], list(range(n1)) if n1 <= 128 else [int(v) for v in rng.permutation(n1)[:100]]):
+        chans = [(L * c, L, 0.88, 1.0) for c in slots]
+        # every width on request; by default only where it measured faster than the spectrum path (l = 128)
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=3, flags=G.FDC_PIPE_WIDE_UNIFORM)
+        assert p.path() == 2
+        assert (G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == 2) == (L == 128)
+        outs = p.work(x)
+        check = range(len(chans)) if len(chans) <= 16 else range(0, len(chans), max(1, len(chans) // 12))
+        ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * (L - L // R)
+            assert_close(outs[c], ref[i], "N %d L %d slot %d" % (N, L, slots[c]))
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+        assert q.path() in (0, 1)
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "N %d L %d slot %d vs the spectrum path" % (N, L, slots[c]))
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 2), (2, 3), (3, 5)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+    # off the L-grid, two windows, a slot twice: not this path
+    assert G.Pipeline(N, R, [(L * 1 + 1, L, 0.88, 1.0), (L * 3, L, 0.88, 1.0)], windowtype=wt, max_blocks=2, flags=G.FDC_PIPE_WIDE_UNIFORM).path() != 2
+    assert G.Pipeline(N, R, [(L * 1, L, 0.7, 0.9), (L * 3, L, 0.88, 1.0)], windowtype=wt, max_blocks=2, flags=G.FDC_PIPE_WIDE_UNIFORM).path() != 2
