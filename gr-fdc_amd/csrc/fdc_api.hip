@@ -140,6 +140,8 @@ struct fdc_pipeline {
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
+    bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
+    float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
                                  // stage 1 on the generic LDS core, two launches; one class, no offset)
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
@@ -369,6 +371,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
+    (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -459,14 +462,15 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const int L = cfg->channels[0].l;
         // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
         // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
-        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || (flags & FDC_PIPE_WIDE_UNIFORM));
+        const bool b512 = L == 512 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
+        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || (flags & FDC_PIPE_WIDE_UNIFORM));
         std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
             if (ch.l != L || (ch.f % L) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
             else usedL[(size_t)(ch.f / L)] = 1;
         }
-        if (uniL) { p->poly_ok = true; p->poly_L = L; }
+        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; }
     }
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
@@ -542,10 +546,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->poly_ok = ok;
         p->poly_r = ok ? p->classes[0].r : 0;
         if (!ok) p->classes.clear();
-        p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
-        if (cfg->min_block_launch >= 1) p->block_min = cfg->min_block_launch;
-        if (const char *bm = fdc::debug_env("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
     }
+    p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
+    if (cfg->min_block_launch >= 1) p->block_min = cfg->min_block_launch;
+    if (const char *bm = fdc::debug_env("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
     std::vector<int32_t> rflat;
     if (p->split) {
         std::map<int, std::vector<int32_t>> rbylen;
@@ -643,8 +647,30 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
                 const double a = -2.0 * M_PI * double(((long long)t * k2) % N) / double(N);
                 t2v[(size_t)k2 * TCg + t] = make_float2(float(std::cos(a)), float(std::sin(a)));
             }
-        CHK_OR_FREE(hipMalloc(&p->d_twq, sizeof(float2) * t2v.size()));       // (d_twq is free on this path: freed with the handle)
-        CHK_OR_FREE(hipMemcpy(p->d_twq, t2v.data(), sizeof(float2) * t2v.size(), hipMemcpyHostToDevice));
+        CHK_OR_FREE(hipMalloc(&p->d_t2g, sizeof(float2) * t2v.size()));
+        CHK_OR_FREE(hipMemcpy(p->d_t2g, t2v.data(), sizeof(float2) * t2v.size(), hipMemcpyHostToDevice));
+        if (p->poly_b512) {
+            // tables of the l = 512 block kernel (fdc_block512.hip): W_512^k; W_N^(16 n1 q); (-1)^n1 W_N^(n1 (b + 256 h)) at [n1][b + 16 h]
+            std::vector<float2> t5(256), tq((size_t)N1 * 16), cb((size_t)N1 * 32);
+            for (int k = 0; k < 256; k++) { const double a = -2.0 * M_PI * k / 512.0; t5[(size_t)k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
+            for (int n1 = 0; n1 < N1; n1++) {
+                for (int q = 0; q < 16; q++) {
+                    const double a = -2.0 * M_PI * double((16ll * n1 * q) % N) / double(N);
+                    tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
+                }
+                for (int e = 0; e < 32; e++) {
+                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * (e >> 4))) % N) / double(N);
+                    const double sg = (n1 & 1) ? -1.0 : 1.0;
+                    cb[(size_t)n1 * 32 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
+                }
+            }
+            CHK_OR_FREE(hipMalloc(&p->d_tw512, sizeof(float2) * t5.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_tw512, t5.data(), sizeof(float2) * t5.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_twq512, sizeof(float2) * tq.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_twq512, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_cbt512, sizeof(float2) * cb.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_cbt512, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+        }
     } else if (p->poly_ok) {
         const int N1 = N / 256;
         std::vector<float2> tq((size_t)N1 * 16);
@@ -757,7 +783,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // G scratch of the two-launch form.  With the one-kernel form only launch groups shorter than block_min take the two
         // launches, and only plans of one on-grid class can (see fdc_pipeline_process_device)
         const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
-        const int gblocks = p->poly_block ? std::min(chunk, p->block_min) : chunk;
+        const int gblocks = (p->poly_block || p->poly_b512) ? std::min(chunk, p->block_min) : chunk;
         if (two_launch)
             CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(p->poly_L - p->poly_L / R) * (size_t)(N / p->poly_L)));
     }
@@ -799,7 +825,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
     if (p->poly_block && p->split) return 4;
-    if (p->poly_block) return 3;
+    if (p->poly_block || p->poly_b512) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -968,12 +994,23 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
+        if (use_poly && p->poly_b512 && !few) {
+            HIPCHK(fdc::launch_poly_block512(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
+                                             p->d_tw512, p->d_twq512, p->d_cbt512, p->d_shn, p->d_slot_off,
+                                             (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
+                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
+            if (tg) {
+                span[2] = span[3] = span[1];
+                p->ev_spans.push_back(span);
+            }
+            continue;
+        }
         if (use_poly) {
             // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the two launches
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
             if (p->poly_L != 256)
                 HIPCHK(fdc::launch_poly_stage1_generic(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N, p->poly_L, p->R, nb, p->d_shn, p->d_tw,
-                                                       p->ntab, p->d_twq, s));
+                                                       p->ntab, p->d_t2g, s));
             else
                 HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N / 256, p->R, nb,
                                                p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->ncu, s));

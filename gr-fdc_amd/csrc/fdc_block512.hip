@@ -1,0 +1,283 @@
+// gfx950 one-block-per-CU form of the uniform-plan path for channels of l = 512 bins (N = 65536 = 512 rows x 128 columns, R = 2,
+// every channel on the 512-bin grid, one window): the machinery of fdc_block256.hip with each column's 512 rows split by PARITY.
+//
+// Why not "the same kernel with a bigger number": G is 256 KiB whatever l is, but a 512-point column in the lane layout of
+// fdc_block256.hip (16 lanes x 16 row registers per column) would need 32 row registers per lane and pass — 64 VGPRs beside the 64 of
+// the prefetch and the 128 of G.  Instead the column's rows n2 = 2 mu + par are two 256-point sub-sequences, each of which is exactly a
+// "column" of the 256 kernel: a QUAD of lanes is (column c, parity 0), (c + 1, 0), (c, 1), (c + 1, 1), both parities run the 256-point
+// transforms of the old stage 1 in lockstep on the same instructions, and the radix-2 layer that joins them is an exchange with lane ^ 2
+// (DPP quad_perm [2, 3, 0, 1]):
+//     forward (decimation in time):   A[kap]       = E[kap] + W_512^kap O[kap]          kap = 0 .. 255
+//                                     A[kap + 256] = E[kap] - W_512^kap O[kap]          -> parity-0 lanes hold the lower half of k2, parity-1 the upper
+//     product: shape[k2]/N (-1)^n1 W_N^(n1 k2), k2 = kap + 256 h — all of it BEFORE the inverse layer (its h part differs between the lanes
+//              that are about to be added); the ifftshift of the 512-point inverse (k2 ^ 256) swaps the roles of the two lanes of a pair
+//     inverse (decimation in frequency): with P = the value the h = 1 lane holds (index kap after the shift), Q = the h = 0 lane's (kap + 256):
+//                                     even samples g[2m]     = IFFT256{ P + Q }[m]                       in the parity-0 lanes
+//                                     odd samples  g[2m + 1] = IFFT256{ (P - Q) conj(W_512^kap) }[m]     in the parity-1 lanes
+//     kept: t = 2m + par >= 256 <=> m >= 128: eight values per lane and pass, as before: G is 8 passes x 8 = 128 VGPRs.
+// A wave owns 2 columns per pass, the workgroup 16: 8 passes for the 128 columns.  Stage 2 is the FFT-128 over the columns n1 = 16 pass + c4:
+// DFT-8 over the pass index in registers, W_128^(c4 klo), one trip through LDS ([64 rows][8 klo][16 c4], four trips for the 256 kept rows),
+// DFT-16 over c4 in the lane that owns (row, klo); a wave's store is 64 consecutive samples of one channel.
+//
+// The arithmetic is that of k_p1g + k_p2g (fdc_kernels.hip) regrouped; parity against the oracle: tests/test_parity_gpu.py.
+#include <hip/hip_ext.h>
+#include "fdc_kernels.h"
+#include "fdc_radix16.hpp"
+#include "fdc_devutil.hpp"
+
+namespace fdc {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_b512[];
+
+typedef unsigned long long g8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned long long pack512(cf v) { return ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x); }
+__device__ __forceinline__ cf unpack512(unsigned long long u) { return mk(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))); }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FDC_PLAIN_DS512 __attribute__((target("no-load-store-opt")))
+#else
+#define FDC_PLAIN_DS512
+#endif
+
+// the value of the lane two further on in the quad (lane ^ 2): the other parity of the same column
+__device__ __forceinline__ cf swap_parity(cf x)
+{
+    return mk(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.x), 0x4E, 0xF, 0xF, true)),
+              __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.y), 0x4E, 0xF, 0xF, true)));
+}
+
+// LDS map (bytes)
+constexpr int k5ScrPts = 1084;                                   // per-wave exchange strip, as in fdc_block256.hip
+constexpr int k5OffX = 8 * k5ScrPts * 8;                         // 69376: end of the strips
+constexpr int k5Ld = 8 * 16 + 6;                                 // stage-2 trip rows: [8 klo][16 c4] + 6 (row stride 268 dwords = 12 mod 64)
+constexpr int k5Trip = 64 * k5Ld * 8;                            // 68608 <= the strips: the trip buffer lies over them
+constexpr int k5OffCt = k5OffX;                                  // [16 c4][8 klo]  W_128^(c4 klo)
+constexpr int k5OffWrow = k5OffCt + 16 * 8 * 8;                  // [16][18]  W_256^(b p)
+constexpr int k5OffT512 = k5OffWrow + 16 * 18 * 8;               // [2 par][16][18]  par 1: W_512^(b + 16 q); par 0: 1 (the same code for both lanes of a pair)
+constexpr int k5OffB = k5OffT512 + 2 * 16 * 18 * 8;              // [8 pass][16 c4][18]  W_N^(16 n1 q), n1 = 16 pass + c4 (the LDS has the room)
+constexpr int k5OffSh = k5OffB + 8 * 16 * 18 * 8;                // [32 = b + 16 h][16] floats: shape[b + 16 q + 256 h] / N
+constexpr int k5OffSoff = k5OffSh + 32 * 16 * 4;                 // [8 klo][16] output offsets (bytes)
+constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 80896
+static_assert(k5Trip <= k5OffX, "the trip buffer lies over the strips, below the tables");
+
+template <bool NT>
+__global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
+                                                      const float2 *__restrict__ tw256, const float2 *__restrict__ tw512 /* W_512^k, k < 256 */,
+                                                      const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
+                                                      const float2 *__restrict__ cbt /* [n1][32] (-1)^n1 W_N^(n1 (b + 256 h)) at b + 16 h */,
+                                                      const float *__restrict__ shn /* [512] shape / N */,
+                                                      const long long *__restrict__ slot_off, long long out_base, long long nb_call,
+                                                      unsigned out_bytes, int nb, int hints)
+{
+    float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b512);
+    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffCt);
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffWrow);
+    float2 *t512 = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffT512);
+    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffB);
+    float *Sh = reinterpret_cast<float *>(fdc_smem_b512 + k5OffSh);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_b512 + k5OffSoff);
+    const int tid = threadIdx.x;
+    // lane = vc + 4 b: vc = creal + 2 par (a quad = two columns x two parities), b = row group of the 256-point sub-transform
+    const int w = tid >> 6, lane = tid & 63, vc = lane & 3, creal = vc & 1, par = vc >> 1, b = lane >> 2, c4 = 2 * w + creal;
+
+    const int grid = gridDim.x, per = grid >> 3;
+    const bool xmap = (grid & 7) == 0;
+    const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (first >= nb) return;
+
+    constexpr unsigned inbytes = 65536u * 8u;
+    // row n2 = 2 (16 a + b) + par of column 16 pass + c4: 128 columns per row; a adds 32 rows = 32 KiB, a pass 16 columns = 128 B
+    const unsigned voff = (unsigned)((2 * b + par) * 128 + c4) * 8u;
+    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 128u * 32u * 8u);
+    const unsigned voffc = (unsigned)(c4 * 32 + b + 16 * par) * 8u;
+    cf LA[16], LB[16], cbA, cbB;
+    {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
+#pragma unroll
+        for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * 32768u);
+        cbA = bld2(rcb, voffc, 0);
+    }
+    // ---- tables
+    for (int i = tid; i < 256; i += 512) {
+        wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
+        t512[(16 + (i & 15)) * 18 + (i >> 4)] = tw512[i];                // [1][b][q] = W_512^(b + 16 q), i = b + 16 q
+        t512[(i & 15) * 18 + (i >> 4)] = make_float2(1.f, 0.f);
+    }
+    for (int i = tid; i < 2048; i += 512) Bt[(i >> 4) * 18 + (i & 15)] = twq[i];   // [n1 = i >> 4][q]: twq is [n1][16] already
+    for (int i = tid; i < 128; i += 512) {
+        const long long o = slot_off[i];                                  // slot i = klo + 8 khi is entry [klo][rev16(khi)]
+        soff[(i & 7) * 16 + rev16(i >> 3)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+        ctab[i] = tw256[(2 * (i >> 3) * (i & 7)) & 255];                  // [c4][klo] = W_128^(c4 klo)
+    }
+    for (int i = tid; i < 512; i += 512) Sh[((i & 15) + 16 * (i >> 8)) * 16 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 h
+    __syncthreads();
+
+    float2 *const scrw = scr + w * k5ScrPts + lane;
+    const float2 *const scrr = scr + w * k5ScrPts + vc + 68 * b;
+    const float2 *const wr = wrow + b * 18;
+    const float2 *const t5r = t512 + (16 * par + b) * 18;
+    const float2 *const btr = Bt + c4 * 18;                              // + pass * 16 rows
+    const float *const shr = Sh + (b + 16 * par) * 16;
+    const float fsgn = par ? -1.0f : 1.0f;                                // the sign of a lane's own term in both radix-2 layers
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+
+    for (int m = first; m < nb; m += grid) {
+        const int mnext = m + grid < nb ? m + grid : m;
+        g8v G[8];
+        auto one_pass = [&](const int ps, cf (&cur)[16], const cf cb, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
+            {
+                const int pn = ps < 7 ? ps + 1 : 0;
+                const int mb = ps < 7 ? m : mnext;
+                const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
+                if (hints & 2) {
+#pragma unroll
+                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * 32768u);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+                }
+                cbn = bld2(rcb, voffc, (unsigned)pn * 4096u);
+            }
+            // ---- the 256-point forward transform of this lane's parity: exactly the old stage 1
+            dft16<false>(cur);
+            {
+                cf tw[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = ld4(&wr[2 * i]);
+                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
+                }
+                st2(&scrw[0], cur[rev16(0)]);
+#pragma unroll
+                for (int p = 1; p < 16; p++) st2(&scrw[68 * p], cmul(cur[rev16(p)], tw[p]));
+            }
+            __builtin_amdgcn_wave_barrier();
+            cf v[16];
+#pragma unroll
+            for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&scrr[4 * bb]);
+            dft16<false>(v);                                      // E (par 0) / O (par 1) at kap = b + 16 q in v[rev16(q)]
+            // ---- forward radix-2 layer, product, inverse radix-2 layer (the parity-0 lanes' "twiddle" is a table row of ones: no branches).
+            // One value at a time, 8-byte table reads: the kernel has no registers for wider ones.
+            cf u[16];
+            {
+                const float2 *bpr = btr + ps * (16 * 18);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const cf w5 = ld2(&t5r[q]);
+                    const cf x = cmul(v[rev16(q)], w5);                              // par 1: O W_512^kap; par 0: E
+                    const cf a = swap_parity(x) + x * fsgn;                          // par 0: E + O' = A[kap]; par 1: E - O' = A[kap + 256]
+                    // shape / N, W_N^(16 n1 q), (-1)^n1 W_N^(n1 (b + 256 h)) = cb
+                    const cf y = cmul(cmul(a, ld2(&bpr[q])), cb) * shr[q];
+                    // ifftshift: the h = 1 lane's value is P (index kap), the h = 0 lane's is Q (index kap + 256)
+                    const cf z = y + swap_parity(y) * fsgn;                          // par 0: Q + P; par 1: P - Q
+                    u[q] = cmulc(z, w5);                                             // par 1: conj(W_512^kap)
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);             // four values at a time: table reads are not hoisted further
+                }
+            }
+            // ---- the 256-point inverse transform of this lane's parity (no q ^ 8: the shift was the half swap)
+            dft16<true>(u);
+            {
+                cf tw[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = ld4(&wr[2 * i]);
+                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
+                }
+#pragma unroll
+                for (int p = 1; p < 16; p++) u[rev16(p)] = cmulc(u[rev16(p)], tw[p]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < 16; p++) st2(&scrw[68 * p], u[rev16(p)]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&scrr[4 * bb]);
+            dft16<true>(u);                                       // g[2 m + par], m = b + 16 q in u[rev16(q)]; keep q >= 8
+#pragma unroll
+            for (int j = 0; j < 8; j++) G[j][ps] = pack512(u[rev16(8 + j)]);
+        };
+#pragma nounroll
+        for (int pp = 0; pp < 8; pp += 2) {
+            one_pass(pp, LA, cbA, LB, cbB);
+            one_pass(pp + 1, LB, cbB, LA, cbA);
+        }
+        // ---------------- stage 2: FFT-128 over n1 = 16 pass + c4 of every row t' = 2 (b + 16 j) + par ----------------
+        __syncthreads();                                          // every wave is done with its strip
+        {
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
+            const int vc2 = lane2 & 3, b_2 = lane2 >> 2, c4_2 = 2 * w2 + (vc2 & 1), par2 = vc2 >> 1;
+            float2 *const gw = scr + (2 * b_2 + par2) * k5Ld + c4_2;             // element (row 2 b + par + 32 jj, klo) at + 32 jj kLd + 16 klo
+            const float2 *const gr = scr + lane2 * k5Ld + 16 * w2;                // row = lane, klo = wave: 16 consecutive points
+            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 16 * w2);
+            cf ct[8];
+            {
+                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_b512 + k5OffCt) + c4_2 * 8;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 t = ld4(&ctr[2 * i]);
+                    ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
+                }
+            }
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    cf a[8];
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) a[ps] = unpack512(G[2 * tr + jj][ps]);
+                    dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
+                    float2 *const g = gw + jj * 32 * k5Ld;
+                    st2(&g[0], a[0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) st2(&g[16 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                      // the trip is in LDS
+                cf v[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = ld4(&gr[2 * i]);
+                    v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                }
+                __syncthreads();                                      // every read of the trip is done
+                __builtin_amdgcn_sched_barrier(0);
+                dft16<false>(v);                                      // khi in v[rev16(khi)]
+                const unsigned rb = (unsigned)(m * 256 + 64 * tr + lane2) * 8u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 t = sow[q];
+                    const unsigned so[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+hipError_t init_block512_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    return e;
+}
+
+hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
+                                const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
+                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (nb_chunk <= 0) return hipSuccess;
+    int grid = ncu > 0 ? ncu : 256;
+    if (grid > nb_chunk) grid = nb_chunk;
+    if (hints & 1)
+        hipExtLaunchKernelGGL((k_blk512<true>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq,
+                              cbt, shn, slot_off, (long long)mbase * 256, (long long)nb_call, out_bytes, nb_chunk, hints);
+    else
+        hipExtLaunchKernelGGL((k_blk512<false>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq,
+                              cbt, shn, slot_off, (long long)mbase * 256, (long long)nb_call, out_bytes, nb_chunk, hints);
+    return hipGetLastError();
+}
+
+}  // namespace fdc

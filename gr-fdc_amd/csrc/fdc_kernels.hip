@@ -667,6 +667,7 @@ hipError_t init_kernels()
     if ((e = init_p1g_kernels()) != hipSuccess) return e;
 #undef FDC_SETLDS
     if ((e = init_sink_kernels()) != hipSuccess) return e;
+    if ((e = init_block512_kernels()) != hipSuccess) return e;
     return init_fast_kernels();
 }
 

@@ -881,9 +881,10 @@ def test_uniform_banks_of_other_widths(oracle, N, L, R, wt):
     for slots in ([int(v) for v in rng.permutation(n1)[:7]], list(range(n1)) if n1 <= 128 else [int(v) for v in rng.permutation(n1)[:100]]):
         chans = [(L * c, L, 0.88, 1.0) for c in slots]
         # every width on request; by default only where it measured faster than the spectrum path (l = 128)
-        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=3, flags=G.FDC_PIPE_WIDE_UNIFORM)
+        # (FDC_PIPE_NO_BLOCK: l = 512 at N = 65536, R = 2 has a block kernel of its own, tested below)
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=3, flags=G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK)
         assert p.path() == 2
-        assert (G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == 2) == (L == 128)
+        assert (G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK).path() == 2) == (L == 128)
         outs = p.work(x)
         check = range(len(chans)) if len(chans) <= 16 else range(0, len(chans), max(1, len(chans) // 12))
         ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x, nthreads=8)
@@ -901,3 +902,45 @@ def test_uniform_banks_of_other_widths(oracle, N, L, R, wt):
     # off the L-grid, two windows, a slot twice: not this path
     assert G.Pipeline(N, R, [(L * 1 + 1, L, 0.88, 1.0), (L * 3, L, 0.88, 1.0)], windowtype=wt, max_blocks=2, flags=G.FDC_PIPE_WIDE_UNIFORM).path() != 2
     assert G.Pipeline(N, R, [(L * 1, L, 0.7, 0.9), (L * 3, L, 0.88, 1.0)], windowtype=wt, max_blocks=2, flags=G.FDC_PIPE_WIDE_UNIFORM).path() != 2
+
+
+@pytest.mark.parametrize("nslots,nb", [(128, 7), (128, 300), (9, 261), (1, 3), (128, 530)])
+def test_one_kernel_path_for_512_bin_channels(oracle, nslots, nb):
+    """l = 512 at N = 65536, R = 2 (fdc_block512.hip): the parities of a column's 512 rows as two 256-point columns in the lanes of
+    a quad, joined by radix-2 layers through DPP.  Against the oracle (head and tail), against the generic two-launch form on every
+    sample, block counts below and above one round of workgroups, ragged calls bit for bit, all three window shapes."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, L = 65536, 2, 512
+    H = N - N // R
+    rng = np.random.default_rng(nslots * 7 + nb)
+    slots = [int(v) for v in rng.permutation(128)[:nslots]]
+    wt = nb % 3
+    chans = [(L * c, L, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 512 + nb)
+    G.defaults["FDC_HOST_SUB"] = str(nb)
+    try:
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+    finally:
+        G.defaults.pop("FDC_HOST_SUB", None)
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, wt, chans, x[:k * H], nthreads=8)
+    for c in range(len(chans)):
+        assert outs[c].size == nb * 256
+        assert_close(outs[c][:k * 256], ref[c], "slot %d head" % slots[c])
+    if nb > k:
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, chans, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for c in range(len(chans)):
+            assert_close(outs[c][t0 * 256:], ref2[c], "slot %d tail" % slots[c])
+    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
+    assert q.path() == 2
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "slot %d vs the two-launch form" % slots[c])
+    p.reset()
+    cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
