@@ -462,7 +462,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const int L = cfg->channels[0].l;
         // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
         // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
-        const bool b512 = L == 512 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
+        const bool b512 = L == 512 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
         uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || (flags & FDC_PIPE_WIDE_UNIFORM));
         std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
         for (int c = 0; uniL && c < p->C; c++) {
@@ -744,7 +744,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizer's rows 64..127
-    if (p->fwd_block || (p->poly_block && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    if (p->fwd_block || ((p->poly_block || p->poly_b512) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
         std::vector<char> g64((size_t)N / 64, 0);
         bool all = true;
@@ -998,7 +998,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             HIPCHK(fdc::launch_poly_block512(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
                                              p->d_tw512, p->d_twq512, p->d_cbt512, p->d_shn, p->d_slot_off,
                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
+                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

@@ -21,6 +21,7 @@
 //
 // The arithmetic is that of k_p1g + k_p2g (fdc_kernels.hip) regrouped; parity against the oracle: tests/test_parity_gpu.py.
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
 #include "fdc_devutil.hpp"
@@ -59,14 +60,17 @@ constexpr int k5OffSoff = k5OffSh + 32 * 16 * 4;                 // [8 klo][16] 
 constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 80896
 static_assert(k5Trip <= k5OffX, "the trip buffer lies over the strips, below the tables");
 
-template <bool NT>
+// R4 = true: relinvovl = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept.  The rows m >= 128 of
+// both parities stay in the G registers as for R = 2 (output rows 128 ..); the rows 64 <= m < 128 go to 128 KiB of per-workgroup scratch
+// ([pass][q - 4][thread]: the L2 holds it) and come back for a third, 128-row run of stage 2 (output rows 0 .. 127), as in fdc_block256.hip.
+template <bool NT, bool R4>
 __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw256, const float2 *__restrict__ tw512 /* W_512^k, k < 256 */,
                                                       const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
                                                       const float2 *__restrict__ cbt /* [n1][32] (-1)^n1 W_N^(n1 (b + 256 h)) at b + 16 h */,
                                                       const float *__restrict__ shn /* [512] shape / N */,
                                                       const long long *__restrict__ slot_off, long long out_base, long long nb_call,
-                                                      unsigned out_bytes, int nb, int hints)
+                                                      unsigned out_bytes, int nb, int hints, float2 *__restrict__ scratch)
 {
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b512);
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffCt);
@@ -119,6 +123,8 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     const float *const shr = Sh + (b + 16 * par) * 16;
     const float fsgn = par ? -1.0f : 1.0f;                                // the sign of a lane's own term in both radix-2 layers
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(R4 ? scratch + (size_t)blockIdx.x * 32768 : scratch, R4 ? 32768u * 8u : 0u);
+    constexpr int kRows = R4 ? 384 : 256;                                 // kept samples per block and channel
 
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
@@ -194,15 +200,21 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             dft16<true>(u);                                       // g[2 m + par], m = b + 16 q in u[rev16(q)]; keep q >= 8
 #pragma unroll
             for (int j = 0; j < 8; j++) G[j][ps] = pack512(u[rev16(8 + j)]);
+            if constexpr (R4) {                                   // R = 4 keeps q >= 4: m = 64 .. 127 go to the scratch, [pass][q - 4][thread]
+#pragma unroll
+                for (int j = 0; j < 4; j++) bst2(rscr, (unsigned)tid * 8u + (unsigned)j * 4096u, (unsigned)ps * 16384u, u[rev16(4 + j)]);
+            }
         };
 #pragma nounroll
         for (int pp = 0; pp < 8; pp += 2) {
             one_pass(pp, LA, cbA, LB, cbB);
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
-        // ---------------- stage 2: FFT-128 over n1 = 16 pass + c4 of every row t' = 2 (b + 16 j) + par ----------------
-        __syncthreads();                                          // every wave is done with its strip
-        {
+        // ---------------- stage 2: FFT-128 over n1 = 16 pass + c4 of every row t' = rowbase + 2 (b + 16 j) + par ----------------
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of 64-row trips (two j each)
+        auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
+            constexpr int kNTrip = decltype(ntripc)::value;
+            __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
@@ -220,12 +232,17 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 }
             }
 #pragma unroll
-            for (int tr = 0; tr < 4; tr++) {
+            for (int tr = 0; tr < kNTrip; tr++) {
+                cf src[2][8];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(2 * tr + jj, ps);
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) {
                     cf a[8];
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) a[ps] = unpack512(G[2 * tr + jj][ps]);
+                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
                     dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
                     float2 *const g = gw + jj * 32 * k5Ld;
                     st2(&g[0], a[0]);
@@ -243,7 +260,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 __syncthreads();                                      // every read of the trip is done
                 __builtin_amdgcn_sched_barrier(0);
                 dft16<false>(v);                                      // khi in v[rev16(khi)]
-                const unsigned rb = (unsigned)(m * 256 + 64 * tr + lane2) * 8u;
+                const unsigned rb = (unsigned)(m * kRows + rowbase + 64 * tr + lane2) * 8u;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint4 t = sow[q];
@@ -253,30 +270,40 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        stage2([&](int j, int ps) { return unpack512(G[j][ps]); }, R4 ? 128 : 0, std::integral_constant<int, 4>{});
+        if constexpr (R4) {
+            // m = 64 .. 127 = output rows 0 .. 127: this lane's own stores, served by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
+                   std::integral_constant<int, 2>{});
         }
     }
 }
 
 hipError_t init_block512_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
     return e;
 }
 
 hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                 const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch)
 {
     if (nb_chunk <= 0) return hipSuccess;
+    if ((R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
-    if (hints & 1)
-        hipExtLaunchKernelGGL((k_blk512<true>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq,
-                              cbt, shn, slot_off, (long long)mbase * 256, (long long)nb_call, out_bytes, nb_chunk, hints);
-    else
-        hipExtLaunchKernelGGL((k_blk512<false>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq,
-                              cbt, shn, slot_off, (long long)mbase * 256, (long long)nb_call, out_bytes, nb_chunk, hints);
+#define FDC_L512(A, B) \
+    hipExtLaunchKernelGGL((k_blk512<A, B>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq, \
+                          cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr)
+    if (R == 4) { if (hints & 1) FDC_L512(true, true); else FDC_L512(false, true); }
+    else { if (hints & 1) FDC_L512(true, false); else FDC_L512(false, false); }
+#undef FDC_L512
     return hipGetLastError();
 }
 

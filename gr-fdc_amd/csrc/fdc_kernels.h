@@ -124,14 +124,15 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              int N = 65536 /* block length: 16384, 32768 or 65536 (poly_block_supports) */);
 bool poly_block_supports(int N);
 
-// uniform plan of 512-bin channels on the 512-bin grid, N = 65536, R = 2: one kernel, one block per CU (fdc_block512.hip): the two
+// uniform plan of 512-bin channels on the 512-bin grid, N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_block512.hip): the two
 // parities of a column's 512 rows run the 256-point machinery side by side in the lanes of a quad.
 //   tw512[k] = W_512^k (k < 256); twq[n1][q] = W_N^(16 n1 q) (128 x 16); cbt[n1][b + 16 h] = (-1)^n1 W_N^(n1 (b + 256 h)) (128 x 32);
 //   shn[k2] = shape[k2] / N (512); slot_off[128]
 hipError_t init_block512_kernels();
 hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                 const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                                int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */);
 
 // forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,

@@ -944,3 +944,33 @@ def test_one_kernel_path_for_512_bin_channels(oracle, nslots, nb):
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
     for c in range(len(chans)):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("wt", [0, 1])
+def test_512_bin_block_kernel_at_relinvovl_4(oracle, wt):
+    """l = 512 at R = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept — 256 in the G
+    registers, 128 through the per-workgroup scratch and a third run of stage 2.  All 128 slots and a subset, against the oracle and against the
+    generic two-launch form on every sample; several workgroup rounds; ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, L, nb = 65536, 4, 512, 7
+    H = N - N // R
+    x = noise(nb * H, 99 + wt)
+    for slots in (list(range(128)), [127, 0, 3, 64, 100, 17]):
+        chans = [(L * c, L, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = range(len(chans)) if len(chans) < 16 else (0, 1, 63, 64, 126, 127)
+        ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * 384
+            assert_close(outs[c], ref[i], "slot %d" % slots[c])
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
+        assert q.path() == 2
+        for a, b_ in zip(outs, q.work(x)):
+            assert_close(a, b_, "block kernel vs two launches")
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, 7)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
