@@ -167,16 +167,24 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             {
                 const float2 *bpr = btr + ps * (16 * 18);
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const cf w5 = ld2(&t5r[q]);
-                    const cf x = cmul(v[rev16(q)], w5);                              // par 1: O W_512^kap; par 0: E
-                    const cf a = swap_parity(x) + x * fsgn;                          // par 0: E + O' = A[kap]; par 1: E - O' = A[kap + 256]
-                    // shape / N, W_N^(16 n1 q), (-1)^n1 W_N^(n1 (b + 256 h)) = cb
-                    const cf y = cmul(cmul(a, ld2(&bpr[q])), cb) * shr[q];
-                    // ifftshift: the h = 1 lane's value is P (index kap), the h = 0 lane's is Q (index kap + 256)
-                    const cf z = y + swap_parity(y) * fsgn;                          // par 0: Q + P; par 1: P - Q
-                    u[q] = cmulc(z, w5);                                             // par 1: conj(W_512^kap)
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);             // four values at a time: table reads are not hoisted further
+                for (int g4 = 0; g4 < 4; g4++) {                                     // four values at a time: 16-byte table reads, not hoisted further
+                    const float4 ta = ld4(&t5r[4 * g4]), tb = ld4(&t5r[4 * g4 + 2]), ba = ld4(&bpr[4 * g4]), bb4 = ld4(&bpr[4 * g4 + 2]);
+                    const float4 sh = *reinterpret_cast<const float4 *>(&shr[4 * g4]);
+                    const cf w5s[4] = {mk(ta.x, ta.y), mk(ta.z, ta.w), mk(tb.x, tb.y), mk(tb.z, tb.w)};
+                    const cf bps[4] = {mk(ba.x, ba.y), mk(ba.z, ba.w), mk(bb4.x, bb4.y), mk(bb4.z, bb4.w)};
+                    const float shs[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int q = 4 * g4 + e;
+                        const cf x = cmul(v[rev16(q)], w5s[e]);                      // par 1: O W_512^kap; par 0: E
+                        const cf a = swap_parity(x) + x * fsgn;                      // par 0: E + O' = A[kap]; par 1: E - O' = A[kap + 256]
+                        // shape / N, W_N^(16 n1 q), (-1)^n1 W_N^(n1 (b + 256 h)) = cb
+                        const cf y = cmul(cmul(a, bps[e]), cb) * shs[e];
+                        // ifftshift: the h = 1 lane's value is P (index kap), the h = 0 lane's is Q (index kap + 256)
+                        const cf z = y + swap_parity(y) * fsgn;                      // par 0: Q + P; par 1: P - Q
+                        u[q] = cmulc(z, w5s[e]);                                     // par 1: conj(W_512^kap)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- the 256-point inverse transform of this lane's parity (no q ^ 8: the shift was the half swap)
