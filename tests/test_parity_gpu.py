@@ -946,6 +946,55 @@ def test_one_kernel_path_for_512_bin_channels(oracle, nslots, nb):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
 
 
+@pytest.mark.parametrize("nslots,nb", [(512, 5), (512, 300), (37, 261), (1, 3), (511, 530)])
+def test_one_kernel_path_for_128_bin_channels(oracle, nslots, nb):
+    """l = 128 at N = 65536, R = 2 (fdc_block128.hip): two adjacent columns interleaved into one 256-point virtual column, separated and
+    re-joined in registers; the last layer of the FFT-512 over the slots between neighbouring lanes.  Against the oracle (head and tail; all
+    slots of small banks, a spread of a full one), against the generic two-launch form on every sample, block counts below and above one
+    round of workgroups, ragged calls bit for bit, all three window shapes."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, L = 65536, 2, 128
+    H = N - N // R
+    rng = np.random.default_rng(nslots * 11 + nb)
+    slots = [int(v) for v in rng.permutation(512)[:nslots]]
+    wt = nb % 3
+    chans = [(L * c, L, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 128 + nb)
+    G.defaults["FDC_HOST_SUB"] = str(nb)
+    try:
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+    finally:
+        G.defaults.pop("FDC_HOST_SUB", None)
+    check = list(range(len(chans))) if len(chans) < 48 else sorted(set([0, 1, 2, len(chans) - 1] + [int(v) for v in rng.integers(0, len(chans), 24)]))
+    # the slots next to the seams of the layout: 0, 255 | 256, 511 and a neighbour pair, when the bank has them
+    for sl in (0, 1, 255, 256, 257, 511):
+        if sl in slots and slots.index(sl) not in check:
+            check.append(slots.index(sl))
+    sub = [chans[c] for c in check]
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * 64
+        assert_close(outs[c][:k * 64], ref[i], "slot %d head" % slots[c])
+    if nb > k:
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert_close(outs[c][t0 * 64:], ref2[i], "slot %d tail" % slots[c])
+    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+    assert q.path() == 2
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "slot %d vs the two-launch form" % slots[c])
+    p.reset()
+    cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
 @pytest.mark.parametrize("wt", [0, 1])
 def test_512_bin_block_kernel_at_relinvovl_4(oracle, wt):
     """l = 512 at R = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept — 256 in the G
