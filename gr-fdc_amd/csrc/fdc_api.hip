@@ -142,8 +142,8 @@ struct fdc_pipeline {
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
     float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
-    bool poly_b128 = false;      // l = 128 at N = 65536, R = 2: the block kernel of fdc_block128.hip
-    float2 *d_tab128 = nullptr, *d_cbt128 = nullptr;
+    bool poly_bnar = false;      // l = 128 or 64 at N = 65536, R = 2: the block kernel of fdc_blocknarrow.hip
+    float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
                                  // stage 1 on the generic LDS core, two launches; one class, no offset)
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
@@ -374,7 +374,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
-    (void)hipFree(p->d_tab128); (void)hipFree(p->d_cbt128);
+    (void)hipFree(p->d_tabnar); (void)hipFree(p->d_cbtnar);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -466,15 +466,15 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
         // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
         const bool b512 = L == 512 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
-        const bool b128 = L == 128 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK);
-        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || (flags & FDC_PIPE_WIDE_UNIFORM));
+        const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
+        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
         std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
             if (ch.l != L || (ch.f % L) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
             else usedL[(size_t)(ch.f / L)] = 1;
         }
-        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b128 = b128; }
+        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_bnar = bnar; }
     }
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
@@ -675,21 +675,20 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipMalloc(&p->d_cbt512, sizeof(float2) * cb.size()));
             CHK_OR_FREE(hipMemcpy(p->d_cbt512, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
         }
-        if (p->poly_b128) {
-            // tables of the l = 128 block kernel (fdc_block128.hip): its LDS image (shape / (4 N): two radix-2 layers), and W_N^(2 V b) at [V][b]
-            std::vector<float> s4((size_t)L);
-            for (int k2 = 0; k2 < L; k2++) s4[(size_t)k2] = float(double(shape[(size_t)k2].real()) / (4.0 * double(N)));
-            std::vector<float2> img((size_t)fdc::poly_block128_table_points()), cb(256 * 16);
-            fdc::poly_block128_tables(s4.data(), img.data());
+        if (p->poly_bnar) {
+            // tables of the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l
+            const int S = 256 / L;
+            std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L)), cb(256 * 16);
+            fdc::poly_block_narrow_tables(L, sn.data(), img.data());
             for (int V = 0; V < 256; V++)
                 for (int b = 0; b < 16; b++) {
-                    const double a = -2.0 * M_PI * double((2ll * V * b) % N) / double(N);
+                    const double a = -2.0 * M_PI * double(((long long)S * V * b) % N) / double(N);
                     cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
                 }
-            CHK_OR_FREE(hipMalloc(&p->d_tab128, sizeof(float2) * img.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_tab128, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_cbt128, sizeof(float2) * cb.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_cbt128, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_tabnar, sizeof(float2) * img.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_tabnar, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_cbtnar, sizeof(float2) * cb.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_cbtnar, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
         }
     } else if (p->poly_ok) {
         const int N1 = N / 256;
@@ -803,7 +802,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // G scratch of the two-launch form.  With the one-kernel form only launch groups shorter than block_min take the two
         // launches, and only plans of one on-grid class can (see fdc_pipeline_process_device)
         const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
-        const int gblocks = (p->poly_block || p->poly_b512 || p->poly_b128) ? std::min(chunk, p->block_min) : chunk;
+        const int gblocks = (p->poly_block || p->poly_b512 || p->poly_bnar) ? std::min(chunk, p->block_min) : chunk;
         if (two_launch)
             CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(p->poly_L - p->poly_L / R) * (size_t)(N / p->poly_L)));
     }
@@ -845,7 +844,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
     if (p->poly_block && p->split) return 4;
-    if (p->poly_block || p->poly_b512 || p->poly_b128) return 3;
+    if (p->poly_block || p->poly_b512 || p->poly_bnar) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -1014,9 +1013,9 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        if (use_poly && p->poly_b128 && !few) {
-            HIPCHK(fdc::launch_poly_block128(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tab128,
-                                             p->d_cbt128, p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
+        if (use_poly && p->poly_bnar && !few) {
+            HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tabnar,
+                                             p->d_cbtnar, p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
             if (tg) {
                 span[2] = span[3] = span[1];

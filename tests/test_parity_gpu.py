@@ -946,21 +946,23 @@ def test_one_kernel_path_for_512_bin_channels(oracle, nslots, nb):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
 
 
-@pytest.mark.parametrize("nslots,nb", [(512, 5), (512, 300), (37, 261), (1, 3), (511, 530)])
-def test_one_kernel_path_for_128_bin_channels(oracle, nslots, nb):
-    """l = 128 at N = 65536, R = 2 (fdc_block128.hip): two adjacent columns interleaved into one 256-point virtual column, separated and
-    re-joined in registers; the last layer of the FFT-512 over the slots between neighbouring lanes.  Against the oracle (head and tail; all
-    slots of small banks, a spread of a full one), against the generic two-launch form on every sample, block counts below and above one
-    round of workgroups, ragged calls bit for bit, all three window shapes."""
+@pytest.mark.parametrize("L,nslots,nb", [(128, 512, 5), (128, 512, 300), (128, 37, 261), (128, 1, 3), (128, 511, 530),
+                                         (64, 1024, 5), (64, 1024, 290), (64, 61, 261), (64, 1, 3), (64, 1023, 521)])
+def test_one_kernel_path_for_narrow_channels(oracle, L, nslots, nb):
+    """l = 128 and 64 at N = 65536, R = 2 (fdc_blocknarrow.hip): 256/l adjacent columns interleaved into one 256-point virtual column,
+    separated and re-joined in registers; the last layer of the FFT over the slots between the lanes of a quad.  Against the oracle (head and
+    tail; all slots of small banks, a spread of a full one with the slots at the seams of the layout), against the generic two-launch form on
+    every sample, block counts below and above one round of workgroups, ragged calls bit for bit, all three window shapes."""
     if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
-    N, R, L = 65536, 2, 128
+    N, R = 65536, 2
     H = N - N // R
+    N1, lout = N // L, L // 2
     rng = np.random.default_rng(nslots * 11 + nb)
-    slots = [int(v) for v in rng.permutation(512)[:nslots]]
+    slots = [int(v) for v in rng.permutation(N1)[:nslots]]
     wt = nb % 3
     chans = [(L * c, L, 0.88, 1.0) for c in slots]
-    x = noise(nb * H, 128 + nb)
+    x = noise(nb * H, L + nb)
     G.defaults["FDC_HOST_SUB"] = str(nb)
     try:
         p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
@@ -969,25 +971,25 @@ def test_one_kernel_path_for_128_bin_channels(oracle, nslots, nb):
     finally:
         G.defaults.pop("FDC_HOST_SUB", None)
     check = list(range(len(chans))) if len(chans) < 48 else sorted(set([0, 1, 2, len(chans) - 1] + [int(v) for v in rng.integers(0, len(chans), 24)]))
-    # the slots next to the seams of the layout: 0, 255 | 256, 511 and a neighbour pair, when the bank has them
-    for sl in (0, 1, 255, 256, 257, 511):
+    # the slots next to the seams of the layout (k and k + 256 i sit in the lanes of one quad), when the bank has them
+    for sl in (0, 1, 255, 256, 257, 511, 512, 513, 767, 768, 1023):
         if sl in slots and slots.index(sl) not in check:
             check.append(slots.index(sl))
     sub = [chans[c] for c in check]
     k = min(nb, 3)
     ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
     for i, c in enumerate(check):
-        assert outs[c].size == nb * 64
-        assert_close(outs[c][:k * 64], ref[i], "slot %d head" % slots[c])
+        assert outs[c].size == nb * lout
+        assert_close(outs[c][:k * lout], ref[i], "l %d slot %d head" % (L, slots[c]))
     if nb > k:
         t0 = nb - k
         ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
         for i, c in enumerate(check):
-            assert_close(outs[c][t0 * 64:], ref2[i], "slot %d tail" % slots[c])
-    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+            assert_close(outs[c][t0 * lout:], ref2[i], "l %d slot %d tail" % (L, slots[c]))
+    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
     assert q.path() == 2
     for c, (a, b_) in enumerate(zip(outs, q.work(x))):
-        assert_close(a, b_, "slot %d vs the two-launch form" % slots[c])
+        assert_close(a, b_, "l %d slot %d vs the two-launch form" % (L, slots[c]))
     p.reset()
     cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
