@@ -142,7 +142,7 @@ struct fdc_pipeline {
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
     float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
-    bool poly_bnar = false;      // l = 128 or 64 at N = 65536, R = 2: the block kernel of fdc_blocknarrow.hip
+    bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
     float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
                                  // stage 1 on the generic LDS core, two launches; one class, no offset)
@@ -763,7 +763,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizer's rows 64..127
-    if (p->fwd_block || ((p->poly_block || p->poly_b512) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    if (p->fwd_block || ((p->poly_block || p->poly_b512 || p->poly_bnar) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
         std::vector<char> g64((size_t)N / 64, 0);
         bool all = true;
@@ -1016,7 +1016,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         if (use_poly && p->poly_bnar && !few) {
             HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tabnar,
                                              p->d_cbtnar, p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
+                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

@@ -82,7 +82,7 @@ struct NarGeom {
     static_assert(kNarTrip <= kNarOffTab && 8 * kNarScrPts * 8 <= kNarOffTab && kLds <= 160 * 1024, "LDS budget");
 };
 
-bool poly_block_narrow_supports(int N, int L, int R) { return N == 65536 && R == 2 && (L == 128 || L == 64); }
+bool poly_block_narrow_supports(int N, int L, int R) { return N == 65536 && (R == 2 || R == 4) && (L == 128 || L == 64); }
 int poly_block_narrow_table_points(int L) { return L == 128 ? NarGeom<2>::kTabPts : NarGeom<4>::kTabPts; }
 
 // The table image (host side; N = 65536).  shn[kap] = shape[kap] / N (l values); the factor 1/S^2 of the two radix-S layers is applied here.
@@ -127,14 +127,18 @@ void poly_block_narrow_tables(int L, const float *shn, float2 *img)
     if (L == 128) narrow_tables<2>(shn, img); else narrow_tables<4>(shn, img);
 }
 
-template <int S, bool NT>
+// R4 = true: relinvovl = 4 (the reference's default overlap): three quarters of every inverse transform are kept.  The rows t >= 128 of the
+// virtual column stay in the G registers as for R = 2; the rows 64 <= t < 128 go to 128 KiB of per-workgroup scratch ([pass][q - 4][thread]: the
+// L2 holds it) and come back for a second, 64-row run of stage 2 (the first 64/S output rows of the block), as in fdc_block256.hip.
+template <int S, bool NT, bool R4>
 __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                     const float2 *__restrict__ tab /* the table image */,
                                                     const float2 *__restrict__ cbt /* [256 V][16 b]  W_N^(S V b) */,
                                                     const long long *__restrict__ slot_off /* [256 S] */, long long out_base, long long nb_call,
-                                                    unsigned out_bytes, int nb, int hints)
+                                                    unsigned out_bytes, int nb, int hints, float2 *__restrict__ scratch)
 {
     typedef NarGeom<S> GM;
+    constexpr int kRows = R4 ? 3 * GM::kL / 4 : GM::kL / 2;        // kept samples per block and channel: 3 l / 4 or l / 2
     constexpr int kQG = GM::kQG, kLS = S == 2 ? 1 : 2;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_nar);
     float2 *tbl = reinterpret_cast<float2 *>(fdc_smem_nar + kNarOffTab);
@@ -177,6 +181,7 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
     const float2 *const sab = tbl + GM::kTSA + b * GM::kRowQ;             // + pass * 16 rows
     const float2 *const tdr = tbl + GM::kTTD + b * GM::kRowT;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(R4 ? scratch + (size_t)blockIdx.x * 16384 : scratch, R4 ? 16384u * 8u : 0u);
 
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
@@ -273,6 +278,10 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
             dft16<true>(u);                                       // y[t = b + 16 q] in u[rev16(q)]; keep q >= 8
 #pragma unroll
             for (int j = 0; j < 8; j++) G[j][ps] = pack_nar(u[rev16(8 + j)]);
+            if constexpr (R4) {                                   // R = 4 keeps q >= 4: rows 64..127 go to the scratch, [pass][q - 4][thread]
+#pragma unroll
+                for (int j = 0; j < 4; j++) bst2(rscr, (unsigned)tid * 8u + (unsigned)j * 4096u, (unsigned)ps * 16384u, u[rev16(4 + j)]);
+            }
         };
 #pragma nounroll
         for (int pp = 0; pp < 8; pp += 2) {
@@ -280,8 +289,10 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
         // ---------------- stage 2: the FFT over n1 = S (32 pass + c5) + e of every row t' = b + 16 j = S m' + e ----------------
-        {
-            __syncthreads();                                          // every wave is done with its strip
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of 64-row trips (four j each)
+        auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
+            constexpr int kNTrip = decltype(ntripc)::value;
+            __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6), b_2 = lane2 >> 2, c5_2 = 4 * w2 + (lane2 & 3);
@@ -291,7 +302,7 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
             float2 *const gw1 = gw0 + rowjb;
             const float2 *const gr = scr + lane2 * kNarLd + 32 * w2;  // row = lane, klo = wave: 32 consecutive points
 #pragma unroll
-            for (int tr = 0; tr < 2; tr++) {
+            for (int tr = 0; tr < kNTrip; tr++) {
                 cf ct[8];
                 {
                     const float2 *ctr = tbl + GM::kTCt + c5_2 * 8;
@@ -301,11 +312,16 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                         ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
                     }
                 }
+                cf src[4][8];                                         // (runs that come back from the scratch: all loads in flight at once)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(4 * tr + jj, ps);
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
                     cf a[8];
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) a[ps] = unpack_nar(G[4 * tr + jj][ps]);
+                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
                     dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
                     float2 *const gw = (jj < 2 ? gw0 : gw1) + (jj & 1) * 16 * kNarLd;
                     st2(&gw[0], a[0]);
@@ -349,7 +365,7 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                     __builtin_amdgcn_sched_barrier(0);                // one table read at a time: the phase has no registers for more
                 }
                 // row m' = (64 tr + lane) / S of the lane's slot
-                const unsigned rb = (unsigned)(m * GM::kLout + (64 / S) * tr + ((t3 & 63) >> kLS)) * 8u;
+                const unsigned rb = (unsigned)(m * kRows + rowbase + (64 / S) * tr + ((t3 & 63) >> kLS)) * 8u;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint4 t = sow[q];
@@ -359,6 +375,13 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        stage2([&](int j, int ps) { return unpack_nar(G[j][ps]); }, R4 ? 64 / S : 0, std::integral_constant<int, 2>{});
+        if constexpr (R4) {
+            // rows 64..127 of the inverse transforms = the first output rows: this lane's own stores, served by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
+                   std::integral_constant<int, 1>{});
         }
         // the trip region (= the strips) was last read before the barrier above: the next block starts without one
     }
@@ -366,26 +389,34 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
 
 hipError_t init_block_narrow_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<2>::kLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<2>::kLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<4>::kLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<4>::kLds);
+    hipError_t e = hipSuccess;
+#define FDC_SETN(S, A, B) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<S, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<S>::kLds);
+    FDC_SETN(2, true, false) FDC_SETN(2, false, false) FDC_SETN(2, true, true) FDC_SETN(2, false, true)
+    FDC_SETN(4, true, false) FDC_SETN(4, false, false) FDC_SETN(4, true, true) FDC_SETN(4, false, true)
+#undef FDC_SETN
     return e;
 }
 
 hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tab,
                                     const float2 *cbt, const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                                    hipEvent_t ev_start, hipEvent_t ev_stop)
+                                    hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch)
 {
     if (nb_chunk <= 0) return hipSuccess;
-    if (L != 128 && L != 64) return hipErrorInvalidValue;
+    if ((L != 128 && L != 64) || (R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
-#define FDC_LNAR(S, A) \
-    hipExtLaunchKernelGGL((k_blknar<S, A>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
-                          slot_off, (long long)mbase * NarGeom<S>::kLout, (long long)nb_call, out_bytes, nb_chunk, hints)
-    if (L == 128) { if (hints & 1) FDC_LNAR(2, true); else FDC_LNAR(2, false); }
-    else { if (hints & 1) FDC_LNAR(4, true); else FDC_LNAR(4, false); }
+    const int rows = R == 4 ? 3 * L / 4 : L / 2;
+#define FDC_LNAR(S, A, B) \
+    hipExtLaunchKernelGGL((k_blknar<S, A, B>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
+                          slot_off, (long long)mbase * rows, (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr)
+#define FDC_LNARS(S) \
+    do { \
+        if (R == 4) { if (hints & 1) FDC_LNAR(S, true, true); else FDC_LNAR(S, false, true); } \
+        else { if (hints & 1) FDC_LNAR(S, true, false); else FDC_LNAR(S, false, false); } \
+    } while (0)
+    if (L == 128) FDC_LNARS(2); else FDC_LNARS(4);
+#undef FDC_LNARS
 #undef FDC_LNAR
     return hipGetLastError();
 }

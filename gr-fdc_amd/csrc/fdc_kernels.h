@@ -134,7 +134,7 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                                 int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */);
 
-// uniform plan of narrow channels (l = 128 or 64 bins on the l-bin grid), N = 65536, R = 2: one kernel, one block per CU (fdc_blocknarrow.hip):
+// uniform plan of narrow channels (l = 128 or 64 bins on the l-bin grid), N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_blocknarrow.hip):
 // S = 256/l adjacent columns interleaved into one 256-point virtual column, separated and re-joined in registers.
 //   tab = the table image of poly_block_narrow_tables() (shn[k2] = shape[k2] / N, l values); cbt[V][b] = W_N^(S V b) (256 x 16); slot_off[256 S]
 bool poly_block_narrow_supports(int N, int L, int R);
@@ -143,7 +143,8 @@ int poly_block_narrow_table_points(int L);
 void poly_block_narrow_tables(int L, const float *shn, float2 *img);
 hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tab,
                                     const float2 *cbt, const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int R = 2 /* 2 or 4 */,
+                                    float2 *scratch = nullptr /* R = 4: ncu x 16384 points */);
 
 // forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,

@@ -1025,3 +1025,38 @@ def test_512_bin_block_kernel_at_relinvovl_4(oracle, wt):
         parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, 7)]]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("L,wt", [(128, 0), (128, 1), (64, 0), (64, 2)])
+def test_narrow_block_kernel_at_relinvovl_4(oracle, L, wt):
+    """l = 128 / 64 at R = 4 (the reference's default overlap): three quarters of every inverse transform are kept — the rows t >= 128 of a
+    virtual column in the G registers, the rows 64 .. 127 through the per-workgroup scratch and a second run of stage 2.  The full bank and a
+    subset, against the oracle and against the generic two-launch form on every sample; several workgroup rounds; ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R = 65536, 4
+    H = N - N // R
+    N1, lout = N // L, 3 * L // 4
+    for nb, slots in ((7, list(range(N1))), (263, [N1 - 1, 0, 3, 256, 257, N1 // 2 + 5, 100, 17])):
+        chans = [(L * c, L, 0.88, 1.0) for c in slots]
+        x = noise(nb * H, 77 + wt + L)
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = range(len(chans)) if len(chans) < 16 else (0, 1, 255, 256, 257, N1 // 2, N1 - 2, N1 - 1)
+        k = min(nb, 4)
+        ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x[:k * H], nthreads=8)
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * lout
+            assert_close(outs[c][:k * lout], ref[i], "l %d slot %d head" % (L, slots[c]))
+            assert_close(outs[c][t0 * lout:], ref2[i], "l %d slot %d tail" % (L, slots[c]))
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
+        assert q.path() == 2
+        for a, b_ in zip(outs, q.work(x)):
+            assert_close(a, b_, "block kernel vs two launches")
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, nb)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
