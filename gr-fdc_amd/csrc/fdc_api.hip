@@ -142,6 +142,8 @@ struct fdc_pipeline {
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
     float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
+    bool poly_b1024 = false;     // l = 1024 at N = 65536, R = 2: the block kernel of fdc_block1024.hip
+    float2 *d_tw1k = nullptr, *d_twq1k = nullptr, *d_cbt1k = nullptr;
     bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
     float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
@@ -375,6 +377,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
     (void)hipFree(p->d_tabnar); (void)hipFree(p->d_cbtnar);
+    (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k); (void)hipFree(p->d_cbt1k);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -466,15 +469,18 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
         // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
         const bool b512 = L == 512 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
+        // l = 1024: the block kernel costs 0.335 ms per 1024 blocks whatever the number of channels, the spectrum path 0.25 + 0.19 C/64 by the
+        // cost rule of the split plans (measured: 0.42 for the full bank): the kernel from 29 channels up
+        const bool b1024 = L == 1024 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 29 || (flags & FDC_PIPE_WIDE_UNIFORM));
         const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
-        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
+        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || b1024 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
         std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
             if (ch.l != L || (ch.f % L) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
             else usedL[(size_t)(ch.f / L)] = 1;
         }
-        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_bnar = bnar; }
+        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; }
     }
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
@@ -675,6 +681,28 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             CHK_OR_FREE(hipMalloc(&p->d_cbt512, sizeof(float2) * cb.size()));
             CHK_OR_FREE(hipMemcpy(p->d_cbt512, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
         }
+        if (p->poly_b1024) {
+            // tables of the l = 1024 block kernel (fdc_block1024.hip): W_1024^k; W_N^(16 n1 q); (-1)^n1 W_N^(n1 (b + 256 i)) at [n1][b + 16 i]
+            std::vector<float2> t1(1024), tq((size_t)N1 * 16), cb((size_t)N1 * 64);
+            for (int k = 0; k < 1024; k++) { const double a = -2.0 * M_PI * k / 1024.0; t1[(size_t)k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
+            for (int n1 = 0; n1 < N1; n1++) {
+                for (int q = 0; q < 16; q++) {
+                    const double a = -2.0 * M_PI * double((16ll * n1 * q) % N) / double(N);
+                    tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
+                }
+                for (int e = 0; e < 64; e++) {
+                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * (e >> 4))) % N) / double(N);
+                    const double sg = (n1 & 1) ? -1.0 : 1.0;
+                    cb[(size_t)n1 * 64 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
+                }
+            }
+            CHK_OR_FREE(hipMalloc(&p->d_tw1k, sizeof(float2) * t1.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_tw1k, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_twq1k, sizeof(float2) * tq.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_twq1k, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&p->d_cbt1k, sizeof(float2) * cb.size()));
+            CHK_OR_FREE(hipMemcpy(p->d_cbt1k, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+        }
         if (p->poly_bnar) {
             // tables of the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l
             const int S = 256 / L;
@@ -802,7 +830,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // G scratch of the two-launch form.  With the one-kernel form only launch groups shorter than block_min take the two
         // launches, and only plans of one on-grid class can (see fdc_pipeline_process_device)
         const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
-        const int gblocks = (p->poly_block || p->poly_b512 || p->poly_bnar) ? std::min(chunk, p->block_min) : chunk;
+        const int gblocks = (p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) ? std::min(chunk, p->block_min) : chunk;
         if (two_launch)
             CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(p->poly_L - p->poly_L / R) * (size_t)(N / p->poly_L)));
     }
@@ -844,7 +872,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
     if (p->poly_block && p->split) return 4;
-    if (p->poly_block || p->poly_b512 || p->poly_bnar) return 3;
+    if (p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -1008,6 +1036,17 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 if (rcr != FDC_OK) return rcr;
                 if (tg) p->ev_spans.push_back(span);
             } else if (tg) {
+                span[2] = span[3] = span[1];
+                p->ev_spans.push_back(span);
+            }
+            continue;
+        }
+        if (use_poly && p->poly_b1024 && !few) {
+            HIPCHK(fdc::launch_poly_block1024(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
+                                              p->d_tw1k, p->d_twq1k, p->d_cbt1k, p->d_shn, p->d_slot_off,
+                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
+                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
+            if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);
             }

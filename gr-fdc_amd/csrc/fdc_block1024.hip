@@ -1,0 +1,297 @@
+// gfx950 one-block-per-CU form of the uniform-plan path for channels of l = 1024 bins (N = 65536 = 1024 rows x 64 columns, R = 2, every
+// channel on the 1024-bin grid, one window): fdc_block512.hip taken one step further — a column's 1024 rows split into FOUR PHASES
+// n2 = 4 mu + rho, each a 256-point sub-sequence that is exactly a "column" of fdc_block256.hip.  A quad of lanes is the four phases of ONE
+// column; all four run the 256-point transforms of the old stage 1 in lockstep, and the radix-4 layers that join them are two DPP exchanges
+// inside the quad (lane ^ 2, a -j / +j on lane 3, lane ^ 1):
+//     forward (decimation in time):  A[kap + 256 i] = sum_rho W_4^(i rho) (W_1024^(kap rho) E_rho[kap])          kap = 0 .. 255
+//                                    natural phase order in, lane lam holds i = bit-swapped lam afterwards
+//     product: shape[k2]/N (-1)^n1 W_N^(n1 k2), k2 = kap + 256 i, all of it before the inverse layer (its i part differs between the lanes that
+//              are about to be added); the ifftshift of the 1024-point inverse (k2 ^ 512: i ^ 2) is a factor (-1)^rho' on the result
+//     inverse (decimation in frequency):  g[4 m + rho'] = IFFT256{ (-1)^rho' conj(W_1024^(kap rho')) sum_i W_4^(-i rho') U[kap + 256 i] }[m]
+//                                    bit-swapped lane order in, lane rho' holds phase rho' afterwards
+//     kept: t = 4 m + rho' >= 512  <=>  m >= 128: eight values per lane and pass, as before: G is 8 passes x 8 = 128 VGPRs.
+// A wave owns one column per pass, the workgroup 8: 8 passes for the 64 columns.  A wave's load instruction is 64 single 8-byte samples, one per row
+// (the eight waves of the workgroup cover 64 contiguous bytes of each row in the same pass): the worst-shaped loads of the family.
+// Stage 2 is the FFT-64 over the columns n1 = 8 pass + c3: DFT-8 over the pass index in registers, W_64^(c3 klo), one trip through LDS
+// ([128 rows][8 klo][8 c3], four trips for the 512 kept rows), DFT-8 over c3 in the lane that owns (row, klo); a wave's store is 64 consecutive
+// samples of one channel.
+//
+// The arithmetic is that of k_p1g + k_p2g (fdc_kernels.hip) regrouped; parity against the oracle: tests/test_parity_gpu.py.
+#include <hip/hip_ext.h>
+#include <type_traits>
+#include "fdc_kernels.h"
+#include "fdc_radix16.hpp"
+#include "fdc_devutil.hpp"
+
+namespace fdc {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_b1k[];
+
+typedef unsigned long long k8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned long long pack1k(cf v) { return ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x); }
+__device__ __forceinline__ cf unpack1k(unsigned long long u) { return mk(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))); }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FDC_PLAIN_DS1K __attribute__((target("no-load-store-opt")))
+#else
+#define FDC_PLAIN_DS1K
+#endif
+
+__device__ __forceinline__ cf q1k_xor1(cf x)
+{
+    return mk(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.x), 0xB1, 0xF, 0xF, true)),
+              __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.y), 0xB1, 0xF, 0xF, true)));
+}
+__device__ __forceinline__ cf q1k_xor2(cf x)
+{
+    return mk(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.x), 0x4E, 0xF, 0xF, true)),
+              __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.y), 0x4E, 0xF, 0xF, true)));
+}
+
+// LDS map (bytes)
+constexpr int kKScrPts = 1084;                                   // per-wave exchange strip, as in fdc_block256.hip
+constexpr int kKOffX = 8 * kKScrPts * 8;                         // 69376: end of the strips
+constexpr int kKLd = 8 * 8 + 2;                                  // stage-2 trip rows: [8 klo][8 c3] + 2 (row stride 132 dwords = 4 mod 64)
+constexpr int kKTrip = 128 * kKLd * 8;                           // 67584 <= the strips: the trip buffer lies over them
+constexpr int kKOffCt = kKOffX;                                  // [8 c3][8 klo]  W_64^(c3 klo)
+constexpr int kKOffWrow = kKOffCt + 8 * 8 * 8;                   // [16][18]  W_256^(b p)
+constexpr int kKOffT1k = kKOffWrow + 16 * 18 * 8;                // [4 rho][16 b][18]  W_1024^(rho (b + 16 q))
+constexpr int kKOffB = kKOffT1k + 4 * 16 * 18 * 8;               // [64 n1][18]  W_N^(16 n1 q)
+constexpr int kKOffSh = kKOffB + 64 * 18 * 8;                    // [4 i][16 b][20] floats: shape[b + 16 q + 256 i] / N (rows of 20: the b rows of a 16-byte read on different banks)
+constexpr int kKOffSoff = kKOffSh + 4 * 16 * 20 * 4;             // [8 klo][8] output offsets (bytes)
+constexpr int kKLds = kKOffSoff + 64 * 4;                        // 96000
+static_assert(kKTrip <= kKOffX, "the trip buffer lies over the strips, below the tables");
+
+template <bool NT>
+__global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
+                                                      const float2 *__restrict__ tw256, const float2 *__restrict__ tw1024 /* W_1024^k, k < 1024 */,
+                                                      const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
+                                                      const float2 *__restrict__ cbt /* [n1][64] (-1)^n1 W_N^(n1 (b + 256 i)) at b + 16 i */,
+                                                      const float *__restrict__ shn /* [1024] shape / N */,
+                                                      const long long *__restrict__ slot_off, long long out_base, long long nb_call,
+                                                      unsigned out_bytes, int nb, int hints)
+{
+    float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b1k);
+    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffCt);
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffWrow);
+    float2 *t1k = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffT1k);
+    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffB);
+    float *Sh = reinterpret_cast<float *>(fdc_smem_b1k + kKOffSh);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_b1k + kKOffSoff);
+    const int tid = threadIdx.x;
+    // lane = rho + 4 b: rho = phase of the column's rows, b = row group of the 256-point sub-transform; the wave is the column of the pass
+    const int w = tid >> 6, lane = tid & 63, rho = lane & 3, b = lane >> 2;
+    const int iq = ((rho & 1) << 1) | (rho >> 1);                         // the quarter i of k2 this lane holds between the two radix-4 layers
+
+    const int grid = gridDim.x, per = grid >> 3;
+    const bool xmap = (grid & 7) == 0;
+    const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (first >= nb) return;
+
+    constexpr unsigned inbytes = 65536u * 8u;
+    // row n2 = 4 (16 a + b) + rho of column 8 pass + w: 64 columns per row; a adds 64 rows = 32 KiB, a pass 8 columns = 64 B
+    const unsigned voff = (unsigned)((4 * b + rho) * 64 + w) * 8u;
+    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 64u * 64u * 8u);
+    const unsigned voffc = (unsigned)(w * 64 + b + 16 * iq) * 8u;
+    cf LA[16], LB[16], cbA, cbB;
+    {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
+#pragma unroll
+        for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * 32768u);
+        cbA = bld2(rcb, voffc, 0);
+    }
+    // ---- tables
+    for (int i = tid; i < 256; i += 512) wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
+    for (int i = tid; i < 1024; i += 512) {
+        const int r = i >> 8, kap = i & 255;                              // [rho][b][q], kap = b + 16 q
+        t1k[(r * 16 + (kap & 15)) * 18 + (kap >> 4)] = tw1024[(r * kap) & 1023];
+        Sh[((i >> 8) * 16 + (i & 15)) * 20 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 quarter
+        Bt[(i >> 4) * 18 + (i & 15)] = twq[i];                            // [n1 = i >> 4][q]: twq is [n1][16] already
+    }
+    for (int i = tid; i < 64; i += 512) {
+        const long long o = slot_off[i];                                  // slot i = klo + 8 khi, khi = k0 + 2 k1, is entry [klo][4 k0 + k1]
+        soff[(i & 7) * 8 + 4 * ((i >> 3) & 1) + (i >> 4)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+        ctab[i] = tw256[(4 * (i >> 3) * (i & 7)) & 255];                  // [c3][klo] = W_64^(c3 klo)
+    }
+    __syncthreads();
+
+    float2 *const scrw = scr + w * kKScrPts + lane;
+    const float2 *const scrr = scr + w * kKScrPts + rho + 68 * b;
+    const float2 *const wr = wrow + b * 18;
+    const float2 *const t1r = t1k + (16 * rho + b) * 18;
+    const float2 *const btw = Bt + w * 18;                                // + pass * 8 rows
+    const float *const shr = Sh + (16 * iq + b) * 20;
+    // the sign of a lane's own term in the lane ^ 1 and lane ^ 2 layers; lane 3 turns its value by -j (forward) / +j (inverse) between them
+    const float sg1 = (rho & 1) ? -1.0f : 1.0f, sg2 = (rho & 2) ? -1.0f : 1.0f;
+    const bool rot = rho == 3;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+
+    for (int m = first; m < nb; m += grid) {
+        const int mnext = m + grid < nb ? m + grid : m;
+        k8v G[8];
+        auto one_pass = [&](const int ps, cf (&cur)[16], const cf cb, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
+            {
+                const int pn = ps < 7 ? ps + 1 : 0;
+                const int mb = ps < 7 ? m : mnext;
+                const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 8 * pn, inbytes);
+                if (hints & 2) {
+#pragma unroll
+                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * 32768u);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+                }
+                cbn = bld2(rcb, voffc, (unsigned)pn * 4096u);
+            }
+            // ---- the 256-point forward transform of this lane's phase: exactly the old stage 1
+            dft16<false>(cur);
+            {
+                cf tw[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = ld4(&wr[2 * i]);
+                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
+                }
+                st2(&scrw[0], cur[rev16(0)]);
+#pragma unroll
+                for (int p = 1; p < 16; p++) st2(&scrw[68 * p], cmul(cur[rev16(p)], tw[p]));
+            }
+            __builtin_amdgcn_wave_barrier();
+            cf v[16];
+#pragma unroll
+            for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&scrr[4 * bb]);
+            dft16<false>(v);                                      // E_rho at kap = b + 16 q in v[rev16(q)]
+            // ---- forward radix-4 layer, product, inverse radix-4 layer: two values at a time, 16-byte table reads
+            cf u[16];
+            {
+                const float2 *bpr = btw + ps * (8 * 18);
+#pragma unroll
+                for (int g2 = 0; g2 < 8; g2++) {
+                    const float4 ta = ld4(&t1r[2 * g2]), ba = ld4(&bpr[2 * g2]);
+                    const float2 sh = *reinterpret_cast<const float2 *>(&shr[2 * g2]);
+                    const cf w1s[2] = {mk(ta.x, ta.y), mk(ta.z, ta.w)}, bps[2] = {mk(ba.x, ba.y), mk(ba.z, ba.w)};
+                    const float shs[2] = {sh.x, sh.y};
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int q = 2 * g2 + e;
+                        cf x = cmul(v[rev16(q)], w1s[e]);                            // E_rho W_1024^(kap rho)
+                        x = q1k_xor2(x) + x * sg2;                                   // lanes 0, 1: x_rho + x_(rho+2); lanes 2, 3: x_(rho-2) - x_rho
+                        x = rot ? mk(x.y, -x.x) : x;                                 // lane 3: -j
+                        x = q1k_xor1(x) + x * sg1;                                   // A[kap + 256 iq]
+                        // shape / N, W_N^(16 n1 q), (-1)^n1 W_N^(n1 (b + 256 iq)) = cb
+                        cf y = cmul(cmul(x, bps[e]), cb) * shs[e];
+                        y = q1k_xor1(y) + y * sg1;                                   // lanes (0, 1) hold quarters 0, 2; lanes (2, 3) quarters 1, 3
+                        y = rot ? mk(-y.y, y.x) : y;                                 // lane 3: +j
+                        y = q1k_xor2(y) + y * sg2;                                   // sum_i W_4^(-i rho) U[kap + 256 i] in lane rho
+                        u[q] = cmulc(y, w1s[e]) * sg1;                               // conj(W_1024^(kap rho)), and (-1)^rho: the ifftshift
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- the 256-point inverse transform of this lane's phase (no q ^ 8: the shift was the sign above)
+            dft16<true>(u);
+            {
+                cf tw[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = ld4(&wr[2 * i]);
+                    tw[2 * i] = mk(t.x, t.y); tw[2 * i + 1] = mk(t.z, t.w);
+                }
+#pragma unroll
+                for (int p = 1; p < 16; p++) u[rev16(p)] = cmulc(u[rev16(p)], tw[p]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < 16; p++) st2(&scrw[68 * p], u[rev16(p)]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int bb = 0; bb < 16; bb++) u[bb] = ld2(&scrr[4 * bb]);
+            dft16<true>(u);                                       // g[4 m + rho], m = b + 16 q in u[rev16(q)]; keep q >= 8
+#pragma unroll
+            for (int j = 0; j < 8; j++) G[j][ps] = pack1k(u[rev16(8 + j)]);
+        };
+#pragma nounroll
+        for (int pp = 0; pp < 8; pp += 2) {
+            one_pass(pp, LA, cbA, LB, cbB);
+            one_pass(pp + 1, LB, cbB, LA, cbA);
+        }
+        // ---------------- stage 2: FFT-64 over n1 = 8 pass + c3 of every row t' = 4 (b + 16 j) + rho = lane + 64 j ----------------
+        {
+            __syncthreads();                                          // every wave is done with its strip
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
+            float2 *const gw = scr + lane2 * kKLd + w2;               // element (row lane + 64 jj, klo) at + 64 jj kLd + 8 klo
+            const float2 *const gr = scr + lane2 * kKLd + 8 * w2;     // row = lane (+ 64 hh), klo = wave: 8 consecutive points
+            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 8 * w2);
+            cf ct[8];
+            {
+                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_b1k + kKOffCt) + w2 * 8;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 t = ld4(&ctr[2 * i]);
+                    ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
+                }
+            }
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    cf a[8];
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) a[ps] = unpack1k(G[2 * tr + jj][ps]);
+                    dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
+                    float2 *const g = gw + jj * 64 * kKLd;
+                    st2(&g[0], a[0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) st2(&g[8 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                      // the trip is in LDS
+                cf v[2][8];
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float4 t = ld4(&gr[hh * 64 * kKLd + 2 * i]);
+                        v[hh][2 * i] = mk(t.x, t.y); v[hh][2 * i + 1] = mk(t.z, t.w);
+                    }
+                __syncthreads();                                      // every read of the trip is done
+                __builtin_amdgcn_sched_barrier(0);
+                const uint4 s0 = sow[0], s1 = sow[1];
+                const unsigned so[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    dft8<false>(v[hh]);                               // khi = k0 + 2 k1 in v[4 k0 + k1]
+                    const unsigned rb = (unsigned)(m * 512 + 128 * tr + 64 * hh + lane2) * 8u;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[hh][e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+hipError_t init_block1024_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kKLds);
+    return e;
+}
+
+hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
+                                 const float2 *tw1024, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
+                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (nb_chunk <= 0) return hipSuccess;
+    int grid = ncu > 0 ? ncu : 256;
+    if (grid > nb_chunk) grid = nb_chunk;
+#define FDC_L1K(A) \
+    hipExtLaunchKernelGGL((k_blk1024<A>), dim3((unsigned)grid), dim3(512), kKLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw1024, twq, \
+                          cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints)
+    if (hints & 1) FDC_L1K(true); else FDC_L1K(false);
+#undef FDC_L1K
+    return hipGetLastError();
+}
+
+}  // namespace fdc

@@ -668,6 +668,7 @@ hipError_t init_kernels()
 #undef FDC_SETLDS
     if ((e = init_sink_kernels()) != hipSuccess) return e;
     if ((e = init_block512_kernels()) != hipSuccess) return e;
+    if ((e = init_block1024_kernels()) != hipSuccess) return e;
     if ((e = init_block_narrow_kernels()) != hipSuccess) return e;
     return init_fast_kernels();
 }

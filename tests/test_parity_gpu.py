@@ -1060,3 +1060,49 @@ def test_narrow_block_kernel_at_relinvovl_4(oracle, L, wt):
         parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, nb)]]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("nslots,nb", [(64, 7), (64, 300), (9, 261), (1, 3), (63, 530)])
+def test_one_kernel_path_for_1024_bin_channels(oracle, nslots, nb):
+    """l = 1024 at N = 65536, R = 2 (fdc_block1024.hip): the four phases of a column's 1024 rows as four 256-point columns in the lanes of a
+    quad, joined by radix-4 layers through DPP.  Against the oracle (head and tail), against the generic two-launch form on every sample,
+    block counts below and above one round of workgroups, ragged calls bit for bit, all three window shapes."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, L = 65536, 2, 1024
+    H = N - N // R
+    rng = np.random.default_rng(nslots * 13 + nb)
+    slots = [int(v) for v in rng.permutation(64)[:nslots]]
+    wt = nb % 3
+    chans = [(L * c, L, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 1024 + nb)
+    G.defaults["FDC_HOST_SUB"] = str(nb)
+    try:
+        # banks of fewer than 29 channels take the spectrum path unless asked (the kernel's cost does not depend on the number of channels)
+        assert G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == (3 if nslots >= 29 else 1)
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_WIDE_UNIFORM)
+        assert p.path() == 3
+        outs = p.work(x)
+    finally:
+        G.defaults.pop("FDC_HOST_SUB", None)
+    k = min(nb, 3)
+    check = range(len(chans)) if len(chans) < 12 else (0, 1, 2, 31, 32, len(chans) - 2, len(chans) - 1)
+    sub = [chans[c] for c in check]
+    ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * 512
+        assert_close(outs[c][:k * 512], ref[i], "slot %d head" % slots[c])
+    if nb > k:
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert_close(outs[c][t0 * 512:], ref2[i], "slot %d tail" % slots[c])
+    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
+    assert q.path() == 2
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "slot %d vs the two-launch form" % slots[c])
+    p.reset()
+    cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])

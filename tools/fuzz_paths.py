@@ -26,8 +26,8 @@ def rel(a, b):
 
 def draw_plan(rng):
     kind = rng.integers(0, 8)
-    if kind >= 6:                                     # uniform banks of another width on its grid: 512, 128, 64 (block kernels), others (spectrum path)
-        L = int([512, 128, 128, 1024, 64, 64][int(rng.integers(0, 6))])
+    if kind >= 6:                                     # uniform banks of another width on its grid: 1024, 512, 128, 64 (block kernels), others (spectrum path)
+        L = int([512, 128, 1024, 1024, 64, 2048][int(rng.integers(0, 6))])
         slots = rng.permutation(N // L)[:rng.integers(1, N // L + 1)]
         return [(L * int(c), L, 0.88, 1.0) for c in slots], "bank l=%d" % L
     if kind == 0:                                     # on-grid subset
