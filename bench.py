@@ -63,6 +63,8 @@ def parse():
                                                              "dropped): a tiling that does not start at bin 0")
     ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum", "wide-uniform"), default=None,
                     help="diagnostics: fdc_pipeline_cfg.flags FDC_PIPE_NO_BLOCK / NO_POLY / FORCE_GENERIC (the slower forms of the path)")
+    ap.add_argument("--block-hints", type=int, default=None, metavar="H",
+                    help="diagnostics: memory hints of the block kernels (bit 0: streamed output stores, bit 1: streamed input loads; default 1)")
     ap.add_argument("--input-rings", type=int, default=3,
                     help="distinct device-resident input rings the steps rotate over (configs 1/2/4): with 3 rings of 537 MB (2048 blocks of "
                          "262144 B) no input byte of a step can still sit in the 256 MiB memory-side cache when its ring comes round again "
@@ -431,6 +433,8 @@ def main():
     if a.force_path:
         G.defaults[{"no-block": "FDC_NO_BLOCK", "no-poly": "FDC_NO_POLY", "generic": "FDC_FORCE_GENERIC",
                     "full-spectrum": "FDC_FULL_SPECTRUM", "wide-uniform": "FDC_WIDE_UNIFORM"}[a.force_path]] = "1"
+    if a.block_hints is not None:
+        G.defaults["FDC_BLOCK_HINTS"] = str(a.block_hints)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     ndev = torch.cuda.device_count()

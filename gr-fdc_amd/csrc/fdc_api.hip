@@ -142,6 +142,7 @@ struct fdc_pipeline {
     bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
     bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
     float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
+    bool poly_half = false;      // the bank of a width's block kernel sits half a channel higher: f = l slot + l/2 (channels centred on multiples of l)
     bool poly_b1024 = false;     // l = 1024 at N = 65536, R = 2: the block kernel of fdc_block1024.hip
     float2 *d_tw1k = nullptr, *d_twq1k = nullptr, *d_cbt1k = nullptr;
     bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
@@ -474,13 +475,17 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const bool b1024 = L == 1024 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 29 || (flags & FDC_PIPE_WIDE_UNIFORM));
         const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
         uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || b1024 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
+        // on the l-bin grid, or (block kernels of the other widths only) all half a channel higher: a bank centred on multiples of l
+        const int r0 = cfg->channels[0].f % L;
+        const bool halfb = r0 == L / 2 && (b512 || b1024 || bnar);
+        uniL = uniL && (r0 == 0 || halfb);
         std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != L || (ch.f % L) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
+            if (ch.l != L || (ch.f % L) != r0 || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
             else usedL[(size_t)(ch.f / L)] = 1;
         }
-        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; }
+        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; p->poly_half = halfb; }
     }
     // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
     // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
@@ -645,7 +650,13 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->classes.push_back(pc);
         auto &q = p->classes.back();
         CHK_OR_FREE(hipMalloc(&q.d_shn, sizeof(float) * (size_t)L));
-        CHK_OR_FREE(hipMemcpy(q.d_shn, sn.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
+        {
+            // the 512- and 1024-bin block kernels at half a channel's offset read the window with its halves swapped (their lanes hold the other half)
+            std::vector<float> snd(sn);
+            if (p->poly_half && (p->poly_b512 || p->poly_b1024))
+                for (int k2 = 0; k2 < L; k2++) snd[(size_t)k2] = sn[(size_t)(k2 ^ (L / 2))];
+            CHK_OR_FREE(hipMemcpy(q.d_shn, snd.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
+        }
         CHK_OR_FREE(hipMalloc(&q.d_slot_off, sizeof(long long) * (size_t)N1));
         CHK_OR_FREE(hipMemcpy(q.d_slot_off, so.data(), sizeof(long long) * (size_t)N1, hipMemcpyHostToDevice));
         p->d_shn = q.d_shn; p->d_slot_off = q.d_slot_off;
@@ -669,7 +680,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
                     tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
                 }
                 for (int e = 0; e < 32; e++) {
-                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * (e >> 4))) % N) / double(N);
+                    // half: the lane of half h holds half h ^ 1 of the modulated column, whose constant W_N^(256 n1) joins the table
+                    const int h = p->poly_half ? (e >> 4) ^ 1 : e >> 4;
+                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * h + (p->poly_half ? 256 : 0))) % N) / double(N);
                     const double sg = (n1 & 1) ? -1.0 : 1.0;
                     cb[(size_t)n1 * 32 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
                 }
@@ -691,7 +704,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
                     tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
                 }
                 for (int e = 0; e < 64; e++) {
-                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * (e >> 4))) % N) / double(N);
+                    // half: the lane of quarter i holds quarter i ^ 2 of the modulated column, whose constant W_N^(512 n1) joins the table
+                    const int iq = p->poly_half ? (e >> 4) ^ 2 : e >> 4;
+                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * iq + (p->poly_half ? 512 : 0))) % N) / double(N);
                     const double sg = (n1 & 1) ? -1.0 : 1.0;
                     cb[(size_t)n1 * 64 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
                 }
@@ -707,10 +722,10 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             // tables of the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l
             const int S = 256 / L;
             std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L)), cb(256 * 16);
-            fdc::poly_block_narrow_tables(L, sn.data(), img.data());
+            fdc::poly_block_narrow_tables(L, sn.data(), img.data(), p->poly_half);
             for (int V = 0; V < 256; V++)
                 for (int b = 0; b < 16; b++) {
-                    const double a = -2.0 * M_PI * double(((long long)S * V * b) % N) / double(N);
+                    const double a = -2.0 * M_PI * double(((long long)S * V * (b + (p->poly_half ? L / 2 : 0))) % N) / double(N);   // half: W_N^((l/2) S V)
                     cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
                 }
             CHK_OR_FREE(hipMalloc(&p->d_tabnar, sizeof(float2) * img.size()));
@@ -1041,32 +1056,33 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        if (use_poly && p->poly_b1024 && !few) {
+        // (a bank at half a channel's offset has no two-launch form: short launch groups take the block kernel too)
+        if (use_poly && p->poly_b1024 && (!few || p->poly_half)) {
             HIPCHK(fdc::launch_poly_block1024(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
                                               p->d_tw1k, p->d_twq1k, p->d_cbt1k, p->d_shn, p->d_slot_off,
                                               (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr));
+                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->poly_half));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);
             }
             continue;
         }
-        if (use_poly && p->poly_bnar && !few) {
+        if (use_poly && p->poly_bnar && (!few || p->poly_half)) {
             HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tabnar,
                                              p->d_cbtnar, p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr));
+                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->poly_half));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);
             }
             continue;
         }
-        if (use_poly && p->poly_b512 && !few) {
+        if (use_poly && p->poly_b512 && (!few || p->poly_half)) {
             HIPCHK(fdc::launch_poly_block512(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
                                              p->d_tw512, p->d_twq512, p->d_cbt512, p->d_shn, p->d_slot_off,
                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr));
+                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->poly_half));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

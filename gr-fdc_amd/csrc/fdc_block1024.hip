@@ -68,8 +68,11 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
                                                       const float2 *__restrict__ cbt /* [n1][64] (-1)^n1 W_N^(n1 (b + 256 i)) at b + 16 i */,
                                                       const float *__restrict__ shn /* [1024] shape / N */,
                                                       const long long *__restrict__ slot_off, long long out_base, long long nb_call,
-                                                      unsigned out_bytes, int nb, int hints)
+                                                      unsigned out_bytes, int nb, int hints, int half)
 {
+    // half: the bank 512 bins higher (f = 1024 slot + 512).  The block modulated by exp(-2 pi i 512 n / N) = W_N^(512 n1) (-1)^n2 moves every column's
+    // spectrum by half its length: the lane that holds quarter i of k2 holds quarter i ^ 2 of the modulated column (the host moves the quarters of shn
+    // and cbt and puts W_N^(512 n1) into cbt), and the ifftshift — the same move again — no longer leaves a sign.
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b1k);
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffCt);
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffWrow);
@@ -123,6 +126,7 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     // the sign of a lane's own term in the lane ^ 1 and lane ^ 2 layers; lane 3 turns its value by -j (forward) / +j (inverse) between them
     const float sg1 = (rho & 1) ? -1.0f : 1.0f, sg2 = (rho & 2) ? -1.0f : 1.0f;
     const bool rot = rho == 3;
+    const float osg = half ? 1.0f : sg1;                                  // (-1)^rho: the ifftshift (half: cancelled)
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
 
     for (int m = first; m < nb; m += grid) {
@@ -182,7 +186,7 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
                         y = q1k_xor1(y) + y * sg1;                                   // lanes (0, 1) hold quarters 0, 2; lanes (2, 3) quarters 1, 3
                         y = rot ? mk(-y.y, y.x) : y;                                 // lane 3: +j
                         y = q1k_xor2(y) + y * sg2;                                   // sum_i W_4^(-i rho) U[kap + 256 i] in lane rho
-                        u[q] = cmulc(y, w1s[e]) * sg1;                               // conj(W_1024^(kap rho)), and (-1)^rho: the ifftshift
+                        u[q] = cmulc(y, w1s[e]) * osg;                               // conj(W_1024^(kap rho)), and (-1)^rho: the ifftshift
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -281,14 +285,14 @@ hipError_t init_block1024_kernels()
 
 hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                  const float2 *tw1024, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool half)
 {
     if (nb_chunk <= 0) return hipSuccess;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
 #define FDC_L1K(A) \
     hipExtLaunchKernelGGL((k_blk1024<A>), dim3((unsigned)grid), dim3(512), kKLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw1024, twq, \
-                          cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints)
+                          cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints, half ? 1 : 0)
     if (hints & 1) FDC_L1K(true); else FDC_L1K(false);
 #undef FDC_L1K
     return hipGetLastError();

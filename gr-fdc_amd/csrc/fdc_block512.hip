@@ -70,8 +70,12 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                                                       const float2 *__restrict__ cbt /* [n1][32] (-1)^n1 W_N^(n1 (b + 256 h)) at b + 16 h */,
                                                       const float *__restrict__ shn /* [512] shape / N */,
                                                       const long long *__restrict__ slot_off, long long out_base, long long nb_call,
-                                                      unsigned out_bytes, int nb, int hints, float2 *__restrict__ scratch)
+                                                      unsigned out_bytes, int nb, int hints, float2 *__restrict__ scratch, int half)
 {
+    // half: the bank 256 bins higher (f = 512 slot + 256).  The block modulated by exp(-2 pi i 256 n / N) = W_N^(256 n1) (-1)^n2 moves every column's
+    // spectrum by half its length: the lane that holds half h of k2 holds half h ^ 1 of the modulated column.  The host swaps the halves of the
+    // tables (shn, cbt) and puts W_N^(256 n1) into cbt; with the ifftshift (another swap) the inverse layer sees its halves in place, which leaves
+    // one sign in the parity-1 lanes.
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b512);
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffCt);
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffWrow);
@@ -122,6 +126,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     const float2 *const btr = Bt + c4 * 18;                              // + pass * 16 rows
     const float *const shr = Sh + (b + 16 * par) * 16;
     const float fsgn = par ? -1.0f : 1.0f;                                // the sign of a lane's own term in both radix-2 layers
+    const float hsgn = (half && par) ? -1.0f : 1.0f;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
     const __amdgpu_buffer_rsrc_t rscr = make_rsrc(R4 ? scratch + (size_t)blockIdx.x * 32768 : scratch, R4 ? 32768u * 8u : 0u);
     constexpr int kRows = R4 ? 384 : 256;                                 // kept samples per block and channel
@@ -182,7 +187,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                         const cf y = cmul(cmul(a, bps[e]), cb) * shs[e];
                         // ifftshift: the h = 1 lane's value is P (index kap), the h = 0 lane's is Q (index kap + 256)
                         const cf z = y + swap_parity(y) * fsgn;                      // par 0: Q + P; par 1: P - Q
-                        u[q] = cmulc(z, w5s[e]);                                     // par 1: conj(W_512^kap)
+                        u[q] = cmulc(z, w5s[e]) * hsgn;                              // par 1: conj(W_512^kap)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -300,7 +305,8 @@ hipError_t init_block512_kernels()
 
 hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                 const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch)
+                                unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch,
+                                bool half)
 {
     if (nb_chunk <= 0) return hipSuccess;
     if ((R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
@@ -308,7 +314,7 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
     if (grid > nb_chunk) grid = nb_chunk;
 #define FDC_L512(A, B) \
     hipExtLaunchKernelGGL((k_blk512<A, B>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq, \
-                          cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr)
+                          cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr, half ? 1 : 0)
     if (R == 4) { if (hints & 1) FDC_L512(true, true); else FDC_L512(false, true); }
     else { if (hints & 1) FDC_L512(true, false); else FDC_L512(false, false); }
 #undef FDC_L512

@@ -86,8 +86,12 @@ bool poly_block_narrow_supports(int N, int L, int R) { return N == 65536 && (R =
 int poly_block_narrow_table_points(int L) { return L == 128 ? NarGeom<2>::kTabPts : NarGeom<4>::kTabPts; }
 
 // The table image (host side; N = 65536).  shn[kap] = shape[kap] / N (l values); the factor 1/S^2 of the two radix-S layers is applied here.
+// half: the bank sits half a channel higher (f = l slot + l/2: channels centred on multiples of l).  That is the on-grid plan of the block
+// modulated by exp(-2 pi i (l/2) n / N) = W_N^((l/2) n1) (-1)^n2: the (-1)^n2 moves every column's spectrum by l/2 bins, which together with the
+// ifftshift of the inverse is the identity — the data stays in its registers and only the tables move (entries of kap ^ l/2), the separation's
+// and the re-join's twiddles cancel, and the per-column constant W_N^((l/2) n1) goes into TD (its e part) and cbt (its V part, fdc_api.hip).
 template <int S>
-static void narrow_tables(const float *shn, float2 *img)
+static void narrow_tables(const float *shn, float2 *img, bool half)
 {
     typedef NarGeom<S> GM;
     const double N = 65536.0;
@@ -97,11 +101,15 @@ static void narrow_tables(const float *shn, float2 *img)
     for (int b = 0; b < 16; b++)
         for (int p = 0; p < 16; p++) img[GM::kTWrow + b * 18 + p] = W(double((b * p) & 255), 256.0);
     for (int c = 0; c < 32; c++)
-        for (int q = 0; q < GM::kQG; q++) img[GM::kTB + c * GM::kRowQ + q] = W(double((16 * S * c * q) & 65535), N);
+        for (int q = 0; q < GM::kQG; q++) {
+            const int qt = half ? q ^ (GM::kQG / 2) : q;                 // the table entry of kap ^ l/2
+            img[GM::kTB + c * GM::kRowQ + q] = W(double((16 * S * c * qt) & 65535), N);
+        }
     for (int ps = 0; ps < 8; ps++)
         for (int b = 0; b < 16; b++)
             for (int q = 0; q < GM::kQG; q++) {
-                const double a = -2.0 * M_PI * double((512 * S * ps * q) & 65535) / N, s = double(shn[b + 16 * q]) / double(S * S);
+                const int qt = half ? q ^ (GM::kQG / 2) : q;
+                const double a = -2.0 * M_PI * double((512 * S * ps * qt) & 65535) / N, s = double(shn[b + 16 * qt]) / double(S * S);
                 img[GM::kTSA + (ps * 16 + b) * GM::kRowQ + q] = make_float2(float(s * std::cos(a)), float(s * std::sin(a)));
             }
     for (int b = 0; b < 16; b++)
@@ -109,7 +117,9 @@ static void narrow_tables(const float *shn, float2 *img)
             for (int q = 0; q < GM::kQG; q++) {
                 // column e: (-1)^n1 = (-1)^e, W_N^(e kap), the separation's conj(W_256^(e kap)) and the re-join's W_256^(e kap') at the shifted place
                 const int kap = b + 16 * q, kp = kap ^ (GM::kL / 2);
-                const double a = -2.0 * M_PI * double(e) * (double(kap) / N - double(kap) / 256.0 + double(kp) / 256.0);
+                // on the grid: W_N^(e kap), separation at kap, re-join at kap'; half: W_N^(e kap') W_N^(e l/2), separation and re-join both at kap
+                const double a = half ? -2.0 * M_PI * double(e) * (double(kp) + double(GM::kL / 2)) / N
+                                      : -2.0 * M_PI * double(e) * (double(kap) / N - double(kap) / 256.0 + double(kp) / 256.0);
                 const double sg = (e & 1) ? -1.0 : 1.0;
                 img[GM::kTTD + b * GM::kRowT + (e - 1) * GM::kQG + q] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
             }
@@ -122,15 +132,16 @@ static void narrow_tables(const float *shn, float2 *img)
     for (int c = 0; c < 32; c++)
         for (int klo = 0; klo < 8; klo++) img[GM::kTCt + c * 8 + klo] = W(double((c * klo) & 255), 256.0);
 }
-void poly_block_narrow_tables(int L, const float *shn, float2 *img)
+void poly_block_narrow_tables(int L, const float *shn, float2 *img, bool half)
 {
-    if (L == 128) narrow_tables<2>(shn, img); else narrow_tables<4>(shn, img);
+    if (L == 128) narrow_tables<2>(shn, img, half); else narrow_tables<4>(shn, img, half);
 }
 
 // R4 = true: relinvovl = 4 (the reference's default overlap): three quarters of every inverse transform are kept.  The rows t >= 128 of the
 // virtual column stay in the G registers as for R = 2; the rows 64 <= t < 128 go to 128 KiB of per-workgroup scratch ([pass][q - 4][thread]: the
 // L2 holds it) and come back for a second, 64-row run of stage 2 (the first 64/S output rows of the block), as in fdc_block256.hip.
-template <int S, bool NT, bool R4>
+// HALF = true: the bank half a channel higher (tables: narrow_tables(half)); in the kernel only the place the re-joined values go to changes.
+template <int S, bool NT, bool R4, bool HALF>
 __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                     const float2 *__restrict__ tab /* the table image */,
                                                     const float2 *__restrict__ cbt /* [256 V][16 b]  W_N^(S V b) */,
@@ -234,7 +245,7 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                     }
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const int q = 2 * g + h, qs = q ^ (kQG / 2);          // the shifted place
+                        const int q = 2 * g + h, qs = HALF ? q : q ^ (kQG / 2);   // the shifted place (HALF: the two shifts cancel)
                         const cf f = cmul(bt[h], sa[h]);                      // shape/(S^2 N) W_N^(S V 16 q) without the lane's W_N^(S V b) (cb, below)
                         if constexpr (S == 2) {
                             const cf z0 = v[rev16(q)], z1 = v[rev16(q + 8)];
@@ -390,33 +401,35 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
 hipError_t init_block_narrow_kernels()
 {
     hipError_t e = hipSuccess;
-#define FDC_SETN(S, A, B) \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<S, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<S>::kLds);
-    FDC_SETN(2, true, false) FDC_SETN(2, false, false) FDC_SETN(2, true, true) FDC_SETN(2, false, true)
-    FDC_SETN(4, true, false) FDC_SETN(4, false, false) FDC_SETN(4, true, true) FDC_SETN(4, false, true)
+#define FDC_SETN(S, A, B, H) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<S, A, B, H>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<S>::kLds);
+#define FDC_SETNS(S, H) FDC_SETN(S, true, false, H) FDC_SETN(S, false, false, H) FDC_SETN(S, true, true, H) FDC_SETN(S, false, true, H)
+    FDC_SETNS(2, false) FDC_SETNS(2, true) FDC_SETNS(4, false) FDC_SETNS(4, true)
+#undef FDC_SETNS
 #undef FDC_SETN
     return e;
 }
 
 hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tab,
                                     const float2 *cbt, const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                                    hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch)
+                                    hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch, bool half)
 {
     if (nb_chunk <= 0) return hipSuccess;
     if ((L != 128 && L != 64) || (R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
     const int rows = R == 4 ? 3 * L / 4 : L / 2;
-#define FDC_LNAR(S, A, B) \
-    hipExtLaunchKernelGGL((k_blknar<S, A, B>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
+#define FDC_LNAR(S, A, B, H) \
+    hipExtLaunchKernelGGL((k_blknar<S, A, B, H>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
                           slot_off, (long long)mbase * rows, (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr)
-#define FDC_LNARS(S) \
+#define FDC_LNARH(S, H) \
     do { \
-        if (R == 4) { if (hints & 1) FDC_LNAR(S, true, true); else FDC_LNAR(S, false, true); } \
-        else { if (hints & 1) FDC_LNAR(S, true, false); else FDC_LNAR(S, false, false); } \
+        if (R == 4) { if (hints & 1) FDC_LNAR(S, true, true, H); else FDC_LNAR(S, false, true, H); } \
+        else { if (hints & 1) FDC_LNAR(S, true, false, H); else FDC_LNAR(S, false, false, H); } \
     } while (0)
-    if (L == 128) FDC_LNARS(2); else FDC_LNARS(4);
-#undef FDC_LNARS
+    if (L == 128) { if (half) FDC_LNARH(2, true); else FDC_LNARH(2, false); }
+    else { if (half) FDC_LNARH(4, true); else FDC_LNARH(4, false); }
+#undef FDC_LNARH
 #undef FDC_LNAR
     return hipGetLastError();
 }

@@ -132,7 +132,8 @@ hipError_t init_block512_kernels();
 hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                 const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                                int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */);
+                                int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
+                                bool half = false /* the bank at f = 512 slot + 256: shn and cbt with their halves swapped, W_N^(256 n1) in cbt */);
 
 // uniform plan of 1024-bin channels on the 1024-bin grid, N = 65536, R = 2: one kernel, one block per CU (fdc_block1024.hip): the four phases of a
 // column's 1024 rows run the 256-point machinery side by side in the lanes of a quad.
@@ -141,7 +142,8 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
 hipError_t init_block1024_kernels();
 hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                  const float2 *tw1024, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                                 bool half = false /* the bank at f = 1024 slot + 512: the quarters of shn and cbt moved by two, W_N^(512 n1) in cbt */);
 
 // uniform plan of narrow channels (l = 128 or 64 bins on the l-bin grid), N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_blocknarrow.hip):
 // S = 256/l adjacent columns interleaved into one 256-point virtual column, separated and re-joined in registers.
@@ -149,11 +151,11 @@ hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out
 bool poly_block_narrow_supports(int N, int L, int R);
 hipError_t init_block_narrow_kernels();
 int poly_block_narrow_table_points(int L);
-void poly_block_narrow_tables(int L, const float *shn, float2 *img);
+void poly_block_narrow_tables(int L, const float *shn, float2 *img, bool half = false /* the bank at f = l slot + l/2; cbt then W_N^(S V (b + l/2)) */);
 hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tab,
                                     const float2 *cbt, const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int R = 2 /* 2 or 4 */,
-                                    float2 *scratch = nullptr /* R = 4: ncu x 16384 points */);
+                                    float2 *scratch = nullptr /* R = 4: ncu x 16384 points */, bool half = false);
 
 // forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
 hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,

@@ -1106,3 +1106,46 @@ def test_one_kernel_path_for_1024_bin_channels(oracle, nslots, nb):
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
     for c in range(len(chans)):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("L,R,nb", [(128, 2, 261), (64, 2, 37), (512, 2, 270), (1024, 2, 261), (128, 4, 9), (64, 4, 261), (512, 4, 7)])
+def test_banks_half_a_channel_higher(oracle, L, R, nb):
+    """Banks centred on multiples of l (f = l slot + l/2) on the block kernels of the widths other than 256: the block modulated by
+    exp(-2 pi i (l/2) n / N) moves every column's spectrum by half its length, which the kernels absorb in their tables (and one sign): the full
+    bank (all slots but the last, which would wrap) and a subset; against the oracle, against the spectrum path on every sample, ragged calls
+    (short launch groups included: this form has no two-launch fallback) bit for bit."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N = 65536
+    H = N - N // R
+    N1, lout = N // L, L - L // R
+    rng = np.random.default_rng(L + R)
+    wt = (L // 64 + R) % 3
+    x = noise(nb * H, 5 * L + R)
+    for slots in (list(range(N1 - 1)), sorted(int(v) for v in rng.permutation(N1 - 1)[:max(30, N1 // 9)])):
+        chans = [(L * c + L // 2, L, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = sorted(set([0, 1, len(chans) // 2, len(chans) - 1] + [int(v) for v in rng.integers(0, len(chans), 6)]))
+        for sl in (0, 255, 256, 511, 767):
+            if sl in slots and slots.index(sl) not in check:
+                check.append(slots.index(sl))
+        sub = [chans[c] for c in check]
+        k = min(nb, 3)
+        ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * lout
+            assert_close(outs[c][:k * lout], ref[i], "l %d slot %d head" % (L, slots[c]))
+            assert_close(outs[c][t0 * lout:], ref2[i], "l %d slot %d tail" % (L, slots[c]))
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+        assert q.path() == 1
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "l %d slot %d vs the spectrum path" % (L, slots[c]))
+        p.reset()
+        cuts = [(0, 1), (1, 3), (3, max(3, nb // 2)), (max(3, nb // 2), nb)]
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])

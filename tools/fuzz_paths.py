@@ -28,8 +28,9 @@ def draw_plan(rng):
     kind = rng.integers(0, 8)
     if kind >= 6:                                     # uniform banks of another width on its grid: 1024, 512, 128, 64 (block kernels), others (spectrum path)
         L = int([512, 128, 1024, 1024, 64, 2048][int(rng.integers(0, 6))])
-        slots = rng.permutation(N // L)[:rng.integers(1, N // L + 1)]
-        return [(L * int(c), L, 0.88, 1.0) for c in slots], "bank l=%d" % L
+        half = L // 2 if rng.integers(0, 3) == 0 else 0      # a bank centred on multiples of l (block kernels: tables moved by half a channel)
+        slots = rng.permutation(N // L - (1 if half else 0))[:rng.integers(1, N // L + (0 if half else 1))]
+        return [(L * int(c) + half, L, 0.88, 1.0) for c in slots], "bank l=%d%s" % (L, "+l/2" if half else "")
     if kind == 0:                                     # on-grid subset
         slots = rng.permutation(256)[:rng.integers(1, 257)]
         return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "grid"
