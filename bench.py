@@ -656,9 +656,10 @@ def main():
     # (Its sub-batches of 32 blocks take the tiled kernels, not the block kernel: the rocprofv3 average of the dominant kernel over
     # this command is still the average of the settle / warm-up / timed launches.)
     end_to_end, end_to_end_group = None, None
-    if sinks is None and a.config == 2 and not a.no_end_to_end and not a.no_kernel_timing:
+    if sinks is None and a.config in (1, 2) and not a.no_end_to_end and not a.no_kernel_timing:
         fence()
-        end_to_end = host_entry_leg(G, np, N, R, plan, sum_lout, [local], 256)
+        e2e_blocks = 256 if N >= 65536 else max(256, (256 * 65536) // N)      # about the same bytes per call whatever the block length
+        end_to_end = host_entry_leg(G, np, N, R, plan, sum_lout, [local], e2e_blocks)
         if dist is not None:
             t = torch.tensor([end_to_end["value"]], device="cpu" if rehearse else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -667,7 +668,7 @@ def main():
             end_to_end["ranks"] = world
         elif not rehearse:
             devs = list(range(ndev)) if ndev > 1 else [0, 0]
-            end_to_end_group = host_entry_leg(G, np, N, R, plan, sum_lout, devs, 256)
+            end_to_end_group = host_entry_leg(G, np, N, R, plan, sum_lout, devs, e2e_blocks)
             if ndev == 1:
                 end_to_end_group["note"] = "one GPU visible: two VIRTUAL members on device 0 share its one PCIe link (dispatcher exercised, no gain expected)"
     msps = world * nb * H * a.steps / dt / 1e6
