@@ -1149,3 +1149,21 @@ def test_banks_half_a_channel_higher(oracle, L, R, nb):
         parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+def test_hier_block_with_a_bank_centred_on_multiples_of_the_channel_width(oracle):
+    """The hier block face with 511 channels of 0.8/512 of the band centred on k/512 (user frequencies k/512 - 0.5): the reference's parameter
+    derivation gives l = 128 at f = 128 k - 64, a bank half a channel off the 128-bin grid, which takes the narrow-channel block kernel."""
+    N, R, C = 65536, 2, 512
+    user = [[k / C - 0.5, 0.8 / C] for k in range(1, C)]
+    fdc = G.FrequencyDomainChannelizer(8, 1, N, R, user, None, 6.0, 1.0, 0.0, 'normalized', 1,
+                                       False, False, "", False, None, 10.0, 0.005, 1, 0.2, 0, 0, 128, 128, False, max_blocks=8)
+    assert [cp[:3] for cp in fdc.channel_params[:3]] == [(64, 128, 64), (192, 128, 64), (320, 128, 64)]
+    assert fdc.pipeline.path() == 3
+    x = noise(8 * fdc.inpblocklen, 4242)
+    ports = fdc.work(x)
+    check = [0, 1, 255, 256, 509, 510]
+    plan = [tuple(fdc.channel_params[c][i] for i in (0, 1, 3, 4)) for c in check]
+    ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+    for i, c in enumerate(check):
+        assert_close(ports[c], ref[i], "port %d" % c)
