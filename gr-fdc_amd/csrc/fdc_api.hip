@@ -404,6 +404,15 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (ch.stopbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be <= 0", c);
         if (ch.stopbw < ch.passbw) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be < PassBw", c);
     }
+    {
+        // several kernels address a call's output with 32-bit byte offsets (buffer descriptors; offsets from 0xFFFFFFF0 up mean "no store"):
+        // one call produces less than 4 GiB.  A stream is cut into more calls, not bigger ones.
+        int64_t per_block = 0;
+        for (int c = 0; c < cfg->nchannels; c++) per_block += cfg->channels[c].l - cfg->channels[c].l / R;
+        if (per_block * 8 * (int64_t)cfg->max_blocks > 0xFFFFF000ll)
+            return fail(FDC_ERR_INVALID_ARGUMENT, "max_blocks %d x %lld output samples per block is more than the 4 GiB one call may produce (at most %lld blocks per call for this plan)",
+                        cfg->max_blocks, (long long)per_block, (long long)(0xFFFFF000ll / (per_block * 8)));
+    }
     int rc = select_device(cfg->device_id);
     if (rc != FDC_OK) return rc;
 

@@ -77,7 +77,9 @@ typedef struct {
     int32_t windowtype;     /* FDC_WIN_* (hier block "windowtype", py:227)                            */
     int32_t nchannels;
     const fdc_channel *channels;
-    int32_t max_blocks;     /* largest nblocks a single work()/process call will carry               */
+    int32_t max_blocks;     /* largest nblocks a single work()/process call will carry; max_blocks x (sum of the channels' kept
+                               samples per block) x 8 bytes must stay below 4 GiB (32-bit output offsets inside one call):
+                               FDC_ERR_INVALID_ARGUMENT otherwise                                    */
     int32_t chunk_blocks;   /* blocks per internal launch group (0 = as many as a 2 GiB scratch budget
                                allows: long launches measured faster than cache-sized ones)          */
     int32_t keep_spectrum;  /* != 0: keep the whole normalised spectrum of a call (debug port, py:314) */

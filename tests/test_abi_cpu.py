@@ -179,3 +179,14 @@ def test_group_entry_points_validate_without_a_device():
     assert G.lib().fdc_pipeline_group_create(C.byref(cfg), devs, 65, 0, C.byref(h)) == -1
     assert G.lib().fdc_pipeline_group_size(None) == -1 and not G.lib().fdc_pipeline_group_member(None, 0)
     G.lib().fdc_pipeline_group_destroy(None)
+
+
+def test_a_call_may_not_produce_4_gib_of_output():
+    """Several kernels address one call's output with 32-bit byte offsets: max_blocks x (kept samples per block) x 8 bytes below 4 GiB is checked
+    before any device is touched (the headline plan: 32768 samples per block -> at most 16383 blocks per call)."""
+    import ctypes as C
+    chans = (_lib.fdc_channel * 256)(*[_lib.fdc_channel(256 * c, 256, 0.88, 1.0) for c in range(256)])
+    h = C.c_void_p()
+    cfg = _lib.fdc_pipeline_cfg(0, 65536, 2, 1, 256, chans, 16384, 0, 0, 0, 0, 0)
+    assert G.lib().fdc_pipeline_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"4 GiB" in G.lib().fdc_last_error() and b"16383" in G.lib().fdc_last_error()
