@@ -60,8 +60,18 @@ constexpr int kKOffSh = kKOffB + 64 * 18 * 8;                    // [4 i][16 b][
 constexpr int kKOffSoff = kKOffSh + 4 * 16 * 20 * 4;             // [8 klo][8] output offsets (bytes)
 constexpr int kKLds = kKOffSoff + 64 * 4;                        // 96000
 static_assert(kKTrip <= kKOffX, "the trip buffer lies over the strips, below the tables");
+// STAGED loads (below): the next pass's 8 columns x 1024 rows as [column][row] planes, 8 points of padding per plane (a 16-byte load's two
+// columns and the four column pairs of a store instruction on different bank halves)
+constexpr int kKStagePlane = 1024 + 8;
+constexpr int kKOffStage = kKLds;
+constexpr int kKLdsStaged = kKOffStage + 8 * kKStagePlane * 8;   // 162048 <= 163840
+static_assert(kKLdsStaged <= 160 * 1024, "LDS budget");
 
-template <bool NT>
+// STAGED = true: the rows reach the lanes through LDS.  One column per wave means a wave's own load instruction is 64 single samples from 64 rows
+// (64 cache lines); staged, the workgroup's eight waves fetch the pass's 8 columns x 1024 rows in 16-byte pieces of whole 64-byte row segments (wave w:
+// rows 128 w .., 16 rows x 4 column pairs per instruction: 16 lines, half the instructions), park them in registers for a pass as before, write them to
+// [column][row] planes in LDS at the pass boundary and read their own column back: two workgroup barriers per pass for an eighth of the line requests.
+template <bool NT, bool STAGED>
 __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw256, const float2 *__restrict__ tw1024 /* W_1024^k, k < 1024 */,
                                                       const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
@@ -96,7 +106,30 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 64u * 64u * 8u);
     const unsigned voffc = (unsigned)(w * 64 + b + 16 * iq) * 8u;
     cf LA[16], LB[16], cbA, cbB;
-    {
+    // staged: wave w fetches rows 128 w + 16 i + (lane >> 2), columns 2 (lane & 3), + 1 of the pass (16 bytes); instruction i adds 16 rows = 8 KiB
+    float2 *stg = reinterpret_cast<float2 *>(fdc_smem_b1k + kKOffStage);
+    const unsigned voffs = (unsigned)((128 * w + (lane >> 2)) * 64 + 2 * (lane & 3)) * 8u;
+    float2 *const stw = stg + 2 * (lane & 3) * kKStagePlane + 128 * w + (lane >> 2);       // + 16 i rows; second column: + one plane
+    const float2 *const strd = stg + w * kKStagePlane + lane;                              // this lane's rows 64 a + lane of column w
+    u32x4 PF[8];
+    auto stage_load = [&](int mb, int pn) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 8 * pn, inbytes);
+#pragma unroll
+        for (int i = 0; i < 8; i++) PF[i] = bld4(rin, voffs, (unsigned)i * 8192u);
+    };
+    auto stage_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            st2(&stw[16 * i], mk(__uint_as_float(PF[i].x), __uint_as_float(PF[i].y)));
+            st2(&stw[kKStagePlane + 16 * i], mk(__uint_as_float(PF[i].z), __uint_as_float(PF[i].w)));
+        }
+    };
+    if constexpr (STAGED) {
+        stage_load(first, 0);
+        cbA = bld2(rcb, voffc, 0);
+        stage_write();                                           // pass 0 of the first block: visible after the barrier behind the tables
+        stage_load(first, 1);
+    } else {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
         for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * 32768u);
@@ -133,7 +166,17 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
         const int mnext = m + grid < nb ? m + grid : m;
         k8v G[8];
         auto one_pass = [&](const int ps, cf (&cur)[16], const cf cb, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
-            {
+            if constexpr (STAGED) {
+                // the pass's rows are in the planes (written a pass ago, or by the prologue): take this lane's sixteen, then hand the planes over to
+                // the rows that arrived in the meantime (pass + 1) and request pass + 2
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < 16; a++) cur[a] = ld2(&strd[64 * a]);
+                __syncthreads();
+                stage_write();
+                stage_load(ps < 6 ? m : mnext, (ps + 2) & 7);
+                cbn = bld2(rcb, voffc, (unsigned)((ps + 1) & 7) * 4096u);
+            } else {
                 const int pn = ps < 7 ? ps + 1 : 0;
                 const int mb = ps < 7 ? m : mnext;
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 8 * pn, inbytes);
@@ -276,10 +319,17 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     }
 }
 
+#ifndef FDC_1K_STAGED
+#define FDC_1K_STAGED 1
+#endif
+
 hipError_t init_block1024_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kKLds);
+    hipError_t e = hipSuccess;
+#define FDC_SET1K(A, B) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kKLdsStaged : kKLds);
+    FDC_SET1K(true, false) FDC_SET1K(false, false) FDC_SET1K(true, true) FDC_SET1K(false, true)
+#undef FDC_SET1K
     return e;
 }
 
@@ -290,9 +340,10 @@ hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out
     if (nb_chunk <= 0) return hipSuccess;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
+    constexpr bool kStaged = FDC_1K_STAGED != 0;
 #define FDC_L1K(A) \
-    hipExtLaunchKernelGGL((k_blk1024<A>), dim3((unsigned)grid), dim3(512), kKLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw1024, twq, \
-                          cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints, half ? 1 : 0)
+    hipExtLaunchKernelGGL((k_blk1024<A, kStaged>), dim3((unsigned)grid), dim3(512), kStaged ? kKLdsStaged : kKLds, s, ev_start, ev_stop, 0u, in, in_stride, \
+                          out, tw256, tw1024, twq, cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints, half ? 1 : 0)
     if (hints & 1) FDC_L1K(true); else FDC_L1K(false);
 #undef FDC_L1K
     return hipGetLastError();

@@ -67,6 +67,11 @@ __device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p
 
 // 16-byte buffer store of two complex values (NT: streamed, aux bit 1)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte buffer load (two complex values)
+__device__ __forceinline__ u32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
 template <bool NT>
 __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, cf a, cf b)
 {
