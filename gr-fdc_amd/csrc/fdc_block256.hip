@@ -83,6 +83,18 @@ struct BlkGeom {
     static constexpr int kOffWrowF = kOffSoffOff + kN1 * 4;
     static constexpr int kLdsOff = kOffWrowF + 16 * 18 * 8;       // P = 8: 163584 <= 163840
     static_assert(kLdsOff <= 160 * 1024 && kLds <= 160 * 1024, "LDS budget");
+    // STG (P = 8): the pass's 32 columns x 256 rows staged in LDS as [row][34] (rows 68 dwords apart: the sixteen lanes of a 16-byte store cover a row's
+    // 64 banks, the sixteen row groups x four columns of an 8-byte read fall on every bank twice — the minimum for 512 bytes), behind the strips;
+    // the tables move up by 2 KiB and the SA rows give up their padding for it
+    static constexpr int kPlLd = 34;
+    static constexpr int kOffPl = kBlkOffX;
+    static constexpr int kPlBytes = 256 * kPlLd * 8;              // 69632
+    static constexpr int kOffWrowS = kOffPl + kPlBytes;           // 139008
+    static constexpr int kOffBS = kOffWrowS + 16 * 18 * 8;
+    static constexpr int kOffSAS = kOffBS + 32 * 18 * 8;
+    static constexpr int kOffSoffS = kOffSAS + 16 * P * 16 * 8;
+    static constexpr int kLdsS = kOffSoffS + kN1 * 4;             // P = 8: 163328
+    static_assert(P != 8 || kLdsS <= 160 * 1024, "LDS budget (staged)");
     static_assert(kOffCt >= kBlkOffX && kOffCt + 32 * P * 8 <= kOffWrow, "stage-2 trip buffer and twiddles below the tables, tables above the strips");
     static_assert((16 * (kJB - 1) * kLd + 32 * (P - 1)) * 8 < 65536, "ds offsets of a base register");
 };
@@ -113,7 +125,12 @@ __device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
     }
 }
 
-template <int P, bool NT, bool OFF, bool FWD, bool R4 = false>
+// STG = true (P = 8, the plain channelizer): the input rows reach the lanes through LDS.  A wave's own load instruction is 16 rows x 32 bytes (16 cache
+// lines, each of which four waves ask for); staged, wave w fetches rows 32 w .. of the pass's 32 columns in 16-byte pieces of whole 256-byte row
+// segments (4 rows per instruction: 8 lines, half the instructions: a quarter of the line requests), keeps them in registers for a pass as before, writes
+// them to [row][34] in LDS at the pass boundary and reads its own column's sixteen rows back: two workgroup barriers per pass (profiles/r04/NOTES.md
+// section 11; the same move took k_blk1024 from 0.20 to 0.30; here it costs 1.5 %: a build variant, -DFDC_BLK_STAGED=1).
+template <int P, bool NT, bool OFF, bool FWD, bool R4 = false, bool STG = false>
 __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -124,14 +141,15 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
 {
     typedef BlkGeom<P> GM;
     static_assert(!FWD || P == 8, "the forward-transform variant exists for N = 65536 only");
+    static_assert(!STG || (P == 8 && !OFF && !FWD && !R4), "staged loads: the plain channelizer at N = 65536");
     constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: the trip buffer
-    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffWrow);     // [b][p] = W256^(b p), rows of 18
-    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffB);          // [c5][q] = W_N^(16 c5 q)
-    float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffSA);         // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
-    // offset plans need a second twiddle table: the SA rows give up their padding for it (2-way conflicts on 8 reads per pass)
-    constexpr int kSaLd = OFF ? 16 : 18;
-    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (OFF ? GM::kOffSoffOff : GM::kOffSoff));
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffWrowS : GM::kOffWrow));     // [b][p] = W256^(b p), rows of 18
+    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffBS : GM::kOffB));             // [c5][q] = W_N^(16 c5 q)
+    float2 *SA = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffSAS : GM::kOffSA));           // [pass][b][q] = shape[b+16q]/N * W_N^(512 pass q)
+    // offset plans need a second twiddle table, staged loads 2 KiB more for the rows: the SA rows give up their padding (2-way conflicts on 8 reads per pass)
+    constexpr int kSaLd = (OFF || STG) ? 16 : 18;
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_blk + (STG ? GM::kOffSoffS : OFF ? GM::kOffSoffOff : GM::kOffSoff));
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffCt);       // [c5][klo] = W_N1^(c5 klo): stage 2, after the DFT-P
     const int tid = threadIdx.x;
     // stage-1 roles
@@ -166,7 +184,21 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
     const unsigned voffc = (unsigned)(c5 * 16 + b) * 8u;
     // two row sets: a pass computes on one while the rows of the next pass arrive in the other (no register copies between passes)
     cf LA[16], LB[16], cbA, cbB;
-    {
+    // staged: wave w fetches rows 32 w + 4 i + (lane >> 4), columns 2 (lane & 15), + 1 of the pass (16 bytes); instruction i adds 4 rows = 8 KiB
+    [[maybe_unused]] float2 *pl = reinterpret_cast<float2 *>(fdc_smem_blk + GM::kOffPl);
+    [[maybe_unused]] const unsigned voffs = (unsigned)((32 * w + (lane >> 4)) * kN1 + 2 * (lane & 15)) * 8u;
+    [[maybe_unused]] float2 *const plw = pl + (32 * w + (lane >> 4)) * GM::kPlLd + 2 * (lane & 15);      // + 4 i rows
+    [[maybe_unused]] const float2 *const plr = pl + b * GM::kPlLd + c5;                                   // this lane's rows 16 a + b of column c5
+    [[maybe_unused]] u32x4 PF[8];
+    [[maybe_unused]] auto stage_load = [&](int mb, int pn) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 32 * pn, inbytes);
+#pragma unroll
+        for (int i = 0; i < 8; i++) PF[i] = bld4(rin, voffs, (unsigned)i * 4u * (unsigned)kN1 * 8u);
+    };
+    if constexpr (STG) {
+        stage_load(first, 0);
+        cbA = bld2(rcb, voffc, 0);
+    } else {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
         for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * kRowGrp);
@@ -253,7 +285,22 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
             }
 #endif
             const cf cb = OFF ? cbc * sgn : cbc;
-            {
+            if constexpr (STG) {
+                // the rows of this pass arrived in PF during the pass before: into the planes, this lane's sixteen back out, then the next pass's
+                // rows (of this block, or pass 0 of this workgroup's next block, kept in PF across stage 2) are requested
+#pragma unroll
+                for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4 *>(&plw[4 * i * GM::kPlLd]) = PF[i];
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < 16; a++) cur[a] = ld2(&plr[16 * a * GM::kPlLd]);
+                __syncthreads();                                  // every lane has its rows: the planes may be rewritten
+                stage_load(ps < P - 1 ? m : mnext, ps < P - 1 ? ps + 1 : 0);
+                cbn = bld2(rcb, voffc, (unsigned)(ps < P - 1 ? ps + 1 : 0) * 4096u);
+                if (ps == P - 1) {
+                    // stage 2's twiddles live where the planes' last rows were: rebuilt for every block (stage 2 reads them behind its first barrier)
+                    for (int i = tid; i < 32 * P; i += 512) ctab[i] = tw256[((i / P) * (i % P) * (8 / P)) & 255];
+                }
+            } else {
                 const int pn = ps < P - 1 ? ps + 1 : 0;
                 const int mb = ps < P - 1 ? m : mnext;
                 // the pass offset (32 columns) sits in the descriptor's base: every pass uses the same per-lane offset and the
@@ -484,6 +531,12 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
     }
 }
 
+// -DFDC_BLK_STAGED=1: the plain channelizer at N = 65536 with its loads staged through LDS (the STG variant above): measured 1.5 % SLOWER than the
+// shipped form (profiles/r04/NOTES.md section 11), kept as a build variant
+#ifndef FDC_BLK_STAGED
+#define FDC_BLK_STAGED 0
+#endif
+
 hipError_t init_block_kernels()
 {
     hipError_t e;
@@ -498,6 +551,12 @@ hipError_t init_block_kernels()
     FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false)
 #undef FDC_SETP
 #undef FDC_SETB
+#if FDC_BLK_STAGED
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, false, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
+    if (e != hipSuccess) return e;
+#endif
     return hipSuccess;
 }
 
@@ -530,6 +589,17 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
         else if (r & 255) { if (hints & 1) FDC_LB(P, true, true, false); else FDC_LB(P, false, true, false); } \
         else { if (hints & 1) FDC_LB(P, true, false, false); else FDC_LB(P, false, false, false); } \
     } while (0)
+#if FDC_BLK_STAGED
+    if (N == 65536 && R == 2 && !(r & 255)) {
+        // the plain channelizer with its loads staged through LDS
+#define FDC_LS(A) \
+        hipExtLaunchKernelGGL((k_blk256<8, A, false, false, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<8>::kLdsS, s, ev_start, ev_stop, 0u, in, \
+                              in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, 0, \
+                              first_block, (float2 *)nullptr, (const unsigned *)nullptr)
+        if (hints & 1) FDC_LS(true); else FDC_LS(false);
+#undef FDC_LS
+    } else
+#endif
     if (N == 65536) FDC_LP(8); else if (N == 32768) FDC_LP(4); else FDC_LP(2);
 #undef FDC_LP
 #undef FDC_LB
