@@ -54,16 +54,26 @@ constexpr int k5Trip = 64 * k5Ld * 8;                            // 68608 <= the
 constexpr int k5OffCt = k5OffX;                                  // [16 c4][8 klo]  W_128^(c4 klo)
 constexpr int k5OffWrow = k5OffCt + 16 * 8 * 8;                  // [16][18]  W_256^(b p)
 constexpr int k5OffT512 = k5OffWrow + 16 * 18 * 8;               // [2 par][16][18]  par 1: W_512^(b + 16 q); par 0: 1 (the same code for both lanes of a pair)
-constexpr int k5OffB = k5OffT512 + 2 * 16 * 18 * 8;              // [8 pass][16 c4][18]  W_N^(16 n1 q), n1 = 16 pass + c4 (the LDS has the room)
-constexpr int k5OffSh = k5OffB + 8 * 16 * 18 * 8;                // [32 = b + 16 h][16] floats: shape[b + 16 q + 256 h] / N
+constexpr int k5OffB = k5OffT512 + 2 * 16 * 18 * 8;              // [8 pass][16 c4][16]  W_N^(16 n1 q), n1 = 16 pass + c4 (rows unpadded: a wave reads two of them, broadcast)
+constexpr int k5OffSh = k5OffB + 8 * 16 * 16 * 8;                // [32 = b + 16 h][16] floats: shape[b + 16 q + 256 h] / N
 constexpr int k5OffSoff = k5OffSh + 32 * 16 * 4;                 // [8 klo][16] output offsets (bytes)
-constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 80896
+constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 96256
 static_assert(k5Trip <= k5OffX, "the trip buffer lies over the strips, below the tables");
+// STAGED loads (below): the next pass's 16 columns x 512 rows as [column][row] planes, 4 points of padding per plane (the eight column pairs of a store
+// instruction, 8 rows each, on all banks twice: the minimum)
+constexpr int k5StagePlane = 512 + 4;
+constexpr int k5OffStage = k5Lds;
+constexpr int k5LdsStaged = k5OffStage + 16 * k5StagePlane * 8;   // 162304
+static_assert(k5LdsStaged <= 160 * 1024, "LDS budget");
 
 // R4 = true: relinvovl = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept.  The rows m >= 128 of
 // both parities stay in the G registers as for R = 2 (output rows 128 ..); the rows 64 <= m < 128 go to 128 KiB of per-workgroup scratch
 // ([pass][q - 4][thread]: the L2 holds it) and come back for a third, 128-row run of stage 2 (output rows 0 .. 127), as in fdc_block256.hip.
-template <bool NT, bool R4>
+// STAGED = true: the rows reach the lanes through LDS, as in fdc_block1024.hip.  A wave's own load instruction is 32 rows x 16 bytes (32 cache lines);
+// staged, wave w fetches rows 64 w .. of the pass's 16 columns in 16-byte pieces of whole 128-byte row segments (8 rows per instruction: 8 lines, half the
+// instructions), parks them in registers for a pass, writes them to [column][row] planes in LDS at the pass boundary and reads its own columns' rows back:
+// two workgroup barriers per pass for an eighth of the line requests.
+template <bool NT, bool R4, bool STAGED>
 __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw256, const float2 *__restrict__ tw512 /* W_512^k, k < 256 */,
                                                       const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
@@ -98,7 +108,30 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 128u * 32u * 8u);
     const unsigned voffc = (unsigned)(c4 * 32 + b + 16 * par) * 8u;
     cf LA[16], LB[16], cbA, cbB;
-    {
+    // staged: wave w fetches rows 64 w + 8 i + (lane >> 3), columns 2 (lane & 7), + 1 of the pass (16 bytes); instruction i adds 8 rows = 8 KiB
+    [[maybe_unused]] float2 *stg = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffStage);
+    [[maybe_unused]] const unsigned voffs = (unsigned)((64 * w + (lane >> 3)) * 128 + 2 * (lane & 7)) * 8u;
+    [[maybe_unused]] float2 *const stw = stg + 2 * (lane & 7) * k5StagePlane + 64 * w + (lane >> 3);     // + 8 i rows; second column: + one plane
+    [[maybe_unused]] const float2 *const strd = stg + c4 * k5StagePlane + 2 * b + par;                    // this lane's rows 32 a + 2 b + par of column c4
+    [[maybe_unused]] u32x4 PF[8];
+    [[maybe_unused]] auto stage_load = [&](int mb, int pn) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
+#pragma unroll
+        for (int i = 0; i < 8; i++) PF[i] = bld4(rin, voffs, (unsigned)i * 8192u);
+    };
+    [[maybe_unused]] auto stage_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            st2(&stw[8 * i], mk(__uint_as_float(PF[i].x), __uint_as_float(PF[i].y)));
+            st2(&stw[k5StagePlane + 8 * i], mk(__uint_as_float(PF[i].z), __uint_as_float(PF[i].w)));
+        }
+    };
+    if constexpr (STAGED) {
+        stage_load(first, 0);
+        cbA = bld2(rcb, voffc, 0);
+        stage_write();                                           // pass 0 of the first block: visible after the barrier behind the tables
+        stage_load(first, 1);
+    } else {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
         for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * 32768u);
@@ -110,7 +143,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
         t512[(16 + (i & 15)) * 18 + (i >> 4)] = tw512[i];                // [1][b][q] = W_512^(b + 16 q), i = b + 16 q
         t512[(i & 15) * 18 + (i >> 4)] = make_float2(1.f, 0.f);
     }
-    for (int i = tid; i < 2048; i += 512) Bt[(i >> 4) * 18 + (i & 15)] = twq[i];   // [n1 = i >> 4][q]: twq is [n1][16] already
+    for (int i = tid; i < 2048; i += 512) Bt[i] = twq[i];                                 // [n1 = i >> 4][q]: twq is [n1][16] already
     for (int i = tid; i < 128; i += 512) {
         const long long o = slot_off[i];                                  // slot i = klo + 8 khi is entry [klo][rev16(khi)]
         soff[(i & 7) * 16 + rev16(i >> 3)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
@@ -123,7 +156,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     const float2 *const scrr = scr + w * k5ScrPts + vc + 68 * b;
     const float2 *const wr = wrow + b * 18;
     const float2 *const t5r = t512 + (16 * par + b) * 18;
-    const float2 *const btr = Bt + c4 * 18;                              // + pass * 16 rows
+    const float2 *const btr = Bt + c4 * 16;                              // + pass * 16 rows
     const float *const shr = Sh + (b + 16 * par) * 16;
     const float fsgn = par ? -1.0f : 1.0f;                                // the sign of a lane's own term in both radix-2 layers
     const float hsgn = (half && par) ? -1.0f : 1.0f;
@@ -135,7 +168,17 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
         const int mnext = m + grid < nb ? m + grid : m;
         g8v G[8];
         auto one_pass = [&](const int ps, cf (&cur)[16], const cf cb, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
-            {
+            if constexpr (STAGED) {
+                // the pass's rows are in the planes (written a pass ago, or by the prologue): take this lane's sixteen, then hand the planes over to
+                // the rows that arrived in the meantime (pass + 1) and request pass + 2
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < 16; a++) cur[a] = ld2(&strd[32 * a]);
+                __syncthreads();
+                stage_write();
+                stage_load(ps < 6 ? m : mnext, (ps + 2) & 7);
+                cbn = bld2(rcb, voffc, (unsigned)((ps + 1) & 7) * 4096u);
+            } else {
                 const int pn = ps < 7 ? ps + 1 : 0;
                 const int mb = ps < 7 ? m : mnext;
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
@@ -170,7 +213,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             // One value at a time, 8-byte table reads: the kernel has no registers for wider ones.
             cf u[16];
             {
-                const float2 *bpr = btr + ps * (16 * 18);
+                const float2 *bpr = btr + ps * (16 * 16);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {                                     // four values at a time: 16-byte table reads, not hoisted further
                     const float4 ta = ld4(&t5r[4 * g4]), tb = ld4(&t5r[4 * g4 + 2]), ba = ld4(&bpr[4 * g4]), bb4 = ld4(&bpr[4 * g4 + 2]);
@@ -294,12 +337,18 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     }
 }
 
+#ifndef FDC_512_STAGED
+#define FDC_512_STAGED 1
+#endif
+
 hipError_t init_block512_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, k5Lds);
+    hipError_t e = hipSuccess;
+#define FDC_SET5(A, B, C) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, C ? k5LdsStaged : k5Lds);
+    FDC_SET5(true, false, false) FDC_SET5(false, false, false) FDC_SET5(true, true, false) FDC_SET5(false, true, false)
+    FDC_SET5(true, false, true) FDC_SET5(false, false, true) FDC_SET5(true, true, true) FDC_SET5(false, true, true)
+#undef FDC_SET5
     return e;
 }
 
@@ -312,9 +361,11 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
     if ((R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
+    constexpr bool kStaged = FDC_512_STAGED != 0;
 #define FDC_L512(A, B) \
-    hipExtLaunchKernelGGL((k_blk512<A, B>), dim3((unsigned)grid), dim3(512), k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, tw256, tw512, twq, \
-                          cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr, half ? 1 : 0)
+    hipExtLaunchKernelGGL((k_blk512<A, B, kStaged>), dim3((unsigned)grid), dim3(512), kStaged ? k5LdsStaged : k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
+                          tw256, tw512, twq, cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, \
+                          B ? scratch : (float2 *)nullptr, half ? 1 : 0)
     if (R == 4) { if (hints & 1) FDC_L512(true, true); else FDC_L512(false, true); }
     else { if (hints & 1) FDC_L512(true, false); else FDC_L512(false, false); }
 #undef FDC_L512
