@@ -10,8 +10,8 @@
 //     inverse (decimation in frequency):  g[4 m + rho'] = IFFT256{ (-1)^rho' conj(W_1024^(kap rho')) sum_i W_4^(-i rho') U[kap + 256 i] }[m]
 //                                    bit-swapped lane order in, lane rho' holds phase rho' afterwards
 //     kept: t = 4 m + rho' >= 512  <=>  m >= 128: eight values per lane and pass, as before: G is 8 passes x 8 = 128 VGPRs.
-// A wave owns one column per pass, the workgroup 8: 8 passes for the 64 columns.  A wave's load instruction is 64 single 8-byte samples, one per row
-// (the eight waves of the workgroup cover 64 contiguous bytes of each row in the same pass): the worst-shaped loads of the family.
+// A wave owns one column per pass, the workgroup 8: 8 passes for the 64 columns.  A wave's own load instruction would be 64 single 8-byte samples, one
+// per row (64 cache lines): the rows are fetched by the workgroup as whole 64-byte row segments and handed over through LDS instead (STAGED, below).
 // Stage 2 is the FFT-64 over the columns n1 = 8 pass + c3: DFT-8 over the pass index in registers, W_64^(c3 klo), one trip through LDS
 // ([128 rows][8 klo][8 c3], four trips for the 512 kept rows), DFT-8 over c3 in the lane that owns (row, klo); a wave's store is 64 consecutive
 // samples of one channel.
