@@ -143,7 +143,7 @@ struct fdc_pipeline {
     bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
     float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
     bool poly_half = false;      // the bank of a width's block kernel sits half a channel higher: f = l slot + l/2 (channels centred on multiples of l)
-    bool poly_b1024 = false;     // l = 1024 at N = 65536, R = 2: the block kernel of fdc_block1024.hip
+    bool poly_b1024 = false;     // l = 1024 at N = 65536, R = 2 or 4: the block kernel of fdc_block1024.hip
     float2 *d_tw1k = nullptr, *d_twq1k = nullptr, *d_cbt1k = nullptr;
     bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
     float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
@@ -479,9 +479,9 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
         // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
         const bool b512 = L == 512 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
-        // l = 1024: the block kernel costs 0.335 ms per 1024 blocks whatever the number of channels, the spectrum path 0.25 + 0.19 C/64 by the
-        // cost rule of the split plans (measured: 0.42 for the full bank): the kernel from 29 channels up
-        const bool b1024 = L == 1024 && N == 65536 && R == 2 && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 29 || (flags & FDC_PIPE_WIDE_UNIFORM));
+        // l = 1024: the block kernel costs 0.222 ms per 1024 blocks whatever the number of channels, the spectrum path 0.20 + 0.24 C/64 by the
+        // cost rule of the split plans: the kernel from 6 channels up
+        const bool b1024 = L == 1024 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 6 || (flags & FDC_PIPE_WIDE_UNIFORM));
         const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
         uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || b1024 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
         // on the l-bin grid, or (block kernels of the other widths only) all half a channel higher: a bank centred on multiples of l
@@ -815,7 +815,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizer's rows 64..127
-    if (p->fwd_block || ((p->poly_block || p->poly_b512 || p->poly_bnar) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    if (p->fwd_block || ((p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
     if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
         std::vector<char> g64((size_t)N / 64, 0);
         bool all = true;
@@ -1070,7 +1070,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             HIPCHK(fdc::launch_poly_block1024(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
                                               p->d_tw1k, p->d_twq1k, p->d_cbt1k, p->d_shn, p->d_slot_off,
                                               (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->poly_half));
+                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->poly_half, p->R, p->d_fscr));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

@@ -71,14 +71,17 @@ static_assert(kKLdsStaged <= 160 * 1024, "LDS budget");
 // (64 cache lines); staged, the workgroup's eight waves fetch the pass's 8 columns x 1024 rows in 16-byte pieces of whole 64-byte row segments (wave w:
 // rows 128 w .., 16 rows x 4 column pairs per instruction: 16 lines, half the instructions), park them in registers for a pass as before, write them to
 // [column][row] planes in LDS at the pass boundary and read their own column back: two workgroup barriers per pass for an eighth of the line requests.
-template <bool NT, bool STAGED>
+// R4 = true: relinvovl = 4 (the reference's default overlap): 768 of the 1024 samples of every inverse transform are kept.  The rows m >= 128 of all four
+// phases stay in the G registers as for R = 2 (output rows 256 ..); the rows 64 <= m < 128 go to 128 KiB of per-workgroup scratch ([pass][q - 4][thread]:
+// the L2 holds it) and come back for a second, 256-row run of stage 2 (output rows 0 .. 255), as in fdc_block512.hip.
+template <bool NT, bool STAGED, bool R4>
 __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw256, const float2 *__restrict__ tw1024 /* W_1024^k, k < 1024 */,
                                                       const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
                                                       const float2 *__restrict__ cbt /* [n1][64] (-1)^n1 W_N^(n1 (b + 256 i)) at b + 16 i */,
                                                       const float *__restrict__ shn /* [1024] shape / N */,
                                                       const long long *__restrict__ slot_off, long long out_base, long long nb_call,
-                                                      unsigned out_bytes, int nb, int hints, int half)
+                                                      unsigned out_bytes, int nb, int hints, int half, float2 *__restrict__ scratch)
 {
     // half: the bank 512 bins higher (f = 1024 slot + 512).  The block modulated by exp(-2 pi i 512 n / N) = W_N^(512 n1) (-1)^n2 moves every column's
     // spectrum by half its length: the lane that holds quarter i of k2 holds quarter i ^ 2 of the modulated column (the host moves the quarters of shn
@@ -161,6 +164,8 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     const bool rot = rho == 3;
     const float osg = half ? 1.0f : sg1;                                  // (-1)^rho: the ifftshift (half: cancelled)
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(R4 ? scratch + (size_t)blockIdx.x * 16384 : scratch, R4 ? 16384u * 8u : 0u);
+    constexpr int kRows = R4 ? 768 : 512;                                 // kept samples per block and channel
 
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
@@ -255,15 +260,21 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
             dft16<true>(u);                                       // g[4 m + rho], m = b + 16 q in u[rev16(q)]; keep q >= 8
 #pragma unroll
             for (int j = 0; j < 8; j++) G[j][ps] = pack1k(u[rev16(8 + j)]);
+            if constexpr (R4) {                                   // R = 4 keeps q >= 4: m = 64 .. 127 go to the scratch, [pass][q - 4][thread]
+#pragma unroll
+                for (int j = 0; j < 4; j++) bst2(rscr, (unsigned)tid * 8u + (unsigned)j * 4096u, (unsigned)ps * 16384u, u[rev16(4 + j)]);
+            }
         };
 #pragma nounroll
         for (int pp = 0; pp < 8; pp += 2) {
             one_pass(pp, LA, cbA, LB, cbB);
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
-        // ---------------- stage 2: FFT-64 over n1 = 8 pass + c3 of every row t' = 4 (b + 16 j) + rho = lane + 64 j ----------------
-        {
-            __syncthreads();                                          // every wave is done with its strip
+        // ---------------- stage 2: FFT-64 over n1 = 8 pass + c3 of every row t' = rowbase + 4 (b + 16 j) + rho = rowbase + lane + 64 j ----------------
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of 128-row trips (two j each)
+        auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
+            constexpr int kNTrip = decltype(ntripc)::value;
+            __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
@@ -280,12 +291,17 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
                 }
             }
 #pragma unroll
-            for (int tr = 0; tr < 4; tr++) {
+            for (int tr = 0; tr < kNTrip; tr++) {
+                cf src[2][8];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(2 * tr + jj, ps);
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) {
                     cf a[8];
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) a[ps] = unpack1k(G[2 * tr + jj][ps]);
+                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
                     dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
                     float2 *const g = gw + jj * 64 * kKLd;
                     st2(&g[0], a[0]);
@@ -309,12 +325,19 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
                     dft8<false>(v[hh]);                               // khi = k0 + 2 k1 in v[4 k0 + k1]
-                    const unsigned rb = (unsigned)(m * 512 + 128 * tr + 64 * hh + lane2) * 8u;
+                    const unsigned rb = (unsigned)(m * kRows + rowbase + 128 * tr + 64 * hh + lane2) * 8u;
 #pragma unroll
                     for (int e = 0; e < 8; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[hh][e]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        stage2([&](int j, int ps) { return unpack1k(G[j][ps]); }, R4 ? 256 : 0, std::integral_constant<int, 4>{});
+        if constexpr (R4) {
+            // m = 64 .. 127 = output rows 0 .. 255: this lane's own stores, served by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
+                   std::integral_constant<int, 2>{});
         }
     }
 }
@@ -326,25 +349,30 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
 hipError_t init_block1024_kernels()
 {
     hipError_t e = hipSuccess;
-#define FDC_SET1K(A, B) \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kKLdsStaged : kKLds);
-    FDC_SET1K(true, false) FDC_SET1K(false, false) FDC_SET1K(true, true) FDC_SET1K(false, true)
+#define FDC_SET1K(A, B, C) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk1024<A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, B ? kKLdsStaged : kKLds);
+    FDC_SET1K(true, false, false) FDC_SET1K(false, false, false) FDC_SET1K(true, true, false) FDC_SET1K(false, true, false)
+    FDC_SET1K(true, false, true) FDC_SET1K(false, false, true) FDC_SET1K(true, true, true) FDC_SET1K(false, true, true)
 #undef FDC_SET1K
     return e;
 }
 
 hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                  const float2 *tw1024, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
-                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool half)
+                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool half, int R,
+                                 float2 *scratch)
 {
     if (nb_chunk <= 0) return hipSuccess;
+    if ((R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
     constexpr bool kStaged = FDC_1K_STAGED != 0;
-#define FDC_L1K(A) \
-    hipExtLaunchKernelGGL((k_blk1024<A, kStaged>), dim3((unsigned)grid), dim3(512), kStaged ? kKLdsStaged : kKLds, s, ev_start, ev_stop, 0u, in, in_stride, \
-                          out, tw256, tw1024, twq, cbt, shn, slot_off, (long long)mbase * 512, (long long)nb_call, out_bytes, nb_chunk, hints, half ? 1 : 0)
-    if (hints & 1) FDC_L1K(true); else FDC_L1K(false);
+#define FDC_L1K(A, C) \
+    hipExtLaunchKernelGGL((k_blk1024<A, kStaged, C>), dim3((unsigned)grid), dim3(512), kStaged ? kKLdsStaged : kKLds, s, ev_start, ev_stop, 0u, in, in_stride, \
+                          out, tw256, tw1024, twq, cbt, shn, slot_off, (long long)mbase * (C ? 768 : 512), (long long)nb_call, out_bytes, nb_chunk, hints, \
+                          half ? 1 : 0, C ? scratch : (float2 *)nullptr)
+    if (R == 4) { if (hints & 1) FDC_L1K(true, true); else FDC_L1K(false, true); }
+    else { if (hints & 1) FDC_L1K(true, false); else FDC_L1K(false, false); }
 #undef FDC_L1K
     return hipGetLastError();
 }

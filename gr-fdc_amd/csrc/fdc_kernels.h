@@ -135,7 +135,7 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
                                 int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
                                 bool half = false /* the bank at f = 512 slot + 256: shn and cbt with their halves swapped, W_N^(256 n1) in cbt */);
 
-// uniform plan of 1024-bin channels on the 1024-bin grid, N = 65536, R = 2: one kernel, one block per CU (fdc_block1024.hip): the four phases of a
+// uniform plan of 1024-bin channels on the 1024-bin grid, N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_block1024.hip): the four phases of a
 // column's 1024 rows run the 256-point machinery side by side in the lanes of a quad.
 //   tw1024[k] = W_1024^k (k < 1024); twq[n1][q] = W_N^(16 n1 q) (64 x 16); cbt[n1][b + 16 i] = (-1)^n1 W_N^(n1 (b + 256 i)) (64 x 64);
 //   shn[k2] = shape[k2] / N (1024); slot_off[64]
@@ -143,7 +143,8 @@ hipError_t init_block1024_kernels();
 hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                  const float2 *tw1024, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
                                  unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                                 bool half = false /* the bank at f = 1024 slot + 512: the quarters of shn and cbt moved by two, W_N^(512 n1) in cbt */);
+                                 bool half = false /* the bank at f = 1024 slot + 512: the quarters of shn and cbt moved by two, W_N^(512 n1) in cbt */,
+                                 int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 16384 points */);
 
 // uniform plan of narrow channels (l = 128 or 64 bins on the l-bin grid), N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_blocknarrow.hip):
 // S = 256/l adjacent columns interleaved into one 256-point virtual column, separated and re-joined in registers.

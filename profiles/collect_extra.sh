@@ -1,10 +1,10 @@
 #!/bin/bash
 # Lines the default collection does not cover: the reference's default overlap (R = 4) at configs[1], a mixed-width
 # 256-channel plan, and PMC traffic for configs other than the headline.  Usage: profiles/collect_extra.sh <tag> [what...]
-#   what: r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5   (default: all)
+#   what: r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5   (default: all)
 set -u
 TAG=${1:-r03}; shift || true
-WHAT=${*:-r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5}
+WHAT=${*:-r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/extra_$TAG
 mkdir -p $OUT
@@ -36,6 +36,7 @@ for w in $WHAT; do
     w512) stats w512 --width 512 --no-cpu-baseline ;;
     w512r4) stats w512r4 --width 512 --relinvovl 4 --no-cpu-baseline ;;
     w1024) stats w1024 --width 1024 --no-cpu-baseline ;;
+    w1024r4) stats w1024r4 --width 1024 --relinvovl 4 --no-cpu-baseline ;;
     w128) stats w128 --width 128 --no-cpu-baseline ;;
     w64) stats w64 --width 64 --no-cpu-baseline ;;
     w128r4) stats w128r4 --width 128 --relinvovl 4 --no-cpu-baseline ;;

@@ -1078,8 +1078,8 @@ def test_one_kernel_path_for_1024_bin_channels(oracle, nslots, nb):
     x = noise(nb * H, 1024 + nb)
     G.defaults["FDC_HOST_SUB"] = str(nb)
     try:
-        # banks of fewer than 29 channels take the spectrum path unless asked (the kernel's cost does not depend on the number of channels)
-        assert G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == (3 if nslots >= 29 else 1)
+        # banks of fewer than 6 channels take the spectrum path unless asked (the kernel's cost does not depend on the number of channels)
+        assert G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == (3 if nslots >= 6 else 1)
         p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_WIDE_UNIFORM)
         assert p.path() == 3
         outs = p.work(x)
@@ -1108,7 +1108,7 @@ def test_one_kernel_path_for_1024_bin_channels(oracle, nslots, nb):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
 
 
-@pytest.mark.parametrize("L,R,nb", [(128, 2, 261), (64, 2, 37), (512, 2, 270), (1024, 2, 261), (128, 4, 9), (64, 4, 261), (512, 4, 7)])
+@pytest.mark.parametrize("L,R,nb", [(128, 2, 261), (64, 2, 37), (512, 2, 270), (1024, 2, 261), (128, 4, 9), (64, 4, 261), (512, 4, 7), (1024, 4, 9)])
 def test_banks_half_a_channel_higher(oracle, L, R, nb):
     """Banks centred on multiples of l (f = l slot + l/2) on the block kernels of the widths other than 256: the block modulated by
     exp(-2 pi i (l/2) n / N) moves every column's spectrum by half its length, which the kernels absorb in their tables (and one sign): the full
@@ -1167,3 +1167,38 @@ def test_hier_block_with_a_bank_centred_on_multiples_of_the_channel_width(oracle
     ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
     for i, c in enumerate(check):
         assert_close(ports[c], ref[i], "port %d" % c)
+
+
+@pytest.mark.parametrize("wt", [0, 1])
+def test_1024_bin_block_kernel_at_relinvovl_4(oracle, wt):
+    """l = 1024 at R = 4 (the reference's default overlap): 768 of the 1024 samples of every inverse transform are kept — 512 in the G registers, 256
+    through the per-workgroup scratch and a second run of stage 2.  The full bank and a subset, against the oracle and against the generic two-launch
+    form on every sample; several workgroup rounds; ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N, R, L = 65536, 4, 1024
+    H = N - N // R
+    for nb, slots in ((7, list(range(64))), (263, [63, 0, 3, 32, 33, 50, 17])):
+        x = noise(nb * H, 199 + wt + nb)
+        chans = [(L * c, L, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = range(len(chans)) if len(chans) < 16 else (0, 1, 31, 32, 62, 63)
+        k = min(nb, 4)
+        sub = [chans[c] for c in check]
+        ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * 768
+            assert_close(outs[c][:k * 768], ref[i], "slot %d head" % slots[c])
+            assert_close(outs[c][t0 * 768:], ref2[i], "slot %d tail" % slots[c])
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | G.FDC_PIPE_WIDE_UNIFORM)
+        assert q.path() == 2
+        for a, b_ in zip(outs, q.work(x)):
+            assert_close(a, b_, "block kernel vs two launches")
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, nb)]]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
