@@ -130,7 +130,12 @@ __device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
 // segments (4 rows per instruction: 8 lines, half the instructions: a quarter of the line requests), keeps them in registers for a pass as before, writes
 // them to [row][34] in LDS at the pass boundary and reads its own column's sixteen rows back: two workgroup barriers per pass (profiles/r04/NOTES.md
 // section 11; the same move took k_blk1024 from 0.20 to 0.30; here it costs 1.5 %: a build variant, -DFDC_BLK_STAGED=1).
-template <int P, bool NT, bool OFF, bool FWD, bool R4 = false, bool STG = false>
+// HALF = true: every channel half a slot higher (f = 256 slot + 128: a bank centred on multiples of 256 bins) WITHOUT the offset machinery.  The block
+// modulated by exp(-2 pi i 128 n / N) = W_N^(128 n1) (-1)^n2: the (-1)^n2 moves every column's spectrum by half its length, which together with the
+// ifftshift of the inverse is the identity — the value stays in its register, the tables are read at k2 ^ 128 (q ^ 8), W_N^(128 n1) is in cbt (the host
+// builds it for r = 128 as for any offset).  No second twiddle table, no rotated exchange, both row sets: the on-grid rate, and relinvovl 4 too
+// (128 mod 4 = 0: the window phase stays 0).
+template <int P, bool NT, bool OFF, bool FWD, bool R4 = false, bool STG = false, bool HALF = false>
 __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
@@ -142,6 +147,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
     typedef BlkGeom<P> GM;
     static_assert(!FWD || P == 8, "the forward-transform variant exists for N = 65536 only");
     static_assert(!STG || (P == 8 && !OFF && !FWD && !R4), "staged loads: the plain channelizer at N = 65536");
+    static_assert(!HALF || (!OFF && !FWD && !STG), "the half-slot form is a variant of the on-grid channelizer");
     constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: the trip buffer
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffWrowS : GM::kOffWrow));     // [b][p] = W256^(b p), rows of 18
@@ -221,11 +227,11 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
         soff[(i % P) * 32 + ((i / P) & 1) * 16 + rev16((i / P) >> 1)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
     for (int i = tid; i < 32 * P; i += 512) ctab[i] = tw256[((i / P) * (i % P) * (8 / P)) & 255];     // [c5][klo] = W_N1^(c5 klo)
-    Bt[(tid >> 4) * 18 + (tid & 15)] = twq[tid];                                // c5 = tid >> 4 < 32, q = tid & 15
+    Bt[(tid >> 4) * 18 + (tid & 15)] = twq[HALF ? tid ^ 8 : tid];               // c5 = tid >> 4 < 32, q = tid & 15 (HALF: the entry of q ^ 8)
     for (int i = tid; i < 256 * P; i += 512) {
-        const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15;
-        const float2 t = twq[(size_t)(32 * ps) * 16 + q];                        // W_N^(16 * 32 ps * q)
-        const float s = shn[bb + 16 * q];
+        const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15, qt = HALF ? q ^ 8 : q;
+        const float2 t = twq[(size_t)(32 * ps) * 16 + qt];                       // W_N^(16 * 32 ps * q)
+        const float s = shn[bb + 16 * qt];
         SA[(ps * 16 + bb) * kSaLd + q] = make_float2(t.x * s, t.y * s);
     }
     __syncthreads();
@@ -363,8 +369,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
                     for (int i = 0; i < 8; i++) {
                         const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
                         // window * inter-pass twiddle, placed at the ifftshifted position (k2 ^ 128 <=> q ^ 8)
-                        u[(2 * i) ^ 8] = cmul(cmul(v[rev16(2 * i)], mk(t0.x, t0.y)), mk(t1.x, t1.y));
-                        u[(2 * i + 1) ^ 8] = cmul(cmul(v[rev16(2 * i + 1)], mk(t0.z, t0.w)), mk(t1.z, t1.w));
+                        u[HALF ? 2 * i : (2 * i) ^ 8] = cmul(cmul(v[rev16(2 * i)], mk(t0.x, t0.y)), mk(t1.x, t1.y));
+                        u[HALF ? 2 * i + 1 : (2 * i + 1) ^ 8] = cmul(cmul(v[rev16(2 * i + 1)], mk(t0.z, t0.w)), mk(t1.z, t1.w));
                     }
                 }
                 dft16<true>(u);
@@ -551,6 +557,13 @@ hipError_t init_block_kernels()
     FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false)
 #undef FDC_SETP
 #undef FDC_SETB
+#define FDC_SETH(P, A, R4) \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<P, A, false, false, R4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<P>::kLds); \
+    if (e != hipSuccess) return e;
+#define FDC_SETHP(P) FDC_SETH(P, true, false) FDC_SETH(P, false, false) FDC_SETH(P, true, true) FDC_SETH(P, false, true)
+    FDC_SETHP(2) FDC_SETHP(4) FDC_SETHP(8)
+#undef FDC_SETHP
+#undef FDC_SETH
 #if FDC_BLK_STAGED
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
     if (e != hipSuccess) return e;
@@ -569,11 +582,12 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              float2 *scratch, int N)
 {
     if (nb_chunk <= 0) return hipSuccess;
-    if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && ((r & 255) || !scratch))) return hipErrorInvalidValue;
+    const bool halfslot = (r & 255) == 128;                 // half a slot: the on-grid kernel with its tables moved (HALF), R = 2 and 4
+    if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && (((r & 255) && !halfslot) || !scratch))) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: up to 159.5 KiB each)
     // N = 16384 on the grid at R = 2: 126 registers and 79.75 KiB of LDS per workgroup: two workgroups per CU, one's stage 2 beside the
     // other's stage 1
-    if (N == 16384 && R == 2 && !(r & 255)) grid *= 2;
+    if (N == 16384 && R == 2 && (!(r & 255) || halfslot)) grid *= 2;
     if (grid > nb_chunk) grid = nb_chunk;
     // output samples are written once and never read back here: streamed (nt) stores, measured 0.186 -> 0.172 ms (hints bit 0)
     // ev_start / ev_stop (timing): the dispatch packet's own begin / end time stamps (hipExtLaunchKernel) — no barrier packet
@@ -583,9 +597,16 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
     hipExtLaunchKernelGGL((k_blk256<P, A, B, false, R4>), dim3((unsigned)grid), dim3(512), B ? BlkGeom<P>::kLdsOff : BlkGeom<P>::kLds, s, ev_start, \
                           ev_stop, 0u, in, in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * (R4 ? 192 : 128), (long long)nb_call, \
                           out_bytes, nb_chunk, hints, dbg, r & 255, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr)
+#define FDC_LH(P, A, R4) \
+    hipExtLaunchKernelGGL((k_blk256<P, A, false, false, R4, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<P>::kLds, s, ev_start, \
+                          ev_stop, 0u, in, in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * (R4 ? 192 : 128), (long long)nb_call, \
+                          out_bytes, nb_chunk, hints, dbg, 0, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr)
 #define FDC_LP(P) \
     do { \
-        if (R == 4) { if (hints & 1) FDC_LB(P, true, false, true); else FDC_LB(P, false, false, true); } \
+        if (halfslot) { \
+            if (R == 4) { if (hints & 1) FDC_LH(P, true, true); else FDC_LH(P, false, true); } \
+            else { if (hints & 1) FDC_LH(P, true, false); else FDC_LH(P, false, false); } \
+        } else if (R == 4) { if (hints & 1) FDC_LB(P, true, false, true); else FDC_LB(P, false, false, true); } \
         else if (r & 255) { if (hints & 1) FDC_LB(P, true, true, false); else FDC_LB(P, false, true, false); } \
         else { if (hints & 1) FDC_LB(P, true, false, false); else FDC_LB(P, false, false, false); } \
     } while (0)
@@ -602,6 +623,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 #endif
     if (N == 65536) FDC_LP(8); else if (N == 32768) FDC_LP(4); else FDC_LP(2);
 #undef FDC_LP
+#undef FDC_LH
 #undef FDC_LB
     return hipGetLastError();
 }

@@ -1202,3 +1202,41 @@ def test_1024_bin_block_kernel_at_relinvovl_4(oracle, wt):
         parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 3), (3, 4), (4, nb)]]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("N,R,nb", [(65536, 2, 261), (65536, 4, 261), (32768, 2, 9), (32768, 4, 300), (16384, 2, 530), (16384, 4, 7)])
+def test_256_bin_bank_half_a_slot_higher(oracle, N, R, nb):
+    """Channels of 256 bins centred on multiples of 256 (f = 256 slot + 128) on the block kernel's HALF form: the on-grid kernel with its tables read
+    at k2 ^ 128 and no ifftshift — at relinvovl 4 too (the general offset form is R = 2 only).  Against the oracle, against the spectrum path on every
+    sample, ragged calls bit for bit."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    H = N - N // R
+    N1, lout = N // 256, 256 - 256 // R
+    rng = np.random.default_rng(N // 256 + R)
+    wt = (N // 16384 + R) % 3
+    x = noise(nb * H, N // 64 + R)
+    for slots in (list(range(N1 - 1)), sorted(int(v) for v in rng.permutation(N1 - 1)[:N1 // 3])):
+        chans = [(256 * c + 128, 256, 0.88, 1.0) for c in slots]
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3
+        outs = p.work(x)
+        check = sorted(set([0, 1, len(chans) // 2, len(chans) - 1] + [int(v) for v in rng.integers(0, len(chans), 5)]))
+        sub = [chans[c] for c in check]
+        k = min(nb, 3)
+        ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert outs[c].size == nb * lout
+            assert_close(outs[c][:k * lout], ref[i], "N %d R %d slot %d head" % (N, R, slots[c]))
+            assert_close(outs[c][t0 * lout:], ref2[i], "N %d R %d slot %d tail" % (N, R, slots[c]))
+        q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+        assert q.path() in (0, 1)
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "slot %d vs the spectrum path" % slots[c])
+        p.reset()
+        cuts = [(0, 1), (1, 3), (3, max(3, nb // 2)), (max(3, nb // 2), nb)]
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+        for c in range(len(chans)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
