@@ -509,7 +509,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const bool may_split = block_form && N == 65536;
         for (int c = 0; ok && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != 256 || (block_form && R == 4 && (ch.f & 255) && (ch.f & 255) != 128)) {   // another width; R = 4: off the grid and not half a slot (the window phase would rotate)
+            if (ch.l != 256) {                                                   // another width
                 if (!may_split) { ok = false; break; }
                 p->rem.push_back(c);
                 continue;

@@ -109,7 +109,7 @@ struct BlkGeom {
 // R4 = true: the channelizer at relinvovl = 4 (the reference's default overlap, grc/FDC_FrequencyDomainChannelizer.xml:61): three
 // quarters of every inverse transform are kept, G is 192 rows x N1 columns.  The rows t >= 128 stay in the G registers
 // as for R = 2; the rows 64 <= t < 128 take the route of the forward-transform variant: per-workgroup scratch (L2),
-// read back for a third, 64-row run of stage 2.  On-grid plans only (f = 256 slot: the window phase stays 0).
+// read back for a third, 64-row run of stage 2.  Off the grid (OFF) the window phase counter runs: a constant j^p per block in cb.
 
 // DFT over the pass index (the register index of G): P points in place; the result X[k] is read through blk_pass_idx<P>(k)
 template <int P> __device__ __forceinline__ constexpr int blk_pass_idx(int k) { return P == 8 ? 4 * (k & 1) + (k >> 1) : k; }
@@ -265,7 +265,14 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
 #ifdef FDC_BLK_STAMPS
         unsigned long long st[32] = {};
 #endif
-        const float sgn = (OFF && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
+        const float sgn = (OFF && !R4 && (roff & 1) && ((first_block + m) & 1)) ? -1.0f : 1.0f;
+        // R = 4 off the grid: the window phase counter (phase_shifting_windowing_vcc_impl.cc:82) is (block * (f mod 4)) mod 4, and phase p of the window
+        // table is the window times exp(2 pi i p / 4) = j^p: one constant per block
+        cf phs = mk(1.f, 0.f);
+        if constexpr (OFF && R4) {
+            const int pc = (int)((((first_block + m) & 3) * (roff & 3)) & 3);
+            phs = mk(pc == 0 ? 1.f : pc == 2 ? -1.f : 0.f, pc == 1 ? 1.f : pc == 3 ? -1.f : 0.f);
+        }
         FDC_STAMP(0);
         // G[j][pass]: row t' = b + 16 j, column 32 pass + c5.  One complex value = one 64-bit vector element (two floats packed
         // into an integer): the element index is the pass number at run time, and with 64-bit elements the compiler brackets
@@ -290,7 +297,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
                 pfd = __builtin_amdgcn_raw_buffer_load_b32(rpf, (unsigned)((tid >> 1) * (kN1 * 8) + (tid & 1) * 128), 0u, 0);
             }
 #endif
-            const cf cb = OFF ? cbc * sgn : cbc;
+            const cf cb = (OFF && R4) ? cmul(cbc, phs) : OFF ? cbc * sgn : cbc;
             if constexpr (STG) {
                 // the rows of this pass arrived in PF during the pass before: into the planes, this lane's sixteen back out, then the next pass's
                 // rows (of this block, or pass 0 of this workgroup's next block, kept in PF across stage 2) are requested
@@ -552,7 +559,8 @@ hipError_t init_block_kernels()
     if (e != hipSuccess) return e;
 #define FDC_SETP(P) \
     FDC_SETB(P, true, false, false, false) FDC_SETB(P, false, false, false, false) FDC_SETB(P, true, true, false, false) \
-    FDC_SETB(P, false, true, false, false) FDC_SETB(P, true, false, false, true) FDC_SETB(P, false, false, false, true)
+    FDC_SETB(P, false, true, false, false) FDC_SETB(P, true, false, false, true) FDC_SETB(P, false, false, false, true) \
+    FDC_SETB(P, true, true, false, true) FDC_SETB(P, false, true, false, true)
     FDC_SETP(2) FDC_SETP(4) FDC_SETP(8)
     FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false)
 #undef FDC_SETP
@@ -583,7 +591,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 {
     if (nb_chunk <= 0) return hipSuccess;
     const bool halfslot = (r & 255) == 128;                 // half a slot: the on-grid kernel with its tables moved (HALF), R = 2 and 4
-    if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && (((r & 255) && !halfslot) || !scratch))) return hipErrorInvalidValue;
+    if (!poly_block_supports(N) || (R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;                         // one 512-thread workgroup per CU (LDS: up to 159.5 KiB each)
     // N = 16384 on the grid at R = 2: 126 registers and 79.75 KiB of LDS per workgroup: two workgroups per CU, one's stage 2 beside the
     // other's stage 1
@@ -606,7 +614,8 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
         if (halfslot) { \
             if (R == 4) { if (hints & 1) FDC_LH(P, true, true); else FDC_LH(P, false, true); } \
             else { if (hints & 1) FDC_LH(P, true, false); else FDC_LH(P, false, false); } \
-        } else if (R == 4) { if (hints & 1) FDC_LB(P, true, false, true); else FDC_LB(P, false, false, true); } \
+        } else if (R == 4 && (r & 255)) { if (hints & 1) FDC_LB(P, true, true, true); else FDC_LB(P, false, true, true); } \
+        else if (R == 4) { if (hints & 1) FDC_LB(P, true, false, true); else FDC_LB(P, false, false, true); } \
         else if (r & 255) { if (hints & 1) FDC_LB(P, true, true, false); else FDC_LB(P, false, true, false); } \
         else { if (hints & 1) FDC_LB(P, true, false, false); else FDC_LB(P, false, false, false); } \
     } while (0)

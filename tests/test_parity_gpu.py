@@ -735,9 +735,9 @@ def test_one_kernel_form_at_relinvovl_4(oracle, wt):
         parts = [p.work(x[a * p.H:b * p.H]) for a, b in [(0, 3), (3, 4), (4, 7)]]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
-    # an offset tiling at R = 4 keeps the spectrum path (the window phase would rotate from block to block)
+    # an offset tiling at R = 4 takes the one-kernel form too (the window phase is a constant j^p per block: test_offset_tilings_at_relinvovl_4)
     off = G.Pipeline(N, R, [(256 * c + 37, 256, 0.88, 1.0) for c in range(8)], windowtype=1, max_blocks=2)
-    assert off.path() == 1
+    assert off.path() == 3
 
 
 @pytest.mark.parametrize("N,R,nb", [(16384, 2, 7), (16384, 2, 600), (32768, 2, 5), (32768, 2, 530), (16384, 4, 9), (32768, 4, 300)])
@@ -1240,3 +1240,34 @@ def test_256_bin_bank_half_a_slot_higher(oracle, N, R, nb):
         parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
         for c in range(len(chans)):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("N,r,nslots", [(65536, 1, 255), (65536, 2, 40), (65536, 3, 255), (65536, 37, 100), (65536, 130, 255), (65536, 255, 9),
+                                        (32768, 5, 127), (16384, 66, 63)])
+def test_offset_tilings_at_relinvovl_4(oracle, N, r, nslots):
+    """Tilings off the 256-bin grid at R = 4 (the reference's default overlap): the window phase counter (block * (f mod 4)) mod 4 runs
+    (lib/phase_shifting_windowing_vcc_impl.cc:57-58,82) and phase p of the window is the window times j^p — a constant per block in the block
+    kernel.  Every residue of r mod 4; against the oracle, against the spectrum path, ragged calls starting at every block index mod 4."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    R, nb = 4, 11
+    H = N - N // R
+    rng = np.random.default_rng(r * 17 + nslots)
+    slots = [int(v) for v in rng.permutation(N // 256 - 1)[:nslots]]
+    chans = [(256 * c + r, 256, 0.88, 1.0) for c in slots]
+    x = noise(nb * H, 400 + r)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3
+    outs = p.work(x)
+    ref, _ = oracle.channelizer(N, R, 1, chans, x, nthreads=8)
+    for c in range(0, len(chans), max(1, len(chans) // 12)):
+        assert outs[c].size == nb * 192
+        assert_close(outs[c], ref[c], "slot %d offset %d" % (slots[c], r))
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+    assert q.path() in (0, 1)
+    for a, b_ in zip(outs, q.work(x)):
+        assert_close(a, b_)
+    p.reset()
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 1), (1, 3), (3, 6), (6, 11)]]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([q_[c] for q_ in parts]), outs[c])

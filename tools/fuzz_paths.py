@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2.  Every case draws a plan (on-grid,
+"""GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2 (or R = 4: third argument).  Every case draws a plan (on-grid,
 offset, two or three classes, mixed widths, or a split plan: tilings plus a remainder), a block count, a chunk size and a call pattern, runs it on the default
 dispatch and on the spectrum-in-memory path (FDC_NO_POLY=1) and compares every output sample; every fifth case is also
-compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed]"""
+compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed] [R]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import gr_fdc_amd as G  # noqa: E402
 import oracle as O      # noqa: E402  (checker)
 
-N, R = 65536, 2
+N, R = 65536, (int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 H = N - N // R
 TOL = 1e-5
 
