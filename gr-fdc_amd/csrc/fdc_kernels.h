@@ -120,7 +120,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
                              int r = 0 /* common offset f mod 256 of the channels; cbt must then hold (-1)^n1 W_N^(n1 (b + r)) */,
                              long long first_block = 0 /* global index of block 0 of this launch (window phase of odd r) */,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* timing: stamped by the dispatch itself */,
-                             int R = 2 /* 2 or 4 (4: r = 0 only) */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
+                             int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
                              int N = 65536 /* block length: 16384, 32768 or 65536 (poly_block_supports) */);
 bool poly_block_supports(int N);
 
