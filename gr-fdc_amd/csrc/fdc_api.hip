@@ -147,6 +147,13 @@ struct fdc_pipeline {
     float2 *d_tw1k = nullptr, *d_twq1k = nullptr, *d_cbt1k = nullptr;
     bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
     float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
+    // a second bank of the same width and window, the other of the two places (on the l-bin grid / half a channel higher): its own launch.
+    // What the reference's parameter derivation makes of a bank centred on multiples of l: channel 0 wraps and is clamped onto the grid.
+    bool bank2 = false, bank2_half = false;
+    std::vector<int> bank1_chan, bank2_chan;
+    float *d_shn2 = nullptr;
+    long long *d_slot_off2 = nullptr;
+    float2 *d_cbtk2 = nullptr, *d_tabnar2 = nullptr;       // the width's kernel's cbt (512 / 1024 / narrow), the narrow kernel's table image
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
                                  // stage 1 on the generic LDS core, two launches; one class, no offset)
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
@@ -378,6 +385,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
     (void)hipFree(p->d_tabnar); (void)hipFree(p->d_cbtnar);
+    (void)hipFree(p->d_shn2); (void)hipFree(p->d_slot_off2); (void)hipFree(p->d_cbtk2); (void)hipFree(p->d_tabnar2);
     (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k); (void)hipFree(p->d_cbt1k);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -484,15 +492,32 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const bool b1024 = L == 1024 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 6 || (flags & FDC_PIPE_WIDE_UNIFORM));
         const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
         uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || b1024 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
-        // on the l-bin grid, or (block kernels of the other widths only) all half a channel higher: a bank centred on multiples of l
-        const int r0 = cfg->channels[0].f % L;
-        const bool halfb = r0 == L / 2 && (b512 || b1024 || bnar);
-        uniL = uniL && (r0 == 0 || halfb);
-        std::vector<char> usedL(uniL ? (size_t)(N / L) : 0, 0);
+        // on the l-bin grid, or (block kernels of the other widths only) half a channel higher: a bank centred on multiples of l — or both: two banks,
+        // two launches (the reference's parameter derivation clamps the wrapped channel 0 of a centred bank onto the grid).  Bank 1 is the bigger one.
+        const bool blockL = b512 || b1024 || bnar;
+        std::vector<int> on, hf;
+        std::vector<char> usedOn(uniL ? (size_t)(N / L) : 0, 0), usedHf(usedOn);
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != L || (ch.f % L) != r0 || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw || usedL[(size_t)(ch.f / L)]) uniL = false;
-            else usedL[(size_t)(ch.f / L)] = 1;
+            const int r = ch.f % L;
+            if (ch.l != L || (r != 0 && r != L / 2) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw) { uniL = false; break; }
+            auto &used = r ? usedHf : usedOn;
+            if (used[(size_t)(ch.f / L)]) { uniL = false; break; }
+            used[(size_t)(ch.f / L)] = 1;
+            (r ? hf : on).push_back(c);
+        }
+        if (uniL && !hf.empty() && !blockL) uniL = false;                      // half a channel off the grid: block kernels only
+        if (uniL && !hf.empty() && !on.empty() && N == 65536) {
+            // two launches against the spectrum path, ms per 1024 blocks (the kernels' cost does not depend on the number of channels)
+            const double per = L == 1024 ? 0.222 : L == 512 ? 0.19 : L == 128 ? 0.177 : 0.19, bins = double(p->C) * L / 65536.0;
+            if (2.0 * per >= 0.20 + 0.05 * std::min(1.0, bins) + 0.19 * bins) uniL = false;
+        }
+        const bool halfb = uniL && hf.size() > on.size();
+        if (uniL) {
+            p->bank1_chan = halfb ? hf : on;
+            p->bank2_chan = halfb ? on : hf;
+            p->bank2 = !p->bank2_chan.empty();
+            p->bank2_half = p->bank2 && !halfb;
         }
         if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; p->poly_half = halfb; }
     }
@@ -649,26 +674,63 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         const int L = p->poly_L, N1 = N / L;
         fdc_pipeline::PolyClass pc;
         pc.r = 0; pc.passbw = cfg->channels[0].passbw; pc.stopbw = cfg->channels[0].stopbw;
-        for (int c = 0; c < p->C; c++) pc.chan.push_back(c);
+        pc.chan = p->bank1_chan;
         std::vector<std::complex<float>> shape((size_t)L);
         fdc::window_table(cfg->windowtype, L, pc.passbw, pc.stopbw, 1, 0, true, shape.data());
         std::vector<float> sn((size_t)L);
         for (int k2 = 0; k2 < L; k2++) sn[(size_t)k2] = float(double(shape[(size_t)k2].real()) / double(N));
-        std::vector<long long> so((size_t)N1, -1);
-        for (int c = 0; c < p->C; c++) so[(size_t)(p->chans[c].f / L)] = p->chans[c].out_off;
         p->classes.push_back(pc);
-        auto &q = p->classes.back();
-        CHK_OR_FREE(hipMalloc(&q.d_shn, sizeof(float) * (size_t)L));
-        {
+        // one bank's tables: window, slot table, and what its width's block kernel wants (cbt; the narrow kernel's image).  half: the bank sits half a
+        // channel off the grid (tables moved)
+        auto build_bank = [&](const std::vector<int> &ids, bool half, float *&d_shn, long long *&d_so, float2 *&d_cbt, float2 *&d_tab) -> int {
+            std::vector<long long> so((size_t)N1, -1);
+            for (int c : ids) so[(size_t)(p->chans[c].f / L)] = p->chans[c].out_off;
             // the 512- and 1024-bin block kernels at half a channel's offset read the window with its halves swapped (their lanes hold the other half)
             std::vector<float> snd(sn);
-            if (p->poly_half && (p->poly_b512 || p->poly_b1024))
+            if (half && (p->poly_b512 || p->poly_b1024))
                 for (int k2 = 0; k2 < L; k2++) snd[(size_t)k2] = sn[(size_t)(k2 ^ (L / 2))];
-            CHK_OR_FREE(hipMemcpy(q.d_shn, snd.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
-        }
-        CHK_OR_FREE(hipMalloc(&q.d_slot_off, sizeof(long long) * (size_t)N1));
-        CHK_OR_FREE(hipMemcpy(q.d_slot_off, so.data(), sizeof(long long) * (size_t)N1, hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&d_shn, sizeof(float) * (size_t)L));
+            CHK_OR_FREE(hipMemcpy(d_shn, snd.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&d_so, sizeof(long long) * (size_t)N1));
+            CHK_OR_FREE(hipMemcpy(d_so, so.data(), sizeof(long long) * (size_t)N1, hipMemcpyHostToDevice));
+            std::vector<float2> cb;
+            if (p->poly_b512 || p->poly_b1024) {
+                // (-1)^n1 W_N^(n1 (b + 256 i)) at [n1][b + 16 i], i = half (512: two) or quarter (1024: four) of k2.  half: the lane of part i holds part
+                // i ^ (parts / 2) of the modulated column, whose constant W_N^((l/2) n1) joins the table
+                const int parts = L / 256;
+                cb.resize((size_t)N1 * 16 * parts);
+                for (int n1 = 0; n1 < N1; n1++)
+                    for (int e = 0; e < 16 * parts; e++) {
+                        const int i = half ? (e >> 4) ^ (parts / 2) : e >> 4;
+                        const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * i + (half ? L / 2 : 0))) % N) / double(N);
+                        const double sg = (n1 & 1) ? -1.0 : 1.0;
+                        cb[(size_t)n1 * 16 * parts + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
+                    }
+            } else if (p->poly_bnar) {
+                // the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l (half: W_N^((l/2) S V) with it)
+                const int S = 256 / L;
+                std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L));
+                fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half);
+                CHK_OR_FREE(hipMalloc(&d_tab, sizeof(float2) * img.size()));
+                CHK_OR_FREE(hipMemcpy(d_tab, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
+                cb.resize(256 * 16);
+                for (int V = 0; V < 256; V++)
+                    for (int b = 0; b < 16; b++) {
+                        const double a = -2.0 * M_PI * double(((long long)S * V * (b + (half ? L / 2 : 0))) % N) / double(N);
+                        cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
+                    }
+            }
+            if (!cb.empty()) {
+                CHK_OR_FREE(hipMalloc(&d_cbt, sizeof(float2) * cb.size()));
+                CHK_OR_FREE(hipMemcpy(d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+            }
+            return FDC_OK;
+        };
+        auto &q = p->classes.back();
+        float2 *&cbt1 = p->poly_b512 ? p->d_cbt512 : p->poly_b1024 ? p->d_cbt1k : p->d_cbtnar;
+        { const int rcb = build_bank(p->bank1_chan, p->poly_half, q.d_shn, q.d_slot_off, cbt1, p->d_tabnar); if (rcb != FDC_OK) return rcb; }
         p->d_shn = q.d_shn; p->d_slot_off = q.d_slot_off;
+        if (p->bank2) { const int rcb = build_bank(p->bank2_chan, p->bank2_half, p->d_shn2, p->d_slot_off2, p->d_cbtk2, p->d_tabnar2); if (rcb != FDC_OK) return rcb; }
         // the tile-local factor of the inter-pass twiddle, in the tile's own order: t2[k2][t] = W_N^(t k2)
         const int TCg = fdc::poly_stage1_generic_tile_columns(N, L);
         std::vector<float2> t2v((size_t)L * TCg);
@@ -679,68 +741,20 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             }
         CHK_OR_FREE(hipMalloc(&p->d_t2g, sizeof(float2) * t2v.size()));
         CHK_OR_FREE(hipMemcpy(p->d_t2g, t2v.data(), sizeof(float2) * t2v.size(), hipMemcpyHostToDevice));
-        if (p->poly_b512) {
-            // tables of the l = 512 block kernel (fdc_block512.hip): W_512^k; W_N^(16 n1 q); (-1)^n1 W_N^(n1 (b + 256 h)) at [n1][b + 16 h]
-            std::vector<float2> t5(256), tq((size_t)N1 * 16), cb((size_t)N1 * 32);
-            for (int k = 0; k < 256; k++) { const double a = -2.0 * M_PI * k / 512.0; t5[(size_t)k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
-            for (int n1 = 0; n1 < N1; n1++) {
-                for (int q = 0; q < 16; q++) {
-                    const double a = -2.0 * M_PI * double((16ll * n1 * q) % N) / double(N);
-                    tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        if (p->poly_b512 || p->poly_b1024) {
+            // tables both banks share: W_l^k (k < 256 for 512, all 1024 for 1024) and W_N^(16 n1 q)
+            std::vector<float2> t5(p->poly_b512 ? 256 : 1024), tq((size_t)N1 * 16);
+            for (size_t k = 0; k < t5.size(); k++) { const double a = -2.0 * M_PI * double(k) / double(L); t5[k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
+            for (int n1 = 0; n1 < N1; n1++)
+                for (int qq = 0; qq < 16; qq++) {
+                    const double a = -2.0 * M_PI * double((16ll * n1 * qq) % N) / double(N);
+                    tq[(size_t)n1 * 16 + qq] = make_float2(float(std::cos(a)), float(std::sin(a)));
                 }
-                for (int e = 0; e < 32; e++) {
-                    // half: the lane of half h holds half h ^ 1 of the modulated column, whose constant W_N^(256 n1) joins the table
-                    const int h = p->poly_half ? (e >> 4) ^ 1 : e >> 4;
-                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * h + (p->poly_half ? 256 : 0))) % N) / double(N);
-                    const double sg = (n1 & 1) ? -1.0 : 1.0;
-                    cb[(size_t)n1 * 32 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
-                }
-            }
-            CHK_OR_FREE(hipMalloc(&p->d_tw512, sizeof(float2) * t5.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_tw512, t5.data(), sizeof(float2) * t5.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_twq512, sizeof(float2) * tq.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_twq512, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_cbt512, sizeof(float2) * cb.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_cbt512, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-        }
-        if (p->poly_b1024) {
-            // tables of the l = 1024 block kernel (fdc_block1024.hip): W_1024^k; W_N^(16 n1 q); (-1)^n1 W_N^(n1 (b + 256 i)) at [n1][b + 16 i]
-            std::vector<float2> t1(1024), tq((size_t)N1 * 16), cb((size_t)N1 * 64);
-            for (int k = 0; k < 1024; k++) { const double a = -2.0 * M_PI * k / 1024.0; t1[(size_t)k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
-            for (int n1 = 0; n1 < N1; n1++) {
-                for (int q = 0; q < 16; q++) {
-                    const double a = -2.0 * M_PI * double((16ll * n1 * q) % N) / double(N);
-                    tq[(size_t)n1 * 16 + q] = make_float2(float(std::cos(a)), float(std::sin(a)));
-                }
-                for (int e = 0; e < 64; e++) {
-                    // half: the lane of quarter i holds quarter i ^ 2 of the modulated column, whose constant W_N^(512 n1) joins the table
-                    const int iq = p->poly_half ? (e >> 4) ^ 2 : e >> 4;
-                    const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * iq + (p->poly_half ? 512 : 0))) % N) / double(N);
-                    const double sg = (n1 & 1) ? -1.0 : 1.0;
-                    cb[(size_t)n1 * 64 + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
-                }
-            }
-            CHK_OR_FREE(hipMalloc(&p->d_tw1k, sizeof(float2) * t1.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_tw1k, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_twq1k, sizeof(float2) * tq.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_twq1k, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_cbt1k, sizeof(float2) * cb.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_cbt1k, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-        }
-        if (p->poly_bnar) {
-            // tables of the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l
-            const int S = 256 / L;
-            std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L)), cb(256 * 16);
-            fdc::poly_block_narrow_tables(L, sn.data(), img.data(), p->poly_half);
-            for (int V = 0; V < 256; V++)
-                for (int b = 0; b < 16; b++) {
-                    const double a = -2.0 * M_PI * double(((long long)S * V * (b + (p->poly_half ? L / 2 : 0))) % N) / double(N);   // half: W_N^((l/2) S V)
-                    cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
-                }
-            CHK_OR_FREE(hipMalloc(&p->d_tabnar, sizeof(float2) * img.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_tabnar, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&p->d_cbtnar, sizeof(float2) * cb.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_cbtnar, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
+            float2 *&dtw = p->poly_b512 ? p->d_tw512 : p->d_tw1k, *&dtq = p->poly_b512 ? p->d_twq512 : p->d_twq1k;
+            CHK_OR_FREE(hipMalloc(&dtw, sizeof(float2) * t5.size()));
+            CHK_OR_FREE(hipMemcpy(dtw, t5.data(), sizeof(float2) * t5.size(), hipMemcpyHostToDevice));
+            CHK_OR_FREE(hipMalloc(&dtq, sizeof(float2) * tq.size()));
+            CHK_OR_FREE(hipMemcpy(dtq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
         }
     } else if (p->poly_ok) {
         const int N1 = N / 256;
@@ -1065,33 +1079,27 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             }
             continue;
         }
-        // (a bank at half a channel's offset has no two-launch form: short launch groups take the block kernel too)
-        if (use_poly && p->poly_b1024 && (!few || p->poly_half)) {
-            HIPCHK(fdc::launch_poly_block1024(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
-                                              p->d_tw1k, p->d_twq1k, p->d_cbt1k, p->d_shn, p->d_slot_off,
-                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                              tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->poly_half, p->R, p->d_fscr));
-            if (tg) {
-                span[2] = span[3] = span[1];
-                p->ev_spans.push_back(span);
+        // (a bank at half a channel's offset, or a plan of two banks, has no two-launch form: short launch groups take the block kernel too)
+        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->poly_half || p->bank2)) {
+            const unsigned out_bytes = (unsigned)((int64_t)nblocks * p->sum_lout * 8);
+            const float2 *in0 = ring + (size_t)m0 * p->H;
+            float2 *o = static_cast<float2 *>(d_out);
+            // one launch per bank; the timing events take the first launch's begin and the last one's end
+            for (int k = 0; k < (p->bank2 ? 2 : 1); k++) {
+                const bool half = k ? p->bank2_half : p->poly_half;
+                const float *shn = k ? p->d_shn2 : p->d_shn;
+                const long long *so = k ? p->d_slot_off2 : p->d_slot_off;
+                hipEvent_t e0 = tg && k == 0 ? p->events[span[0]] : nullptr, e1 = tg && k == (p->bank2 ? 1 : 0) ? p->events[span[1]] : nullptr;
+                if (p->poly_b1024)
+                    HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, k ? p->d_cbtk2 : p->d_cbt1k, shn, so,
+                                                      out_bytes, p->ncu, p->block_hints, s, e0, e1, half, p->R, p->d_fscr));
+                else if (p->poly_bnar)
+                    HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, in0, (size_t)p->H, o, nb, m0, nblocks, k ? p->d_tabnar2 : p->d_tabnar, k ? p->d_cbtk2 : p->d_cbtnar,
+                                                         so, out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
+                else
+                    HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, k ? p->d_cbtk2 : p->d_cbt512, shn, so,
+                                                     out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
             }
-            continue;
-        }
-        if (use_poly && p->poly_bnar && (!few || p->poly_half)) {
-            HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tabnar,
-                                             p->d_cbtnar, p->d_slot_off, (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->poly_half));
-            if (tg) {
-                span[2] = span[3] = span[1];
-                p->ev_spans.push_back(span);
-            }
-            continue;
-        }
-        if (use_poly && p->poly_b512 && (!few || p->poly_half)) {
-            HIPCHK(fdc::launch_poly_block512(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks, p->d_tw256,
-                                             p->d_tw512, p->d_twq512, p->d_cbt512, p->d_shn, p->d_slot_off,
-                                             (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s,
-                                             tg ? p->events[span[0]] : nullptr, tg ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->poly_half));
             if (tg) {
                 span[2] = span[3] = span[1];
                 p->ev_spans.push_back(span);

@@ -1271,3 +1271,43 @@ def test_offset_tilings_at_relinvovl_4(oracle, N, r, nslots):
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 1), (1, 3), (3, 6), (6, 11)]]
     for c in range(len(chans)):
         assert np.array_equal(np.concatenate([q_[c] for q_ in parts]), outs[c])
+
+
+@pytest.mark.parametrize("C,R,nb", [(512, 2, 261), (1024, 2, 9), (128, 2, 261), (512, 4, 7), (128, 4, 263)])
+def test_centred_bank_through_the_parameter_derivation_is_two_banks(oracle, C, R, nb):
+    """C channels of 0.8/C of the band centred on k/C, k = 0 .. C-1, through get_opt_channelparams (python/FrequencyDomainChannelizer.py:322-345):
+    l = 65536/C at f = l k - l/2, except channel 0, whose slice wraps below zero and is clamped to the top of the band — on the l-bin grid.  A bank half a
+    channel off the grid plus one channel on it: two launches of the width's block kernel instead of the spectrum path.  Channel 0 and its neighbours
+    against the oracle, every sample against the spectrum path, ragged calls bit for bit."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N = 65536
+    H = N - N // R
+    prm = [G.get_opt_channelparams(N, R, (k / C) % 1.0, 0.8 / C) for k in range(C)]
+    L = prm[0][1]
+    assert L == N // C and prm[0][0] == N - L and all(p_[0] == L * k - L // 2 and p_[1] == L for k, p_ in enumerate(prm) if k)
+    chans = [(f, l, pb, sb) for (f, l, _lo, pb, sb) in prm]
+    lout = L - L // R
+    x = noise(nb * H, 9000 + C + R)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3
+    outs = p.work(x)
+    check = [0, 1, 2, C // 2, C - 2, C - 1]
+    sub = [chans[c] for c in check]
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, 1, sub, x[:k * H], nthreads=8)
+    t0 = nb - k
+    ref2, _ = oracle.channelizer(N, R, 1, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * lout
+        assert_close(outs[c][:k * lout], ref[i], "channel %d head" % c)
+        assert_close(outs[c][t0 * lout:], ref2[i], "channel %d tail" % c)
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+    assert q.path() == 1
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "channel %d vs the spectrum path" % c)
+    p.reset()
+    cuts = [(0, 1), (1, 3), (3, max(3, nb // 2)), (max(3, nb // 2), nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
