@@ -87,7 +87,7 @@ def parse():
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
     ap.add_argument("--width", type=int, default=0, metavar="L", help="diagnostics (config 2): a uniform bank of channels L bins wide (N / L channels "
                                                                       "on the L-bin grid) instead of 256: the generic-width two-launch path")
-    ap.add_argument("--centred", action="store_true", help="--width: the channels centred on k/C instead of (k + 1/2)/C (a bank half a channel off "
+    ap.add_argument("--centred", action="store_true", help="the channels centred on k/C instead of (k + 1/2)/C (a bank half a channel off "
                                                           "the grid plus the wrapped channel 0 on it: two launches of the width's kernel)")
     ap.add_argument("--extra", type=int, default=0, metavar="K", help="diagnostics (config 2): K more channels of widths 512 / 128 / 1024 at odd bins beside "
                                                                       "the 256-channel bank: an ALMOST uniform plan (split: the bank on the one-kernel "
@@ -475,7 +475,7 @@ def main():
                 assert all(p_[1] == a.width and p_[0] == a.width * c for c, p_ in enumerate(params)), "not a bank on the %d-bin grid" % a.width
         else:
             bws = (0.8, 0.4, 0.8, 1.6) if a.mixed else (0.8,)
-            params = [G.get_opt_channelparams(N, R, ((c + 0.5) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
+            params = [G.get_opt_channelparams(N, R, ((c + (0.0 if a.centred else 0.5)) / C - 0.5 + 0.5) % 1.0, bws[c % len(bws)] / C) for c in range(C)]
         if a.offset:
             params = [(f + a.offset, l, lo, p, s) for (f, l, lo, p, s) in params[:-1]]
         if a.extra:
