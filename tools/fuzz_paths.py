@@ -30,7 +30,15 @@ def draw_plan(rng):
         L = int([512, 128, 1024, 1024, 64, 2048][int(rng.integers(0, 6))])
         half = L // 2 if rng.integers(0, 3) == 0 else 0      # a bank centred on multiples of l (block kernels: tables moved by half a channel)
         slots = rng.permutation(N // L - (1 if half else 0))[:rng.integers(1, N // L + (0 if half else 1))]
-        return [(L * int(c) + half, L, 0.88, 1.0) for c in slots], "bank l=%d%s" % (L, "+l/2" if half else "")
+        plan = [(L * int(c) + half, L, 0.88, 1.0) for c in slots]
+        two = ""
+        if rng.integers(0, 3) == 0:                          # a few channels on the OTHER grid: two banks, two launches (or the spectrum path by the cost rule)
+            other = 0 if half else L // 2
+            oslots = rng.permutation(N // L - (1 if other else 0))[:rng.integers(1, 5)]
+            plan += [(L * int(c) + other, L, 0.88, 1.0) for c in oslots]
+            plan = [plan[int(i)] for i in rng.permutation(len(plan))]
+            two = " x2"
+        return plan, "bank l=%d%s%s" % (L, "+l/2" if half else "", two)
     if kind == 0:                                     # on-grid subset
         slots = rng.permutation(256)[:rng.integers(1, 257)]
         return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "grid"
