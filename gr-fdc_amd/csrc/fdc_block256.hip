@@ -407,7 +407,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
         };
         // two passes per trip: the row sets swap roles (the pass count is even for every P).  The offset-plan variant at P = 8 has no
         // registers for the second set's live range (32 bytes of scratch): it copies the rows at the top of a pass as before.
-        if constexpr (OFF && P == 8) {
+#ifndef FDC_BLK_COPYFORM
+#define FDC_BLK_COPYFORM 0
+#endif
+        if constexpr ((OFF || (FDC_BLK_COPYFORM && !STG)) && P == 8) {
 #pragma nounroll
             for (int ps = 0; ps < P; ps++) {
                 cf cur[16];
