@@ -239,6 +239,12 @@ class Pipeline:
         """0 generic kernels, 1 radix-16 kernels with a spectrum in memory, 2 uniform-plan two-stage path."""
         return int(_lib.lib().fdc_pipeline_path(self._h))
 
+    def describe(self):
+        """fdc_pipeline_describe: which kernels the plan was given, in words."""
+        buf = C.create_string_buffer(512)
+        _lib.lib().fdc_pipeline_describe(self._h, buf, 512)
+        return buf.value.decode()
+
     def chunk_blocks(self):
         return int(_lib.lib().fdc_pipeline_chunk_blocks(self._h))
 

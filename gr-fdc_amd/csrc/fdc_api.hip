@@ -916,6 +916,31 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
     return 0;
 }
 
+int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
+{
+    if (!p || !buf || n < 1) return -1;
+    char t[512];
+    const int path = fdc_pipeline_path(p);
+    int k = std::snprintf(t, sizeof(t), "N = %d, R = %d, %d channels; path %d: ", p->N, p->R, p->C, path);
+    auto add = [&](const char *fmt, auto... a) { if (k < (int)sizeof(t)) k += std::snprintf(t + k, sizeof(t) - (size_t)k, fmt, a...); };
+    if (p->poly_b512 || p->poly_b1024 || p->poly_bnar) {
+        add("%s, l = %d, bank of %d %s", p->poly_bnar ? "k_blknar" : p->poly_b512 ? "k_blk512" : "k_blk1024", p->poly_L, (int)p->bank1_chan.size(),
+            p->poly_half ? "half a channel off the grid" : "on the grid");
+        if (p->bank2) add(" + bank of %d %s (two launches)", (int)p->bank2_chan.size(), p->bank2_half ? "half a channel off the grid" : "on the grid");
+    } else if (p->poly_block) {
+        add("k_blk256, %d tiling%s (r =", (int)p->classes.size(), p->classes.size() == 1 ? "" : "s");
+        for (const auto &pc : p->classes) add(" %d", pc.r);
+        add("%s", ")");
+        if (p->split) add(" + %d other channels on a partial spectrum", (int)p->rem.size());
+    } else if (p->poly_ok) {
+        add("two launches (stage 1 + stage 2), l = %d", p->poly_L);
+    } else {
+        add("%s", "forward transform to a spectrum in memory + channel kernels");
+    }
+    std::snprintf(buf, (size_t)n, "%s", t);
+    return k;
+}
+
 int fdc_pipeline_synchronize(fdc_pipeline *p)
 {
     FDC_ENTRY("fdc_pipeline_synchronize")

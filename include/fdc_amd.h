@@ -178,6 +178,10 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * rest — other widths, a fourth tiling — take the spectrum path on a partial spectrum that holds only what they read (forward
  * transform ms[1], channel kernels ms[2]); chosen where that is estimated cheaper than the whole plan on path 1. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
+/* The same in words, for logs: which kernels the handle's plan was given ("N = 65536, R = 2, 512 channels; path 3: k_blknar, l = 128, bank of 511 half a
+ * channel off the grid + bank of 1 on the grid (two launches)").  Writes at most n bytes including the terminator; returns the untruncated length, -1 for
+ * bad arguments.  (No counterpart in the reference, which has one implementation.) */
+int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n);
 
 /* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's
  * roofline leg).  While enabled, every process_device call brackets its launches with events; the readout

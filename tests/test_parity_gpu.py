@@ -1160,6 +1160,7 @@ def test_hier_block_with_a_bank_centred_on_multiples_of_the_channel_width(oracle
                                        False, False, "", False, None, 10.0, 0.005, 1, 0.2, 0, 0, 128, 128, False, max_blocks=8)
     assert [cp[:3] for cp in fdc.channel_params[:3]] == [(64, 128, 64), (192, 128, 64), (320, 128, 64)]
     assert fdc.pipeline.path() == 3
+    assert "k_blknar, l = 128, bank of 511 half a channel off the grid" in fdc.pipeline.describe()
     x = noise(8 * fdc.inpblocklen, 4242)
     ports = fdc.work(x)
     check = [0, 1, 255, 256, 509, 510]
@@ -1291,6 +1292,7 @@ def test_centred_bank_through_the_parameter_derivation_is_two_banks(oracle, C, R
     x = noise(nb * H, 9000 + C + R)
     p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
     assert p.path() == 3
+    assert "bank of %d half a channel off the grid + bank of 1 on the grid (two launches)" % (C - 1) in p.describe()
     outs = p.work(x)
     check = [0, 1, 2, C // 2, C - 2, C - 1]
     sub = [chans[c] for c in check]
