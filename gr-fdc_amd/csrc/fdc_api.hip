@@ -151,6 +151,7 @@ struct fdc_pipeline {
     // What the reference's parameter derivation makes of a bank centred on multiples of l: channel 0 wraps and is clamped onto the grid.
     bool bank2 = false, bank2_half = false;
     std::vector<int> bank1_chan, bank2_chan;
+    std::vector<std::pair<int, int>> bank_alias;             // (channel, the earlier channel with the same slice): computed once, copied
     float *d_shn2 = nullptr;
     long long *d_slot_off2 = nullptr;
     float2 *d_cbtk2 = nullptr, *d_tabnar2 = nullptr;       // the width's kernel's cbt (512 / 1024 / narrow), the narrow kernel's table image
@@ -502,7 +503,14 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             const int r = ch.f % L;
             if (ch.l != L || (r != 0 && r != L / 2) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw) { uniL = false; break; }
             auto &used = r ? usedHf : usedOn;
-            if (used[(size_t)(ch.f / L)]) { uniL = false; break; }
+            if (used[(size_t)(ch.f / L)]) {
+                // the same slice again (the reference's derivation clamps a wrapped channel onto its neighbour's place): computed once, copied
+                int first = -1;
+                for (int c0 : (r ? hf : on)) if (cfg->channels[c0].f == ch.f) { first = c0; break; }
+                if (first < 0 || !blockL) { uniL = false; break; }
+                p->bank_alias.emplace_back(c, first);
+                continue;
+            }
             used[(size_t)(ch.f / L)] = 1;
             (r ? hf : on).push_back(c);
         }
@@ -513,6 +521,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
             if (2.0 * per >= 0.20 + 0.05 * std::min(1.0, bins) + 0.19 * bins) uniL = false;
         }
         const bool halfb = uniL && hf.size() > on.size();
+        if (!uniL) p->bank_alias.clear();
         if (uniL) {
             p->bank1_chan = halfb ? hf : on;
             p->bank2_chan = halfb ? on : hf;
@@ -927,6 +936,7 @@ int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
         add("%s, l = %d, bank of %d %s", p->poly_bnar ? "k_blknar" : p->poly_b512 ? "k_blk512" : "k_blk1024", p->poly_L, (int)p->bank1_chan.size(),
             p->poly_half ? "half a channel off the grid" : "on the grid");
         if (p->bank2) add(" + bank of %d %s (two launches)", (int)p->bank2_chan.size(), p->bank2_half ? "half a channel off the grid" : "on the grid");
+        if (!p->bank_alias.empty()) add(" + %d copies of channels with the same slice", (int)p->bank_alias.size());
     } else if (p->poly_block) {
         add("k_blk256, %d tiling%s (r =", (int)p->classes.size(), p->classes.size() == 1 ? "" : "s");
         for (const auto &pc : p->classes) add(" %d", pc.r);
@@ -1105,7 +1115,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             continue;
         }
         // (a bank at half a channel's offset, or a plan of two banks, has no two-launch form: short launch groups take the block kernel too)
-        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->poly_half || p->bank2)) {
+        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->poly_half || p->bank2 || !p->bank_alias.empty())) {
             const unsigned out_bytes = (unsigned)((int64_t)nblocks * p->sum_lout * 8);
             const float2 *in0 = ring + (size_t)m0 * p->H;
             float2 *o = static_cast<float2 *>(d_out);
@@ -1124,6 +1134,11 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                 else
                     HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, k ? p->d_cbtk2 : p->d_cbt512, shn, so,
                                                      out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
+            }
+            for (const auto &al : p->bank_alias) {
+                const fdc::ChanDev &dc = p->chans[(size_t)al.first], &sc = p->chans[(size_t)al.second];
+                HIPCHK(hipMemcpyAsync(o + (size_t)nblocks * dc.out_off + (size_t)m0 * dc.lout, o + (size_t)nblocks * sc.out_off + (size_t)m0 * sc.lout,
+                                      sizeof(float2) * (size_t)nb * dc.lout, hipMemcpyDeviceToDevice, s));
             }
             if (tg) {
                 span[2] = span[3] = span[1];

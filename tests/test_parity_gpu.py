@@ -1313,3 +1313,43 @@ def test_centred_bank_through_the_parameter_derivation_is_two_banks(oracle, C, R
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
     for c in range(len(chans)):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("C,R,nb", [(256, 2, 261), (1024, 2, 9), (256, 4, 7)])
+def test_centred_bank_of_half_overlapping_channels(oracle, C, R, nb):
+    """C channels of 1/C of the band (no gaps) centred on k/C: the derivation doubles the slice (l = 2 N / C: neighbours overlap by half), the
+    channels alternate between the l-bin grid and half a channel off it — two banks — and channel 0, wrapped and clamped, lands on channel C - 1's slice:
+    computed once, copied.  Against the oracle, against the spectrum path, ragged calls."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N = 65536
+    H = N - N // R
+    prm = [G.get_opt_channelparams(N, R, (k / C) % 1.0, 1.0 / C) for k in range(C)]
+    L = prm[0][1]
+    assert L == 2 * N // C and prm[0][0] == prm[C - 1][0] == N - L
+    chans = [(f, l, pb, sb) for (f, l, _lo, pb, sb) in prm]
+    lout = L - L // R
+    x = noise(nb * H, 9100 + C + R)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3 and "two launches" in p.describe() and "1 copies" in p.describe()
+    outs = p.work(x)
+    assert np.array_equal(outs[0], outs[C - 1])
+    check = [0, 1, 2, 3, C // 2, C - 2, C - 1]
+    sub = [chans[c] for c in check]
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, 1, sub, x[:k * H], nthreads=8)
+    t0 = nb - k
+    ref2, _ = oracle.channelizer(N, R, 1, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * lout
+        assert_close(outs[c][:k * lout], ref[i], "channel %d head" % c)
+        assert_close(outs[c][t0 * lout:], ref2[i], "channel %d tail" % c)
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+    assert q.path() == 1
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "channel %d vs the spectrum path" % c)
+    p.reset()
+    cuts = [(0, 1), (1, 3), (3, max(3, nb // 2)), (max(3, nb // 2), nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
