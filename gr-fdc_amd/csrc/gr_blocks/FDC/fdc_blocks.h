@@ -114,6 +114,8 @@ public:
     virtual bool pin_buffer(void *base, size_t bytes) = 0;
     virtual void unpin_buffers() = 0;
     virtual int output_item_len(int port) const = 0;
+    // which kernels the plan was given, in words (fdc_pipeline_describe; the first member of a group)
+    virtual std::string kernel_plan() const = 0;
 };
 
 }  // namespace FDC

@@ -70,6 +70,7 @@ int main(int argc, char **argv)
             gr_vector_const_void_star pi{x.data()};
             gr_vector_void_star pv;
             for (auto &v : po) pv.push_back(v.data());
+            if (pipe->kernel_plan().find("path ") == std::string::npos) throw std::runtime_error("fdc_pipeline_vcc: no kernel plan description");
             if (pipe->work(n1, pi, pv) != n1) throw std::runtime_error("fdc_pipeline_vcc: first work() failed");
             std::vector<gr_complex> xin(x.begin() + (size_t)n1 * H, x.end());
             bool pinned = pipe->pin_buffer(xin.data(), xin.size() * sizeof(gr_complex));

@@ -209,6 +209,13 @@ public:
         d_pinned.clear();
     }
     int output_item_len(int port) const override { return port >= 0 && port < (int)d_lout.size() ? d_lout[port] : -1; }
+    std::string kernel_plan() const override
+    {
+        char buf[512] = "";
+        const fdc_pipeline *p0 = d_g ? fdc_pipeline_group_member(d_g, 0) : d_p;
+        if (p0) fdc_pipeline_describe(p0, buf, (int32_t)sizeof(buf));
+        return buf;
+    }
 };
 
 // shared by the two sink faces: PDU records -> messages on "msgout" and raw files
