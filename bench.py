@@ -87,6 +87,8 @@ def parse():
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
     ap.add_argument("--width", type=int, default=0, metavar="L", help="diagnostics (config 2): a uniform bank of channels L bins wide (N / L channels "
                                                                       "on the L-bin grid) instead of 256: the generic-width two-launch path")
+    ap.add_argument("--gapless", type=int, default=0, metavar="C", help="diagnostics (config 2): C channels of 1/C of the band each (no gaps): slices of 2 N / C bins "
+                                                                          "overlapping by half, a quarter of a channel off their grid (with --centred: on it and half off it)")
     ap.add_argument("--centred", action="store_true", help="the channels centred on k/C instead of (k + 1/2)/C (a bank half a channel off "
                                                           "the grid plus the wrapped channel 0 on it: two launches of the width's kernel)")
     ap.add_argument("--extra", type=int, default=0, metavar="K", help="diagnostics (config 2): K more channels of widths 512 / 128 / 1024 at odd bins beside "
@@ -466,6 +468,9 @@ def main():
         elif a.sparse:
             wid = tuple(int(v) for v in a.sparse_widths.split(","))
             params = [G.get_opt_channelparams(N, R, ((c + 0.37) / a.sparse) % 1.0, 0.8 * wid[c % len(wid)] / N) for c in range(a.sparse)]
+        elif a.gapless:     # C channels of 1/C of the band each: the derivation doubles the slices (l = 2 N / C), neighbours overlap by half
+            C = a.gapless
+            params = [G.get_opt_channelparams(N, R, ((c + (0.0 if a.centred else 0.5)) / C) % 1.0, 1.0 / C) for c in range(C)]
         elif a.width:
             C = N // a.width
             if a.centred:     # centres on k/C: half a channel off the grid, channel 0 wrapped and clamped onto it by the reference's derivation
@@ -700,7 +705,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or a.width or R != 2):
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or a.width or a.gapless or a.centred or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
                              "not counters of this process"

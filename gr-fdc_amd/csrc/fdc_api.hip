@@ -149,12 +149,13 @@ struct fdc_pipeline {
     float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
     // a second bank of the same width and window, the other of the two places (on the l-bin grid / half a channel higher): its own launch.
     // What the reference's parameter derivation makes of a bank centred on multiples of l: channel 0 wraps and is clamped onto the grid.
-    bool bank2 = false, bank2_half = false;
-    std::vector<int> bank1_chan, bank2_chan;
+    int nbanks = 1;                                          // 1 .. 3 (what the cost rule allows)
+    int bank1_r = 0, bankx_r[2] = {0, 0};                    // the banks' offsets from the l-bin grid, bins (0, l/2; the narrow kernel: l/4 and 3l/4 too)
+    std::vector<int> bank1_chan, bankx_chan[2];              // bank 1 (the biggest), banks 2 and 3
     std::vector<std::pair<int, int>> bank_alias;             // (channel, the earlier channel with the same slice): computed once, copied
-    float *d_shn2 = nullptr;
-    long long *d_slot_off2 = nullptr;
-    float2 *d_cbtk2 = nullptr, *d_tabnar2 = nullptr;       // the width's kernel's cbt (512 / 1024 / narrow), the narrow kernel's table image
+    float *d_shnx[2] = {nullptr, nullptr};
+    long long *d_slot_offx[2] = {nullptr, nullptr};
+    float2 *d_cbtx[2] = {nullptr, nullptr}, *d_tabx[2] = {nullptr, nullptr};   // the width's kernel's cbt (512 / 1024 / narrow), the narrow kernel's table image
     int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
                                  // stage 1 on the generic LDS core, two launches; one class, no offset)
     int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
@@ -386,7 +387,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
     (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
     (void)hipFree(p->d_tabnar); (void)hipFree(p->d_cbtnar);
-    (void)hipFree(p->d_shn2); (void)hipFree(p->d_slot_off2); (void)hipFree(p->d_cbtk2); (void)hipFree(p->d_tabnar2);
+    for (int k = 0; k < 2; k++) { (void)hipFree(p->d_shnx[k]); (void)hipFree(p->d_slot_offx[k]); (void)hipFree(p->d_cbtx[k]); (void)hipFree(p->d_tabx[k]); }
     (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k); (void)hipFree(p->d_cbt1k);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -496,37 +497,42 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         // on the l-bin grid, or (block kernels of the other widths only) half a channel higher: a bank centred on multiples of l — or both: two banks,
         // two launches (the reference's parameter derivation clamps the wrapped channel 0 of a centred bank onto the grid).  Bank 1 is the bigger one.
         const bool blockL = b512 || b1024 || bnar;
-        std::vector<int> on, hf;
-        std::vector<char> usedOn(uniL ? (size_t)(N / L) : 0, 0), usedHf(usedOn);
+        const int rstep = bnar ? L / 4 : L / 2;                                 // the narrow kernel also takes banks a quarter of a channel off the grid
+        std::map<int, std::vector<int>> byr;                                    // offset from the grid -> its channels
+        std::map<int, std::vector<char>> usedr;
         for (int c = 0; uniL && c < p->C; c++) {
             const fdc_channel &ch = cfg->channels[c];
             const int r = ch.f % L;
-            if (ch.l != L || (r != 0 && r != L / 2) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw) { uniL = false; break; }
-            auto &used = r ? usedHf : usedOn;
+            if (ch.l != L || (r % rstep) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw) { uniL = false; break; }
+            auto &used = usedr[r];
+            if (used.empty()) used.assign((size_t)(N / L), 0);
             if (used[(size_t)(ch.f / L)]) {
                 // the same slice again (the reference's derivation clamps a wrapped channel onto its neighbour's place): computed once, copied
                 int first = -1;
-                for (int c0 : (r ? hf : on)) if (cfg->channels[c0].f == ch.f) { first = c0; break; }
+                for (int c0 : byr[r]) if (cfg->channels[c0].f == ch.f) { first = c0; break; }
                 if (first < 0 || !blockL) { uniL = false; break; }
                 p->bank_alias.emplace_back(c, first);
                 continue;
             }
             used[(size_t)(ch.f / L)] = 1;
-            (r ? hf : on).push_back(c);
+            byr[r].push_back(c);
         }
-        if (uniL && !hf.empty() && !blockL) uniL = false;                      // half a channel off the grid: block kernels only
-        if (uniL && !hf.empty() && !on.empty() && N == 65536) {
-            // two launches against the spectrum path, ms per 1024 blocks (the kernels' cost does not depend on the number of channels)
+        if (uniL && byr.size() > 3) uniL = false;                               // at most three banks
+        if (uniL && !blockL && (byr.size() > 1 || byr.begin()->first != 0)) uniL = false;   // off the grid, or several banks: block kernels only
+        if (uniL && byr.size() > 1 && N == 65536) {
+            // one launch per bank against the spectrum path, ms per 1024 blocks (the kernels' cost does not depend on the number of channels)
             const double per = L == 1024 ? 0.222 : L == 512 ? 0.19 : L == 128 ? 0.177 : 0.19, bins = double(p->C) * L / 65536.0;
-            if (2.0 * per >= 0.20 + 0.05 * std::min(1.0, bins) + 0.19 * bins) uniL = false;
+            if (double(byr.size()) * per >= 0.20 + 0.05 * std::min(1.0, bins) + 0.19 * bins) uniL = false;
         }
-        const bool halfb = uniL && hf.size() > on.size();
         if (!uniL) p->bank_alias.clear();
+        bool halfb = false;
         if (uniL) {
-            p->bank1_chan = halfb ? hf : on;
-            p->bank2_chan = halfb ? on : hf;
-            p->bank2 = !p->bank2_chan.empty();
-            p->bank2_half = p->bank2 && !halfb;
+            std::vector<std::pair<int, std::vector<int>>> bk(byr.begin(), byr.end());
+            std::stable_sort(bk.begin(), bk.end(), [](const auto &x, const auto &y) { return x.second.size() > y.second.size(); });   // the biggest first
+            p->nbanks = (int)bk.size();
+            p->bank1_chan = bk[0].second; p->bank1_r = bk[0].first;
+            for (int k = 1; k < p->nbanks; k++) { p->bankx_chan[k - 1] = bk[(size_t)k].second; p->bankx_r[k - 1] = bk[(size_t)k].first; }
+            halfb = p->bank1_r == L / 2;
         }
         if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; p->poly_half = halfb; }
     }
@@ -691,7 +697,8 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         p->classes.push_back(pc);
         // one bank's tables: window, slot table, and what its width's block kernel wants (cbt; the narrow kernel's image).  half: the bank sits half a
         // channel off the grid (tables moved)
-        auto build_bank = [&](const std::vector<int> &ids, bool half, float *&d_shn, long long *&d_so, float2 *&d_cbt, float2 *&d_tab) -> int {
+        auto build_bank = [&](const std::vector<int> &ids, int rb, float *&d_shn, long long *&d_so, float2 *&d_cbt, float2 *&d_tab) -> int {
+            const bool half = rb == L / 2;
             std::vector<long long> so((size_t)N1, -1);
             for (int c : ids) so[(size_t)(p->chans[c].f / L)] = p->chans[c].out_off;
             // the 512- and 1024-bin block kernels at half a channel's offset read the window with its halves swapped (their lanes hold the other half)
@@ -719,13 +726,13 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
                 // the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l (half: W_N^((l/2) S V) with it)
                 const int S = 256 / L;
                 std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L));
-                fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half);
+                fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half, half ? 0 : rb);
                 CHK_OR_FREE(hipMalloc(&d_tab, sizeof(float2) * img.size()));
                 CHK_OR_FREE(hipMemcpy(d_tab, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
                 cb.resize(256 * 16);
                 for (int V = 0; V < 256; V++)
                     for (int b = 0; b < 16; b++) {
-                        const double a = -2.0 * M_PI * double(((long long)S * V * (b + (half ? L / 2 : 0))) % N) / double(N);
+                        const double a = -2.0 * M_PI * double(((long long)S * V * (b + rb)) % N) / double(N);
                         cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
                     }
             }
@@ -737,9 +744,12 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         };
         auto &q = p->classes.back();
         float2 *&cbt1 = p->poly_b512 ? p->d_cbt512 : p->poly_b1024 ? p->d_cbt1k : p->d_cbtnar;
-        { const int rcb = build_bank(p->bank1_chan, p->poly_half, q.d_shn, q.d_slot_off, cbt1, p->d_tabnar); if (rcb != FDC_OK) return rcb; }
+        { const int rcb = build_bank(p->bank1_chan, p->bank1_r, q.d_shn, q.d_slot_off, cbt1, p->d_tabnar); if (rcb != FDC_OK) return rcb; }
         p->d_shn = q.d_shn; p->d_slot_off = q.d_slot_off;
-        if (p->bank2) { const int rcb = build_bank(p->bank2_chan, p->bank2_half, p->d_shn2, p->d_slot_off2, p->d_cbtk2, p->d_tabnar2); if (rcb != FDC_OK) return rcb; }
+        for (int k = 1; k < p->nbanks; k++) {
+            const int rcb = build_bank(p->bankx_chan[k - 1], p->bankx_r[k - 1], p->d_shnx[k - 1], p->d_slot_offx[k - 1], p->d_cbtx[k - 1], p->d_tabx[k - 1]);
+            if (rcb != FDC_OK) return rcb;
+        }
         // the tile-local factor of the inter-pass twiddle, in the tile's own order: t2[k2][t] = W_N^(t k2)
         const int TCg = fdc::poly_stage1_generic_tile_columns(N, L);
         std::vector<float2> t2v((size_t)L * TCg);
@@ -933,9 +943,10 @@ int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
     int k = std::snprintf(t, sizeof(t), "N = %d, R = %d, %d channels; path %d: ", p->N, p->R, p->C, path);
     auto add = [&](const char *fmt, auto... a) { if (k < (int)sizeof(t)) k += std::snprintf(t + k, sizeof(t) - (size_t)k, fmt, a...); };
     if (p->poly_b512 || p->poly_b1024 || p->poly_bnar) {
-        add("%s, l = %d, bank of %d %s", p->poly_bnar ? "k_blknar" : p->poly_b512 ? "k_blk512" : "k_blk1024", p->poly_L, (int)p->bank1_chan.size(),
-            p->poly_half ? "half a channel off the grid" : "on the grid");
-        if (p->bank2) add(" + bank of %d %s (two launches)", (int)p->bank2_chan.size(), p->bank2_half ? "half a channel off the grid" : "on the grid");
+        auto where = [&](int r) { return r == 0 ? "on the grid" : 2 * r == p->poly_L ? "half a channel off the grid" : 4 * r == p->poly_L ? "a quarter of a channel off the grid" : "three quarters of a channel off the grid"; };
+        add("%s, l = %d, bank of %d %s", p->poly_bnar ? "k_blknar" : p->poly_b512 ? "k_blk512" : "k_blk1024", p->poly_L, (int)p->bank1_chan.size(), where(p->bank1_r));
+        for (int k = 1; k < p->nbanks; k++) add(" + bank of %d %s", (int)p->bankx_chan[k - 1].size(), where(p->bankx_r[k - 1]));
+        if (p->nbanks > 1) add(" (%s launches)", p->nbanks == 2 ? "two" : "three");
         if (!p->bank_alias.empty()) add(" + %d copies of channels with the same slice", (int)p->bank_alias.size());
     } else if (p->poly_block) {
         add("k_blk256, %d tiling%s (r =", (int)p->classes.size(), p->classes.size() == 1 ? "" : "s");
@@ -1115,24 +1126,25 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             continue;
         }
         // (a bank at half a channel's offset, or a plan of two banks, has no two-launch form: short launch groups take the block kernel too)
-        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->poly_half || p->bank2 || !p->bank_alias.empty())) {
+        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->bank1_r || p->nbanks > 1 || !p->bank_alias.empty())) {
             const unsigned out_bytes = (unsigned)((int64_t)nblocks * p->sum_lout * 8);
             const float2 *in0 = ring + (size_t)m0 * p->H;
             float2 *o = static_cast<float2 *>(d_out);
             // one launch per bank; the timing events take the first launch's begin and the last one's end
-            for (int k = 0; k < (p->bank2 ? 2 : 1); k++) {
-                const bool half = k ? p->bank2_half : p->poly_half;
-                const float *shn = k ? p->d_shn2 : p->d_shn;
-                const long long *so = k ? p->d_slot_off2 : p->d_slot_off;
-                hipEvent_t e0 = tg && k == 0 ? p->events[span[0]] : nullptr, e1 = tg && k == (p->bank2 ? 1 : 0) ? p->events[span[1]] : nullptr;
+            for (int k = 0; k < p->nbanks; k++) {
+                const int rk = k ? p->bankx_r[k - 1] : p->bank1_r;
+                const bool half = rk == p->poly_L / 2;
+                const float *shn = k ? p->d_shnx[k - 1] : p->d_shn;
+                const long long *so = k ? p->d_slot_offx[k - 1] : p->d_slot_off;
+                hipEvent_t e0 = tg && k == 0 ? p->events[span[0]] : nullptr, e1 = tg && k == p->nbanks - 1 ? p->events[span[1]] : nullptr;
                 if (p->poly_b1024)
-                    HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, k ? p->d_cbtk2 : p->d_cbt1k, shn, so,
+                    HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, k ? p->d_cbtx[k - 1] : p->d_cbt1k, shn, so,
                                                       out_bytes, p->ncu, p->block_hints, s, e0, e1, half, p->R, p->d_fscr));
                 else if (p->poly_bnar)
-                    HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, in0, (size_t)p->H, o, nb, m0, nblocks, k ? p->d_tabnar2 : p->d_tabnar, k ? p->d_cbtk2 : p->d_cbtnar,
-                                                         so, out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
+                    HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, in0, (size_t)p->H, o, nb, m0, nblocks, k ? p->d_tabx[k - 1] : p->d_tabnar, k ? p->d_cbtx[k - 1] : p->d_cbtnar,
+                                                         so, out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, rk));
                 else
-                    HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, k ? p->d_cbtk2 : p->d_cbt512, shn, so,
+                    HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, k ? p->d_cbtx[k - 1] : p->d_cbt512, shn, so,
                                                      out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
             }
             for (const auto &al : p->bank_alias) {

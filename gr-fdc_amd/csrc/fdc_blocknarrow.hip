@@ -91,7 +91,7 @@ int poly_block_narrow_table_points(int L) { return L == 128 ? NarGeom<2>::kTabPt
 // ifftshift of the inverse is the identity — the data stays in its registers and only the tables move (entries of kap ^ l/2), the separation's
 // and the re-join's twiddles cancel, and the per-column constant W_N^((l/2) n1) goes into TD (its e part) and cbt (its V part, fdc_api.hip).
 template <int S>
-static void narrow_tables(const float *shn, float2 *img, bool half)
+static void narrow_tables(const float *shn, float2 *img, bool half, int r)
 {
     typedef NarGeom<S> GM;
     const double N = 65536.0;
@@ -118,8 +118,9 @@ static void narrow_tables(const float *shn, float2 *img, bool half)
                 // column e: (-1)^n1 = (-1)^e, W_N^(e kap), the separation's conj(W_256^(e kap)) and the re-join's W_256^(e kap') at the shifted place
                 const int kap = b + 16 * q, kp = kap ^ (GM::kL / 2);
                 // on the grid: W_N^(e kap), separation at kap, re-join at kap'; half: W_N^(e kap') W_N^(e l/2), separation and re-join both at kap
+                // r (a quarter or three quarters of a channel; not with half): column e's constant W_N^(r e) conj(W_256^(r e)) with it
                 const double a = half ? -2.0 * M_PI * double(e) * (double(kp) + double(GM::kL / 2)) / N
-                                      : -2.0 * M_PI * double(e) * (double(kap) / N - double(kap) / 256.0 + double(kp) / 256.0);
+                                      : -2.0 * M_PI * double(e) * ((double(kap) + double(r)) / N - (double(kap) + double(r)) / 256.0 + double(kp) / 256.0);
                 const double sg = (e & 1) ? -1.0 : 1.0;
                 img[GM::kTTD + b * GM::kRowT + (e - 1) * GM::kQG + q] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
             }
@@ -132,16 +133,20 @@ static void narrow_tables(const float *shn, float2 *img, bool half)
     for (int c = 0; c < 32; c++)
         for (int klo = 0; klo < 8; klo++) img[GM::kTCt + c * 8 + klo] = W(double((c * klo) & 255), 256.0);
 }
-void poly_block_narrow_tables(int L, const float *shn, float2 *img, bool half)
+void poly_block_narrow_tables(int L, const float *shn, float2 *img, bool half, int r)
 {
-    if (L == 128) narrow_tables<2>(shn, img, half); else narrow_tables<4>(shn, img, half);
+    if (L == 128) narrow_tables<2>(shn, img, half, r); else narrow_tables<4>(shn, img, half, r);
 }
 
 // R4 = true: relinvovl = 4 (the reference's default overlap): three quarters of every inverse transform are kept.  The rows t >= 128 of the
 // virtual column stay in the G registers as for R = 2; the rows 64 <= t < 128 go to 128 KiB of per-workgroup scratch ([pass][q - 4][thread]: the
 // L2 holds it) and come back for a second, 64-row run of stage 2 (the first 64/S output rows of the block), as in fdc_block256.hip.
 // HALF = true: the bank half a channel higher (tables: narrow_tables(half)); in the kernel only the place the re-joined values go to changes.
-template <int S, bool NT, bool R4, bool HALF>
+// ROT != 0: the bank a QUARTER of a channel off the grid (f = l slot + r, r = l/4 or 3l/4: doubled slices centred between the raster points).  The block
+// modulated by exp(-2 pi i r n / N): on the virtual column that is W_256^(r nu) — its 256-point spectrum moved by r bins, i.e. by ROT = r/16 REGISTERS of the
+// same lane — times one constant per column: W_N^(r e) conj(W_256^(r e)) (in TD, host) and W_N^(r S V) (in cbt).  The kernel differs in which registers the
+// separation reads.
+template <int S, bool NT, bool R4, bool HALF, int ROT = 0>
 __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                     const float2 *__restrict__ tab /* the table image */,
                                                     const float2 *__restrict__ cbt /* [256 V][16 b]  W_N^(S V b) */,
@@ -149,6 +154,7 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                                                     unsigned out_bytes, int nb, int hints, float2 *__restrict__ scratch)
 {
     typedef NarGeom<S> GM;
+    static_assert(!(HALF && ROT), "half a channel off the grid is its own form");
     constexpr int kRows = R4 ? 3 * GM::kL / 4 : GM::kL / 2;        // kept samples per block and channel: 3 l / 4 or l / 2
     constexpr int kQG = GM::kQG, kLS = S == 2 ? 1 : 2;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_nar);
@@ -248,13 +254,13 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
                         const int q = 2 * g + h, qs = HALF ? q : q ^ (kQG / 2);   // the shifted place (HALF: the two shifts cancel)
                         const cf f = cmul(bt[h], sa[h]);                      // shape/(S^2 N) W_N^(S V 16 q) without the lane's W_N^(S V b) (cb, below)
                         if constexpr (S == 2) {
-                            const cf z0 = v[rev16(q)], z1 = v[rev16(q + 8)];
+                            const cf z0 = v[rev16((q + ROT) & 15)], z1 = v[rev16((q + 8 + ROT) & 15)];
                             const cf u0 = cmul(z0 + z1, f);                   // column 2V
                             const cf x1 = cmul(cmul(z0 - z1, td[0][h]), f);   // column 2V + 1, with the re-join's twiddle
                             u[qs] = u0 + x1;
                             u[qs + 8] = u0 - x1;
                         } else {
-                            cf z0 = v[rev16(q)], z1 = v[rev16(q + 4)], z2 = v[rev16(q + 8)], z3 = v[rev16(q + 12)];
+                            cf z0 = v[rev16((q + ROT) & 15)], z1 = v[rev16((q + 4 + ROT) & 15)], z2 = v[rev16((q + 8 + ROT) & 15)], z3 = v[rev16((q + 12 + ROT) & 15)];
                             dft4<true>(z0, z1, z2, z3);                       // 4 W_256^(kap e) A_e[kap], e = 0 .. 3
                             z0 = cmul(z0, f);
                             z1 = cmul(cmul(z1, td[0][h]), f);
@@ -401,34 +407,39 @@ __global__ FDC_PLAIN_DSN __launch_bounds__(512) void k_blknar(const float2 *__re
 hipError_t init_block_narrow_kernels()
 {
     hipError_t e = hipSuccess;
-#define FDC_SETN(S, A, B, H) \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<S, A, B, H>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<S>::kLds);
-#define FDC_SETNS(S, H) FDC_SETN(S, true, false, H) FDC_SETN(S, false, false, H) FDC_SETN(S, true, true, H) FDC_SETN(S, false, true, H)
-    FDC_SETNS(2, false) FDC_SETNS(2, true) FDC_SETNS(4, false) FDC_SETNS(4, true)
+#define FDC_SETN(S, A, B, H, Q) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blknar<S, A, B, H, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, NarGeom<S>::kLds);
+#define FDC_SETNS(S, H, Q) FDC_SETN(S, true, false, H, Q) FDC_SETN(S, false, false, H, Q) FDC_SETN(S, true, true, H, Q) FDC_SETN(S, false, true, H, Q)
+    FDC_SETNS(2, false, 0) FDC_SETNS(2, true, 0) FDC_SETNS(2, false, 2) FDC_SETNS(2, false, 6)
+    FDC_SETNS(4, false, 0) FDC_SETNS(4, true, 0) FDC_SETNS(4, false, 1) FDC_SETNS(4, false, 3)
 #undef FDC_SETNS
 #undef FDC_SETN
     return e;
 }
 
+// r: the bank's offset from the l-bin grid: 0, l/4, l/2 (= half), 3l/4
 hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tab,
                                     const float2 *cbt, const long long *slot_off, unsigned out_bytes, int ncu, int hints, hipStream_t s,
-                                    hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch, bool half)
+                                    hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch, int r)
 {
     if (nb_chunk <= 0) return hipSuccess;
-    if ((L != 128 && L != 64) || (R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
+    if ((L != 128 && L != 64) || (R != 2 && R != 4) || (R == 4 && !scratch) || r < 0 || r >= L || (r % (L / 4))) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
-    const int rows = R == 4 ? 3 * L / 4 : L / 2;
-#define FDC_LNAR(S, A, B, H) \
-    hipExtLaunchKernelGGL((k_blknar<S, A, B, H>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
+    const int rows = R == 4 ? 3 * L / 4 : L / 2, quarter = r / (L / 4);
+#define FDC_LNAR(S, A, B, H, Q) \
+    hipExtLaunchKernelGGL((k_blknar<S, A, B, H, Q>), dim3((unsigned)grid), dim3(512), NarGeom<S>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, tab, cbt, \
                           slot_off, (long long)mbase * rows, (long long)nb_call, out_bytes, nb_chunk, hints, B ? scratch : (float2 *)nullptr)
-#define FDC_LNARH(S, H) \
+#define FDC_LNARH(S, H, Q) \
     do { \
-        if (R == 4) { if (hints & 1) FDC_LNAR(S, true, true, H); else FDC_LNAR(S, false, true, H); } \
-        else { if (hints & 1) FDC_LNAR(S, true, false, H); else FDC_LNAR(S, false, false, H); } \
+        if (R == 4) { if (hints & 1) FDC_LNAR(S, true, true, H, Q); else FDC_LNAR(S, false, true, H, Q); } \
+        else { if (hints & 1) FDC_LNAR(S, true, false, H, Q); else FDC_LNAR(S, false, false, H, Q); } \
     } while (0)
-    if (L == 128) { if (half) FDC_LNARH(2, true); else FDC_LNARH(2, false); }
-    else { if (half) FDC_LNARH(4, true); else FDC_LNARH(4, false); }
+    if (L == 128) {
+        if (quarter == 2) FDC_LNARH(2, true, 0); else if (quarter == 1) FDC_LNARH(2, false, 2); else if (quarter == 3) FDC_LNARH(2, false, 6); else FDC_LNARH(2, false, 0);
+    } else {
+        if (quarter == 2) FDC_LNARH(4, true, 0); else if (quarter == 1) FDC_LNARH(4, false, 1); else if (quarter == 3) FDC_LNARH(4, false, 3); else FDC_LNARH(4, false, 0);
+    }
 #undef FDC_LNARH
 #undef FDC_LNAR
     return hipGetLastError();

@@ -1353,3 +1353,78 @@ def test_centred_bank_of_half_overlapping_channels(oracle, C, R, nb):
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
     for c in range(len(chans)):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("C,R,nb", [(1024, 2, 261), (2048, 2, 9), (1024, 4, 7), (2048, 4, 261)])
+def test_bank_of_half_overlapping_narrow_channels_between_the_raster_points(oracle, C, R, nb):
+    """C channels of 1/C of the band centred on (k + 1/2)/C: doubled slices (l = 2 N / C = 128 or 64) at f = (l/2)(k - 1/2) — a quarter and three quarters of a
+    channel off the l-bin grid, alternately: two banks of the narrow-channel kernel's ROT forms (the virtual column's spectrum moved by whole registers).
+    Against the oracle, against the spectrum path on every sample, ragged calls bit for bit."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N = 65536
+    H = N - N // R
+    prm = [G.get_opt_channelparams(N, R, ((k + 0.5) / C) % 1.0, 1.0 / C) for k in range(C)]
+    L = prm[0][1]
+    assert L == 2 * N // C and sorted(set(p_[0] % L for p_ in prm[1:C - 1])) == [L // 4, 3 * L // 4]
+    # the first and the last channel are clamped at the band edges by the derivation: dropped here (they sit on the grid: a third bank)
+    chans = [(f, l, pb, sb) for (f, l, _lo, pb, sb) in prm[1:C - 1]]
+    lout = L - L // R
+    x = noise(nb * H, 9300 + C + R)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3 and "quarter" in p.describe() and "two launches" in p.describe()
+    outs = p.work(x)
+    n = len(chans)
+    check = [0, 1, 2, 3, n // 2, n // 2 + 1, n - 2, n - 1]
+    sub = [chans[c] for c in check]
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, 1, sub, x[:k * H], nthreads=8)
+    t0 = nb - k
+    ref2, _ = oracle.channelizer(N, R, 1, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * lout
+        assert_close(outs[c][:k * lout], ref[i], "channel %d head" % c)
+        assert_close(outs[c][t0 * lout:], ref2[i], "channel %d tail" % c)
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+    assert q.path() == 1
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "channel %d vs the spectrum path" % c)
+    p.reset()
+    cuts = [(0, 1), (1, 3), (3, max(3, nb // 2)), (max(3, nb // 2), nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
+@pytest.mark.parametrize("C,R,nb", [(1024, 2, 9), (2048, 4, 7)])
+def test_the_whole_raster_of_half_overlapping_narrow_channels_is_three_banks(oracle, C, R, nb):
+    """All C channels of the plan above: the first and the last slice are clamped at the band edges onto the grid — the same slice, N - l — beside the two
+    banks a quarter and three quarters of a channel off it: three banks, three launches and one copy, where the cost rule still prefers that to the spectrum
+    path.  The edge channels and their neighbours against the oracle, every sample against the spectrum path."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    N = 65536
+    H = N - N // R
+    prm = [G.get_opt_channelparams(N, R, ((k + 0.5) / C) % 1.0, 1.0 / C) for k in range(C)]
+    L = prm[0][1]
+    assert prm[0][0] == prm[C - 1][0] == N - L
+    chans = [(f, l, pb, sb) for (f, l, _lo, pb, sb) in prm]
+    lout = L - L // R
+    x = noise(nb * H, 9400 + C + R)
+    p = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb)
+    assert p.path() == 3 and "three launches" in p.describe() and "1 copies" in p.describe(), p.describe()
+    outs = p.work(x)
+    assert np.array_equal(outs[0], outs[C - 1])
+    check = [0, 1, 2, C // 2, C - 2, C - 1]
+    ref, _ = oracle.channelizer(N, R, 1, [chans[c] for c in check], x, nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * lout
+        assert_close(outs[c], ref[i], "channel %d" % c)
+    q = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK)
+    assert q.path() == 1
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "channel %d vs the spectrum path" % c)
+    p.reset()
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 2), (2, 3), (3, nb)]]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
