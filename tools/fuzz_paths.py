@@ -28,12 +28,12 @@ def draw_plan(rng):
     kind = rng.integers(0, 8)
     if kind >= 6:                                     # uniform banks of another width on its grid: 1024, 512, 128, 64 (block kernels), others (spectrum path)
         L = int([512, 128, 1024, 1024, 64, 2048][int(rng.integers(0, 6))])
-        half = L // 2 if rng.integers(0, 3) == 0 else 0      # a bank centred on multiples of l (block kernels: tables moved by half a channel)
+        half = int(rng.choice([L // 2, L // 4, 3 * L // 4])) if rng.integers(0, 3) == 0 else 0      # a bank off its grid by a multiple of a quarter channel (narrow kernel: all; 512 / 1024: half only)
         slots = rng.permutation(N // L - (1 if half else 0))[:rng.integers(1, N // L + (0 if half else 1))]
         plan = [(L * int(c) + half, L, 0.88, 1.0) for c in slots]
         two = ""
         if rng.integers(0, 3) == 0:                          # a few channels on the OTHER grid: two banks, two launches (or the spectrum path by the cost rule)
-            other = 0 if half else L // 2
+            other = int(rng.choice([r_ for r_ in (0, L // 4, L // 2, 3 * L // 4) if r_ != half]))
             oslots = rng.permutation(N // L - (1 if other else 0))[:rng.integers(1, 5)]
             plan += [(L * int(c) + other, L, 0.88, 1.0) for c in oslots]
             plan = [plan[int(i)] for i in rng.permutation(len(plan))]
