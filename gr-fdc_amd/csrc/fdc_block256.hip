@@ -176,6 +176,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
     const bool xmap = (grid & 7) == 0;
     const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (first >= nb) return;
+#ifdef FDC_BLK_WGTIMES
+    // diagnostics (tools/wg_times.py): when every workgroup starts and ends, 100 MHz clock: [0..255] starts, [256..511] ends
+    if (dbg && tid == 0) dbg[blockIdx.x] = wall_clock64();
+#endif
 #ifdef FDC_BLK_STAGGER
     // experiment: half of the workgroups (by slot parity inside their XCD) start FDC_BLK_STAGGER x 8128 cycles late, so that the
     // store bursts of one half meet the load phases of the other
@@ -545,6 +549,9 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
         dbgk++;
         // the trip region (= stage-1 scratch) was last read before the barrier above: the next block starts without one
     }
+#ifdef FDC_BLK_WGTIMES
+    if (dbg && tid == 0) dbg[256 + blockIdx.x] = wall_clock64();
+#endif
 }
 
 // -DFDC_BLK_STAGED=1: the plain channelizer at N = 65536 with its loads staged through LDS (the STG variant above): measured 1.5 % SLOWER than the
