@@ -56,6 +56,62 @@ __device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff,
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 2);
 }
+// ---- loads the compiler's s_waitcnt pass does not see (round 5) -------------------------------------------------------------------
+// hipcc places s_waitcnt vmcnt(N) from a per-register scoreboard that is MERGED over all predecessors of a loop header.  In a persistent
+// loop of the form { request the NEXT tile's rows; compute; store this tile } the preheader (nothing younger than the first rows) and
+// the back edge (eight stores younger than the prefetched rows) disagree, the merge takes the smaller count, and the loop waits with
+// vmcnt(0) — for its own stores of the tile before, every tile (k_p1: 16 us of 119 per 256 blocks at N = 262144, profiles/r05/NOTES.md) —
+// or, in the block kernels, with vmcnt(1..9) right behind the sixteen prefetch loads it has just issued.  vmcnt counts loads and stores of
+// one wave in issue order on gfx9 (LLVM's own model: one event type on the counter), so the exact wait is known at every point:
+// "at most the number of vector-memory instructions issued after the ones I need".  These helpers issue the loads as inline assembly
+// (the scoreboard sees no pending load) and the kernel states the wait itself with vm_wait<N>(values...), which also ties the values
+// so that no use can be scheduled in front of it.  Rule for a kernel that uses them: no compiler-visible load may be pending at a
+// loop header inside which they are used (force such values with vm_settle before the loop).
+typedef int srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srd_t make_srd(const void *base, unsigned bytes)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    srd_t r;
+    r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = 0x00020000;   // as make_rsrc: stride 0, raw
+    return r;
+}
+// -DFDC_AUTO_WAITS=1 (A/B builds, tools/build_variant.sh): the same kernels with compiler-visible loads and the compiler's own waits
+#ifndef FDC_AUTO_WAITS
+#define FDC_AUTO_WAITS 0
+#endif
+template <bool NT>
+__device__ __forceinline__ cf ald2(srd_t r, unsigned voff, unsigned soff)
+{
+#if FDC_AUTO_WAITS
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)(unsigned)(r.y & 0xFFFF) << 32) | (unsigned)r.x), 0, r.z, 0x00020000);
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rr, voff, soff, NT ? 2 : 0);
+    return mk(__uint_as_float(t.x), __uint_as_float(t.y));
+#else
+    cf v;
+    if constexpr (NT) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    return v;
+#endif
+}
+// wait until at most N vector-memory instructions of this wave are outstanding; the listed values are the ones the wait is for
+#if FDC_AUTO_WAITS
+#define FDC_VMWAIT ""
+#else
+#define FDC_VMWAIT "s_waitcnt vmcnt(%8)"
+#endif
+template <int N> __device__ __forceinline__ void vm_wait(cf (&a)[8])
+{
+    asm volatile(FDC_VMWAIT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait(cf (&a)[16])
+{
+    asm volatile(FDC_VMWAIT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "n"(N) : "memory");
+    asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) :: "memory");
+}
+// a value from a compiler-visible load, made ready HERE (the compiler puts its own wait in front of this use)
+__device__ __forceinline__ void vm_settle(cf &v) { asm volatile("" : "+v"(v) :: "memory"); }
+
 template <bool NT>
 __device__ __forceinline__ void bst2t(__amdgpu_buffer_rsrc_t r, unsigned voff, cf v)
 {

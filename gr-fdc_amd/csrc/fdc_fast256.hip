@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, 4) void k_x256(const float2 *__restrict__ spec
 // 16(a + 16 - KEEP) + b of this one — and only 16 - KEEP rows per thread are loaded (R = 2: half the input reads;
 // measured 0.144 -> 0.129 ms per 1024 blocks).  TC = 32: 512 threads, 2 workgroups/CU; TC = 16: 256 threads, 4/CU.
 // ABL (diagnostic builds only, FDC_ABLATE env): 0 = real kernel, 1 = memory only (loads -> stores, no math, no LDS),
-// 2 = math + LDS only (one load per thread, data kept live), results are garbage for ABL != 0.
+// 2 = math + LDS only (one load per thread, data kept live), 3 = loads + math, one store per thread, 4 = one load per thread + math + all
+// stores; results are garbage for ABL != 0.
 template <int TC, int ABL, int KEEP>
 __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in, size_t in_stride,
                                                    float2 *__restrict__ g, const float2 *__restrict__ tw256,
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         sh[i] = shn[(i >> 4) + 16 * (i & 15)];
     }
     tq[col * 18 + b] = twq[(size_t)(c0 + col) * 16 + b];    // b plays q here
-    const cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
+    cf cb = ld2(&cbt[(size_t)(c0 + col) * 16 + b]);
+    vm_settle(cb);                                          // no compiler-visible load is pending when the loop starts (fdc_devutil.hpp)
     // per-lane byte offset inside a block (row b, column c0+col); rows 16a+b add a*16*N1*8 bytes (scalar)
     const unsigned voff = (unsigned)(b * N1 + c0 + col) * 8u;
     const unsigned rowstep = 16u * (unsigned)N1 * 8u;
@@ -319,10 +321,13 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     // One tile: consume `cur` (block m), prefetch block mn (the next block of the run: overlap handed over in registers;
     // or the first block of this workgroup's next run: all rows loaded; or none, mn < 0) into `nbuf`.
     auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int m, int mn) {
+        // The row loads are inline assembly and the wait for them is stated at the END of the tile, behind this tile's stores
+        // (vm_wait, fdc_devutil.hpp): left to the compiler, the loop header waits with vmcnt(0) — for the eight stores of the tile
+        // before, once per tile (16 us of k_p1's 119 per 256 blocks at N = 262144; profiles/r05/NOTES.md).
         if (mn >= 0) {
-            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mn * in_stride, inbytes);
-            if (ABL == 2) {
-                nbuf[0] = bld2(rin, voff, 0);
+            const srd_t rin = make_srd(in + (size_t)mn * in_stride, inbytes);
+            if (ABL == 2 || ABL == 4) {
+                nbuf[0] = ald2<false>(rin, voff, 0);
 #pragma unroll
                 for (int a = 1; a < 16; a++) nbuf[a] = nbuf[0] * (float)a;
             } else if (KEEP > 0 && mn == m + 1) {
@@ -330,14 +335,14 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
                 for (int a = 0; a < KEEP; a++) nbuf[a] = cur[a + 16 - KEEP];       // the overlap, already on chip
                 if (hints & 2) {
 #pragma unroll
-                    for (int a = KEEP; a < 16; a++) nbuf[a] = bld2_nt(rin, voff, a * rowstep);
+                    for (int a = KEEP; a < 16; a++) nbuf[a] = ald2<true>(rin, voff, a * rowstep);
                 } else {
 #pragma unroll
-                    for (int a = KEEP; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+                    for (int a = KEEP; a < 16; a++) nbuf[a] = ald2<false>(rin, voff, a * rowstep);
                 }
             } else {
 #pragma unroll
-                for (int a = 0; a < 16; a++) nbuf[a] = bld2(rin, voff, a * rowstep);
+                for (int a = 0; a < 16; a++) nbuf[a] = ald2<false>(rin, voff, a * rowstep);
             }
         }
         // G is stored tile-major, G[m][column tile][t'][TC]: this workgroup's whole output (lout*TC points) is
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 if (q >= qs) bst2(rg, goff, (unsigned)(q - qs) * gstep, cur[q]);
+            vm_wait<0>(nbuf);
             return;
         }
         dft16<false>(cur);
@@ -397,18 +403,24 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
         if (hints & 8) {
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (q >= qs && (ABL != 2 || q == 15)) bst2_nt(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
+                if (q >= qs && ((ABL != 2 && ABL != 3) || q == 15)) bst2_nt(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (q >= qs && (ABL != 2 || q == 15)) bst2(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
+                if (q >= qs && ((ABL != 2 && ABL != 3) || q == 15)) bst2(rg, goff, (unsigned)(q - qs) * gstep, u[rev16(q)]);
         }
+        // the next block's rows were requested a tile ago: waited for HERE, behind the stores (vmcnt counts in issue order: "at most
+        // the stores of this tile outstanding" = every row load has landed, no store is waited for)
+        if (KEEP > 0 && ABL == 0) vm_wait<16 - KEEP>(nbuf);
+        else if (ABL == 2 || ABL == 3) vm_wait<1>(nbuf);
+        else vm_wait<0>(nbuf);
     };
     cf L[16];
     {
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)(grp * bpg) * in_stride, inbytes);
+        const srd_t rin = make_srd(in + (size_t)(grp * bpg) * in_stride, inbytes);
 #pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, a * rowstep);
+        for (int a = 0; a < 16; a++) L[a] = ald2<false>(rin, voff, a * rowstep);
+        vm_wait<0>(L);
     }
     for (int run = grp; run * bpg < nb; run += ngrp) {
         const int m0 = run * bpg, m1 = m0 + bpg < nb ? m0 + bpg : nb;
@@ -454,22 +466,23 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
     const unsigned ctstep = (unsigned)lout * TCG * 8u;         // bytes between column tiles of one block
     // TCG = 16: ct = a, column = b.  TCG = 32: ct = a >> 1, column = 16*(a & 1) + b.
     const unsigned voff = (unsigned)(r * TCG + b) * 8u;
-    cf L[16];
-    auto issue = [&](int t) {
+    cf L[16];                                        // loads as inline assembly, waited for behind the stores: see k_p2k
+    auto issue = [&](int t) __attribute__((always_inline)) {
         const size_t m = t / tpb;
         const int t0 = (t - (int)m * tpb) * TR;
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 256 + (size_t)t0 * TCG, (unsigned)lout * 256u * 8u);
+        const srd_t rg = make_srd(g + m * (size_t)lout * 256 + (size_t)t0 * TCG, (unsigned)lout * 256u * 8u);
         if (hints & 4) {
 #pragma unroll
             for (int a = 0; a < 16; a++)
-                L[a] = bld2_nt(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
+                L[a] = ald2<true>(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
         } else {
 #pragma unroll
             for (int a = 0; a < 16; a++)
-                L[a] = bld2(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
+                L[a] = ald2<false>(rg, voff + (TCG == 32 ? (unsigned)(a & 1) * 128u : 0u), (unsigned)(TCG == 32 ? a >> 1 : a) * ctstep);
         }
     };
     issue(tl);
+    vm_wait<0>(L);
     for (;;) {
         cf v[16];
 #pragma unroll
@@ -498,18 +511,23 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
             v[bb] = ld2(&tile[(p2 * 16 + (bb ^ (p2 & 1))) * TR + ((r2 ^ bb) & (TR - 1))]);
         dft16<false>(v);
         const long long rho = (long long)tl * TR + r2;
-        if (rho < nrows) {
-            const unsigned rbytes = (unsigned)rho * 8u;
+        const bool live = rho < nrows;
+        const unsigned rbytes = (unsigned)rho * 8u;
+        unsigned so[16];                                       // always sixteen stores (unused slot / row beyond the call: dropped by the range check)
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const unsigned off = soff[p2 + 16 * q];         // start of the stream of the channel in this slot
-                if (off != 0xFFFFFFFFu) {
-                    if (hints & 1) bst2_nt(rout, off + rbytes, 0, v[rev16(q)]);
-                    else bst2(rout, off + rbytes, 0, v[rev16(q)]);
-                }
-            }
+        for (int q = 0; q < 16; q++) {
+            const unsigned off = soff[p2 + 16 * q];             // start of the stream of the channel in this slot
+            so[q] = (off == 0xFFFFFFFFu || !live) ? 0xFFFFFFF0u : off + rbytes;
+        }
+        if (hints & 1) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) bst2_nt(rout, so[q], 0, v[rev16(q)]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) bst2(rout, so[q], 0, v[rev16(q)]);
         }
         if (nxt >= ntiles) break;
+        vm_wait<16>(L);
         tl = nxt;
     }
 }
@@ -562,15 +580,18 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
     const float2 *rd2[2];                                                          // d' even / odd: + (d'*16 + 4f)*16
     rd2[0] = tile + (p2 * 64 + d) * 16 + r2;
     rd2[1] = tile + (p2 * 64 + (d ^ 1)) * 16 + r2;
+    // the tile loads are inline assembly and waited for behind the tile's stores (vm_wait, fdc_devutil.hpp): the compiler's own wait at
+    // the loop latch was vmcnt(0) — every wave of the one workgroup a compute unit has sat out the completion of its sixteen stores
     cf L[16];
-    auto issue = [&](int t) {
+    auto issue = [&](int t) __attribute__((always_inline)) {
         const size_t m = t / tpb;
         const int t0 = (t - (int)m * tpb) * TR;
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 1024 + (size_t)t0 * 16, (unsigned)lout * 1024u * 8u);
+        const srd_t rg = make_srd(g + m * (size_t)lout * 1024 + (size_t)t0 * 16, (unsigned)lout * 1024u * 8u);
 #pragma unroll
-        for (int a = 0; a < 16; a++) L[a] = bld2(rg, voff, (unsigned)a * astep);
+        for (int a = 0; a < 16; a++) L[a] = ald2<false>(rg, voff, (unsigned)a * astep);
     };
     issue(tl);
+    vm_wait<0>(L);
     for (;;) {
         cf v[16];
 #pragma unroll
@@ -618,21 +639,28 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
             for (int dd = 0; dd < 4; dd++) v[4 * f + dd] = ld2(rd2[dd & 1] + (dd * 16 + 4 * f) * 16);
 #pragma unroll
         for (int f = 0; f < 4; f++) dft4<false>(v[4 * f], v[4 * f + 1], v[4 * f + 2], v[4 * f + 3]);
+        // Always sixteen stores per lane: a slot the plan does not use, or a row beyond the call, gets an offset beyond the descriptor's
+        // extent and is dropped by its range check (no branch per store; the count is what the wait below is stated in)
         const long long rho = (long long)tl * TR + r2;
-        if (rho < nrows) {
-            const unsigned rbytes = (unsigned)rho * 8u;
+        const bool live = rho < nrows;
+        const unsigned rbytes = (unsigned)rho * 8u;
+        unsigned so[16];
 #pragma unroll
-            for (int f = 0; f < 4; f++)
+        for (int f = 0; f < 4; f++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned off = soff[p2 + 16 * (4 * f + d) + 256 * u];
-                    if (off != 0xFFFFFFFFu) {
-                        if (hints & 1) bst2_nt(rout, off + rbytes, 0, v[4 * f + u]);
-                        else bst2(rout, off + rbytes, 0, v[4 * f + u]);
-                    }
-                }
+            for (int u = 0; u < 4; u++) {
+                const unsigned off = soff[p2 + 16 * (4 * f + d) + 256 * u];
+                so[4 * f + u] = (off == 0xFFFFFFFFu || !live) ? 0xFFFFFFF0u : off + rbytes;
+            }
+        if (hints & 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) bst2_nt(rout, so[i], 0, v[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) bst2(rout, so[i], 0, v[i]);
         }
         if (nxt >= ntiles) break;
+        vm_wait<16>(L);                                              // the next tile has landed; this tile's stores are not waited for
         tl = nxt;
     }
 }
@@ -654,6 +682,7 @@ hipError_t init_fast_kernels()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p1<T, A, K>), hipFuncAttributeMaxDynamicSharedMemorySize, a); \
     if (e != hipSuccess) return e;
     FDC_SETP1(32, 0, 0) FDC_SETP1(16, 0, 0) FDC_SETP1(16, 1, 0) FDC_SETP1(16, 2, 0) FDC_SETP1(32, 1, 0) FDC_SETP1(32, 2, 0)
+    FDC_SETP1(16, 3, 8) FDC_SETP1(16, 4, 0)
     FDC_SETP1(16, 0, 8) FDC_SETP1(16, 0, 4) FDC_SETP1(16, 0, 2) FDC_SETP1(16, 0, 1)
     FDC_SETP1(32, 0, 8) FDC_SETP1(32, 0, 4) FDC_SETP1(32, 0, 2) FDC_SETP1(32, 0, 1)
 #undef FDC_SETP1
@@ -756,7 +785,7 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
         const char *g4 = debug_env("FDC_POLY_NOREUSE"); noreuse = g4 ? atoi(g4) : 0;
     }
     // the overlap of consecutive blocks travels in registers when the items are exactly N - N/R apart
-    const bool reuse = !noreuse && abl == 0 && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
+    const bool reuse = !noreuse && (abl == 0 || abl == 3) && in_stride == (size_t)256 * N1 - (size_t)256 * N1 / R && R <= 16;
 #define FDC_LP1(T, A, K) \
     hipLaunchKernelGGL((k_p1<T, A, K>), dim3(g1), dim3(T * 16), lds1, s, in, in_stride, g, tw256, twq, cbt, shn, N1, log2ct, \
                        nb_chunk, bpg, skip / 16, lout, nt_hints())
@@ -764,7 +793,8 @@ hipError_t launch_poly_stage1(const float2 *in, size_t in_stride, float2 *g, int
     do { if (!reuse) FDC_LP1(T, 0, 0); else if (R == 2) FDC_LP1(T, 0, 8); else if (R == 4) FDC_LP1(T, 0, 4); \
          else if (R == 8) FDC_LP1(T, 0, 2); else FDC_LP1(T, 0, 1); } while (0)
     if (TC == 32) { if (abl == 1) FDC_LP1(32, 1, 0); else if (abl == 2) FDC_LP1(32, 2, 0); else FDC_LP1K(32); }
-    else { if (abl == 1) FDC_LP1(16, 1, 0); else if (abl == 2) FDC_LP1(16, 2, 0); else FDC_LP1K(16); }
+    else { if (abl == 1) FDC_LP1(16, 1, 0); else if (abl == 2) FDC_LP1(16, 2, 0); else if (abl == 3 && reuse && R == 2) FDC_LP1(16, 3, 8);
+           else if (abl == 4) FDC_LP1(16, 4, 0); else FDC_LP1K(16); }
 #undef FDC_LP1K
 #undef FDC_LP1
     return hipGetLastError();

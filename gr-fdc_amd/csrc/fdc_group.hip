@@ -67,13 +67,15 @@ void worker_main(Worker *w)
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [w] { return w->state == 1 || w->state == 3; });
         if (w->state == 3) return;
-        const std::function<int()> j = w->job;
+        std::function<int()> j = std::move(w->job);        // moved, not copied: no allocation on this thread (nothing may throw out of it)
+        w->job = nullptr;
         lk.unlock();
-        int rc = j();
+        int rc;
         std::string err;
-        if (rc < 0) {
-            try { err = fdc_last_error(); } catch (...) { rc = FDC_ERR_NOMEM; }     // this thread's text: handed to the caller
-        }
+        try {
+            rc = j();
+            if (rc < 0) err = fdc_last_error();             // this thread's text: handed to the caller
+        } catch (...) { rc = FDC_ERR_NOMEM; }
         lk.lock();
         w->rc = rc; w->err.swap(err);
         w->state = 2;
@@ -127,6 +129,7 @@ struct fdc_pipeline_group {
     std::vector<std::unique_ptr<Worker>> workers;          // workers[i - 1] serves member i
     int N = 0, R = 0, ovl = 0, H = 0, C = 0;
     int max_blocks = 0, min_span = 0, member_max = 0;
+    bool keep_spectrum = false;
     std::vector<int32_t> lout;
     std::vector<unsigned char> hist;                        // the last N/R samples of the stream so far (zeros at start, overlap_save_impl.cc:52)
     size_t hist_item = 0;                                   // bytes per history sample: 8 (complex) until a real-input call makes it 4
@@ -161,6 +164,11 @@ int group_work(fdc_pipeline_group *g, const void *in, int nblocks, void *const *
     if (nblocks == 0) return 0;
     if (nblocks > g->max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, g->max_blocks);
     if (!in || (g->C > 0 && !outs)) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    // everything a member would refuse is refused here, before any span is posted: an argument error must not leave half a call written
+    // (and the group dead)
+    for (int c = 0; c < g->C; c++)
+        if (!outs[c]) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null output buffer of channel %d", c);
+    if (spectrum && !g->keep_spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
     const size_t item = real ? sizeof(float) : 2 * sizeof(float);
     if (g->blockcount == 0) g->hist_item = item;
     if (item != g->hist_item)
@@ -233,6 +241,7 @@ int fdc_pipeline_group_create(const fdc_pipeline_cfg *cfg, const int32_t *device
     if (min_span_blocks < 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "negative min_span_blocks");
     std::unique_ptr<fdc_pipeline_group, void (*)(fdc_pipeline_group *)> g(new fdc_pipeline_group(), fdc_pipeline_group_destroy);
     g->max_blocks = cfg->max_blocks;
+    g->keep_spectrum = cfg->keep_spectrum != 0;
     g->min_span = min_span_blocks > 0 ? min_span_blocks : 8;
     g->mem.assign((size_t)ndevices, nullptr);
     g->dev.assign(devices, devices + ndevices);
@@ -401,6 +410,9 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
     if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     int rc = nitems;
     std::string err;
+    // From the first posted job on the members' state machines may stand at different items: the group is dead unless the whole call goes
+    // through — also when this thread throws in between (a thread that does not start, an allocation): the guard outlives the exception.
+    struct DeadUnlessDone { fdc_sinks_group *g; bool armed = false, done = false; ~DeadUnlessDone() { if (armed && !done) g->dead = true; } } guard{g};
     {
         Join join(g->workers);
         int first = -1;
@@ -411,10 +423,12 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
             fdc_sinks *sm = m.s;
             const int32_t lo = m.lo, hi = m.hi;
             if (!g->workers[(size_t)i]->th.joinable()) g->workers[(size_t)i]->th = std::thread(worker_main, g->workers[(size_t)i].get());
+            guard.armed = true;
             join.post(i, [sm, spectrum, nitems, lo, hi] { return fdc_sinks_work_band(sm, spectrum, nitems, lo, hi); });
         }
         if (first >= 0) {
             auto &m = g->mem[(size_t)first];
+            guard.armed = true;
             const int r0 = fdc_sinks_work_band(m.s, spectrum, nitems, m.lo, m.hi);
             if (r0 < 0) { rc = r0; err = "member " + std::to_string(first) + " (device " + std::to_string(m.dev) + "): " + fdc_last_error(); }
         }
@@ -454,6 +468,7 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
     });
     g->pdus.reserve(keys.size());
     for (const Key &k : keys) g->pdus.push_back(got[(size_t)k.member][k.seq]);
+    guard.done = true;
     return nitems;
     FDC_ENTRY_END
 }

@@ -47,6 +47,8 @@ namespace FDC {
 //   set_devices({d})        the block's handle lives on device d
 //   set_devices({d0, d1…})  fdc_pipeline_vcc only: ONE work() call is cut into contiguous spans of items, one per device, run
 //                           concurrently (fdc_pipeline_group, include/fdc_amd.h); the other blocks take the first entry
+//   set_max_items(n)        items per device batch (what one fdc_*_work call takes); also what the scheduler is asked for per
+//                           work() call unless set_scheduler_batch() says otherwise
 class FDC_API amd_device_config {
 public:
     virtual ~amd_device_config() {}
@@ -54,6 +56,12 @@ public:
     virtual void set_max_items(int max_items) = 0;
     virtual std::vector<int> devices() const = 0;
     virtual int max_items() const = 0;
+    // Items per work() call the block asks of the scheduler (set_output_multiple + set_min_output_buffer, fdc_blocks.cc):
+    // 0 = the default — one device batch (max_items) for fdc_pipeline_vcc and the three sink blocks, 1 for the single-block
+    // faces.  Latency and the unprocessed tail of a finite stream are one batch; 1 = the reference's item-by-item behaviour.
+    // Before the flowgraph starts (GNU Radio reads output_multiple when it allocates the buffers).
+    virtual void set_scheduler_batch(int items) = 0;
+    virtual int scheduler_batch() const = 0;
 };
 
 class FDC_API overlap_save : virtual public gr::sync_block, public amd_device_config {

@@ -8,6 +8,9 @@
 #include "FDC/activity_detection_channelizer_vcm.h"
 #include "FDC/SegmentDetection.h"
 #include "FDC/fdc_pipeline_vcc.h"
+#ifndef FDC_HAVE_GNURADIO
+#include "compat/gnuradio/stock_scheduler.h"
+#endif
 
 #include <cstdio>
 #include <cstring>
@@ -39,9 +42,78 @@ template <class B> static std::vector<gr_complex> run(B &blk, const std::vector<
     return out;
 }
 
+#ifndef FDC_HAVE_GNURADIO
+// blocks_demo stock <blocklen> <relinvovl> <channels> <max_items> <total_items> [scheduler_batch] [verify]
+// fdc_pipeline_vcc (a bank of <channels> 256-bin channels on the 256-bin grid) behind the stock-scheduler stand-in
+// (compat/gnuradio/stock_scheduler.h): buffers sized by GNU Radio's rule from what the block asks for, work() offered what fits.
+// Prints one JSON line: buffer sizes, items per call, Gsample/s through work().  "verify": the source copies a seeded stream, the
+// outputs are captured and compared bit for bit with ONE work() call over the same stream on a second handle.
+static int stock_main(int argc, char **argv)
+{
+    if (argc < 7) { std::cerr << "usage: blocks_demo stock <blocklen> <relinvovl> <channels> <max_items> <total_items> [batch] [verify]" << std::endl; return 2; }
+    const int N = std::atoi(argv[2]), R = std::atoi(argv[3]), C = std::atoi(argv[4]), max_items = std::atoi(argv[5]);
+    const long total = std::atol(argv[6]);
+    const int batch = argc > 7 ? std::atoi(argv[7]) : 0;
+    const bool verify = argc > 8 && std::string(argv[8]) == "verify";
+    const int H = N - N / R;
+    std::vector<std::vector<float>> chans;
+    for (int c = 0; c < C; c++) chans.push_back({256.f * (float)c, 256.f, 0.88f, 1.0f});
+    try {
+        auto pipe = fdc_pipeline_vcc::make(N, R, chans, 1, max_items);
+        if (batch > 0) pipe->set_scheduler_batch(batch);
+        // the source's items: a seeded stream when verifying (small), one item's worth of noise otherwise (the free-running source
+        // only moves its write pointer; the buffer holds whatever the first lap left there)
+        const long src_items = verify ? total : 1;
+        std::vector<gr_complex> x((size_t)src_items * (size_t)H);
+        unsigned long long st = 88172645463325252ull;
+        for (auto &v : x) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            v = gr_complex((float)((st & 0xFFFF) / 32768.0 - 1.0), (float)(((st >> 16) & 0xFFFF) / 32768.0 - 1.0));
+        }
+        std::vector<std::vector<char>> cap;
+        auto ports = [&](const std::vector<std::pair<void *, size_t>> &in, const std::vector<std::pair<void *, size_t>> &out) {
+            bool ok = true;                           // what start() does against GNU Radio: detail()->input(i)->buffer(), ->output(i)
+            for (auto &b : in) ok = pipe->pin_buffer(b.first, b.second) && ok;
+            for (auto &b : out) ok = pipe->pin_buffer(b.first, b.second) && ok;
+            return ok;
+        };
+        const gr::compat::stock_result r = gr::compat::run_stock(*pipe, x.data(), src_items, total, verify, verify ? &cap : nullptr, ports);
+        pipe->unpin_buffers();
+        long mismatched = -1;
+        if (verify && r.items > 0) {
+            auto ref = fdc_pipeline_vcc::make(N, R, chans, 1, (int)r.items);
+            std::vector<std::vector<gr_complex>> ro((size_t)C);
+            gr_vector_const_void_star pi{x.data()};
+            gr_vector_void_star pv;
+            for (int c = 0; c < C; c++) { ro[(size_t)c].resize((size_t)r.items * (size_t)ref->output_item_len(c)); pv.push_back(ro[(size_t)c].data()); }
+            if (ref->work((int)r.items, pi, pv) != (int)r.items) throw std::runtime_error("stock: reference work() failed");
+            mismatched = 0;
+            for (int c = 0; c < C; c++)
+                if (cap[(size_t)c].size() != ro[(size_t)c].size() * sizeof(gr_complex) ||
+                    std::memcmp(cap[(size_t)c].data(), ro[(size_t)c].data(), cap[(size_t)c].size()) != 0) mismatched++;
+        }
+        std::printf("{\"mode\": \"stock scheduler stand-in\", \"blocklen\": %d, \"relinvovl\": %d, \"channels\": %d, \"max_items\": %d, "
+                    "\"scheduler_batch\": %d, \"in_buffer_items\": %ld, \"out_buffer_items\": %ld, \"pinned\": %s, \"items\": %ld, \"calls\": %ld, "
+                    "\"items_per_call_min\": %ld, \"items_per_call_max\": %ld, \"wall_s\": %.6f, \"work_s\": %.6f, "
+                    "\"gsamples_per_s_wall\": %.4f, \"gsamples_per_s_in_work\": %.4f, \"status\": %d, \"channels_mismatched\": %ld, \"plan\": \"%s\"}\n",
+                    N, R, C, pipe->max_items(), pipe->scheduler_batch(), r.in_buffer_items, r.out_buffer_items.empty() ? 0L : r.out_buffer_items[0],
+                    r.pinned ? "true" : "false", r.items, r.calls, r.min_call, r.max_call, r.wall_seconds, r.work_seconds,
+                    r.wall_seconds > 0 ? (double)r.items * H / r.wall_seconds / 1e9 : 0.0, r.work_seconds > 0 ? (double)r.items * H / r.work_seconds / 1e9 : 0.0,
+                    r.status, mismatched, pipe->kernel_plan().c_str());
+        return (r.status == 0 && mismatched <= 0) ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::cerr << "blocks_demo stock: " << e.what() << std::endl;
+        return 1;
+    }
+}
+#endif
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
+#ifndef FDC_HAVE_GNURADIO
+    if (std::string(argv[1]) == "stock") return stock_main(argc, argv);
+#endif
     const std::string dir = argv[1];
     const int N = 1024, R = 4, ovl = N / R, H = N - ovl;
     try {

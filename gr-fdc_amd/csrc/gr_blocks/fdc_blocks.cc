@@ -3,10 +3,13 @@
 #include "FDC/fdc_blocks.h"
 #include "../../../include/fdc_amd.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <iostream>
 #include <stdexcept>
 #ifdef FDC_HAVE_GNURADIO
+#include <gnuradio/block_detail.h>
+#include <gnuradio/buffer.h>
 #include <pmt/pmt.h>
 #endif
 
@@ -29,11 +32,30 @@ int report(const char *who, int n)
     return n;
 }
 
+// What the block asks of the scheduler (gr::block's own knobs, read by flat_flowgraph::allocate_buffer and the executor when the
+// flowgraph starts): work() calls of whole batches and port buffers that hold two of them.  GNU Radio sizes a buffer at 64 KiB
+// unless the writing block's output_multiple, its min_output_buffer or a reader's output_multiple ask for more, and hands a block
+// at most half a buffer per call — with 256-KiB items that is ONE item per work() (0.7 Gsample/s through fdc_pipeline_work against
+// 4.5 at 256 items).  output_multiple = batch makes (i) every upstream buffer hold >= 2 batches (the
+// reader's multiple counts), (ii) this block's buffers hold >= 2 batches, (iii) every call a whole number of batches.
+// The price, as for every block with an output multiple: latency of one batch, and the last partial batch of a finite stream is
+// not processed when the flowgraph drains.  set_scheduler_batch(1) is the reference's item-by-item behaviour.
+template <class Blk>
+void apply_scheduler_hints(Blk *blk, int batch, int max_items, int nout)
+{
+    blk->set_output_multiple(batch);
+    blk->set_max_noutput_items(std::max(max_items, batch) / batch * batch);     // never more than one device batch (whole multiples)
+    for (int c = 0; c < nout; c++) blk->set_min_output_buffer(c, 2L * batch);   // the executor offers min(space, bufsize / 2)
+}
+
 // per-block device state (amd_device_config): the setters rebuild the handle through the block's own create()
 class device_state {
 protected:
     std::vector<int> d_devices{0};
     int d_max_items = 64;
+    int d_batch = 0;                       // items per work() call asked of the scheduler; 0 = the class default (sched_batch())
+    bool d_batch_follows = true;           // fused chain and sinks: one device batch; single-block faces: 1
+    int sched_batch() const { return d_batch > 0 ? std::min(d_batch, d_max_items) : d_batch_follows ? d_max_items : 1; }
     virtual ~device_state() {}
     virtual void rebuild() = 0;            // destroy the handle(s), create them again from d_devices / d_max_items; throws like make()
     void assign_devices(const std::vector<int> &devices)
@@ -50,10 +72,18 @@ protected:
         d_max_items = n;
         try { rebuild(); } catch (...) { d_max_items = before; try { rebuild(); } catch (...) {} throw; }
     }
+    void assign_batch(int n)
+    {
+        if (n < 0) throw std::invalid_argument("set_scheduler_batch: must be >= 0 (0 = the default)");
+        d_batch = n;
+        rebuild();                         // re-applies the scheduler hints; the handle is rebuilt with the same arguments
+    }
 };
 #define FDC_DEVICE_CONFIG                                                                       \
     void set_devices(const std::vector<int> &devices) override { assign_devices(devices); }      \
     void set_max_items(int n) override { assign_max_items(n); }                                   \
+    void set_scheduler_batch(int n) override { assign_batch(n); }                                 \
+    int scheduler_batch() const override { return sched_batch(); }                                \
     std::vector<int> devices() const override { return d_devices; }                               \
     int max_items() const override { return d_max_items; }
 
@@ -64,6 +94,7 @@ class overlap_save_impl : public overlap_save, device_state {
     {
         fdc_overlap_save_destroy(d_h); d_h = nullptr;
         check_create(fdc_overlap_save_create(d_devices[0], d_itemsize, d_outputlen, d_overlaplen, &d_h));
+        apply_scheduler_hints(this, sched_batch(), d_max_items, 1);
     }
 public:
     FDC_DEVICE_CONFIG
@@ -72,6 +103,7 @@ public:
                          gr::io_signature::make(1, 1, itemsize * outputlen)),
           d_itemsize(itemsize), d_outputlen(outputlen), d_overlaplen(overlaplen)
     {
+        d_batch_follows = false;           // a byte copy per item: no batch asked for unless set_scheduler_batch() does
         rebuild();
     }
     ~overlap_save_impl() override { fdc_overlap_save_destroy(d_h); }
@@ -88,6 +120,7 @@ class vector_cut_vxx_impl : public vector_cut_vxx, device_state {
     {
         fdc_vector_cut_destroy(d_h); d_h = nullptr;
         check_create(fdc_vector_cut_create(d_devices[0], d_itemsize, d_veclen, d_offset, d_blocklen, &d_h));
+        apply_scheduler_hints(this, sched_batch(), d_max_items, 1);
     }
 public:
     FDC_DEVICE_CONFIG
@@ -96,6 +129,7 @@ public:
                          gr::io_signature::make(1, 1, itemsize * blocklen)),
           d_itemsize(itemsize), d_veclen(veclen), d_offset(offset), d_blocklen(blocklen)
     {
+        d_batch_follows = false;
         rebuild();
     }
     ~vector_cut_vxx_impl() override { fdc_vector_cut_destroy(d_h); }
@@ -113,6 +147,7 @@ class phase_shifting_windowing_vcc_impl : public phase_shifting_windowing_vcc, d
     {
         fdc_phase_window_destroy(d_h); d_h = nullptr;
         check_create(fdc_phase_window_create(d_devices[0], d_blocklen, d_states, d_shifts, d_passbw, d_stopbw, d_windowtype, &d_h));
+        apply_scheduler_hints(this, sched_batch(), d_max_items, 1);
     }
 public:
     FDC_DEVICE_CONFIG
@@ -121,6 +156,7 @@ public:
                          gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen)),
           d_blocklen(blocklen), d_states(numphasestates), d_shifts(shifts), d_windowtype(windowtype), d_passbw(passbw), d_stopbw(stopbw)
     {
+        d_batch_follows = false;
         rebuild();
     }
     ~phase_shifting_windowing_vcc_impl() override { fdc_phase_window_destroy(d_h); }
@@ -162,9 +198,8 @@ class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
         fdc_pipeline *p0 = d_g ? fdc_pipeline_group_member(d_g, 0) : d_p;
         d_lout.clear();
         for (size_t i = 0; i < d_ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(p0, (int)i));
-#ifdef FDC_HAVE_GNURADIO
-        set_max_noutput_items(d_max_items);           // the scheduler then never offers more than one device batch
-#endif
+        // the scheduler offers whole device batches and sizes this block's and its upstream buffers for two of them
+        apply_scheduler_hints(this, sched_batch(), d_max_items, (int)d_ch.size());
     }
 public:
     FDC_DEVICE_CONFIG
@@ -182,6 +217,26 @@ public:
         rebuild();
     }
     ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); fdc_pipeline_group_destroy(d_g); }
+#ifdef FDC_HAVE_GNURADIO
+    // the flowgraph has allocated this block's port buffers (flat_flowgraph::setup_connections runs before start()): pin both
+    // mappings of every circular buffer once, so that work() DMAs in place.  A buffer that cannot be pinned stays pageable.
+    bool start() override
+    {
+        gr::block_detail_sptr d = detail();
+        if (d) {
+            for (int i = 0; i < d->ninputs(); i++) {
+                gr::buffer_sptr bf = d->input(i)->buffer();
+                pin_buffer(const_cast<char *>(bf->base()), 2 * (size_t)bf->bufsize() * bf->get_sizeof_item());
+            }
+            for (int i = 0; i < d->noutputs(); i++) {
+                gr::buffer_sptr bf = d->output(i);
+                pin_buffer(const_cast<char *>(bf->base()), 2 * (size_t)bf->bufsize() * bf->get_sizeof_item());
+            }
+        }
+        return true;
+    }
+    bool stop() override { unpin_buffers(); return true; }
+#endif
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
         // noutput_items may exceed the handle's batch size: pieces of at most max_items, every port advanced by its item length
@@ -243,7 +298,9 @@ protected:
         } else {
             check_create(fdc_sinks_create(&d_cfg, &d_s));
         }
+        apply_hints();
     }
+    virtual void apply_hints() = 0;            // the block face applies the scheduler hints (it is the gr::sync_block)
     ~sink_base() override { fdc_sinks_destroy(d_s); fdc_sinks_group_destroy(d_sg); }
     int sink_work(const void *items, int n) { return d_sg ? fdc_sinks_group_work(d_sg, items, n) : fdc_sinks_work(d_s, items, n); }
     void publish(gr::sync_block *blk, bool pac)
@@ -306,6 +363,7 @@ protected:
 };
 
 class PowerActivationChannel_impl : public PowerActivationChannel, sink_base {
+    void apply_hints() override { apply_scheduler_hints(this, sched_batch(), d_max_items, 0); }
 public:
     FDC_DEVICE_CONFIG
     PowerActivationChannel_impl(int blocklen, float cfreq, float bw, int relinvovl, float thresh, int maxblocks,
@@ -325,7 +383,7 @@ public:
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
-        const size_t item = sizeof(gr_complex) * (size_t)input_signature()->sizeof_stream_item / sizeof(gr_complex);
+        const size_t item = (size_t)input_signature()->sizeof_stream_item(0);
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("PowerActivationChannel", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
@@ -336,6 +394,7 @@ public:
 };
 
 class activity_detection_channelizer_vcm_impl : public activity_detection_channelizer_vcm, sink_base {
+    void apply_hints() override { apply_scheduler_hints(this, sched_batch(), d_max_items, 0); }
 public:
     FDC_DEVICE_CONFIG
     activity_detection_channelizer_vcm_impl(int blocklen, std::vector<std::vector<float>> segments, float thresh,
@@ -361,7 +420,7 @@ public:
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
-        const size_t item = (size_t)input_signature()->sizeof_stream_item;
+        const size_t item = (size_t)input_signature()->sizeof_stream_item(0);
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("activity_detection_channelizer_vcm", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;
@@ -372,6 +431,7 @@ public:
 };
 
 class SegmentDetection_impl : public SegmentDetection, sink_base {
+    void apply_hints() override { apply_scheduler_hints(this, sched_batch(), d_max_items, 0); }
 public:
     FDC_DEVICE_CONFIG
     SegmentDetection_impl(int ID, int blocklen, int relinvovl, float seg_start, float seg_stop, float thresh,
@@ -393,7 +453,7 @@ public:
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         const char *p = static_cast<const char *>(in[0]);
-        const size_t item = (size_t)input_signature()->sizeof_stream_item;
+        const size_t item = (size_t)input_signature()->sizeof_stream_item(0);
         for (int a = 0; a < n; a += d_max_items) {
             const int k = n - a < d_max_items ? n - a : d_max_items;
             if (report("SegmentDetection", sink_work(p + (size_t)a * item, k)) != k) return a > 0 ? a : -1;

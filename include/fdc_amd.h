@@ -366,8 +366,10 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v5);
 /* ------------------------------------------------------------------------------------------------
  * The sink blocks over several devices ("shard by channel / by segment").  A sink block's input is the
  * stream of normalised spectrum items (512 KiB each at N = 65536): fed from host memory, ONE device is bound by its PCIe link
- * long before its kernels matter (1024 items: 9.6 ms of copy, 0.5 ms of kernels).  The group cuts the bank BY FREQUENCY: the
- * PowerActivationChannels sorted by centre frequency and the segments, in runs of equal load, one run per member device; every
+ * long before its kernels matter (1024 items: 9.6 ms of copy, 0.5 ms of kernels).  The group cuts the bank into RUNS OF THE BANK
+ * ORDER (cfg->pac[] and cfg->seg[] as given, equal counts per member device), one run per member; a bank listed by ascending
+ * frequency — what the hier block builds — is thereby cut BY FREQUENCY, and only then does a member's band stay narrow (an unsorted
+ * list is still correct, but every member then reads nearly the whole block and the links gain nothing: sort the bank).  Every
  * member copies only the band of bins its run reads (fdc_sinks_work_band) over its own link and runs its state machines and
  * extractions on it, all members concurrently; their PDUs are merged into the order ONE bank emits them in (item by item:
  * PowerActivationChannels in bank order, then the segments in order).  Every channel / segment lives on exactly one member, so
