@@ -59,14 +59,18 @@ __device__ __forceinline__ void bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff,
 // ---- loads the compiler's s_waitcnt pass does not see (round 5) -------------------------------------------------------------------
 // hipcc places s_waitcnt vmcnt(N) from a per-register scoreboard that is MERGED over all predecessors of a loop header.  In a persistent
 // loop of the form { request the NEXT tile's rows; compute; store this tile } the preheader (nothing younger than the first rows) and
-// the back edge (eight stores younger than the prefetched rows) disagree, the merge takes the smaller count, and the loop waits with
-// vmcnt(0) — for its own stores of the tile before, every tile (k_p1: 16 us of 119 per 256 blocks at N = 262144, profiles/r05/NOTES.md) —
-// or, in the block kernels, with vmcnt(1..9) right behind the sixteen prefetch loads it has just issued.  vmcnt counts loads and stores of
-// one wave in issue order on gfx9 (LLVM's own model: one event type on the counter), so the exact wait is known at every point:
-// "at most the number of vector-memory instructions issued after the ones I need".  These helpers issue the loads as inline assembly
-// (the scoreboard sees no pending load) and the kernel states the wait itself with vm_wait<N>(values...), which also ties the values
-// so that no use can be scheduled in front of it.  Rule for a kernel that uses them: no compiler-visible load may be pending at a
-// loop header inside which they are used (force such values with vm_settle before the loop).
+// the back edge (the tile's stores are younger than the prefetched rows) disagree, the merge takes the smaller count, and the loop waits
+// with vmcnt(0) — for its own stores of the tile before, every tile; in the block kernels it is vmcnt(1..9) right behind the sixteen
+// prefetch loads a pass has just issued.  vmcnt counts loads and stores of one wave in issue order on gfx9 (LLVM's own model: one event
+// type on the counter), so the exact wait is known at every point: "at most the number of vector-memory instructions issued after the
+// ones I need".  These helpers issue the loads as inline assembly (the scoreboard sees no pending load) and the kernel states the wait
+// itself with vm_wait<N>(values), which also ties the values so that no use can be scheduled in front of it.  Rules for a kernel that
+// uses them: no compiler-visible load may be pending at a loop header inside which they are used (force such values with vm_settle
+// before the loop), and ONE unconditional vm_wait per set of loads, in front of the loop's back edge (two alternative waits make the
+// compiler copy the tied registers ahead of the wait: it reads rows that have not landed).
+// MEASURED (profiles/r05/NOTES.md section 2, same box, three alternations): the exact waits are worth 1.2 % on the two-launch form at
+// N = 65536 and nothing at N = 262144 or on the headline block kernel (tried there, reverted) — a wave that waits early is covered by the
+// other waves of its SIMD.  Kept in k_p1 / k_p2 / k_p2k, where it also removes a branch per store; -DFDC_AUTO_WAITS=1 builds the old form.
 typedef int srd_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ srd_t make_srd(const void *base, unsigned bytes)
 {

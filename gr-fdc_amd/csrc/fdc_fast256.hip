@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TC * 16, 4) void k_p1(const float2 *__restrict__ in
     auto do_tile = [&](cf (&cur)[16], cf (&nbuf)[16], int m, int mn) {
         // The row loads are inline assembly and the wait for them is stated at the END of the tile, behind this tile's stores
         // (vm_wait, fdc_devutil.hpp): left to the compiler, the loop header waits with vmcnt(0) — for the eight stores of the tile
-        // before, once per tile (16 us of k_p1's 119 per 256 blocks at N = 262144; profiles/r05/NOTES.md).
+        // before, once per tile (worth 1.2 % at N = 65536, nothing at N = 262144: profiles/r05/NOTES.md section 2).
         if (mn >= 0) {
             const srd_t rin = make_srd(in + (size_t)mn * in_stride, inbytes);
             if (ABL == 2 || ABL == 4) {
