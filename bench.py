@@ -85,6 +85,8 @@ def parse():
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
                                                          "0.8/C, 0.4/C, 0.8/C, 1.6/C -> a mixed-width plan (spectrum path)")
+    ap.add_argument("--two-widths", action="store_true", help="diagnostics (config 2): the lower half of the band as 128 channels of 256 bins, the upper half as "
+                                                              "64 channels of 512 bins: two BANKS of different widths, one block-kernel launch each (round 5)")
     ap.add_argument("--width", type=int, default=0, metavar="L", help="diagnostics (config 2): a uniform bank of channels L bins wide (N / L channels "
                                                                       "on the L-bin grid) instead of 256: the generic-width two-launch path")
     ap.add_argument("--gapless", type=int, default=0, metavar="C", help="diagnostics (config 2): C channels of 1/C of the band each (no gaps): slices of 2 N / C bins "
@@ -421,17 +423,24 @@ def main():
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))
         dt = time.perf_counter() - t0
+        per_rank_ms, seen, backend = [round(dt * 1e3, 4)], 1, None
         if world > 1:
             dist.barrier()
-            t = torch.tensor([dt], dtype=torch.float64)
+            mine = torch.tensor([dt], dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank_ms = [round(float(x.item()) * 1e3, 4) for x in every]
+            t = mine.clone()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            seen, backend = dist.get_world_size(), dist.get_backend()
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "dry-run: launcher rehearsal, no GPU work",
-                              "config": {"workload": "none (FDC_BENCH_DRYRUN=1)"}}))
+                              "config": {"workload": "none (FDC_BENCH_DRYRUN=1)", "ranks_seen": seen, "backend": backend,
+                                         "per_rank_ms": per_rank_ms}}))
         return
     import gr_fdc_amd as G
     if a.force_path:
@@ -471,6 +480,10 @@ def main():
         elif a.gapless:     # C channels of 1/C of the band each: the derivation doubles the slices (l = 2 N / C), neighbours overlap by half
             C = a.gapless
             params = [G.get_opt_channelparams(N, R, ((c + (0.0 if a.centred else 0.5)) / C) % 1.0, 1.0 / C) for c in range(C)]
+        elif a.two_widths:
+            assert N == 65536, "--two-widths is defined at N = 65536"
+            params = [(256 * c, 256, 256 - 256 // R, 0.88, 1.0) for c in range(128)] + [(512 * c, 512, 512 - 512 // R, 0.88, 1.0) for c in range(64, 128)]
+            C = len(params)
         elif a.width:
             C = N // a.width
             if a.centred:     # centres on k/C: half a channel off the grid, channel 0 wrapped and clamped onto it by the reference's derivation
@@ -501,6 +514,7 @@ def main():
             else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "") + \
             (", %d input rings in rotation (cache-cold input)" % len(rings) if len(rings) > 1 else ", ONE input ring (stays in the memory-side cache)") + \
             (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "") + \
+            (", TWO BANKS: 128 channels of 256 bins + 64 channels of 512 bins" if a.two_widths else "") + \
             (", plus %d channels of other widths at odd bins (split plan)" % a.extra if a.extra else "") + \
             (", SPARSE plan: %d channels, l = %s, %d of %d bins read" % (len(plan), sorted(set(p_[1] for p_ in params)), sum(p_[1] for p_ in params), N)
              if a.sparse else "")
@@ -617,8 +631,14 @@ def main():
     # stream the kernels are launched on); read out after the region is closed
     last = pipe.last_kernel_ms()
     pipe.enable_timing(False)
+    per_rank_ms = None
     if dist is not None:
-        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
+        # every rank's own time goes into the line (a straggler shows; the gather proves the backend saw `world` ranks), the job's time is the MAX
+        mine = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(x.item()) / a.steps * 1e3, 4) for x in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -698,6 +718,15 @@ def main():
     dom_avg_ms = last[dom] / ngroups            # average duration of ONE launch of the dominant kernel
     blocks_per_launch = nb / nlaunch            # units one launch processes
     achieved = b_alg * blocks_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    # Paths of several kernels: `frac` puts ALL algorithmic bytes over ONE kernel's time (the contract's formula) and reads high; what each
+    # kernel moves of its OWN traffic per second is the number to compare with a copy.  Two-launch uniform path: stage 1 reads the new
+    # samples and writes G (lout * N / l samples per block), stage 2 reads G and writes the output samples.
+    own = None
+    if path == 2 and sinks is None and last[0] > 0 and last[1] > 0:
+        g_bytes = 8.0 * sum_lout if not a.width else 8.0 * (a.width - a.width // R) * (N // a.width)
+        own = {names[0]: {"bytes_per_block": 8.0 * H + g_bytes, "GB_per_s": round((8.0 * H + g_bytes) * blocks_per_launch / (last[0] / ngroups * 1e-3) / 1e9, 1)},
+               names[1]: {"bytes_per_block": g_bytes + 8.0 * sum_lout, "GB_per_s": round((g_bytes + 8.0 * sum_lout) * blocks_per_launch / (last[1] / ngroups * 1e-3) / 1e9, 1)},
+               "note": "own traffic of each kernel (G out and back counts here, not in b_alg): compare these with the copy rate, pipeline_frac with the target"}
     # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)
     traffic, traffic_source = None, None
@@ -705,7 +734,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         ent = pt.get("cfg%d/%s" % (a.config, names[dom]))
-        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or a.width or a.gapless or a.centred or R != 2):
+        if ent and ent.get("blocks_per_launch") == blocks_per_launch and ent.get("blocklen") == N and not (a.offset or a.mixed or a.sparse or a.extra or a.width or a.gapless or a.centred or a.two_widths or R != 2):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on another run (profiles/pmc_run.sh), " \
                              "not counters of this process"
@@ -728,7 +757,11 @@ def main():
                    # memory-side cache), 2 = round 3 on (2048 blocks per step, three 537 MB rings in rotation: cache-cold input, 150 ms
                    # running-in).  Lines of different revisions are not comparable.
                    "workload_rev": 2,
-                   "chunk_blocks": chunk, "kernel_path": path, "parallelism": "block-span sharding x%d, no collective" % world},
+                   "chunk_blocks": chunk, "kernel_path": path, "kernel_plan": pipe.describe(), "parallelism": "block-span sharding x%d, no collective" % world,
+                   # N > 1: what the process group reports (not what the command line asked for) and every rank's own step time
+                   "ranks_seen": dist.get_world_size() if dist is not None else 1,
+                   "backend": dist.get_backend() if dist is not None else None,
+                   "per_rank_ms": per_rank_ms},
         # frac: the contract's definition (all algorithmic bytes of a launch over the dominant kernel's launch time);
         # pipeline_frac: SURVEY.md §8d's headline, algorithmic bytes over the WHOLE step.  With the one-kernel path (3) the
         # dominant kernel IS the step, and the two coincide up to the launch gaps.
@@ -737,7 +770,7 @@ def main():
                      "kernel_ms_per_step": {n: round(v / ngroups * nlaunch, 4) for n, v in zip(names, last) if not n.startswith("unused")},
                      "kernel_avg_launch_ms": round(dom_avg_ms, 5), "blocks_per_launch": blocks_per_launch,
                      "launches_per_step": nlaunch, "timed_launches": ngroups, "timing_stride": max(1, a.timing_stride),
-                     "alg_bytes_per_block": b_alg,
+                     "alg_bytes_per_block": b_alg, "own_traffic_rate": own,
                      "pipeline_achieved": round(pipe_gbs, 2),
                      "pipeline_frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
                      # SURVEY.md §8d also asks for the fraction of the achievable float4-copy rate (6.3 TB/s per the guide)

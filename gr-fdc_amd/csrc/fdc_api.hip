@@ -4,6 +4,7 @@
 #include "fdc_kernels.h"
 #include "fdc_window.hpp"
 #include "fdc_guard.hpp"
+#include "fdc_plan_cost.hpp"
 
 #include <algorithm>
 #include <array>
@@ -139,52 +140,44 @@ struct fdc_pipeline {
     float2 *d_tw1024 = nullptr;  // uniform path with 1024 slots: exp(-2 pi i j/1024)
     float2 *d_twf = nullptr;     // fast path: [k2][n1] inter-pass twiddles of the 256x256 transform
     std::vector<char> g_aligned, g_out_aligned;   // per channel group
-    bool poly_ok = false;        // uniform plan: stage-1/stage-2 path without a spectrum in memory
-    bool poly_b512 = false;      // l = 512 at N = 65536, R = 2: the block kernel of fdc_block512.hip (launch groups of block_min blocks and more)
-    float2 *d_tw512 = nullptr, *d_twq512 = nullptr, *d_cbt512 = nullptr, *d_t2g = nullptr;
-    bool poly_half = false;      // the bank of a width's block kernel sits half a channel higher: f = l slot + l/2 (channels centred on multiples of l)
-    bool poly_b1024 = false;     // l = 1024 at N = 65536, R = 2 or 4: the block kernel of fdc_block1024.hip
-    float2 *d_tw1k = nullptr, *d_twq1k = nullptr, *d_cbt1k = nullptr;
-    bool poly_bnar = false;      // l = 128 or 64 at N = 65536: the block kernel of fdc_blocknarrow.hip (R = 2 or 4)
-    float2 *d_tabnar = nullptr, *d_cbtnar = nullptr;
-    // a second bank of the same width and window, the other of the two places (on the l-bin grid / half a channel higher): its own launch.
-    // What the reference's parameter derivation makes of a bank centred on multiples of l: channel 0 wraps and is clamped onto the grid.
-    int nbanks = 1;                                          // 1 .. 3 (what the cost rule allows)
-    int bank1_r = 0, bankx_r[2] = {0, 0};                    // the banks' offsets from the l-bin grid, bins (0, l/2; the narrow kernel: l/4 and 3l/4 too)
-    std::vector<int> bank1_chan, bankx_chan[2];              // bank 1 (the biggest), banks 2 and 3
-    std::vector<std::pair<int, int>> bank_alias;             // (channel, the earlier channel with the same slice): computed once, copied
-    float *d_shnx[2] = {nullptr, nullptr};
-    long long *d_slot_offx[2] = {nullptr, nullptr};
-    float2 *d_cbtx[2] = {nullptr, nullptr}, *d_tabx[2] = {nullptr, nullptr};   // the width's kernel's cbt (512 / 1024 / narrow), the narrow kernel's table image
-    int poly_L = 256;            // its channel width: 256 (register kernels), or any other power of two on the L-bin grid (round 4:
-                                 // stage 1 on the generic LDS core, two launches; one class, no offset)
-    int poly_r = 0;              // uniform plan: common offset f mod 256 of the channels (0 = the tiling starts at bin 0)
-    bool poly_block = false;     // uniform plan at N = 65536, R = 2: one kernel, one block per CU, G in registers (fdc_block256.hip)
-    // One-kernel form only: a plan may be the union of up to kMaxPolyClasses tilings (classes), each with its own offset r,
-    // window and slot table — e.g. two banks of 256-bin channels 128 bins apart (a 2x oversampled bank), or the same bank with
-    // two window shapes.  One launch per class; class 0 is what poly_r / d_cbt / d_shn / d_slot_off name.
-    struct PolyClass { int r = 0; float passbw = 0, stopbw = 0; std::vector<int> chan; float2 *d_cbt = nullptr; float *d_shn = nullptr; long long *d_slot_off = nullptr; };
-    std::vector<PolyClass> classes;
-    // Split plans (round 4; N = 65536, one-kernel form): the channels that fit no class — other widths, a fourth tiling — are the
-    // REMAINDER: the classes take one block-kernel launch each, the remainder takes the spectrum path on a PARTIAL spectrum (the
-    // forward kernel writes only the 64-bin groups a remainder channel reads) and channel kernels over the remainder's groups.
-    // Taken where its estimated cost is below the whole plan on the spectrum path (fdc_pipeline_create).
+    // ---- the plan (classify_plan): what runs without a spectrum in memory
+    // A BANK is a set of channels of ONE width l on ONE grid f = l slot + r with ONE window, every slot at most once: one launch of the
+    // width's block kernel per launch group (fdc_block256.hip: l = 256, any r; fdc_block512.hip / fdc_block1024.hip: r = 0 or l/2;
+    // fdc_blocknarrow.hip: l = 128 / 64, r a multiple of l/4), or — a plan that is ONE on-grid bank where no block kernel applies, and
+    // launch groups shorter than block_min — the two-launch form (stage 1 + stage 2 through the scratch G).  A plan may line up banks of
+    // DIFFERENT widths (round 5); what fits no bank is the remainder of a split plan.
+    struct Bank {
+        int L = 256, r = 0;
+        float passbw = 0, stopbw = 0;
+        std::vector<int> chan;
+        float2 *d_cbt = nullptr;            // per-column constants of the width's kernel (offset and (-1)^n1 folded in)
+        float *d_shn = nullptr;             // window shape / N (512 / 1024 at r = l/2: halves swapped)
+        long long *d_slot_off = nullptr;    // slot -> output offset of the channel, -1 = unused
+        float2 *d_tab = nullptr;            // narrow kernel: its LDS image
+    };
+    std::vector<Bank> banks;
+    bool poly_ok = false;        // banks is not empty
+    bool poly_block = false;     // every bank has a block kernel: one launch per bank (path 3; with a remainder: path 4)
+    std::vector<std::pair<int, int>> bank_alias;             // (channel, the earlier channel with the same slice and window): computed once, copied
+    // tables the banks of one width share
+    float2 *d_tw512 = nullptr, *d_twq512 = nullptr;          // W_512^k, W_N^(16 n1 q) with 128 columns
+    float2 *d_tw1k = nullptr, *d_twq1k = nullptr;            // W_1024^k, W_N^(16 n1 q) with 64 columns
+    float2 *d_t2g = nullptr;                                 // generic two-launch form of ONE bank of another width: W_N^(t k2), tile order
+    // Split plans (round 4; N = 65536): the channels that fit no bank — other widths, odd offsets, what the cost rule sends back — are the
+    // REMAINDER: the banks take one block-kernel launch each, the remainder takes the spectrum path on a PARTIAL spectrum (the forward
+    // kernel writes only the 64-bin groups a remainder channel reads) and channel kernels over the remainder's groups.
     bool split = false;
     std::vector<int> rem;                                        // channel ids of the remainder
     std::vector<std::pair<int, std::vector<int32_t>>> rgroups;   // the remainder by width, like `groups`
     std::vector<size_t> rgroup_off;
     std::vector<char> rg_aligned, rg_out_aligned;
     int32_t *d_rgroups = nullptr;
-    bool last_was_split = false;
     unsigned long long *d_dbg = nullptr;   // FDC_BLOCK_DEBUG=1: cycle stamps of the block kernel, printed by synchronize
     int block_hints = 1;         // FDC_BLOCK_HINTS: 1 = nt output stores, 2 = nt input loads
     int block_min = kBlockMinBlocks;   // FDC_BLOCK_MIN_BLOCKS (tests: 1 = the block kernels at any size)
     float2 *d_g = nullptr;                       // uniform path (two launches): stage-1 output G, chunk*lout*N/256 samples
-    bool last_was_poly = false;
     int ncu = 0;                                 // compute units of the handle's device
-    float2 *d_twq = nullptr, *d_cbt = nullptr;   // uniform path: W_N^(16 n1 q), (-1)^n1 W_N^(n1 b)
-    float *d_shn = nullptr;                      // uniform path: shape[k2] / N
-    long long *d_slot_off = nullptr;
+    float2 *d_twq = nullptr;                     // banks of 256-bin channels: W_N^(16 n1 q)
     // N = 65536 spectrum path: forward transform by the block kernel (fdc_block256.hip, FWD), own r = 0 tables
     bool fwd_block = false;
     float2 *d_ftwq = nullptr, *d_fcbt = nullptr;
@@ -220,7 +213,7 @@ struct fdc_pipeline {
     long long timing_seq = 0;
     std::vector<hipEvent_t> events;
     size_t ev_used = 0;
-    std::vector<std::array<size_t, 4>> ev_spans;   // start, mid, end-of-fft, end-of-channels
+    std::vector<std::array<size_t, 5>> ev_spans;   // events: start, mid, end-of-fft, end-of-channels; [4]: which form the span ran (kSpan*)
 };
 
 extern "C" {
@@ -382,23 +375,49 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     }
     if (p->pin_tab) (void)hipHostFree(p->pin_tab);
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
-    for (auto &c : p->classes) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); }
+    for (auto &c : p->banks) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); (void)hipFree(c.d_tab); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
     (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
-    (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_cbt512); (void)hipFree(p->d_t2g);
-    (void)hipFree(p->d_tabnar); (void)hipFree(p->d_cbtnar);
-    for (int k = 0; k < 2; k++) { (void)hipFree(p->d_shnx[k]); (void)hipFree(p->d_slot_offx[k]); (void)hipFree(p->d_cbtx[k]); (void)hipFree(p->d_tabx[k]); }
-    (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k); (void)hipFree(p->d_cbt1k);
+    (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_t2g);
+    (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
-int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
+}  // extern "C"
+
+// ==================================================================================================================================
+// fdc_pipeline_create in four steps (round 5; it was one 530-line function): validate -> channel records -> classify_plan (which kernels
+// run the plan: banks, remainder, or the spectrum path; the cost rule and nothing else decides) -> device tables and scratch.
+// ==================================================================================================================================
+namespace {
+
+#define CHK_DEV(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+template <class T>
+int upload(T *&dst, const std::vector<T> &v)
 {
-    FDC_ENTRY("fdc_pipeline_create")
-    if (!cfg || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
-    *out = nullptr;
+    CHK_DEV(hipMalloc(&dst, sizeof(T) * v.size()));
+    CHK_DEV(hipMemcpy(dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return FDC_OK;
+}
+#define UPLOAD(dst, v) do { const int _rc = upload(dst, v); if (_rc != FDC_OK) return _rc; } while (0)
+
+float2 unit(double turns)                     // exp(-2 pi i turns), designed in double, rounded once
+{
+    const double a = -2.0 * M_PI * turns;
+    return make_float2(float(std::cos(a)), float(std::sin(a)));
+}
+
+// ---- step 1: the arguments (the reference constructors' predicates among them)
+int validate_cfg(const fdc_pipeline_cfg *cfg)
+{
     const int N = cfg->blocklen, R = cfg->relinvovl;
     if (!ispow2(N) || N < 2) return fail(FDC_ERR_INVALID_ARGUMENT, "blocklen %d must be a power of two >= 2", N);
     if (!ispow2(R) || R < 2 || R > N) return fail(FDC_ERR_INVALID_ARGUMENT, "relinvovl %d must be a power of two in [2, blocklen]", R);
@@ -414,45 +433,434 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
         if (ch.stopbw <= 0.0f) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be <= 0", c);
         if (ch.stopbw < ch.passbw) return fail(FDC_ERR_INVALID_ARGUMENT, "channel %d: StopBw must not be < PassBw", c);
     }
-    {
-        // several kernels address a call's output with 32-bit byte offsets (buffer descriptors; offsets from 0xFFFFFFF0 up mean "no store"):
-        // one call produces less than 4 GiB.  A stream is cut into more calls, not bigger ones.
-        int64_t per_block = 0;
-        for (int c = 0; c < cfg->nchannels; c++) per_block += cfg->channels[c].l - cfg->channels[c].l / R;
-        if (per_block * 8 * (int64_t)cfg->max_blocks > 0xFFFFF000ll)
-            return fail(FDC_ERR_INVALID_ARGUMENT, "max_blocks %d x %lld output samples per block is more than the 4 GiB one call may produce (at most %lld blocks per call for this plan)",
-                        cfg->max_blocks, (long long)per_block, (long long)(0xFFFFF000ll / (per_block * 8)));
+    // several kernels address a call's output with 32-bit byte offsets (buffer descriptors; offsets from 0xFFFFFFF0 up mean "no store"):
+    // one call produces less than 4 GiB.  A stream is cut into more calls, not bigger ones.
+    int64_t per_block = 0;
+    for (int c = 0; c < cfg->nchannels; c++) per_block += cfg->channels[c].l - cfg->channels[c].l / R;
+    if (per_block * 8 * (int64_t)cfg->max_blocks > 0xFFFFF000ll)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "max_blocks %d x %lld output samples per block is more than the 4 GiB one call may produce (at most %lld blocks per call for this plan)",
+                    cfg->max_blocks, (long long)per_block, (long long)(0xFFFFF000ll / (per_block * 8)));
+    return FDC_OK;
+}
+
+// ---- step 2: channel records, de-duplicated window tables, the channels by width
+void group_by_width(const fdc_pipeline *p, const std::vector<int> *ids, std::vector<std::pair<int, std::vector<int32_t>>> &groups,
+                    std::vector<size_t> &off, std::vector<char> &al, std::vector<char> &oal, std::vector<int32_t> &flat)
+{
+    std::map<int, std::vector<int32_t>> bylen;
+    if (ids) for (int c : *ids) bylen[p->chans[(size_t)c].l].push_back(c);
+    else for (int c = 0; c < p->C; c++) bylen[p->chans[(size_t)c].l].push_back(c);
+    for (auto &kv : bylen) {
+        bool a = true, o = true;
+        for (int c : kv.second) {
+            if (p->chans[(size_t)c].f & 1) a = false;
+            if ((p->chans[(size_t)c].out_off & 1) || (p->chans[(size_t)c].lout & 1)) o = false;
+        }
+        al.push_back(a); oal.push_back(o);
+        off.push_back(flat.size());
+        groups.emplace_back(kv.first, kv.second);
+        flat.insert(flat.end(), kv.second.begin(), kv.second.end());
     }
-    int rc = select_device(cfg->device_id);
-    if (rc != FDC_OK) return rc;
+}
 
-    fdc_pipeline *p = new fdc_pipeline();
-    struct Owner { fdc_pipeline *p; ~Owner() { if (p) fdc_pipeline_destroy(p); } } owner{p};   // error returns and exceptions free the handle
-    p->cfg = *cfg; p->cfg.channels = nullptr;
-    p->N = N; p->R = R; p->ovl = N / R; p->H = N - p->ovl; p->C = cfg->nchannels;
-
-    // channel records + de-duplicated window tables
+void build_channel_records(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, std::vector<std::complex<float>> &pool)
+{
     std::map<std::tuple<int, float, float>, int> winmap;
-    std::vector<std::complex<float>> pool;
     int64_t off = 0;
     for (int c = 0; c < p->C; c++) {
         const fdc_channel &ch = cfg->channels[c];
         fdc::ChanDev d{};
-        d.f = ch.f; d.l = ch.l; d.lout = ch.l - ch.l / R;
-        d.shift = ((ch.f % R) + R) % R;
+        d.f = ch.f; d.l = ch.l; d.lout = ch.l - ch.l / p->R;
+        d.shift = ((ch.f % p->R) + p->R) % p->R;
         d.out_off = off; off += d.lout;
         auto key = std::make_tuple(ch.l, ch.passbw, ch.stopbw);
         auto it = winmap.find(key);
         if (it == winmap.end()) {
             const int o = (int)pool.size();
-            pool.resize(pool.size() + (size_t)R * ch.l);
-            fdc::window_table(cfg->windowtype, ch.l, ch.passbw, ch.stopbw, R, 1, false, pool.data() + o);
+            pool.resize(pool.size() + (size_t)p->R * ch.l);
+            fdc::window_table(cfg->windowtype, ch.l, ch.passbw, ch.stopbw, p->R, 1, false, pool.data() + o);
             it = winmap.emplace(key, o).first;
         }
         d.win_off = it->second;
         p->chans.push_back(d);
     }
     p->sum_lout = off;
+}
+
+// ---- step 3: which kernels run the plan
+// the block kernel that takes a bank of l-bin channels at f = l slot + r, if there is one for this block length and overlap
+bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
+{
+    if ((flags & FDC_PIPE_NO_BLOCK) || (R != 2 && R != 4)) return false;
+    switch (L) {
+    case 256: return fdc::poly_block_supports(N);                                    // k_blk256: N = 16384 / 32768 / 65536, any r
+    case 512: case 1024: return N == 65536 && (r == 0 || r == L / 2);               // k_blk512 / k_blk1024: on the grid or half a channel off it
+    case 128: case 64: return fdc::poly_block_narrow_supports(N, L, R) && r % (L / 4) == 0;   // k_blknar: quarters of a channel
+    default: return false;
+    }
+}
+
+void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
+{
+    const int N = p->N, R = p->R, C = p->C;
+    p->banks.clear(); p->bank_alias.clear(); p->rem.clear();
+    p->poly_ok = p->poly_block = p->split = false;
+    if (C == 0 || p->cfg_generic || (flags & FDC_PIPE_NO_POLY) || N > (1 << 20) || R > 16) return;
+    auto same_window = [&](const fdc_pipeline::Bank &b, const fdc_channel &ch) { return b.passbw == ch.passbw && b.stopbw == ch.stopbw; };
+
+    // (a) every channel whose width has a block kernel at its offset joins the bank of its (width, offset, window); a slice that is
+    //     already in its bank (the reference's parameter derivation clamps a wrapped channel onto its neighbour's place) is computed
+    //     once and copied; everything else is the remainder
+    std::vector<fdc_pipeline::Bank> banks;
+    std::vector<std::vector<char>> used;
+    std::vector<std::pair<int, int>> alias;
+    std::vector<int> rem;
+    for (int c = 0; c < C; c++) {
+        const fdc_channel &ch = cfg->channels[c];
+        const int L = ch.l, r = ch.f % L;
+        if (!bank_has_block_kernel(N, R, L, r, flags)) { rem.push_back(c); continue; }
+        size_t k = 0;
+        for (; k < banks.size(); k++) if (banks[k].L == L && banks[k].r == r && same_window(banks[k], ch)) break;
+        if (k == banks.size()) {
+            fdc_pipeline::Bank b;
+            b.L = L; b.r = r; b.passbw = ch.passbw; b.stopbw = ch.stopbw;
+            banks.push_back(b);
+            used.emplace_back((size_t)(N / L) + 1, 0);
+        }
+        if (used[k][(size_t)(ch.f / L)]) {
+            int first = -1;
+            for (int c0 : banks[k].chan) if (cfg->channels[c0].f == ch.f) { first = c0; break; }
+            alias.emplace_back(c, first);
+            continue;
+        }
+        used[k][(size_t)(ch.f / L)] = 1;
+        banks[k].chan.push_back(c);
+    }
+
+    // (b) no block kernel anywhere (another block length or overlap, FDC_PIPE_NO_BLOCK): the two-launch forms take a plan that is ONE
+    //     bank on its grid, every slot at most once.  l = 256: k_p1 + k_p2 / k_p2k / k_p2g (4096 <= N <= 2^20); other widths on the generic
+    //     LDS core, which measured faster than the spectrum path for l = 128 only (profiles/r04/NOTES.md section 6) — FDC_PIPE_WIDE_UNIFORM
+    //     takes it for every width
+    if (banks.empty()) {
+        const int L = cfg->channels[0].l;
+        const bool fits = L == 256 ? N >= 4096
+                                   : (L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || (flags & FDC_PIPE_WIDE_UNIFORM)));
+        if (!fits) return;
+        fdc_pipeline::Bank b;
+        b.L = L; b.r = 0; b.passbw = cfg->channels[0].passbw; b.stopbw = cfg->channels[0].stopbw;
+        std::vector<char> u((size_t)(N / L) + 1, 0);
+        for (int c = 0; c < C; c++) {
+            const fdc_channel &ch = cfg->channels[c];
+            if (ch.l != L || ch.f % L || !same_window(b, ch) || u[(size_t)(ch.f / L)]) return;
+            u[(size_t)(ch.f / L)] = 1;
+            b.chan.push_back(c);
+        }
+        p->banks.push_back(b);
+        p->poly_ok = true;
+        return;
+    }
+
+    // (c) the cost rule (fdc_plan_cost.hpp; the numbers are measured at N = 65536, where the remainder of a split plan has its forward
+    //     kernel).  Banks go back to the remainder, cheapest plan first, while that lowers the sum; then the sum must beat the whole plan on
+    //     the spectrum path.  Other block lengths (banks of 256-bin channels only): no remainder, no more than kMaxBanks launches.
+    const bool may_split = N == 65536;
+    auto band = [&](const std::vector<int> &ids) { double b = 0; for (int c : ids) b += cfg->channels[c].l; return b / 65536.0; };
+    auto move_to_rem = [&](size_t k) {
+        rem.insert(rem.end(), banks[k].chan.begin(), banks[k].chan.end());
+        for (size_t i = 0; i < alias.size();) {                   // copies of a channel that is no longer computed by a bank are channels again
+            if (std::find(banks[k].chan.begin(), banks[k].chan.end(), alias[i].second) != banks[k].chan.end()) {
+                rem.push_back(alias[i].first);
+                alias.erase(alias.begin() + (long)i);
+            } else i++;
+        }
+        banks.erase(banks.begin() + (long)k);
+    };
+    if (!may_split) {
+        if (!rem.empty() || (int)banks.size() > fdc::cost::kMaxBanks) return;
+    } else {
+        auto total = [&](const std::vector<fdc_pipeline::Bank> &bs, double remband) {
+            double t = fdc::cost::spectrum_path(remband);
+            for (const auto &b : bs) t += fdc::cost::bank_launch(b.L);
+            return t;
+        };
+        const bool forced = (flags & FDC_PIPE_WIDE_UNIFORM) != 0;              // every bank keeps its block kernel, whatever the rule says (A/B, tests)
+        for (;;) {
+            if (banks.empty()) break;
+            const bool too_many = (int)banks.size() > fdc::cost::kMaxBanks;
+            if (forced && !too_many) break;
+            const double now = total(banks, band(rem));
+            size_t best = banks.size();
+            double best_t = too_many ? 1e30 : now;
+            for (size_t k = 0; k < banks.size(); k++) {
+                std::vector<int> r2(rem);
+                r2.insert(r2.end(), banks[k].chan.begin(), banks[k].chan.end());
+                for (const auto &al : alias) if (std::find(banks[k].chan.begin(), banks[k].chan.end(), al.second) != banks[k].chan.end()) r2.push_back(al.first);
+                double t = fdc::cost::spectrum_path(band(r2));
+                for (size_t j = 0; j < banks.size(); j++) if (j != k) t += fdc::cost::bank_launch(banks[j].L);
+                if (t < best_t) { best_t = t; best = k; }
+            }
+            if (best == banks.size()) break;
+            move_to_rem(best);
+        }
+        if (banks.empty()) return;                                            // the spectrum path
+        if (!forced) {
+            std::vector<int> all(C);
+            for (int c = 0; c < C; c++) all[(size_t)c] = c;
+            if (total(banks, band(rem)) >= fdc::cost::spectrum_path(band(all))) return;
+        }
+    }
+    // the biggest bank first (what the timing events and the description call bank 1)
+    std::stable_sort(banks.begin(), banks.end(), [](const fdc_pipeline::Bank &x, const fdc_pipeline::Bank &y) { return x.chan.size() > y.chan.size(); });
+    std::sort(rem.begin(), rem.end());
+    p->banks = std::move(banks);
+    p->bank_alias = std::move(alias);
+    p->rem = std::move(rem);
+    p->split = !p->rem.empty();
+    p->poly_ok = p->poly_block = true;
+}
+
+// ---- step 4a: the tables of one bank (window, slot table, per-column constants of its width's kernel)
+int build_bank_tables(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, fdc_pipeline::Bank &bk)
+{
+    const int N = p->N, L = bk.L, N1 = N / L, rb = bk.r;
+    std::vector<std::complex<float>> shape((size_t)L);
+    fdc::window_table(cfg->windowtype, L, bk.passbw, bk.stopbw, 1, 0, true, shape.data());     // plateau 1: the chain's * l is in it
+    std::vector<float> sn((size_t)L);
+    for (int k2 = 0; k2 < L; k2++) sn[(size_t)k2] = float(double(shape[(size_t)k2].real()) / double(N));
+    std::vector<long long> so((size_t)N1, -1);
+    for (int c : bk.chan) so[(size_t)(p->chans[(size_t)c].f / L)] = p->chans[(size_t)c].out_off;
+    UPLOAD(bk.d_slot_off, so);
+    std::vector<float2> cb;
+    if (L == 256) {
+        // (-1)^n1 W_N^(n1 (b + r)): an offset tiling is the on-grid plan of the block modulated by exp(-2 pi i r n / N)
+        cb.resize((size_t)N1 * 16);
+        for (int n1 = 0; n1 < N1; n1++)
+            for (int j = 0; j < 16; j++) {
+                const float2 w = unit(double(((long long)n1 * (j + rb)) % N) / double(N));
+                const float sg = (n1 & 1) ? -1.0f : 1.0f;
+                cb[(size_t)n1 * 16 + j] = make_float2(sg * w.x, sg * w.y);
+            }
+    } else if ((L == 512 || L == 1024) && p->poly_block) {
+        // (-1)^n1 W_N^(n1 (b + 256 i)) at [n1][b + 16 i], i = half (512: two) or quarter (1024: four) of k2.  Half a channel off the grid: the lane
+        // of part i holds part i ^ (parts / 2) of the modulated column, whose constant W_N^((l/2) n1) joins the table, and the kernels read the window
+        // with its halves swapped
+        const bool half = rb == L / 2;
+        const int parts = L / 256;
+        if (half) {
+            std::vector<float> snd(sn);
+            for (int k2 = 0; k2 < L; k2++) sn[(size_t)k2] = snd[(size_t)(k2 ^ (L / 2))];
+        }
+        cb.resize((size_t)N1 * 16 * parts);
+        for (int n1 = 0; n1 < N1; n1++)
+            for (int e = 0; e < 16 * parts; e++) {
+                const int i = half ? (e >> 4) ^ (parts / 2) : e >> 4;
+                const float2 w = unit(double(((long long)n1 * ((e & 15) + 256 * i + (half ? L / 2 : 0))) % N) / double(N));
+                const float sg = (n1 & 1) ? -1.0f : 1.0f;
+                cb[(size_t)n1 * 16 * parts + e] = make_float2(sg * w.x, sg * w.y);
+            }
+    } else if (p->poly_block) {
+        // the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V (b + r)) at [V][b], S = 256 / l
+        const bool half = rb == L / 2;
+        const int S = 256 / L;
+        std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L));
+        fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half, half ? 0 : rb);
+        UPLOAD(bk.d_tab, img);
+        cb.resize(256 * 16);
+        for (int V = 0; V < 256; V++)
+            for (int b = 0; b < 16; b++) cb[(size_t)V * 16 + b] = unit(double(((long long)S * V * (b + rb)) % N) / double(N));
+    }
+    UPLOAD(bk.d_shn, sn);
+    if (!cb.empty()) UPLOAD(bk.d_cbt, cb);
+    return FDC_OK;
+}
+
+// ---- step 4b: what the banks of one width share, and the generic two-launch form's tile table
+int build_shared_bank_tables(fdc_pipeline *p)
+{
+    const int N = p->N;
+    auto has = [&](int L) { for (const auto &b : p->banks) if (b.L == L) return true; return false; };
+    auto twq_table = [&](int N1) {                      // W_N^(16 n1 q)
+        std::vector<float2> tq((size_t)N1 * 16);
+        for (int n1 = 0; n1 < N1; n1++)
+            for (int q = 0; q < 16; q++) tq[(size_t)n1 * 16 + q] = unit(double((16ll * n1 * q) % N) / double(N));
+        return tq;
+    };
+    if (has(256)) {
+        UPLOAD(p->d_twq, twq_table(N / 256));
+        if (N / 256 == 1024) UPLOAD(p->d_tw1024, make_twiddles(1024));
+    }
+    if (has(512) && p->poly_block) {
+        std::vector<float2> t5(256);
+        for (int k = 0; k < 256; k++) t5[(size_t)k] = unit(double(k) / 512.0);
+        UPLOAD(p->d_tw512, t5);
+        UPLOAD(p->d_twq512, twq_table(N / 512));
+    }
+    if (has(1024) && p->poly_block) {
+        UPLOAD(p->d_tw1k, make_twiddles(1024));
+        UPLOAD(p->d_twq1k, twq_table(N / 1024));
+    }
+    // ONE on-grid bank of another width: its two-launch form (the whole plan where no block kernel applies; launch groups shorter than
+    // block_min otherwise) wants the tile-local factor of the inter-pass twiddle in the tile's own order: t2[k2][t] = W_N^(t k2)
+    if (p->banks.size() == 1 && p->banks[0].L != 256 && p->banks[0].r == 0 && p->bank_alias.empty()) {
+        const int L = p->banks[0].L, TCg = fdc::poly_stage1_generic_tile_columns(N, L);
+        std::vector<float2> t2v((size_t)L * TCg);
+        for (int k2 = 0; k2 < L; k2++)
+            for (int t = 0; t < TCg; t++) t2v[(size_t)k2 * TCg + t] = unit(double(((long long)t * k2) % N) / double(N));
+        UPLOAD(p->d_t2g, t2v);
+    }
+    return FDC_OK;
+}
+
+// ---- step 4c: the block kernel as a forward transform (N = 65536: the spectrum path, the remainder of a split plan, the sinks)
+int build_forward_tables(fdc_pipeline *p)
+{
+    // twq / cbt as for a bank of 256-bin channels with r = 0, a flat "window" 1/N, and the slots of stage 2 mapped to the bins 256 c (+ k2) of
+    // the shifted spectrum
+    const int N = p->N;
+    std::vector<float2> tq(256 * 16), cb(256 * 16);
+    for (int n1 = 0; n1 < 256; n1++)
+        for (int j = 0; j < 16; j++) {
+            tq[(size_t)n1 * 16 + j] = unit(double((16ll * n1 * j) % N) / double(N));
+            const float2 w = unit(double(((long long)n1 * j) % N) / double(N));
+            const float sg = (n1 & 1) ? -1.0f : 1.0f;
+            cb[(size_t)n1 * 16 + j] = make_float2(sg * w.x, sg * w.y);
+        }
+    std::vector<float> sn(256, float(1.0 / double(N)));
+    std::vector<long long> so(256);
+    for (int c = 0; c < 256; c++) so[(size_t)c] = 256ll * c;
+    UPLOAD(p->d_ftwq, tq);
+    UPLOAD(p->d_fcbt, cb);
+    UPLOAD(p->d_fshn, sn);
+    UPLOAD(p->d_fslot, so);
+    return FDC_OK;
+}
+
+// ---- step 4d: plans that read part of the band: the 64-bin groups of the shifted spectrum some channel reads (a split plan's internal
+// spectrum serves its remainder only); the forward kernels that store whole 64-bin runs per wave leave the other groups unwritten
+int build_keep_map(fdc_pipeline *p)
+{
+    const int N = p->N;
+    std::vector<char> g64((size_t)N / 64, 0);
+    bool all = true;
+    for (int c = 0; c < p->C; c++) {
+        if (p->split && !std::binary_search(p->rem.begin(), p->rem.end(), c)) continue;
+        const auto &ch = p->chans[(size_t)c];
+        for (int b = ch.f / 64; b <= (ch.f + ch.l - 1) / 64 && b < N / 64; b++) g64[(size_t)b] = 1;
+    }
+    for (char v : g64) all = all && v;
+    if (all) return FDC_OK;
+    if (N == 4096) {
+        p->keep4096 = 0;
+        for (int b = 0; b < 64; b++) if (g64[(size_t)b]) p->keep4096 |= 1ull << b;
+        return FDC_OK;
+    }
+    // the block kernel's wave klo stores, per 64-row chunk q, the bins 256 c + 64 q .. + 63 of the slots c = klo + 8 khi; slot khi =
+    // k0 + 2 k1 sits in register 16 k0 + rev16(k1) (fdc_block256.hip, soff)
+    std::vector<unsigned> kw(32, 0u);
+    for (int klo = 0; klo < 8; klo++)
+        for (int q = 0; q < 4; q++)
+            for (int r = 0; r < 32; r++) {
+                const int k0 = r >> 4, k1 = 4 * (r & 3) + ((r & 15) >> 2), c = klo + 8 * (k0 + 2 * k1);
+                if (g64[(size_t)(4 * c + q)]) kw[(size_t)(klo * 4 + q)] |= 1u << r;
+            }
+    UPLOAD(p->d_keep, kw);
+    return FDC_OK;
+}
+
+// the two-launch form (stage 1 + stage 2 through the scratch G) exists for a plan that is ONE bank on its grid, no copied channels
+bool two_launch_possible(const fdc_pipeline *p)
+{
+    return p->poly_ok && p->banks.size() == 1 && p->banks[0].r == 0 && p->bank_alias.empty();
+}
+
+// ---- step 4: everything on the device
+int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::vector<std::complex<float>> &pool,
+                       const std::vector<int32_t> &flat, const std::vector<int32_t> &rflat)
+{
+    const int N = p->N, R = p->R, flags = p->cfg.flags, chunk = p->chunk;
+    CHK_DEV(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    p->ntab = N;
+    UPLOAD(p->d_tw, make_twiddles(N));
+    if (p->C > 0) {
+        CHK_DEV(hipMalloc(&p->d_wins, sizeof(float2) * pool.size()));
+        CHK_DEV(hipMemcpy(p->d_wins, pool.data(), sizeof(float2) * pool.size(), hipMemcpyHostToDevice));
+        UPLOAD(p->d_chans, p->chans);
+        UPLOAD(p->d_groups, flat);
+        if (!rflat.empty()) UPLOAD(p->d_rgroups, rflat);
+    }
+    UPLOAD(p->d_tw256, make_twiddles(256));
+    if (N > fdc::kMaxLdsFft) {
+        // inter-pass twiddles of the two-pass transform, laid out like pass A's output: [k2][n1] = W_N^(n1*k2)
+        const fdc::BigGeom bg = fdc::big_geom(N);
+        std::vector<float2> tf((size_t)N);
+        for (int k2 = 0; k2 < bg.N2; k2++)
+            for (int n1 = 0; n1 < bg.N1; n1++) tf[(size_t)k2 * bg.N1 + n1] = unit(double((long long)n1 * k2) / double(N));
+        UPLOAD(p->d_twf, tf);
+    }
+    for (auto &bk : p->banks) { const int rc = build_bank_tables(p, cfg, bk); if (rc != FDC_OK) return rc; }
+    { const int rc = build_shared_bank_tables(p); if (rc != FDC_OK) return rc; }
+    p->fwd_block = N == 65536 && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
+    if (p->fwd_block) { const int rc = build_forward_tables(p); if (rc != FDC_OK) return rc; }
+    {
+        hipDeviceProp_t prop;
+        CHK_DEV(hipGetDeviceProperties(&prop, cfg->device_id));
+        p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizers' rows 64..127
+    if (p->fwd_block || (p->poly_block && R == 4)) CHK_DEV(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
+    if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
+        const int rc = build_keep_map(p);
+        if (rc != FDC_OK) return rc;
+    }
+    if (p->poly_block && !p->banks.empty() && p->banks[0].L == 256) {
+        if (const char *dg = fdc::debug_env("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
+            CHK_DEV(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
+            CHK_DEV(hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 32));
+        }
+    }
+    if (two_launch_possible(p)) {
+        // G scratch of the two-launch form.  With block kernels only launch groups shorter than block_min take it
+        const int L = p->banks[0].L, gblocks = p->poly_block ? std::min(chunk, p->block_min) : chunk;
+        CHK_DEV(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(L - L / R) * (size_t)(N / L)));
+    }
+    {
+        // widest "channels x width" of a group above 4096 bins: a piece of the launch group is as many blocks as fit 32 Mi points
+        size_t widest = 0;
+        for (const auto &gr : p->groups) if (gr.first > 4096) { widest = std::max(widest, gr.second.size() * (size_t)gr.first); p->big_l = std::max(p->big_l, gr.first); }
+        if (widest) {
+            p->big_pts = std::max<size_t>(widest, std::min<size_t>((size_t)32 << 20, widest * (size_t)chunk));
+            CHK_DEV(hipMalloc(&p->d_big, sizeof(float2) * p->big_pts));
+            CHK_DEV(hipMalloc(&p->d_wtasks, sizeof(fdc::ExtractTask) * (p->big_pts / 8192 + (size_t)p->C + 1)));   // a piece: at most big_pts / l tasks, l >= 8192
+        }
+    }
+    // two-pass scratch; with the block kernel only launch groups shorter than block_min take the two-pass kernels
+    if (N > fdc::kMaxLdsFft) CHK_DEV(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)(p->fwd_block ? std::min(chunk, p->block_min) : chunk) * N));
+    CHK_DEV(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
+    return FDC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
+{
+    FDC_ENTRY("fdc_pipeline_create")
+    if (!cfg || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int rc = validate_cfg(cfg);
+    if (rc != FDC_OK) return rc;
+    rc = select_device(cfg->device_id);
+    if (rc != FDC_OK) return rc;
+
+    fdc_pipeline *p = new fdc_pipeline();
+    struct Owner { fdc_pipeline *p; ~Owner() { if (p) fdc_pipeline_destroy(p); } } owner{p};   // error returns and exceptions free the handle
+    const int N = cfg->blocklen, R = cfg->relinvovl;
+    p->cfg = *cfg; p->cfg.channels = nullptr;
+    p->N = N; p->R = R; p->ovl = N / R; p->H = N - p->ovl; p->C = cfg->nchannels;
+    std::vector<std::complex<float>> pool;
+    build_channel_records(p, cfg, pool);
+
     int flags = cfg->flags;
     {
         auto on = [](const char *n) { const char *v = fdc::debug_env(n); return v && v[0] == '1'; };
@@ -467,444 +875,24 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     }
     p->cfg.flags = flags;
     p->cfg_generic = (flags & FDC_PIPE_FORCE_GENERIC) != 0;
-    std::map<int, std::vector<int32_t>> bylen;
-    for (int c = 0; c < p->C; c++) bylen[p->chans[c].l].push_back(c);
-    std::vector<int32_t> flat;
-    for (auto &kv : bylen) {
-        bool al = true, oal = true;
-        for (int c : kv.second) {
-            if (p->chans[c].f & 1) al = false;
-            if ((p->chans[c].out_off & 1) || (p->chans[c].lout & 1)) oal = false;
-        }
-        p->g_aligned.push_back(al); p->g_out_aligned.push_back(oal);
-        p->group_off.push_back(flat.size());
-        p->groups.emplace_back(kv.first, kv.second);
-        flat.insert(flat.end(), kv.second.begin(), kv.second.end());
-    }
-
-    // uniform plan of another width?  every channel l = L != 256 at f = L*slot, one window, every slot at most once, 16 <= N/L <= 4096
-    bool uniL = false;
-    if (p->C > 0 && !p->cfg_generic && !(flags & FDC_PIPE_NO_POLY) && N <= (1 << 20) && R <= 16) {
-        const int L = cfg->channels[0].l;
-        // Measured at N = 65536 (profiles/r04/NOTES.md section 6): on the generic LDS core this form beats the spectrum path for l = 128
-        // only (0.96 against 1.05 ms per 2048 blocks; l = 512: 0.99 against 0.82): taken for l = 128, and for every width on request
-        const bool b512 = L == 512 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);    // its own block kernel
-        // l = 1024: the block kernel costs 0.222 ms per 1024 blocks whatever the number of channels, the spectrum path 0.20 + 0.24 C/64 by the
-        // cost rule of the split plans: the kernel from 6 channels up
-        const bool b1024 = L == 1024 && N == 65536 && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK) && (p->C >= 6 || (flags & FDC_PIPE_WIDE_UNIFORM));
-        const bool bnar = fdc::poly_block_narrow_supports(N, L, R) && !(flags & FDC_PIPE_NO_BLOCK);       // and for 128 / 64
-        uniL = L != 256 && L >= 64 && L <= 4096 && L / R >= 1 && N / L >= 16 && N / L <= 4096 && (L == 128 || b512 || b1024 || bnar || (flags & FDC_PIPE_WIDE_UNIFORM));
-        // on the l-bin grid, or (block kernels of the other widths only) half a channel higher: a bank centred on multiples of l — or both: two banks,
-        // two launches (the reference's parameter derivation clamps the wrapped channel 0 of a centred bank onto the grid).  Bank 1 is the bigger one.
-        const bool blockL = b512 || b1024 || bnar;
-        const int rstep = bnar ? L / 4 : L / 2;                                 // the narrow kernel also takes banks a quarter of a channel off the grid
-        std::map<int, std::vector<int>> byr;                                    // offset from the grid -> its channels
-        std::map<int, std::vector<char>> usedr;
-        for (int c = 0; uniL && c < p->C; c++) {
-            const fdc_channel &ch = cfg->channels[c];
-            const int r = ch.f % L;
-            if (ch.l != L || (r % rstep) || ch.passbw != cfg->channels[0].passbw || ch.stopbw != cfg->channels[0].stopbw) { uniL = false; break; }
-            auto &used = usedr[r];
-            if (used.empty()) used.assign((size_t)(N / L), 0);
-            if (used[(size_t)(ch.f / L)]) {
-                // the same slice again (the reference's derivation clamps a wrapped channel onto its neighbour's place): computed once, copied
-                int first = -1;
-                for (int c0 : byr[r]) if (cfg->channels[c0].f == ch.f) { first = c0; break; }
-                if (first < 0 || !blockL) { uniL = false; break; }
-                p->bank_alias.emplace_back(c, first);
-                continue;
-            }
-            used[(size_t)(ch.f / L)] = 1;
-            byr[r].push_back(c);
-        }
-        if (uniL && byr.size() > 3) uniL = false;                               // at most three banks
-        if (uniL && !blockL && (byr.size() > 1 || byr.begin()->first != 0)) uniL = false;   // off the grid, or several banks: block kernels only
-        if (uniL && byr.size() > 1 && N == 65536) {
-            // one launch per bank against the spectrum path, ms per 1024 blocks (the kernels' cost does not depend on the number of channels)
-            const double per = L == 1024 ? 0.222 : L == 512 ? 0.19 : L == 128 ? 0.177 : 0.19, bins = double(p->C) * L / 65536.0;
-            if (double(byr.size()) * per >= 0.20 + 0.05 * std::min(1.0, bins) + 0.19 * bins) uniL = false;
-        }
-        if (!uniL) p->bank_alias.clear();
-        bool halfb = false;
-        if (uniL) {
-            std::vector<std::pair<int, std::vector<int>>> bk(byr.begin(), byr.end());
-            std::stable_sort(bk.begin(), bk.end(), [](const auto &x, const auto &y) { return x.second.size() > y.second.size(); });   // the biggest first
-            p->nbanks = (int)bk.size();
-            p->bank1_chan = bk[0].second; p->bank1_r = bk[0].first;
-            for (int k = 1; k < p->nbanks; k++) { p->bankx_chan[k - 1] = bk[(size_t)k].second; p->bankx_r[k - 1] = bk[(size_t)k].first; }
-            halfb = p->bank1_r == L / 2;
-        }
-        if (uniL) { p->poly_ok = true; p->poly_L = L; p->poly_b512 = b512; p->poly_b1024 = b1024; p->poly_bnar = bnar; p->poly_half = halfb; }
-    }
-    // uniform plan?  every channel l = 256 on the 256-bin grid, one window, N = 256*N1 with 16 <= N1 <= 4096 slots
-    // (fdc_fast256.hip; stage 2 specialised for 256 and 1024 slots, generic LDS core otherwise)
-    if (!uniL) {
-        bool ok = N >= 4096 && N <= (1 << 20) && p->C > 0 && R <= 16 && !p->cfg_generic && !(flags & FDC_PIPE_NO_POLY);
-        // all channels on ONE 256-bin grid: f = 256*slot + r with a common offset r.  r != 0 (a tiling that does not start at
-        // bin 0) is the on-grid plan of the block modulated by exp(-2 pi i r n / N); only the one-kernel form implements that.
-        // classes: same offset r = f mod 256, same window, every slot at most once
-        const bool block_form = fdc::poly_block_supports(N) && (R == 2 || R == 4) && !(flags & FDC_PIPE_NO_BLOCK);
-        constexpr size_t kMaxPolyClasses = 3;
-        std::vector<std::vector<char>> used;
-        const bool may_split = block_form && N == 65536;
-        for (int c = 0; ok && c < p->C; c++) {
-            const fdc_channel &ch = cfg->channels[c];
-            if (ch.l != 256) {                                                   // another width
-                if (!may_split) { ok = false; break; }
-                p->rem.push_back(c);
-                continue;
-            }
-            size_t k = 0;
-            for (; k < p->classes.size(); k++) {
-                const auto &pc = p->classes[k];
-                if (pc.r == (ch.f & 255) && pc.passbw == ch.passbw && pc.stopbw == ch.stopbw && !used[k][ch.f >> 8]) break;
-            }
-            if (k == p->classes.size()) {
-                if (k == (block_form ? kMaxPolyClasses : 1)) {
-                    if (!may_split) { ok = false; break; }
-                    p->rem.push_back(c);
-                    continue;
-                }
-                fdc_pipeline::PolyClass pc;
-                pc.r = ch.f & 255; pc.passbw = ch.passbw; pc.stopbw = ch.stopbw;
-                p->classes.push_back(pc);
-                used.emplace_back(N / 256 + 1, 0);
-            }
-            used[k][ch.f >> 8] = 1;
-            p->classes[k].chan.push_back(c);
-        }
-        if (ok && p->classes.empty()) ok = false;
-        // the two-launch form knows one class on the grid (r = 0) only
-        if (ok && !block_form && p->classes[0].r != 0) ok = false;
-        // Cost per 1024 blocks, ms, measured on MI355X (profiles/r02-r04): a class launch 0.16 whatever it holds; the spectrum path:
-        // forward transform 0.20 (nothing written) ... 0.25 (everything written), channel kernels 0.19 per 65536 bins read.
-        if (ok && N == 65536) {
-            auto bins = [&](const std::vector<int> *ids) {
-                double b = 0;
-                if (ids) for (int c : *ids) b += cfg->channels[c].l; else for (int c = 0; c < p->C; c++) b += cfg->channels[c].l;
-                return b / 65536.0;
-            };
-            // a tiling of few channels costs a whole launch: once there is a remainder anyway, a small class is cheaper as part of it
-            if (may_split) {
-                for (bool moved = true; moved && p->classes.size() > 1;) {
-                    moved = false;
-                    size_t k = 0;
-                    for (size_t i = 1; i < p->classes.size(); i++) if (p->classes[i].chan.size() < p->classes[k].chan.size()) k = i;
-                    const double bk = (double)p->classes[k].chan.size() * 256.0 / 65536.0;
-                    if ((p->rem.empty() ? 0.20 : 0.0) + 0.24 * bk < 0.16) {
-                        p->rem.insert(p->rem.end(), p->classes[k].chan.begin(), p->classes[k].chan.end());
-                        p->classes.erase(p->classes.begin() + (long)k);
-                        moved = true;
-                    }
-                }
-                std::sort(p->rem.begin(), p->rem.end());
-            }
-            const double all = bins(nullptr), rb = bins(&p->rem);
-            const double cost_spec = 0.20 + 0.05 * std::min(1.0, all) + 0.19 * all;
-            const double cost_split = 0.16 * (double)p->classes.size() + (p->rem.empty() ? 0.0 : 0.20 + 0.05 * std::min(1.0, rb) + 0.19 * rb);
-            if ((p->classes.size() > 1 || !p->rem.empty()) && cost_split >= cost_spec) ok = false;
-        }
-        p->split = ok && !p->rem.empty();
-        if (!ok) p->rem.clear();
-        p->poly_block = ok && block_form;
-        p->poly_ok = ok;
-        p->poly_r = ok ? p->classes[0].r : 0;
-        if (!ok) p->classes.clear();
-    }
     p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
     if (cfg->min_block_launch >= 1) p->block_min = cfg->min_block_launch;
     if (const char *bm = fdc::debug_env("FDC_BLOCK_MIN_BLOCKS")) if (atoi(bm) >= 1) p->block_min = atoi(bm);
-    std::vector<int32_t> rflat;
-    if (p->split) {
-        std::map<int, std::vector<int32_t>> rbylen;
-        for (int c : p->rem) rbylen[p->chans[c].l].push_back(c);
-        for (auto &kv : rbylen) {
-            bool al = true, oal = true;
-            for (int c : kv.second) {
-                if (p->chans[c].f & 1) al = false;
-                if ((p->chans[c].out_off & 1) || (p->chans[c].lout & 1)) oal = false;
-            }
-            p->rg_aligned.push_back(al); p->rg_out_aligned.push_back(oal);
-            p->rgroup_off.push_back(rflat.size());
-            p->rgroups.emplace_back(kv.first, kv.second);
-            rflat.insert(rflat.end(), kv.second.begin(), kv.second.end());
-        }
-    }
+
+    std::vector<int32_t> flat, rflat;
+    group_by_width(p, nullptr, p->groups, p->group_off, p->g_aligned, p->g_out_aligned, flat);
+    classify_plan(p, cfg, flags);
+    if (p->split) group_by_width(p, &p->rem, p->rgroups, p->rgroup_off, p->rg_aligned, p->rg_out_aligned, rflat);
+
     // launch groups.  Measured on MI355X (profiles/r01_*): with one stream, short launches (few tiles per
     // persistent workgroup) cost more than cache residency of the intermediates gains, on both paths, so the
     // default takes groups as large as a 2 GiB scratch budget allows (1024 blocks at N = 65536).
     int chunk = cfg->chunk_blocks;
     if (chunk <= 0) chunk = (int)std::max<int64_t>(1, (2048ll << 20) / (2ll * N * 8));
-    chunk = std::min(chunk, cfg->max_blocks);
-    p->chunk = chunk;
+    p->chunk = std::min(chunk, cfg->max_blocks);
 
-#define CHK_OR_FREE(expr)                                                                       \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess) {                                                                 \
-            return fail(_e == hipErrorOutOfMemory ? FDC_ERR_NOMEM : FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-        }                                                                                       \
-    } while (0)
-
-    CHK_OR_FREE(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    p->ntab = N;
-    const std::vector<float2> tw = make_twiddles(N);
-    CHK_OR_FREE(hipMalloc(&p->d_tw, sizeof(float2) * (size_t)N));
-    CHK_OR_FREE(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
-    if (p->C > 0) {
-        CHK_OR_FREE(hipMalloc(&p->d_wins, sizeof(float2) * pool.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_wins, pool.data(), sizeof(float2) * pool.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_chans, sizeof(fdc::ChanDev) * p->chans.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_chans, p->chans.data(), sizeof(fdc::ChanDev) * p->chans.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_groups, sizeof(int32_t) * flat.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_groups, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
-        if (!rflat.empty()) {
-            CHK_OR_FREE(hipMalloc(&p->d_rgroups, sizeof(int32_t) * rflat.size()));
-            CHK_OR_FREE(hipMemcpy(p->d_rgroups, rflat.data(), sizeof(int32_t) * rflat.size(), hipMemcpyHostToDevice));
-        }
-    }
-    {
-        std::vector<float2> t256(256);
-        for (int j = 0; j < 256; j++) {
-            const double a = -2.0 * M_PI * double(j) / 256.0;
-            t256[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
-        }
-        CHK_OR_FREE(hipMalloc(&p->d_tw256, sizeof(float2) * 256));
-        CHK_OR_FREE(hipMemcpy(p->d_tw256, t256.data(), sizeof(float2) * 256, hipMemcpyHostToDevice));
-    }
-    if (N > fdc::kMaxLdsFft) {
-        // inter-pass twiddles of the two-pass transform, laid out like pass A's output: [k2][n1] = W_N^(n1*k2)
-        const fdc::BigGeom bg = fdc::big_geom(N);
-        std::vector<float2> tf((size_t)N);
-        for (int k2 = 0; k2 < bg.N2; k2++)
-            for (int n1 = 0; n1 < bg.N1; n1++) {
-                const double a = -2.0 * M_PI * double((long long)n1 * k2) / double(N);
-                tf[(size_t)k2 * bg.N1 + n1] = make_float2(float(std::cos(a)), float(std::sin(a)));
-            }
-        CHK_OR_FREE(hipMalloc(&p->d_twf, sizeof(float2) * (size_t)N));
-        CHK_OR_FREE(hipMemcpy(p->d_twf, tf.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
-    }
-    if (p->poly_ok && p->poly_L != 256) {
-        // uniform plan of width L: the window shape (plateau 1: the chain's * l is in it) over N, the slot table; twiddles are d_tw's
-        const int L = p->poly_L, N1 = N / L;
-        fdc_pipeline::PolyClass pc;
-        pc.r = 0; pc.passbw = cfg->channels[0].passbw; pc.stopbw = cfg->channels[0].stopbw;
-        pc.chan = p->bank1_chan;
-        std::vector<std::complex<float>> shape((size_t)L);
-        fdc::window_table(cfg->windowtype, L, pc.passbw, pc.stopbw, 1, 0, true, shape.data());
-        std::vector<float> sn((size_t)L);
-        for (int k2 = 0; k2 < L; k2++) sn[(size_t)k2] = float(double(shape[(size_t)k2].real()) / double(N));
-        p->classes.push_back(pc);
-        // one bank's tables: window, slot table, and what its width's block kernel wants (cbt; the narrow kernel's image).  half: the bank sits half a
-        // channel off the grid (tables moved)
-        auto build_bank = [&](const std::vector<int> &ids, int rb, float *&d_shn, long long *&d_so, float2 *&d_cbt, float2 *&d_tab) -> int {
-            const bool half = rb == L / 2;
-            std::vector<long long> so((size_t)N1, -1);
-            for (int c : ids) so[(size_t)(p->chans[c].f / L)] = p->chans[c].out_off;
-            // the 512- and 1024-bin block kernels at half a channel's offset read the window with its halves swapped (their lanes hold the other half)
-            std::vector<float> snd(sn);
-            if (half && (p->poly_b512 || p->poly_b1024))
-                for (int k2 = 0; k2 < L; k2++) snd[(size_t)k2] = sn[(size_t)(k2 ^ (L / 2))];
-            CHK_OR_FREE(hipMalloc(&d_shn, sizeof(float) * (size_t)L));
-            CHK_OR_FREE(hipMemcpy(d_shn, snd.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&d_so, sizeof(long long) * (size_t)N1));
-            CHK_OR_FREE(hipMemcpy(d_so, so.data(), sizeof(long long) * (size_t)N1, hipMemcpyHostToDevice));
-            std::vector<float2> cb;
-            if (p->poly_b512 || p->poly_b1024) {
-                // (-1)^n1 W_N^(n1 (b + 256 i)) at [n1][b + 16 i], i = half (512: two) or quarter (1024: four) of k2.  half: the lane of part i holds part
-                // i ^ (parts / 2) of the modulated column, whose constant W_N^((l/2) n1) joins the table
-                const int parts = L / 256;
-                cb.resize((size_t)N1 * 16 * parts);
-                for (int n1 = 0; n1 < N1; n1++)
-                    for (int e = 0; e < 16 * parts; e++) {
-                        const int i = half ? (e >> 4) ^ (parts / 2) : e >> 4;
-                        const double a = -2.0 * M_PI * double(((long long)n1 * ((e & 15) + 256 * i + (half ? L / 2 : 0))) % N) / double(N);
-                        const double sg = (n1 & 1) ? -1.0 : 1.0;
-                        cb[(size_t)n1 * 16 * parts + e] = make_float2(float(sg * std::cos(a)), float(sg * std::sin(a)));
-                    }
-            } else if (p->poly_bnar) {
-                // the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V b) at [V][b], S = 256 / l (half: W_N^((l/2) S V) with it)
-                const int S = 256 / L;
-                std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L));
-                fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half, half ? 0 : rb);
-                CHK_OR_FREE(hipMalloc(&d_tab, sizeof(float2) * img.size()));
-                CHK_OR_FREE(hipMemcpy(d_tab, img.data(), sizeof(float2) * img.size(), hipMemcpyHostToDevice));
-                cb.resize(256 * 16);
-                for (int V = 0; V < 256; V++)
-                    for (int b = 0; b < 16; b++) {
-                        const double a = -2.0 * M_PI * double(((long long)S * V * (b + rb)) % N) / double(N);
-                        cb[(size_t)V * 16 + b] = make_float2(float(std::cos(a)), float(std::sin(a)));
-                    }
-            }
-            if (!cb.empty()) {
-                CHK_OR_FREE(hipMalloc(&d_cbt, sizeof(float2) * cb.size()));
-                CHK_OR_FREE(hipMemcpy(d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-            }
-            return FDC_OK;
-        };
-        auto &q = p->classes.back();
-        float2 *&cbt1 = p->poly_b512 ? p->d_cbt512 : p->poly_b1024 ? p->d_cbt1k : p->d_cbtnar;
-        { const int rcb = build_bank(p->bank1_chan, p->bank1_r, q.d_shn, q.d_slot_off, cbt1, p->d_tabnar); if (rcb != FDC_OK) return rcb; }
-        p->d_shn = q.d_shn; p->d_slot_off = q.d_slot_off;
-        for (int k = 1; k < p->nbanks; k++) {
-            const int rcb = build_bank(p->bankx_chan[k - 1], p->bankx_r[k - 1], p->d_shnx[k - 1], p->d_slot_offx[k - 1], p->d_cbtx[k - 1], p->d_tabx[k - 1]);
-            if (rcb != FDC_OK) return rcb;
-        }
-        // the tile-local factor of the inter-pass twiddle, in the tile's own order: t2[k2][t] = W_N^(t k2)
-        const int TCg = fdc::poly_stage1_generic_tile_columns(N, L);
-        std::vector<float2> t2v((size_t)L * TCg);
-        for (int k2 = 0; k2 < L; k2++)
-            for (int t = 0; t < TCg; t++) {
-                const double a = -2.0 * M_PI * double(((long long)t * k2) % N) / double(N);
-                t2v[(size_t)k2 * TCg + t] = make_float2(float(std::cos(a)), float(std::sin(a)));
-            }
-        CHK_OR_FREE(hipMalloc(&p->d_t2g, sizeof(float2) * t2v.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_t2g, t2v.data(), sizeof(float2) * t2v.size(), hipMemcpyHostToDevice));
-        if (p->poly_b512 || p->poly_b1024) {
-            // tables both banks share: W_l^k (k < 256 for 512, all 1024 for 1024) and W_N^(16 n1 q)
-            std::vector<float2> t5(p->poly_b512 ? 256 : 1024), tq((size_t)N1 * 16);
-            for (size_t k = 0; k < t5.size(); k++) { const double a = -2.0 * M_PI * double(k) / double(L); t5[k] = make_float2(float(std::cos(a)), float(std::sin(a))); }
-            for (int n1 = 0; n1 < N1; n1++)
-                for (int qq = 0; qq < 16; qq++) {
-                    const double a = -2.0 * M_PI * double((16ll * n1 * qq) % N) / double(N);
-                    tq[(size_t)n1 * 16 + qq] = make_float2(float(std::cos(a)), float(std::sin(a)));
-                }
-            float2 *&dtw = p->poly_b512 ? p->d_tw512 : p->d_tw1k, *&dtq = p->poly_b512 ? p->d_twq512 : p->d_twq1k;
-            CHK_OR_FREE(hipMalloc(&dtw, sizeof(float2) * t5.size()));
-            CHK_OR_FREE(hipMemcpy(dtw, t5.data(), sizeof(float2) * t5.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&dtq, sizeof(float2) * tq.size()));
-            CHK_OR_FREE(hipMemcpy(dtq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-        }
-    } else if (p->poly_ok) {
-        const int N1 = N / 256;
-        std::vector<float2> tq((size_t)N1 * 16);
-        for (int n1 = 0; n1 < N1; n1++)
-            for (int j = 0; j < 16; j++) {
-                const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
-                tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
-            }
-        CHK_OR_FREE(hipMalloc(&p->d_twq, sizeof(float2) * tq.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_twq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-        for (auto &pc : p->classes) {
-            std::vector<std::complex<float>> shape(256);
-            fdc::window_table(cfg->windowtype, 256, pc.passbw, pc.stopbw, 1, 0, true, shape.data());
-            std::vector<float2> cb((size_t)N1 * 16);
-            std::vector<float> sn(256);
-            for (int n1 = 0; n1 < N1; n1++)
-                for (int j = 0; j < 16; j++) {
-                    const double ab = -2.0 * M_PI * double(((long long)n1 * (j + pc.r)) % N) / double(N);   // offset plans: W_N^(r n1) folded in
-                    const double sg = (n1 & 1) ? -1.0 : 1.0;
-                    cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
-                }
-            for (int k2 = 0; k2 < 256; k2++) sn[k2] = float(double(shape[k2].real()) / double(N));
-            CHK_OR_FREE(hipMalloc(&pc.d_cbt, sizeof(float2) * cb.size()));
-            CHK_OR_FREE(hipMemcpy(pc.d_cbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-            CHK_OR_FREE(hipMalloc(&pc.d_shn, sizeof(float) * 256));
-            CHK_OR_FREE(hipMemcpy(pc.d_shn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
-            std::vector<long long> so(N1, -1);
-            for (int c : pc.chan) so[p->chans[c].f >> 8] = p->chans[c].out_off;
-            CHK_OR_FREE(hipMalloc(&pc.d_slot_off, sizeof(long long) * N1));
-            CHK_OR_FREE(hipMemcpy(pc.d_slot_off, so.data(), sizeof(long long) * N1, hipMemcpyHostToDevice));
-        }
-        p->d_cbt = p->classes[0].d_cbt; p->d_shn = p->classes[0].d_shn; p->d_slot_off = p->classes[0].d_slot_off;   // class 0 (two-launch form)
-        if (N1 == 1024) {
-            std::vector<float2> t1k(1024);
-            for (int j = 0; j < 1024; j++) {
-                const double a = -2.0 * M_PI * double(j) / 1024.0;
-                t1k[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
-            }
-            CHK_OR_FREE(hipMalloc(&p->d_tw1024, sizeof(float2) * 1024));
-            CHK_OR_FREE(hipMemcpy(p->d_tw1024, t1k.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
-        }
-    }
-    p->fwd_block = N == 65536 && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
-    if (p->fwd_block) {
-        // the block kernel as a forward transform: twq / cbt as on the uniform path with r = 0, a flat "window" 1/N, and the
-        // slots of stage 2 mapped to the bins 256 c (+ k2) of the shifted spectrum
-        std::vector<float2> tq(256 * 16), cb(256 * 16);
-        for (int n1 = 0; n1 < 256; n1++)
-            for (int j = 0; j < 16; j++) {
-                const double aq = -2.0 * M_PI * double((16ll * n1 * j) % N) / double(N);
-                const double ab = -2.0 * M_PI * double(((long long)n1 * j) % N) / double(N);
-                const double sg = (n1 & 1) ? -1.0 : 1.0;
-                tq[(size_t)n1 * 16 + j] = make_float2(float(std::cos(aq)), float(std::sin(aq)));
-                cb[(size_t)n1 * 16 + j] = make_float2(float(sg * std::cos(ab)), float(sg * std::sin(ab)));
-            }
-        std::vector<float> sn(256, float(1.0 / double(N)));
-        std::vector<long long> so(256);
-        for (int c = 0; c < 256; c++) so[c] = 256ll * c;
-        CHK_OR_FREE(hipMalloc(&p->d_ftwq, sizeof(float2) * tq.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_ftwq, tq.data(), sizeof(float2) * tq.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_fcbt, sizeof(float2) * cb.size()));
-        CHK_OR_FREE(hipMemcpy(p->d_fcbt, cb.data(), sizeof(float2) * cb.size(), hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_fshn, sizeof(float) * 256));
-        CHK_OR_FREE(hipMemcpy(p->d_fshn, sn.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
-        CHK_OR_FREE(hipMalloc(&p->d_fslot, sizeof(long long) * 256));
-        CHK_OR_FREE(hipMemcpy(p->d_fslot, so.data(), sizeof(long long) * 256, hipMemcpyHostToDevice));
-    }
-    {
-        hipDeviceProp_t prop;
-        CHK_OR_FREE(hipGetDeviceProperties(&prop, cfg->device_id));
-        p->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizer's rows 64..127
-    if (p->fwd_block || ((p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) && R == 4)) CHK_OR_FREE(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
-    if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
-        std::vector<char> g64((size_t)N / 64, 0);
-        bool all = true;
-        // (a split plan's internal spectrum serves its remainder only)
-        for (int c = 0; c < p->C; c++) {
-            if (p->split && std::find(p->rem.begin(), p->rem.end(), c) == p->rem.end()) continue;
-            const auto &ch = p->chans[(size_t)c];
-            for (int b = ch.f / 64; b <= (ch.f + ch.l - 1) / 64 && b < N / 64; b++) g64[(size_t)b] = 1;
-        }
-        for (char v : g64) all = all && v;
-        if (!all && N == 4096) {
-            p->keep4096 = 0;
-            for (int b = 0; b < 64; b++) if (g64[(size_t)b]) p->keep4096 |= 1ull << b;
-        } else if (!all) {
-            // the block kernel's wave klo stores, per 64-row chunk q, the bins 256 c + 64 q .. + 63 of the slots c = klo + 8 khi; slot khi =
-            // k0 + 2 k1 sits in register 16 k0 + rev16(k1) (fdc_block256.hip, soff)
-            std::vector<unsigned> kw(32, 0u);
-            for (int klo = 0; klo < 8; klo++)
-                for (int q = 0; q < 4; q++)
-                    for (int r = 0; r < 32; r++) {
-                        const int k0 = r >> 4, k1 = 4 * (r & 3) + ((r & 15) >> 2), c = klo + 8 * (k0 + 2 * k1);
-                        if (g64[(size_t)(4 * c + q)]) kw[(size_t)(klo * 4 + q)] |= 1u << r;
-                    }
-            CHK_OR_FREE(hipMalloc(&p->d_keep, sizeof(unsigned) * 32));
-            CHK_OR_FREE(hipMemcpy(p->d_keep, kw.data(), sizeof(unsigned) * 32, hipMemcpyHostToDevice));
-        }
-    }
-    if (p->poly_block) {
-        if (const char *dg = fdc::debug_env("FDC_BLOCK_DEBUG")) if (dg[0] == '1') {
-            CHK_OR_FREE(hipMalloc(&p->d_dbg, sizeof(unsigned long long) * 8 * 4 * 32));
-            CHK_OR_FREE(hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 32));
-        }
-    }
-    if (p->poly_ok)
-    {
-        // G scratch of the two-launch form.  With the one-kernel form only launch groups shorter than block_min take the two
-        // launches, and only plans of one on-grid class can (see fdc_pipeline_process_device)
-        const bool two_launch = !p->poly_block || (p->classes.size() == 1 && p->classes[0].r == 0);
-        const int gblocks = (p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) ? std::min(chunk, p->block_min) : chunk;
-        if (two_launch)
-            CHK_OR_FREE(hipMalloc(&p->d_g, sizeof(float2) * (size_t)gblocks * (size_t)(p->poly_L - p->poly_L / R) * (size_t)(N / p->poly_L)));
-    }
-    {
-        // widest "channels x width" of a group above 4096 bins: a piece of the launch group is as many blocks as fit 32 Mi points
-        size_t widest = 0;
-        for (const auto &gr : p->groups) if (gr.first > 4096) { widest = std::max(widest, gr.second.size() * (size_t)gr.first); p->big_l = std::max(p->big_l, gr.first); }
-        if (widest) {
-            p->big_pts = std::max<size_t>(widest, std::min<size_t>((size_t)32 << 20, widest * (size_t)chunk));
-            CHK_OR_FREE(hipMalloc(&p->d_big, sizeof(float2) * p->big_pts));
-            CHK_OR_FREE(hipMalloc(&p->d_wtasks, sizeof(fdc::ExtractTask) * (p->big_pts / 8192 + (size_t)p->C + 1)));   // a piece: at most big_pts / l tasks, l >= 8192
-        }
-    }
-    // two-pass scratch; with the block kernel only launch groups shorter than kBlockMinBlocks take the two-pass kernels
-    if (N > fdc::kMaxLdsFft) CHK_OR_FREE(hipMalloc(&p->d_tmp, sizeof(float2) * (size_t)(p->fwd_block ? std::min(chunk, p->block_min) : chunk) * N));
-    CHK_OR_FREE(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)chunk * N));
-#undef CHK_OR_FREE
+    rc = build_device_state(p, cfg, pool, flat, rflat);
+    if (rc != FDC_OK) return rc;
     owner.p = nullptr;
     *out = p;
     return FDC_OK;
@@ -929,7 +917,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
     if (p->poly_block && p->split) return 4;
-    if (p->poly_block || p->poly_b512 || p->poly_b1024 || p->poly_bnar) return 3;
+    if (p->poly_block) return 3;
     if (p->poly_ok) return 2;
     if (p->N == 65536 && !p->cfg_generic) return 1;
     return 0;
@@ -938,23 +926,34 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
 int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
 {
     if (!p || !buf || n < 1) return -1;
-    char t[512];
+    char t[640];
     const int path = fdc_pipeline_path(p);
     int k = std::snprintf(t, sizeof(t), "N = %d, R = %d, %d channels; path %d: ", p->N, p->R, p->C, path);
     auto add = [&](const char *fmt, auto... a) { if (k < (int)sizeof(t)) k += std::snprintf(t + k, sizeof(t) - (size_t)k, fmt, a...); };
-    if (p->poly_b512 || p->poly_b1024 || p->poly_bnar) {
-        auto where = [&](int r) { return r == 0 ? "on the grid" : 2 * r == p->poly_L ? "half a channel off the grid" : 4 * r == p->poly_L ? "a quarter of a channel off the grid" : "three quarters of a channel off the grid"; };
-        add("%s, l = %d, bank of %d %s", p->poly_bnar ? "k_blknar" : p->poly_b512 ? "k_blk512" : "k_blk1024", p->poly_L, (int)p->bank1_chan.size(), where(p->bank1_r));
-        for (int k = 1; k < p->nbanks; k++) add(" + bank of %d %s", (int)p->bankx_chan[k - 1].size(), where(p->bankx_r[k - 1]));
-        if (p->nbanks > 1) add(" (%s launches)", p->nbanks == 2 ? "two" : "three");
+    auto kernel = [](int L) { return L == 256 ? "k_blk256" : L == 512 ? "k_blk512" : L == 1024 ? "k_blk1024" : "k_blknar"; };
+    auto where = [](int L, int r) { return r == 0 ? "on the grid" : 2 * r == L ? "half a channel off the grid" : 4 * r == L ? "a quarter of a channel off the grid" : "three quarters of a channel off the grid"; };
+    if (p->poly_block) {
+        bool one_width = true, all256 = true;
+        for (const auto &b : p->banks) { one_width = one_width && b.L == p->banks[0].L; all256 = all256 && b.L == 256; }
+        if (all256) {
+            add("k_blk256, %d tiling%s (r =", (int)p->banks.size(), p->banks.size() == 1 ? "" : "s");
+            for (const auto &b : p->banks) add(" %d", b.r);
+            add("%s", ")");
+        } else if (one_width) {
+            add("%s, l = %d, bank of %d %s", kernel(p->banks[0].L), p->banks[0].L, (int)p->banks[0].chan.size(), where(p->banks[0].L, p->banks[0].r));
+            for (size_t i = 1; i < p->banks.size(); i++) add(" + bank of %d %s", (int)p->banks[i].chan.size(), where(p->banks[i].L, p->banks[i].r));
+        } else {
+            for (size_t i = 0; i < p->banks.size(); i++) {
+                const auto &b = p->banks[i];
+                add("%s%s bank of %d, l = %d", i ? " + " : "", kernel(b.L), (int)b.chan.size(), b.L);
+                if (b.L == 256) add(" (r = %d)", b.r); else add(" %s", where(b.L, b.r));
+            }
+        }
+        if (p->banks.size() > 1 && !all256) add(" (%s launches)", p->banks.size() == 2 ? "two" : p->banks.size() == 3 ? "three" : "four");
         if (!p->bank_alias.empty()) add(" + %d copies of channels with the same slice", (int)p->bank_alias.size());
-    } else if (p->poly_block) {
-        add("k_blk256, %d tiling%s (r =", (int)p->classes.size(), p->classes.size() == 1 ? "" : "s");
-        for (const auto &pc : p->classes) add(" %d", pc.r);
-        add("%s", ")");
         if (p->split) add(" + %d other channels on a partial spectrum", (int)p->rem.size());
     } else if (p->poly_ok) {
-        add("two launches (stage 1 + stage 2), l = %d", p->poly_L);
+        add("two launches (stage 1 + stage 2), l = %d", p->banks[0].L);
     } else {
         add("%s", "forward transform to a spectrum in memory + channel kernels");
     }
@@ -1071,6 +1070,35 @@ static int run_remainder(fdc_pipeline *p, const float2 *ring, int m0, int nb, in
     return FDC_OK;
 }
 
+// which form a timed launch group ran (ev_spans[.][4]): how the three intervals between its four events map to ms[0..2]
+enum { kSpanBanks = 0 /* banks | remainder forward | remainder channels */, kSpanTwoLaunch = 1 /* stage 1 | - | stage 2 (+ remainder) */,
+       kSpanSpectrumLds = 2 /* forward transform = a + b | channels */, kSpanSpectrum = 3 /* pass A / block forward | pass B | channels */ };
+
+// one launch of the bank's block kernel over the launch group (ev0 / ev1: stamped by the dispatch itself, may be null)
+static int launch_bank(fdc_pipeline *p, const fdc_pipeline::Bank &bk, const float2 *in0, float2 *o, int nb, int m0, int nblocks, int64_t first_block,
+                       unsigned out_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const bool half = bk.r == bk.L / 2;
+    switch (bk.L) {
+    case 256:
+        HIPCHK(fdc::launch_poly_block(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, bk.d_slot_off, out_bytes, p->ncu,
+                                      p->block_hints, s, p->d_dbg, bk.r, first_block + m0, ev0, ev1, p->R, p->d_fscr, p->N));
+        break;
+    case 512:
+        HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, bk.d_cbt, bk.d_shn, bk.d_slot_off,
+                                         out_bytes, p->ncu, p->block_hints, s, ev0, ev1, p->R, p->d_fscr, half));
+        break;
+    case 1024:
+        HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, bk.d_cbt, bk.d_shn, bk.d_slot_off,
+                                          out_bytes, p->ncu, p->block_hints, s, ev0, ev1, half, p->R, p->d_fscr));
+        break;
+    default:
+        HIPCHK(fdc::launch_poly_block_narrow(bk.L, in0, (size_t)p->H, o, nb, m0, nblocks, bk.d_tab, bk.d_cbt, bk.d_slot_off, out_bytes, p->ncu,
+                                             p->block_hints, s, ev0, ev1, p->R, p->d_fscr, bk.r));
+    }
+    return FDC_OK;
+}
+
 int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
                                 void *d_out, void *d_spectrum, void *stream)
 {
@@ -1080,16 +1108,20 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
     if (nblocks == 0) return FDC_OK;
     if (!d_ring || (p->C > 0 && !d_out)) return fail(FDC_ERR_INVALID_ARGUMENT, "null device buffer");
     if (d_spectrum && !p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    // one call produces less than 4 GiB (32-bit output offsets; checked for max_blocks at create): a longer call is refused, not sent down
+    // a path whose internal spectrum may be partial (a split plan's remainder-only spectrum under the channel kernels of ALL channels)
+    if ((int64_t)nblocks * p->sum_lout * 8 > 0xFFFFF000ll)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d x %lld output samples per block is more than the 4 GiB one call may produce", nblocks, (long long)p->sum_lout);
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const float2 *ring = static_cast<const float2 *>(d_ring);
-    const bool use_poly = p->poly_ok && !d_spectrum && (int64_t)nblocks * p->sum_lout * 8 < 0xFFFFFF00ll;
-    p->last_was_poly = use_poly;
-    p->last_was_split = use_poly && p->split && p->poly_block;
+    float2 *o = static_cast<float2 *>(d_out);
+    const bool use_poly = p->poly_ok && !d_spectrum;
+    const unsigned out_bytes = (unsigned)((int64_t)nblocks * p->sum_lout * 8);
     for (int m0 = 0; m0 < nblocks; m0 += p->chunk) {
         const int nb = std::min(p->chunk, nblocks - m0);
         float2 *spec = d_spectrum ? static_cast<float2 *>(d_spectrum) + (size_t)m0 * p->N : p->d_spec;
-        hipEvent_t ev[3]; hipEvent_t *evp = nullptr; std::array<size_t, 4> span{};
+        hipEvent_t ev[3]; hipEvent_t *evp = nullptr; std::array<size_t, 5> span{};
         // events on every timing_stride-th launch group only: a sample of the launches, so that the packets between the
         // kernels (measured 7-17 us per group) do not slow the region they time
         const bool tg = p->timing && (p->timing_seq++ % p->timing_stride) == 0;
@@ -1098,108 +1130,73 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             for (int i = 0; i < 3; i++) ev[i] = p->events[span[i]];
             evp = ev;
         }
-        // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store
-        // The block kernel gives a whole block to one compute unit: a launch group of fewer blocks than the device has compute
+        const float2 *in0 = ring + (size_t)m0 * p->H;
+        // overlap-save gather fused into the load (item m at ring + m*H), fftshift + 1/N into the store.
+        // A block kernel gives a whole block to one compute unit: a launch group of fewer blocks than the device has compute
         // units leaves the rest idle (one block takes ~42 us there, however few there are).  Short calls — a scheduler handing
-        // over a few items — take the tiled kernels, which spread every block over the device.
+        // over a few items — take the two-launch form where the plan has one (ONE bank on its grid), which spreads every block over the device.
         const bool few = nb < p->block_min;
-        if (use_poly && p->poly_block && !(few && p->classes.size() == 1 && p->classes[0].r == 0)) {
-            // one launch: nothing but the input rows and the output samples crosses the memory interface
-            // timing: the two events take the dispatch's own begin / end stamps, no packets around the kernel
-            for (size_t k = 0; k < p->classes.size(); k++) {         // one launch per class of the plan (normally one)
-                const auto &pc = p->classes[k];
-                HIPCHK(fdc::launch_poly_block(ring + (size_t)m0 * p->H, (size_t)p->H, static_cast<float2 *>(d_out), nb, m0, nblocks,
-                                              p->d_tw256, p->d_twq, pc.d_cbt, pc.d_shn, pc.d_slot_off,
-                                              (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, p->block_hints, s, p->d_dbg,
-                                              pc.r, first_block + m0, tg && k == 0 ? p->events[span[0]] : nullptr,
-                                              tg && k + 1 == p->classes.size() ? p->events[span[1]] : nullptr, p->R, p->d_fscr, p->N));
-            }
-            if (p->split) {
-                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, static_cast<float2 *>(d_out), few, s,
-                                              tg ? p->events[span[2]] : nullptr, tg ? p->events[span[3]] : nullptr);
-                if (rcr != FDC_OK) return rcr;
-                if (tg) p->ev_spans.push_back(span);
-            } else if (tg) {
-                span[2] = span[3] = span[1];
-                p->ev_spans.push_back(span);
-            }
-            continue;
-        }
-        // (a bank at half a channel's offset, or a plan of two banks, has no two-launch form: short launch groups take the block kernel too)
-        if (use_poly && (p->poly_b1024 || p->poly_bnar || p->poly_b512) && (!few || p->bank1_r || p->nbanks > 1 || !p->bank_alias.empty())) {
-            const unsigned out_bytes = (unsigned)((int64_t)nblocks * p->sum_lout * 8);
-            const float2 *in0 = ring + (size_t)m0 * p->H;
-            float2 *o = static_cast<float2 *>(d_out);
-            // one launch per bank; the timing events take the first launch's begin and the last one's end
-            for (int k = 0; k < p->nbanks; k++) {
-                const int rk = k ? p->bankx_r[k - 1] : p->bank1_r;
-                const bool half = rk == p->poly_L / 2;
-                const float *shn = k ? p->d_shnx[k - 1] : p->d_shn;
-                const long long *so = k ? p->d_slot_offx[k - 1] : p->d_slot_off;
-                hipEvent_t e0 = tg && k == 0 ? p->events[span[0]] : nullptr, e1 = tg && k == p->nbanks - 1 ? p->events[span[1]] : nullptr;
-                if (p->poly_b1024)
-                    HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, k ? p->d_cbtx[k - 1] : p->d_cbt1k, shn, so,
-                                                      out_bytes, p->ncu, p->block_hints, s, e0, e1, half, p->R, p->d_fscr));
-                else if (p->poly_bnar)
-                    HIPCHK(fdc::launch_poly_block_narrow(p->poly_L, in0, (size_t)p->H, o, nb, m0, nblocks, k ? p->d_tabx[k - 1] : p->d_tabnar, k ? p->d_cbtx[k - 1] : p->d_cbtnar,
-                                                         so, out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, rk));
-                else
-                    HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, k ? p->d_cbtx[k - 1] : p->d_cbt512, shn, so,
-                                                     out_bytes, p->ncu, p->block_hints, s, e0, e1, p->R, p->d_fscr, half));
+        if (use_poly && p->poly_block && !(few && two_launch_possible(p))) {
+            // one launch per bank: nothing but the input rows and the output samples crosses the memory interface.
+            // timing: the first launch's begin and the last one's end are the dispatches' own stamps, no packets around the kernels
+            for (size_t k = 0; k < p->banks.size(); k++) {
+                const int rcb = launch_bank(p, p->banks[k], in0, o, nb, m0, nblocks, first_block, out_bytes, s,
+                                            tg && k == 0 ? p->events[span[0]] : nullptr, tg && k + 1 == p->banks.size() ? p->events[span[1]] : nullptr);
+                if (rcb != FDC_OK) return rcb;
             }
             for (const auto &al : p->bank_alias) {
                 const fdc::ChanDev &dc = p->chans[(size_t)al.first], &sc = p->chans[(size_t)al.second];
                 HIPCHK(hipMemcpyAsync(o + (size_t)nblocks * dc.out_off + (size_t)m0 * dc.lout, o + (size_t)nblocks * sc.out_off + (size_t)m0 * sc.lout,
                                       sizeof(float2) * (size_t)nb * dc.lout, hipMemcpyDeviceToDevice, s));
             }
-            if (tg) {
-                span[2] = span[3] = span[1];
-                p->ev_spans.push_back(span);
-            }
+            if (p->split) {
+                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, o, few, s, tg ? p->events[span[2]] : nullptr, tg ? p->events[span[3]] : nullptr);
+                if (rcr != FDC_OK) return rcr;
+            } else if (tg) span[2] = span[3] = span[1];
+            if (tg) { span[4] = kSpanBanks; p->ev_spans.push_back(span); }
             continue;
         }
         if (use_poly) {
-            // uniform plan: window + IFFT commuted in front of pass B; only G (lout*N1 per block) between the two launches
+            // ONE bank on its grid: window + IFFT commuted in front of pass B; only G (lout * N / l per block) between the two launches
+            const fdc_pipeline::Bank &bk = p->banks[0];
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
-            if (p->poly_L != 256)
-                HIPCHK(fdc::launch_poly_stage1_generic(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N, p->poly_L, p->R, nb, p->d_shn, p->d_tw,
-                                                       p->ntab, p->d_t2g, s));
+            if (bk.L != 256)
+                HIPCHK(fdc::launch_poly_stage1_generic(in0, (size_t)p->H, p->d_g, p->N, bk.L, p->R, nb, bk.d_shn, p->d_tw, p->ntab, p->d_t2g, s));
             else
-                HIPCHK(fdc::launch_poly_stage1(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_g, p->N / 256, p->R, nb,
-                                               p->d_tw256, p->d_twq, p->d_cbt, p->d_shn, p->ncu, s));
+                HIPCHK(fdc::launch_poly_stage1(in0, (size_t)p->H, p->d_g, p->N / 256, p->R, nb, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, p->ncu, s));
             if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[1]; }   // the end of stage 1 IS the start of stage 2
-            if (p->poly_L != 256)
-                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, static_cast<float2 *>(d_out), p->N / p->poly_L, p->R, nb, m0, nblocks,
-                                                       p->d_slot_off, p->d_tw, p->ntab, s, p->poly_L));
+            if (bk.L != 256)
+                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, o, p->N / bk.L, p->R, nb, m0, nblocks, bk.d_slot_off, p->d_tw, p->ntab, s, bk.L));
             else if (p->N != 65536 && p->N != 262144)
-                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
-                                                       p->d_slot_off, p->d_tw, p->ntab, s));
+                HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, o, p->N / 256, p->R, nb, m0, nblocks, bk.d_slot_off, p->d_tw, p->ntab, s));
             else
-                HIPCHK(fdc::launch_poly_stage2(p->d_g, static_cast<float2 *>(d_out), p->N / 256, p->R, nb, m0, nblocks,
-                                               p->d_tw256, p->d_tw1024, p->d_slot_off,
-                                               (unsigned)((int64_t)nblocks * p->sum_lout * 8), p->ncu, s));
+                HIPCHK(fdc::launch_poly_stage2(p->d_g, o, p->N / 256, p->R, nb, m0, nblocks, p->d_tw256, p->d_tw1024, bk.d_slot_off, out_bytes, p->ncu, s));
             if (p->split) {                                     // (timing: the remainder is counted with stage 2)
-                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, static_cast<float2 *>(d_out), few, s, nullptr, nullptr);
+                const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, o, few, s, nullptr, nullptr);
                 if (rcr != FDC_OK) return rcr;
             }
             if (tg) {
                 HIPCHK(hipEventRecord(p->events[span[3]], s));
+                span[4] = kSpanTwoLaunch;
                 p->ev_spans.push_back(span);
             }
             continue;
         }
+        // a spectrum in memory.  (A split plan's internal spectrum holds its remainder's bins only: whoever gets here with one — a caller's
+        // spectrum buffer — writes a full spectrum into THAT buffer, d_keep is not applied.)
         if (p->fwd_block && !few)
-            HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
+            HIPCHK(fdc::launch_block_fft65536(in0, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
                                               p->d_fshn, p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
         else if (p->N == 65536 && !p->cfg_generic)
-            HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
+            HIPCHK(fdc::launch_fft65536(in0, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
         else
-            HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
+            HIPCHK(fdc::launch_fft(in0, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
                                    1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
-        { const int rcc = run_channel_groups(p, false, spec, static_cast<float2 *>(d_out), nb, m0, nblocks, first_block, s); if (rcc != FDC_OK) return rcc; }
+        { const int rcc = run_channel_groups(p, false, spec, o, nb, m0, nblocks, first_block, s); if (rcc != FDC_OK) return rcc; }
         if (tg) {
             HIPCHK(hipEventRecord(p->events[span[3]], s));
+            span[4] = p->N <= fdc::kMaxLdsFft ? kSpanSpectrumLds : kSpanSpectrum;
             p->ev_spans.push_back(span);
         }
     }
@@ -1219,10 +1216,13 @@ int fdc_pipeline_last_kernel_ms(fdc_pipeline *p, float *ms, int n)
         HIPCHK(hipEventElapsedTime(&a, p->events[sp[0]], p->events[sp[1]]));
         HIPCHK(hipEventElapsedTime(&b, p->events[sp[1]], p->events[sp[2]]));
         HIPCHK(hipEventElapsedTime(&c, p->events[sp[2]], p->events[sp[3]]));
-        if (p->last_was_split) { ms[0] += a; ms[1] += b; ms[2] += c; }          // class launches, remainder: forward transform, channel kernels
-        else if (p->poly_ok && p->last_was_poly) { ms[0] += a; ms[1] += c; }   // stage 1, stage 2 (b = wait between them)
-        else if (p->N <= fdc::kMaxLdsFft) { ms[1] += a + b; ms[2] += c; }
-        else { ms[0] += a; ms[1] += b; ms[2] += c; }
+        // every span says which form it ran (a call may mix them: a short last launch group takes the two-launch form)
+        switch ((int)sp[4]) {
+        case kSpanBanks: ms[0] += a; ms[1] += b; ms[2] += c; break;        // bank launches; remainder: forward transform, channel kernels
+        case kSpanTwoLaunch: ms[0] += a; ms[1] += c; break;                // stage 1, stage 2 (b = the wait between them)
+        case kSpanSpectrumLds: ms[1] += a + b; ms[2] += c; break;
+        default: ms[0] += a; ms[1] += b; ms[2] += c;
+        }
     }
     p->ev_used = 0; p->ev_spans.clear();
     return 4;

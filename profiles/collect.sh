@@ -28,10 +28,10 @@ timeout -k 10 300 python3 bench.py --no-cpu-baseline --force-path no-block > $OU
 timeout -k 10 300 python3 bench.py --blocks 4096 --chunk 4096 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_blocks4096.json 2> /dev/null || echo "bench 4096 failed"
 echo "[collect] bench lines done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $ROOT/bench.py --steps 200 --no-cpu-baseline > $OUT/stats_default.log 2>&1 || echo "rocprof default failed"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg4 -- python3 $ROOT/bench.py --steps 20 --no-cpu-baseline --config 4 > $OUT/stats_cfg4.log 2>&1 || echo "rocprof cfg4 failed"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --payload device --config 3 > $OUT/stats_cfg3.log 2>&1 || echo "rocprof cfg3 failed"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --payload device --config 5 > $OUT/stats_cfg5.log 2>&1 || echo "rocprof cfg5 failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $ROOT/bench.py --steps 200 --no-cpu-baseline --no-end-to-end > $OUT/stats_default.log 2>&1 || echo "rocprof default failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg4 -- python3 $ROOT/bench.py --steps 20 --no-cpu-baseline --no-end-to-end --config 4 > $OUT/stats_cfg4.log 2>&1 || echo "rocprof cfg4 failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --payload device --config 3 > $OUT/stats_cfg3.log 2>&1 || echo "rocprof cfg3 failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --payload device --config 5 > $OUT/stats_cfg5.log 2>&1 || echo "rocprof cfg5 failed"
 echo "[collect] rocprof stats done"
 for t in default cfg4 cfg3 cfg5; do
   f=$(find $OUT/stats_$t -name "*kernel_stats.csv" | head -1)

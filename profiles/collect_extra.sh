@@ -12,7 +12,7 @@ cd $ROOT
 stats() {   # name, bench args...
   local name=$1; shift
   timeout -k 10 300 python3 bench.py --steps 50 --warmup 5 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed"
-  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $OUT/stats_$name.log 2>&1 ) || echo "rocprof $name failed"
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end "$@" > $OUT/stats_$name.log 2>&1 ) || echo "rocprof $name failed"
   local f=$(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then head -1 "$f" > $OUT/rocprof_kernel_stats_$name.csv; grep "fdc::" "$f" >> $OUT/rocprof_kernel_stats_$name.csv; fi
   rm -rf $OUT/stats_$name

@@ -15,7 +15,7 @@ for c in 3 5; do
 done
 cd /tmp && export TMPDIR=/tmp
 for c in 3 5; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg$c -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --payload device --config $c > $OUT/stats_cfg$c.log 2>&1 || echo "rocprof cfg$c failed"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg$c -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --payload device --config $c > $OUT/stats_cfg$c.log 2>&1 || echo "rocprof cfg$c failed"
   f=$(find $OUT/stats_cfg$c -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then head -1 "$f" > $OUT/rocprof_kernel_stats_cfg$c.csv; grep "fdc::" "$f" >> $OUT/rocprof_kernel_stats_cfg$c.csv; fi
   rm -rf $OUT/stats_cfg$c

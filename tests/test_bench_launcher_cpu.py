@@ -27,6 +27,10 @@ def test_gpus_2_starts_two_ranks_by_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and "dry-run" in d["data"]
     assert d["ms_per_step"] >= 20.0                         # MAX over ranks: rank 1 sleeps 20 ms, rank 0 only 10
+    # the line shows every rank's own time (a straggler is visible) and what the process group itself reports
+    c = d["config"]
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and len(c["per_rank_ms"]) == 2
+    assert c["per_rank_ms"][1] >= 20.0 > c["per_rank_ms"][0] >= 10.0 and abs(max(c["per_rank_ms"]) - d["ms_per_step"]) < 1e-6
 
 
 def test_single_rank_plain_start():

@@ -634,10 +634,22 @@ def test_plan_classes_one_kernel_path(oracle):
         parts = [p.work(x[a * H:b * H]) for a, b in [(0, 2), (2, 5)]]
         for c in range(0, len(plan), 41):
             assert_close(np.concatenate([q_[c] for q_ in parts]), outs[c], name)
-    # too few channels for two launches to pay, and four classes: spectrum path
+    # too few channels for two launches to pay: spectrum path
     assert G.Pipeline(N, R, plan_a[:40], windowtype=1, max_blocks=nb).path() == 1
-    four = [(256 * c + r, 256, 0.88, 1.0) for r in (0, 64, 128, 192) for c in range(200)]
-    assert G.Pipeline(N, R, four, windowtype=1, max_blocks=nb).path() == 1
+    # four tilings of 200 channels: four launches still beat 3.1 bands' worth of channel kernels (round 5: up to four banks, fdc_plan_cost.hpp);
+    # six: the smallest ones go back to a remainder (a split plan) — results against the spectrum path either way
+    for nt in (4, 6):
+        many = [(256 * c + r, 256, 0.88, 1.0) for r in (0, 64, 128, 192, 32, 96)[:nt] for c in range(200 if r in (0, 64, 128, 192) else 20)]
+        p = G.Pipeline(N, R, many, windowtype=1, max_blocks=nb)
+        assert p.path() == 3 if nt == 4 else p.path() in (1, 4), p.describe()      # six: whatever the cost rule makes of it
+        outs = p.work(x)
+        G.defaults["FDC_NO_POLY"] = "1"
+        try:
+            outs3 = G.Pipeline(N, R, many, windowtype=1, max_blocks=nb).work(x)
+        finally:
+            del G.defaults["FDC_NO_POLY"]
+        for a, b in zip(outs, outs3):
+            assert_close(a, b, "%d tilings" % nt)
 
 
 def test_short_calls_take_the_tiled_kernels(oracle):
@@ -859,9 +871,16 @@ def test_split_plans_classes_plus_remainder(oracle):
     assert_close(spec, np.asarray(rspec).reshape(-1), "spectrum port")
     for c in (0, 229, 230, 235):
         assert_close(outs[c], ref[c])
-    # where the split does not pay the plan stays on the spectrum path: half the band in other widths (bench.py --mixed) ...
+    # half the band in 128-bin channels half a channel off their grid: since round 5 a second BANK (k_blknar), two launches (tests/test_plan_choice_gpu.py)
     half = [(256 * c, 256, 0.88, 1.0) if c % 2 == 0 else (256 * c + 64, 128, 0.88, 1.0) for c in range(256)]
-    assert G.Pipeline(N, R, half, windowtype=1, max_blocks=2).path() == 1
+    ph = G.Pipeline(N, R, half, windowtype=1, max_blocks=nb)
+    assert ph.path() == 3 and "two launches" in ph.describe(), ph.describe()
+    for c, (a, b_) in enumerate(zip(ph.work(x), G.Pipeline(N, R, half, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY).work(x))):
+        assert_close(a, b_, "two banks of two widths: channel %d vs the spectrum path" % c)
+    # where neither banks nor a split pay the plan stays on the spectrum path: bench.py --mixed (the 512-bin channels sit a quarter off their grid) ...
+    mixed = [(256 * c, 256, 0.88, 1.0) for c in range(0, 256, 2)] + [(256 * c + 64, 128, 0.88, 1.0) for c in range(1, 256, 4)] + \
+            [(256 * c - 128, 512, 0.88, 1.0) for c in range(3, 252, 4)]
+    assert G.Pipeline(N, R, mixed, windowtype=1, max_blocks=2).path() == 1
     # ... and a handful of channels
     assert G.Pipeline(N, R, bank[:20] + odd[:1], windowtype=1, max_blocks=2).path() == 1
 
