@@ -54,15 +54,24 @@ constexpr int kKLd = 8 * 8 + 2;                                  // stage-2 trip
 constexpr int kKTrip = 128 * kKLd * 8;                           // 67584 <= the strips: the trip buffer lies over them
 constexpr int kKOffCt = kKOffX;                                  // [8 c3][8 klo]  W_64^(c3 klo)
 constexpr int kKOffWrow = kKOffCt + 8 * 8 * 8;                   // [16][18]  W_256^(b p)
+// Round 5 (41 % of this kernel's LDS cycles were bank conflicts, profiles/r05/NOTES.md section 5): the four lanes of a quad read the rows (rho, b) /
+// (i, b) of these two tables in ONE instruction, and with rho / i strides of whole multiples of 64 dwords all four fell on the same banks (4-way).
+// T1k: rho stride 296 points (592 dwords = 4 windows of 4 dwords mod 16): the 4 x 4 rows of a 16-byte read's lane group on 16 different windows.
+// Sh: rows of 18 floats, i stride 304 floats (16 mod 64): the 4 x 8 rows of an 8-byte read's 32 lanes on all 64 banks once.
+constexpr int kKT1kRho = 16 * 18 + 8;
+constexpr int kKShRow = 18, kKShQ = 16 * kKShRow + 16;
 constexpr int kKOffT1k = kKOffWrow + 16 * 18 * 8;                // [4 rho][16 b][18]  W_1024^(rho (b + 16 q))
-constexpr int kKOffB = kKOffT1k + 4 * 16 * 18 * 8;               // [64 n1][18]  W_N^(16 n1 q)
-constexpr int kKOffSh = kKOffB + 64 * 18 * 8;                    // [4 i][16 b][20] floats: shape[b + 16 q + 256 i] / N (rows of 20: the b rows of a 16-byte read on different banks)
-constexpr int kKOffSoff = kKOffSh + 4 * 16 * 20 * 4;             // [8 klo][8] output offsets (bytes)
+constexpr int kKOffB = kKOffT1k + 4 * kKT1kRho * 8;              // [64 n1][18]  W_N^(16 n1 q)
+constexpr int kKOffSh = kKOffB + 64 * 18 * 8;                    // [4 i][16 b][18] floats: shape[b + 16 q + 256 i] / N
+constexpr int kKOffSoff = kKOffSh + 4 * kKShQ * 4;               // [8 klo][8] output offsets (bytes)
+static_assert(kKOffB % 16 == 0 && kKOffSh % 16 == 0 && kKOffSoff % 16 == 0, "aligned table reads");
 constexpr int kKLds = kKOffSoff + 64 * 4;                        // 96000
 static_assert(kKTrip <= kKOffX, "the trip buffer lies over the strips, below the tables");
-// STAGED loads (below): the next pass's 8 columns x 1024 rows as [column][row] planes, 8 points of padding per plane (a 16-byte load's two
-// columns and the four column pairs of a store instruction on different bank halves)
-constexpr int kKStagePlane = 1024 + 8;
+// STAGED loads (below): the next pass's 8 columns x 1024 rows as [column][row] planes, 2 points of padding per plane: a store instruction's sixteen
+// contiguous lanes are 4 column pairs x 4 rows, and an 8-byte STORE is banked on 32 dwords (MI355X_MICROARCH.md, LDS table): dword 2 (2 cp 1026 +
+// row) = 8 cp + 2 row mod 32 — four windows of 8 dwords, conflict-free (round 5; 1032-point planes put all four pairs on the same banks: 4-way).
+// A wave reads 64 consecutive rows of its one column: conflict-free either way.
+constexpr int kKStagePlane = 1024 + 2;
 constexpr int kKOffStage = kKLds;
 constexpr int kKLdsStaged = kKOffStage + 8 * kKStagePlane * 8;   // 162048 <= 163840
 static_assert(kKLdsStaged <= 160 * 1024, "LDS budget");
@@ -142,8 +151,8 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     for (int i = tid; i < 256; i += 512) wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
     for (int i = tid; i < 1024; i += 512) {
         const int r = i >> 8, kap = i & 255;                              // [rho][b][q], kap = b + 16 q
-        t1k[(r * 16 + (kap & 15)) * 18 + (kap >> 4)] = tw1024[(r * kap) & 1023];
-        Sh[((i >> 8) * 16 + (i & 15)) * 20 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 quarter
+        t1k[r * kKT1kRho + (kap & 15) * 18 + (kap >> 4)] = tw1024[(r * kap) & 1023];
+        Sh[(i >> 8) * kKShQ + (i & 15) * kKShRow + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 quarter
         Bt[(i >> 4) * 18 + (i & 15)] = twq[i];                            // [n1 = i >> 4][q]: twq is [n1][16] already
     }
     for (int i = tid; i < 64; i += 512) {
@@ -156,9 +165,9 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     float2 *const scrw = scr + w * kKScrPts + lane;
     const float2 *const scrr = scr + w * kKScrPts + rho + 68 * b;
     const float2 *const wr = wrow + b * 18;
-    const float2 *const t1r = t1k + (16 * rho + b) * 18;
+    const float2 *const t1r = t1k + rho * kKT1kRho + b * 18;
     const float2 *const btw = Bt + w * 18;                                // + pass * 8 rows
-    const float *const shr = Sh + (16 * iq + b) * 20;
+    const float *const shr = Sh + iq * kKShQ + b * kKShRow;
     // the sign of a lane's own term in the lane ^ 1 and lane ^ 2 layers; lane 3 turns its value by -j (forward) / +j (inverse) between them
     const float sg1 = (rho & 1) ? -1.0f : 1.0f, sg2 = (rho & 2) ? -1.0f : 1.0f;
     const bool rot = rho == 3;

@@ -53,17 +53,27 @@ constexpr int k5Ld = 8 * 16 + 6;                                 // stage-2 trip
 constexpr int k5Trip = 64 * k5Ld * 8;                            // 68608 <= the strips: the trip buffer lies over them
 constexpr int k5OffCt = k5OffX;                                  // [16 c4][8 klo]  W_128^(c4 klo)
 constexpr int k5OffWrow = k5OffCt + 16 * 8 * 8;                  // [16][18]  W_256^(b p)
-constexpr int k5OffT512 = k5OffWrow + 16 * 18 * 8;               // [2 par][16][18]  par 1: W_512^(b + 16 q); par 0: 1 (the same code for both lanes of a pair)
-constexpr int k5OffB = k5OffT512 + 2 * 16 * 18 * 8;              // [8 pass][16 c4][16]  W_N^(16 n1 q), n1 = 16 pass + c4 (rows unpadded: a wave reads two of them, broadcast)
-constexpr int k5OffSh = k5OffB + 8 * 16 * 16 * 8;                // [32 = b + 16 h][16] floats: shape[b + 16 q + 256 h] / N
-constexpr int k5OffSoff = k5OffSh + 32 * 16 * 4;                 // [8 klo][16] output offsets (bytes)
+// W_512^(b + 16 q) for the parity-1 lanes as [16 b][18] from point k5T512Tab on; the parity-0 lanes' factor is 1: ONE row of ones at point 0, read by all
+// of them (a broadcast).  The table starts 92 dwords behind the ones (= 28 mod 64 + 64): a 16-byte read's lane group then finds the ones and its
+// four b rows on five different 4-dword windows (round 5: two tables [2 par][16][18] put (0, b) and (1, b) on the same banks — 2-way on every read)
+constexpr int k5T512Tab = 46;
+constexpr int k5OffT512 = k5OffWrow + 16 * 18 * 8;
+constexpr int k5OffB = k5OffT512 + (k5T512Tab + 16 * 18) * 8;    // [8 pass][16 c4][16]  W_N^(16 n1 q), n1 = 16 pass + c4 (rows unpadded: a wave reads two of them, broadcast)
+constexpr int k5ShPar = 16 * 16 + 4;                             // floats between the two halves of Sh: the rows (0, b) and (1, b) of a 16-byte read 4 dwords apart
+constexpr int k5OffSh = k5OffB + 8 * 16 * 16 * 8;                // [2 h][16 b][16] floats: shape[b + 16 q + 256 h] / N
+constexpr int k5OffSoff = k5OffSh + (k5ShPar + 16 * 16) * 4;     // [8 klo][16] output offsets (bytes)
+static_assert(k5OffB % 16 == 0 && k5OffSh % 16 == 0 && k5OffSoff % 16 == 0, "16-byte table reads");
 constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 96256
 static_assert(k5Trip <= k5OffX, "the trip buffer lies over the strips, below the tables");
-// STAGED loads (below): the next pass's 16 columns x 512 rows as [column][row] planes, 4 points of padding per plane (the eight column pairs of a store
-// instruction, 8 rows each, on all banks twice: the minimum)
-constexpr int k5StagePlane = 512 + 4;
+// STAGED loads (below): the next pass's 16 columns x 512 rows as [column][row] planes.  Round 5 (the counters said a third of this kernel's LDS
+// cycles were bank conflicts, profiles/r05/NOTES.md section 5): planes 528 points apart and the rows of column pair cp turned by 2 cp —
+//   store (16 contiguous lanes = 8 column pairs x 2 rows, 8 bytes each): dword 2 (col 528 + row + 2 cp) = 32 col + 2 row + 4 cp mod 64: the eight pairs
+//         on eight different 4-dword windows, the two columns of a pair (separate instructions) on the two bank halves: conflict-free;
+//   load  (32 lanes = 8 row groups x two columns x two parities, consecutive rows): 32 creal + 4 b + 2 par + const: all 64 banks once.
+// (516-point planes before: the pairs cp and cp + 4 of a store on the same banks, the two columns of a load 8 dwords apart: 2-way both.)
+constexpr int k5StagePlane = 512 + 16;
 constexpr int k5OffStage = k5Lds;
-constexpr int k5LdsStaged = k5OffStage + 16 * k5StagePlane * 8;   // 162304
+constexpr int k5LdsStaged = k5OffStage + 16 * k5StagePlane * 8;   // 163840: all of it
 static_assert(k5LdsStaged <= 160 * 1024, "LDS budget");
 
 // R4 = true: relinvovl = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept.  The rows m >= 128 of
@@ -111,8 +121,8 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     // staged: wave w fetches rows 64 w + 8 i + (lane >> 3), columns 2 (lane & 7), + 1 of the pass (16 bytes); instruction i adds 8 rows = 8 KiB
     [[maybe_unused]] float2 *stg = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffStage);
     [[maybe_unused]] const unsigned voffs = (unsigned)((64 * w + (lane >> 3)) * 128 + 2 * (lane & 7)) * 8u;
-    [[maybe_unused]] float2 *const stw = stg + 2 * (lane & 7) * k5StagePlane + 64 * w + (lane >> 3);     // + 8 i rows; second column: + one plane
-    [[maybe_unused]] const float2 *const strd = stg + c4 * k5StagePlane + 2 * b + par;                    // this lane's rows 32 a + 2 b + par of column c4
+    [[maybe_unused]] float2 *const stw = stg + 2 * (lane & 7) * k5StagePlane + 64 * w + (lane >> 3) + 2 * (lane & 7);   // + 8 i rows; second column: + one plane
+    [[maybe_unused]] const float2 *const strd = stg + c4 * k5StagePlane + 2 * b + par + 2 * w;            // this lane's rows 32 a + 2 b + par of column c4 (pair w: turned by 2 w)
     [[maybe_unused]] u32x4 PF[8];
     [[maybe_unused]] auto stage_load = [&](int mb, int pn) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
@@ -140,8 +150,8 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     // ---- tables
     for (int i = tid; i < 256; i += 512) {
         wrow[(i >> 4) * 18 + (i & 15)] = tw256[((i >> 4) * (i & 15)) & 255];
-        t512[(16 + (i & 15)) * 18 + (i >> 4)] = tw512[i];                // [1][b][q] = W_512^(b + 16 q), i = b + 16 q
-        t512[(i & 15) * 18 + (i >> 4)] = make_float2(1.f, 0.f);
+        t512[k5T512Tab + (i & 15) * 18 + (i >> 4)] = tw512[i];           // [b][q] = W_512^(b + 16 q), i = b + 16 q
+        if (i < 18) t512[i] = make_float2(1.f, 0.f);                     // the parity-0 lanes' row of ones
     }
     for (int i = tid; i < 2048; i += 512) Bt[i] = twq[i];                                 // [n1 = i >> 4][q]: twq is [n1][16] already
     for (int i = tid; i < 128; i += 512) {
@@ -149,15 +159,15 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
         soff[(i & 7) * 16 + rev16(i >> 3)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
         ctab[i] = tw256[(2 * (i >> 3) * (i & 7)) & 255];                  // [c4][klo] = W_128^(c4 klo)
     }
-    for (int i = tid; i < 512; i += 512) Sh[((i & 15) + 16 * (i >> 8)) * 16 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 h
+    for (int i = tid; i < 512; i += 512) Sh[(i >> 8) * k5ShPar + (i & 15) * 16 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 h
     __syncthreads();
 
     float2 *const scrw = scr + w * k5ScrPts + lane;
     const float2 *const scrr = scr + w * k5ScrPts + vc + 68 * b;
     const float2 *const wr = wrow + b * 18;
-    const float2 *const t5r = t512 + (16 * par + b) * 18;
+    const float2 *const t5r = par ? t512 + k5T512Tab + b * 18 : t512;
     const float2 *const btr = Bt + c4 * 16;                              // + pass * 16 rows
-    const float *const shr = Sh + (b + 16 * par) * 16;
+    const float *const shr = Sh + par * k5ShPar + b * 16;
     const float fsgn = par ? -1.0f : 1.0f;                                // the sign of a lane's own term in both radix-2 layers
     const float hsgn = (half && par) ? -1.0f : 1.0f;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);

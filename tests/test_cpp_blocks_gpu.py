@@ -80,7 +80,7 @@ def test_stock_scheduler_gets_device_sized_batches():
     pinned, the outputs bit-identical to ONE work() over the same stream; without the request (scheduler batch 1, the reference's
     item-by-item behaviour) a 256-KiB item leaves 1 - 3 items per call."""
     import json
-    demo = os.path.join(BLOCKS, "blocks_demo")
+    demo = DEMO
     if not os.path.exists(demo):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "gr-fdc_amd", "csrc")])
     r = subprocess.run([demo, "stock", "65536", "2", "256", "64", "300", "0", "verify"], capture_output=True, text=True, timeout=300)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2 (or R = 4: third argument).  Every case draws a plan (on-grid,
-offset, two or three classes, mixed widths, or a split plan: tilings plus a remainder), a block count, a chunk size and a call pattern, runs it on the default
+offset, two or three classes, mixed widths, a split plan: tilings plus a remainder, or — round 5 — banks of several widths in one plan), a block count, a chunk size and a call pattern, runs it on the default
 dispatch and on the spectrum-in-memory path (FDC_NO_POLY=1) and compares every output sample; every fifth case is also
 compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed] [R]"""
 import os
@@ -25,7 +25,25 @@ def rel(a, b):
 
 
 def draw_plan(rng):
-    kind = rng.integers(0, 8)
+    kind = rng.integers(0, 11)
+    if kind >= 8:                                     # round 5: banks of DIFFERENT widths in one plan (one block-kernel launch each), duplicates of a slice
+        plan, names = [], []                          # (computed once, copied) and, sometimes, a remainder of channels that fit no bank
+        for _ in range(int(rng.integers(2, 5))):
+            L = int(rng.choice([64, 128, 256, 256, 512, 1024]))
+            r = int(rng.integers(0, 256)) if L == 256 else int(rng.choice([0, L // 2] + ([L // 4, 3 * L // 4] if L <= 128 else [])))
+            win = [(0.88, 1.0), (0.7, 0.9)][int(rng.integers(0, 2))]
+            nslot = N // L - (1 if r else 0)
+            slots = rng.permutation(nslot)[:max(1, int(rng.integers(nslot // 3, nslot + 1)))]
+            plan += [(L * int(c) + r, L) + win for c in slots]
+            names.append("%d@%d" % (L, r))
+        for _ in range(int(rng.integers(0, 4))):      # the same slice again
+            plan.append(plan[int(rng.integers(0, len(plan)))])
+        if kind == 10:
+            for _ in range(int(rng.integers(1, 6))):
+                l = int(2 ** rng.integers(5, 12))
+                plan.append((int(rng.integers(0, N - l + 1)) | 1, l, 0.7, 0.9))
+        order = rng.permutation(len(plan))
+        return [plan[int(i)] for i in order], "banks " + "+".join(names)
     if kind >= 6:                                     # uniform banks of another width on its grid: 1024, 512, 128, 64 (block kernels), others (spectrum path)
         L = int([512, 128, 1024, 1024, 64, 2048][int(rng.integers(0, 6))])
         half = int(rng.choice([L // 2, L // 4, 3 * L // 4])) if rng.integers(0, 3) == 0 else 0      # a bank off its grid by a multiple of a quarter channel (narrow kernel: all; 512 / 1024: half only)
@@ -92,7 +110,9 @@ def main():
             G.defaults["FDC_BLOCK_MIN_BLOCKS"] = "1"
         else:
             G.defaults.pop("FDC_BLOCK_MIN_BLOCKS", None)
-        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, chunk_blocks=chunk)
+        # every other multi-width case keeps ALL its banks whatever the cost rule says (FDC_PIPE_WIDE_UNIFORM): the launches are what is tested
+        flags = G.FDC_PIPE_WIDE_UNIFORM if what.startswith("banks") and rng.integers(0, 2) else None
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, chunk_blocks=chunk, flags=flags)
         path = p.path()
         parts = [p.work(x[a * H:b * H]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         outs = [np.concatenate([q[c] for q in parts]) for c in range(len(plan))]
@@ -108,8 +128,8 @@ def main():
             eo = max(rel(a, b) for a, b in zip(outs, oref))
         worst = max(worst, e, eo)
         flag = "" if max(e, eo) <= TOL else "   <-- FAIL"
-        print("case %3d  %-10s path %d  %3d ch  %3d blocks  chunk %3d  cuts %-14s vs spectrum path %.2e  vs oracle %.2e%s"
-              % (case, what, path, len(plan), nb, chunk, cuts, e, eo, flag), flush=True)
+        print("case %3d  %-10s path %d  %3d ch  %3d blocks  chunk %3d  cuts %-14s vs spectrum path %.2e  vs oracle %.2e%s  [%s]"
+              % (case, what[:40], path, len(plan), nb, chunk, cuts, e, eo, flag, p.describe().split("path ")[1][:110]), flush=True)
         if flag:
             sys.exit(1)
     print("all %d cases within %.0e (worst %.2e)" % (cases, TOL, worst))
