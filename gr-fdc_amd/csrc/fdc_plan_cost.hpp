@@ -11,16 +11,16 @@ namespace cost {
 // One launch of a width's block kernel: stage 1 transforms the whole block whatever the number of channels, so the time does not
 // depend on how many slots of the bank are used.
 //   256: k_blk256      0.3251 ms / 2048 blocks   profiles/r04/bench_default.json            (r05: 0.3315-0.3342, profiles/r05/ab_default.txt)
-//   512: k_blk512      0.3741-0.3862 / 2048      profiles/r04/bench_w512.json, NOTES.md section 12
-//  1024: k_blk1024     0.4421-0.4466 / 2048      profiles/r04/bench_w1024.json, NOTES.md section 10
+//   512: k_blk512      0.3660-0.3670 / 2048      profiles/r05/ab_w512.txt (conflict-free LDS layouts; r04: 0.374-0.386)
+//  1024: k_blk1024     0.4170-0.4181 / 2048      profiles/r05/ab_w1024.txt (r04: 0.442-0.447)
 //   128: k_blknar<2>   0.3513-0.3551 / 2048      profiles/r04/bench_w128.json
 //    64: k_blknar<4>   0.3793-0.3855 / 2048      profiles/r04/bench_w64.json
 inline double bank_launch(int width)
 {
     switch (width) {
     case 256: return 0.163;
-    case 512: return 0.19;
-    case 1024: return 0.222;
+    case 512: return 0.184;
+    case 1024: return 0.209;
     case 128: return 0.177;
     case 64: return 0.19;
     default: return 1e9;          // no block kernel of this width

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Lines the default collection does not cover: the reference's default overlap (R = 4) at configs[1], a mixed-width
 # 256-channel plan, and PMC traffic for configs other than the headline.  Usage: profiles/collect_extra.sh <tag> [what...]
-#   what: r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5   (default: all)
+#   what: r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5   (default: all)
 set -u
 TAG=${1:-r03}; shift || true
-WHAT=${*:-r4 mixed n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5}
+WHAT=${*:-r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/extra_$TAG
 mkdir -p $OUT
@@ -27,6 +27,7 @@ for w in $WHAT; do
   case $w in
     r4) stats r4 --relinvovl 4 --no-cpu-baseline ;;
     mixed) stats mixed --mixed --no-cpu-baseline ;;
+    twowidths) stats two_widths --two-widths --no-cpu-baseline ;;    # round 5: a 256-bin bank + a 512-bin bank, two launches
     # the one-kernel form at the other block lengths (round 4): the same number of samples per step as the headline
     n16k) stats n16k --blocklen 16384 --channels 64 --blocks 8192 --no-cpu-baseline ;;
     n32k) stats n32k --blocklen 32768 --channels 128 --blocks 4096 --no-cpu-baseline ;;
