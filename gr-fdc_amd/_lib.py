@@ -112,6 +112,7 @@ SYMBOLS = {
     "fdc_sinks_work_band": (C.c_int, [_vp, _vp, C.c_int, C.c_int32, C.c_int32]),
     "fdc_sinks_read_band": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "fdc_sinks_pdu_emit_items": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
+    "fdc_sinks_pdu_emit_order": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "fdc_sinks_group_create": (C.c_int, [C.POINTER(fdc_sinks_cfg), C.POINTER(C.c_int32), C.c_int, C.POINTER(_vp)]),
     "fdc_sinks_group_destroy": (None, [_vp]),
     "fdc_sinks_group_work": (C.c_int, [_vp, _vp, C.c_int]),

@@ -336,7 +336,7 @@ int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_bl
 }  // extern "C"
 
 struct fdc_sinks_group {
-    struct Member { fdc_sinks *s = nullptr; int32_t dev = 0, lo = 0, hi = 0, npac = 0, nseg = 0; };
+    struct Member { fdc_sinks *s = nullptr; int32_t dev = 0, lo = 0, hi = 0, npac = 0, nseg = 0; std::vector<int32_t> bank_pos; /* member's PAC i -> its place in cfg->pac[] */ };
     std::vector<Member> mem;
     std::vector<std::unique_ptr<Worker>> workers;          // workers[i] serves member i (member 0 runs on the calling thread)
     int N = 0, max_blocks = 0;
@@ -370,6 +370,12 @@ int fdc_sinks_group_create(const fdc_sinks_cfg *cfg, const int32_t *devices, int
         *cnt = base + (i < extra ? 1 : 0);
         *first = i * base + std::min(i, extra);
     };
+    // the PowerActivationChannels in frequency order (stable: equal centres keep the bank's order), so that a member's run is a band
+    std::vector<int32_t> byfreq((size_t)cfg->npac);
+    for (int i = 0; i < cfg->npac; i++) byfreq[(size_t)i] = i;
+    std::stable_sort(byfreq.begin(), byfreq.end(), [cfg](int32_t a, int32_t b) { return cfg->pac[a].cfreq < cfg->pac[b].cfreq; });
+    std::vector<fdc_pac_cfg> sorted((size_t)cfg->npac);
+    for (int i = 0; i < cfg->npac; i++) sorted[(size_t)i] = cfg->pac[byfreq[(size_t)i]];
     for (int i = 0; i < ndevices; i++) {
         auto &m = g->mem[(size_t)i];
         m.dev = devices[i];
@@ -377,10 +383,11 @@ int fdc_sinks_group_create(const fdc_sinks_cfg *cfg, const int32_t *devices, int
         run_of(cfg->npac, i, &p0, &pn);
         run_of(cfg->nseg, i, &s0, &sn);
         m.npac = pn; m.nseg = sn;
+        m.bank_pos.assign(byfreq.begin() + p0, byfreq.begin() + p0 + pn);
         if (pn + sn == 0) continue;                          // more devices than channels and segments: the member stays idle
         fdc_sinks_cfg c = *cfg;
         c.device_id = devices[i];
-        c.npac = pn; c.pac = pn ? cfg->pac + p0 : nullptr;
+        c.npac = pn; c.pac = pn ? sorted.data() + p0 : nullptr;
         c.nseg = sn; c.seg = sn ? cfg->seg + s0 : nullptr;
         c.seg_id_base = cfg->seg_id_base + s0;
         const int rc = fdc_sinks_create(&c, &m.s);
@@ -443,23 +450,30 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
         g->dead = true;                                      // the members' state machines are no longer at the same item
         return fdc::set_error(rc, "%s", err.c_str());
     }
-    // Merge: one bank emits, item by item, the PowerActivationChannels in bank order and then the segments in order; the members hold
-    // runs of that order, so for every item it is member 0's PowerActivationChannel PDUs, member 1's, ..., then the detections likewise.
-    // Inside a member the PDUs are in its own (= the bank's) order already: the sort is stable on (item, kind, member).
+    // Merge: one bank emits, item by item, the PowerActivationChannels in bank order and then the segments in order.  A member holds a run of
+    // the channels in FREQUENCY order: a PowerActivationChannel PDU is put back by the place of its channel in the bank's own list (bank_pos);
+    // the segments are runs of the bank order: member 0's detections, member 1's, ...  Inside one channel / one member's detections the PDUs are
+    // in emission order already: the sort is stable on (item, kind, place).
     struct Key { int32_t item, kind, member; uint32_t seq; };
     std::vector<Key> keys;
     std::vector<std::vector<fdc_pdu>> got(g->mem.size());
-    std::vector<int32_t> items;
+    std::vector<int32_t> items, pacs;
     for (int i = 0; i < (int)g->mem.size(); i++) {
         fdc_sinks *sm = g->mem[(size_t)i].s;
         if (!sm) continue;
         const int n = fdc_sinks_pdu_count(sm);
         if (n <= 0) continue;
         got[(size_t)i].resize((size_t)n);
-        items.resize((size_t)n);
+        items.resize((size_t)n); pacs.resize((size_t)n);
         fdc_sinks_pdus(sm, got[(size_t)i].data(), n);
-        fdc_sinks_pdu_emit_items(sm, items.data(), n);
-        for (int k = 0; k < n; k++) keys.push_back(Key{items[(size_t)k], got[(size_t)i][(size_t)k].kind, i, (uint32_t)k});
+        fdc_sinks_pdu_emit_order(sm, items.data(), pacs.data(), n);
+        const auto &bp = g->mem[(size_t)i].bank_pos;
+        for (int k = 0; k < n; k++) {
+            const int32_t kind = got[(size_t)i][(size_t)k].kind, pc = pacs[(size_t)k];
+            // place: a PowerActivationChannel's index in cfg->pac[]; a detection's member (members own runs of the segment list)
+            const int32_t place = (kind == 0 && pc >= 0 && (size_t)pc < bp.size()) ? bp[(size_t)pc] : i;
+            keys.push_back(Key{items[(size_t)k], kind, place, (uint32_t)(((uint32_t)i << 24) | (uint32_t)k)});
+        }
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
         if (a.item != b.item) return a.item < b.item;
@@ -467,7 +481,7 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
         return a.member < b.member;
     });
     g->pdus.reserve(keys.size());
-    for (const Key &k : keys) g->pdus.push_back(got[(size_t)k.member][k.seq]);
+    for (const Key &k : keys) g->pdus.push_back(got[(size_t)(k.seq >> 24)][k.seq & 0xFFFFFFu]);
     guard.done = true;
     return nitems;
     FDC_ENTRY_END

@@ -1515,6 +1515,23 @@ int fdc_sinks_pdu_emit_items(const fdc_sinks *s, int32_t *item, int cap)
     return n;
 }
 
+int fdc_sinks_pdu_emit_order(const fdc_sinks *s, int32_t *item, int32_t *pac, int cap)
+{
+    FDC_ENTRY("fdc_sinks_pdu_emit_order")
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    const int n = (int)s->pdus.size();
+    // the order key: item index in the high bits (above), and for a PowerActivationChannel its index in this bank's list in the low ones
+    // (host engine: bits 0..22, device engine: 0..38; detections carry bit 23 / 39 and their own sub-order)
+    const int sh = s->dev.on ? 40 : 24;
+    for (int i = 0; i < n && i < cap; i++) {
+        const PduRec &r = s->pdus[(size_t)i];
+        if (item) item[i] = (int32_t)(r.key >> sh);
+        if (pac) pac[i] = r.meta.kind == 0 ? (int32_t)(r.key & ((1ll << (sh - 1)) - 1)) : -1;
+    }
+    return n;
+    FDC_ENTRY_END
+}
+
 void fdc_set_log_callback(fdc_log_fn fn, void *user) { std::lock_guard<std::mutex> g(g_log_mu); g_log_fn = fn; g_log_user = user; }
 
 int fdc_sinks_pdu_count(const fdc_sinks *s) { return s ? (int)s->pdus.size() : 0; }

@@ -358,6 +358,9 @@ int fdc_sinks_pdus(const fdc_sinks *s, fdc_pdu *out, int cap);
 /* for every PDU of the last call, the index (inside that call) of the item at which the block emitted it: what orders the PDUs of
  * several banks that saw the same items (fdc_sinks_group) the way one bank orders its own; returns the PDU count */
 int fdc_sinks_pdu_emit_items(const fdc_sinks *s, int32_t *item, int cap);
+/* the same, and for every PowerActivationChannel PDU the index of its channel in THIS bank's cfg->pac[] (-1 for a detection): a group that hands
+ * its members the bank's channels in frequency order puts their PDUs back into the bank's own order with it (either array may be NULL) */
+int fdc_sinks_pdu_emit_order(const fdc_sinks *s, int32_t *item, int32_t *pac, int cap);
 /* derived geometry (for logs and tests): v[8] = extract_start, extract_stop, extract_width, measure_start,
  * measure_stop, output_len, output_ovl_offset, deltaphase;  v[5] = start, stop, width, decimation, power cells */
 int fdc_sinks_pac_params(const fdc_sinks *s, int i, int32_t *v8);
@@ -366,10 +369,10 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v5);
 /* ------------------------------------------------------------------------------------------------
  * The sink blocks over several devices ("shard by channel / by segment").  A sink block's input is the
  * stream of normalised spectrum items (512 KiB each at N = 65536): fed from host memory, ONE device is bound by its PCIe link
- * long before its kernels matter (1024 items: 9.6 ms of copy, 0.5 ms of kernels).  The group cuts the bank into RUNS OF THE BANK
- * ORDER (cfg->pac[] and cfg->seg[] as given, equal counts per member device), one run per member; a bank listed by ascending
- * frequency — what the hier block builds — is thereby cut BY FREQUENCY, and only then does a member's band stay narrow (an unsorted
- * list is still correct, but every member then reads nearly the whole block and the links gain nothing: sort the bank).  Every
+ * long before its kernels matter (1024 items: 9.6 ms of copy, 0.5 ms of kernels).  The group cuts the bank BY FREQUENCY: the
+ * PowerActivationChannels sorted by centre frequency (round 5: whatever order cfg->pac[] lists them in; the PDUs come back in the
+ * bank's own order) and the segments as listed (their numbers in the message IDs are their places in cfg->seg[]: list them by
+ * frequency), in runs of equal counts, one run per member device.  Every
  * member copies only the band of bins its run reads (fdc_sinks_work_band) over its own link and runs its state machines and
  * extractions on it, all members concurrently; their PDUs are merged into the order ONE bank emits them in (item by item:
  * PowerActivationChannels in bank order, then the segments in order).  Every channel / segment lives on exactly one member, so

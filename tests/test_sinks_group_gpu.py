@@ -40,6 +40,32 @@ def test_pac_bank_over_members_equals_one_bank(devices, maxblocks):
     same(a, b, "pac bank over %d members, maxblocks %d" % (len(devices), maxblocks))
 
 
+def test_unsorted_pac_bank_is_cut_by_frequency_and_emits_in_bank_order():
+    """the group sorts the PowerActivationChannels by centre frequency before it cuts the bank (a member's band stays narrow whatever
+    order cfg->pac[] lists them in) and puts the PDUs back into the bank's own emission order (fdc_sinks_pdu_emit_order)."""
+    N, R, nb = 2048, 2, 120
+    rng = np.random.default_rng(321)
+    plan, carriers = [], []
+    for c in range(60):
+        cf = (c + 0.5) / 62 + 0.005
+        bw = (0.004, 0.008, 0.002)[c % 3]
+        plan.append((cf, bw, 500 + c))
+        carriers.append((int(round((cf - bw / 2) * N)), int(round((cf + bw / 2) * N))))
+    order = [int(v) for v in rng.permutation(len(plan))]
+    shuffled = [plan[i] for i in order]
+    spec = onoff_spectrum(N, nb, carriers, 99)
+    cuts = sorted(set(int(v) for v in rng.integers(1, nb, 7)))
+    one = G.Sinks(N, R, pac=shuffled, pac_thresh=6.0, pac_maxblocks=3, max_blocks=40)
+    for devices in ([0, 0], [0, 0, 0, 0]):
+        grp = G.SinksGroup(N, R, devices, pac=shuffled, pac_thresh=6.0, pac_maxblocks=3, max_blocks=40)
+        mem = grp.members()
+        assert max(hi - lo for (_d, lo, hi, _p, _s) in mem) <= N // len(devices) + 64        # bands, although the list is shuffled
+        a, b = run_calls(grp, spec, cuts), run_calls(G.Sinks(N, R, pac=shuffled, pac_thresh=6.0, pac_maxblocks=3, max_blocks=40), spec, cuts)
+        assert len(b) > 150
+        same(a, b, "shuffled pac bank over %d members" % len(devices))
+    del one
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_detection_segments_over_members_equal_one_bank(variant):
     N, R, nb = 4096, 2, 120
