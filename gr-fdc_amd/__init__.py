@@ -6,7 +6,7 @@ runs in hand-written gfx950 HIP kernels (gr-fdc_amd/csrc); nothing here computes
 """
 from ._lib import FdcError, lib, LIB_PATH                                   # noqa: F401
 from .blocks import overlap_save, vector_cut_vxx, phase_shifting_windowing_vcc, fft_vcc, window_table  # noqa: F401
-from .channelizer import (FrequencyDomainChannelizer, Pipeline, PipelineGroup, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
+from .channelizer import (FrequencyDomainChannelizer, Pipeline, PipelineGroup, plan_preview, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
                           nextpow2, get_opt_channelparams, freq_converters, register_host, unregister_host, defaults)
 from ._lib import (FDC_PIPE_FORCE_GENERIC, FDC_PIPE_NO_POLY, FDC_PIPE_NO_BLOCK, FDC_PIPE_PLAIN_STORES, FDC_PIPE_NT_LOADS,   # noqa: F401
                    FDC_PIPE_FULL_SPECTRUM, FDC_PIPE_WIDE_UNIFORM,

@@ -102,6 +102,7 @@ SYMBOLS = {
     "fdc_pipeline_chunk_blocks": (C.c_int32, [_vp]),
     "fdc_pipeline_path": (C.c_int32, [_vp]),
     "fdc_pipeline_describe": (C.c_int32, [_vp, C.c_char_p, C.c_int32]),
+    "fdc_pipeline_plan_preview": (C.c_int, [C.POINTER(fdc_pipeline_cfg), C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     "fdc_pipeline_enable_timing": (C.c_int, [_vp, C.c_int]),
     "fdc_pipeline_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "fdc_sinks_create": (C.c_int, [C.POINTER(fdc_sinks_cfg), C.POINTER(_vp)]),

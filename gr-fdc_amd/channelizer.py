@@ -120,6 +120,23 @@ def _default_cfg_fields():
     return flags, int(defaults.get("FDC_BLOCK_MIN_BLOCKS", 0) or 0), int(defaults.get("FDC_HOST_SUB", 0) or 0)
 
 
+def plan_preview(blocklen, relinvovl, channels, windowtype=WINDOWTYPES.HANN, max_blocks=64, flags=0):
+    """fdc_pipeline_plan_preview: what fdc_pipeline_create would choose for this plan — (path, description, assignment) — without a device.
+    assignment[c]: k >= 0 = bank k (one block-kernel launch each), -1 = the spectrum path, -2 - c0 = a copy of channel c0's output."""
+    chans = [(int(f), int(l), float(p), float(s)) for (f, l, p, s) in channels]
+    arr = (_lib.fdc_channel * max(1, len(chans)))()
+    for i, (f, l, p, s) in enumerate(chans):
+        arr[i].f, arr[i].l, arr[i].passbw, arr[i].stopbw = f, l, p, s
+    cfg = _lib.fdc_pipeline_cfg(0, int(blocklen), int(relinvovl), int(windowtype), len(chans), arr, int(max_blocks), 0, 0, int(flags), 0, 0)
+    buf = C.create_string_buffer(640)
+    asg = (C.c_int32 * max(1, len(chans)))()
+    rc = _lib.lib().fdc_pipeline_plan_preview(C.byref(cfg), buf, 640, asg)
+    if rc == -1:
+        raise ValueError(_lib.lib().fdc_last_error().decode())
+    _lib.check(rc)
+    return rc, buf.value.decode(), [int(asg[i]) for i in range(len(chans))]
+
+
 class Pipeline:
     """fdc_pipeline handle: channels = [(f, l, passbw, stopbw), ...]."""
 

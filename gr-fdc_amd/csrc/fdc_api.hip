@@ -14,6 +14,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -896,6 +897,30 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     owner.p = nullptr;
     *out = p;
     return FDC_OK;
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_plan_preview(const fdc_pipeline_cfg *cfg, char *buf, int32_t n, int32_t *assignment)
+{
+    FDC_ENTRY("fdc_pipeline_plan_preview")
+    if (!cfg) return fail(FDC_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = validate_cfg(cfg);
+    if (rc != FDC_OK) return rc;
+    // steps 1 - 3 of fdc_pipeline_create on a handle that never touches a device (no stream, no tables): host code only
+    std::unique_ptr<fdc_pipeline> p(new fdc_pipeline());
+    p->cfg = *cfg; p->cfg.channels = nullptr;
+    p->N = cfg->blocklen; p->R = cfg->relinvovl; p->ovl = p->N / p->R; p->H = p->N - p->ovl; p->C = cfg->nchannels;
+    std::vector<std::complex<float>> pool;
+    build_channel_records(p.get(), cfg, pool);
+    p->cfg_generic = (cfg->flags & FDC_PIPE_FORCE_GENERIC) != 0;
+    classify_plan(p.get(), cfg, cfg->flags);
+    if (assignment) {
+        for (int c = 0; c < p->C; c++) assignment[c] = -1;
+        for (size_t k = 0; k < p->banks.size(); k++) for (int c : p->banks[k].chan) assignment[c] = (int32_t)k;
+        for (const auto &al : p->bank_alias) assignment[al.first] = -2 - al.second;
+    }
+    if (buf && n > 0) fdc_pipeline_describe(p.get(), buf, n);
+    return fdc_pipeline_path(p.get());
     FDC_ENTRY_END
 }
 

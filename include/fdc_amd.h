@@ -182,6 +182,12 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p);
  * channel off the grid + bank of 1 on the grid (two launches)").  Writes at most n bytes including the terminator; returns the untruncated length, -1 for
  * bad arguments.  (No counterpart in the reference, which has one implementation.) */
 int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n);
+/* What fdc_pipeline_create WOULD choose for cfg, without a device (round 5: the plan selector — csrc/fdc_api.hip classify_plan, the measured constants of
+ * csrc/fdc_plan_cost.hpp — is host code): returns the path number (as fdc_pipeline_path; the block kernels are those of an MI355X), writes the description
+ * (as fdc_pipeline_describe) into buf if given, and into assignment[c], if given (nchannels entries), where channel c goes: k >= 0 = bank k (one block-kernel
+ * launch each, in launch order; path 2: the one bank of the two-launch form), -1 = the spectrum path (a split plan's remainder, or the whole plan),
+ * -2 - c0 = a copy of channel c0's output (same slice, same window).  Negative return: the status fdc_pipeline_create would give for the arguments. */
+int fdc_pipeline_plan_preview(const fdc_pipeline_cfg *cfg, char *buf, int32_t n, int32_t *assignment);
 
 /* Timing of the kernels with HIP events recorded on the stream they are launched on (bench.py's
  * roofline leg).  While enabled, every process_device call brackets its launches with events; the readout

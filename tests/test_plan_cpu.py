@@ -1,0 +1,166 @@
+"""CPU tests (-m "not gpu") of the plan selector (csrc/fdc_api.hip: classify_plan; csrc/fdc_plan_cost.hpp) through fdc_pipeline_plan_preview,
+which runs fdc_pipeline_create's validation and classification without a device: which channels become banks (one block-kernel launch each),
+copies, or the remainder / the spectrum path.  The GPU side of the same question — is the choice the FASTEST form — is
+tests/test_plan_choice_gpu.py; here: the structure of every plan the selector makes is valid, whatever it is fed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gr_fdc_amd as G
+from test_plan_choice_gpu import plans_for_the_choice_test, bank, two_width_plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 65536
+
+
+def has_block_kernel(n, R, l, r):
+    if R not in (2, 4):
+        return False
+    if l == 256:
+        return n in (16384, 32768, 65536)
+    if l in (512, 1024):
+        return n == 65536 and r in (0, l // 2)
+    if l in (128, 64):
+        return n == 65536 and r % (l // 4) == 0
+    return False
+
+
+def check_structure(n, R, plan, flags=0):
+    path, text, asg = G.plan_preview(n, R, plan, flags=flags)
+    assert len(asg) == len(plan) and ("path %d" % path) in text
+    banks = {}
+    for c, a in enumerate(asg):
+        if a >= 0:
+            banks.setdefault(a, []).append(c)
+    assert sorted(banks) == list(range(len(banks))) and len(banks) <= 4
+    for k, ids in banks.items():
+        f0, l0, p0, s0 = plan[ids[0]]
+        slots = set()
+        for c in ids:
+            f, l, p, s = plan[c]
+            assert (l, f % l, p, s) == (l0, f0 % l0, p0, s0), "bank %d mixes widths / offsets / windows: %s" % (k, text)
+            assert f // l not in slots, "bank %d holds a slot twice" % k
+            slots.add(f // l)
+        if path in (3, 4):
+            assert has_block_kernel(n, R, l0, f0 % l0), (k, text)
+    for c, a in enumerate(asg):
+        if a <= -2:
+            c0 = -2 - a
+            assert asg[c0] >= 0 and plan[c0] == plan[c], "a copy must name a bank channel with the same slice and window"
+    rem = [c for c, a in enumerate(asg) if a == -1]
+    if path == 3:
+        assert not rem and banks
+    elif path == 4:
+        assert rem and banks and n == 65536
+    elif path == 2:
+        assert not rem and list(banks) == [0] and all(plan[c][0] % plan[c][1] == 0 for c in banks[0]) and not any(a <= -2 for a in asg)
+    else:
+        assert len(rem) == len(plan)
+    if flags & G.FDC_PIPE_NO_POLY:
+        assert path in (0, 1)
+    if flags & G.FDC_PIPE_NO_BLOCK:
+        assert path in (0, 1, 2)
+    return path, text, asg
+
+
+def test_the_seventeen_plans_of_the_choice_test_have_the_expected_paths():
+    want = {"configs[1] bank": 3, "offset bank r=37": 3, "two tilings (2x oversampled)": 3, "three tilings": 3, "bank + 4 others": 4, "bank + 32 others": 4,
+            "512-bin bank": 3, "128-bin bank": 3, "64-bin bank": 3, "1024-bin bank": 3, "four 1024-bin channels": 3,
+            "512-bin bank on and half off the grid": 3, "mixed 128/256/512 (bench --mixed)": 1, "sparse: 8 channels": 1,
+            "two widths: 256-bin + 512-bin banks": 3, "three widths: 256 + 128 + 1024": 1, "half a 256-bin bank": 3}
+    plans = plans_for_the_choice_test()
+    assert set(want) == set(plans)
+    for name, plan in plans.items():
+        path, text, _ = check_structure(N, 2, plan)
+        assert path == want[name], (name, text)
+        for flags in (G.FDC_PIPE_NO_POLY, G.FDC_PIPE_NO_BLOCK, G.FDC_PIPE_WIDE_UNIFORM):
+            check_structure(N, 2, plan, flags)
+            check_structure(N, 4, plan, flags)
+
+
+def test_the_cost_rule_at_its_thresholds():
+    # one bank of 256-bin channels beats the spectrum path from ONE channel on (0.163 against 0.20 + ...); 1024-bin channels from three
+    assert G.plan_preview(N, 2, bank(256, [5]))[0] == 3
+    assert G.plan_preview(N, 2, bank(1024, [3, 9]))[0] == 1 and G.plan_preview(N, 2, bank(1024, [3, 9, 20]))[0] == 3
+    assert G.plan_preview(N, 2, bank(1024, [3, 9]), flags=G.FDC_PIPE_WIDE_UNIFORM)[0] == 3
+    # two widths: both banks stay; make one of them tiny and it goes back to a remainder (a split plan) or the plan to the spectrum path
+    assert G.plan_preview(N, 2, two_width_plan())[0] == 3
+    # a bank of ONE 512-bin channel beside a big bank: its launch (0.184) is still cheaper than a forward transform for it alone (0.20): two launches ...
+    path, text, asg = G.plan_preview(N, 2, bank(256, range(200)) + bank(512, [100]))
+    assert path == 3 and asg[-1] == 1, text
+    # ... but once a remainder exists anyway (its forward transform is paid for), the tiny bank is cheaper as part of it
+    path, text, asg = G.plan_preview(N, 2, bank(256, range(200)) + bank(512, [100]) + [(12345, 128, 0.7, 0.9)])
+    assert path == 4 and asg[-2] == -1 and asg[-1] == -1, text
+    # five tilings of 200 channels: at most four launches, the fifth goes to the remainder or everything to the spectrum path
+    many = [(256 * c + r, 256, 0.88, 1.0) for r in (0, 32, 64, 128, 192) for c in range(200)]
+    path, text, asg = check_structure(N, 2, many)
+    assert path in (1, 4) and len({a for a in asg if a >= 0}) <= 4
+    # other block lengths: banks of 256-bin channels only, no remainder
+    assert G.plan_preview(16384, 2, bank(256, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(256, range(100), r=77))[0] == 3
+    assert G.plan_preview(16384, 2, bank(256, range(60)) + [(15001, 128, 0.7, 0.9)])[0] == 0
+    assert G.plan_preview(262144, 2, bank(256, range(1024)))[0] == 2 and G.plan_preview(262144, 2, bank(256, range(1000), r=1))[0] == 0
+    assert G.plan_preview(65536, 8, bank(256, range(256)))[0] == 2          # relinvovl 8: no block kernel, the two-launch form
+    # the same slice twice: a copy, not a second launch
+    path, text, asg = G.plan_preview(N, 2, bank(512, range(128)) + [(512 * 9, 512, 0.88, 1.0)])
+    assert path == 3 and asg[-1] == -2 - 9 and "1 copies" in text
+
+
+def test_every_plan_the_selector_makes_is_well_formed():
+    """Seeded sweep: random mixtures of banks (all widths, legal and illegal offsets, two windows), duplicates and stray channels at both overlaps and
+    three block lengths, under every flag."""
+    rng = np.random.default_rng(2025)
+    seen = set()
+    for case in range(400):
+        n = int(rng.choice([65536, 65536, 65536, 32768, 16384, 4096, 262144]))
+        R = int(rng.choice([2, 2, 4, 8]))
+        plan = []
+        if case % 7 == 0:                                  # ONE bank on its grid: the two-launch form where no block kernel applies
+            l = int(rng.choice([128, 256, 256, 512]))
+            if l <= n // 16:
+                sl = rng.permutation(n // l)[:int(rng.integers(1, n // l + 1))]
+                check_structure(n, R, bank(l, sl), int(rng.choice([0, G.FDC_PIPE_NO_BLOCK, G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK])))
+                seen.add(G.plan_preview(n, R, bank(l, sl), flags=G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK)[0])
+        for _ in range(int(rng.integers(1, 6))):
+            l = int(rng.choice([32, 64, 128, 256, 256, 512, 1024, 2048]))
+            if l > n // 4:
+                continue
+            r = int(rng.choice([0, 0, l // 2, l // 4, 3 * l // 4, int(rng.integers(0, l))]))
+            win = [(0.88, 1.0), (0.7, 0.9)][int(rng.integers(0, 2))]
+            nslot = n // l - 1
+            for c in rng.permutation(nslot)[:int(rng.integers(1, nslot + 1))]:
+                plan.append((l * int(c) + r, l) + win)
+        for _ in range(int(rng.integers(0, 4))):
+            if plan:
+                plan.append(plan[int(rng.integers(0, len(plan)))])
+        for _ in range(int(rng.integers(0, 4))):
+            l = int(2 ** rng.integers(4, 12))
+            if l <= n:
+                plan.append((int(rng.integers(0, n - l + 1)), l, 0.6, 0.8))
+        if not plan:
+            continue
+        plan = [plan[int(i)] for i in rng.permutation(len(plan))]
+        flags = int(rng.choice([0, 0, 0, G.FDC_PIPE_WIDE_UNIFORM, G.FDC_PIPE_NO_BLOCK, G.FDC_PIPE_NO_POLY, G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK]))
+        path, _text, _asg = check_structure(n, R, plan, flags)
+        seen.add(path)
+    assert seen == {0, 1, 2, 3, 4}, seen
+
+
+def test_argument_errors_are_those_of_create():
+    with pytest.raises(ValueError):
+        G.plan_preview(N, 2, [(0, 300, 0.88, 1.0)])
+    with pytest.raises(ValueError):
+        G.plan_preview(N, 2, [(N - 100, 256, 0.88, 1.0)])
+    with pytest.raises(ValueError):
+        G.plan_preview(N, 2, [(0, 256, 0.9, 0.5)])
+    with pytest.raises(ValueError):
+        G.plan_preview(N, 3, [(0, 256, 0.88, 1.0)])
+
+
+def test_every_constant_of_the_cost_table_names_a_file_that_exists():
+    txt = open(os.path.join(ROOT, "gr-fdc_amd", "csrc", "fdc_plan_cost.hpp")).read()
+    files = set(re.findall(r"profiles/r0\d/[A-Za-z0-9_.]+\.(?:json|txt|md)", txt))
+    assert len(files) >= 8, files
+    for f in files:
+        assert os.path.exists(os.path.join(ROOT, f)), "fdc_plan_cost.hpp cites %s, which is not in the repository" % f
