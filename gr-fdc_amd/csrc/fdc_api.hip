@@ -495,7 +495,8 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     if ((flags & FDC_PIPE_NO_BLOCK) || (R != 2 && R != 4)) return false;
     switch (L) {
     case 256: return fdc::poly_block_supports(N);                                    // k_blk256: N = 16384 / 32768 / 65536, any r
-    case 512: case 1024: return N == 65536 && (r == 0 || r == L / 2);               // k_blk512 / k_blk1024: on the grid or half a channel off it
+    case 512: return fdc::poly_block512_supports(N, R) && (r == 0 || r == L / 2);   // k_blk512<P>: N = 16384 (R = 2) / 32768 / 65536; on the grid or half a channel off it
+    case 1024: return N == 65536 && (r == 0 || r == L / 2);                         // k_blk1024
     case 128: case 64: return fdc::poly_block_narrow_supports(N, L, R) && r % (L / 4) == 0;   // k_blknar: quarters of a channel
     default: return false;
     }
@@ -1111,7 +1112,7 @@ static int launch_bank(fdc_pipeline *p, const fdc_pipeline::Bank &bk, const floa
         break;
     case 512:
         HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, bk.d_cbt, bk.d_shn, bk.d_slot_off,
-                                         out_bytes, p->ncu, p->block_hints, s, ev0, ev1, p->R, p->d_fscr, half));
+                                         out_bytes, p->ncu, p->block_hints, s, ev0, ev1, p->R, p->d_fscr, half, p->N));
         break;
     case 1024:
         HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, bk.d_cbt, bk.d_shn, bk.d_slot_off,

@@ -30,7 +30,6 @@ namespace fdc {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_b512[];
 
-typedef unsigned long long g8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned long long pack512(cf v) { return ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x); }
 __device__ __forceinline__ cf unpack512(unsigned long long u) { return mk(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))); }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -46,35 +45,55 @@ __device__ __forceinline__ cf swap_parity(cf x)
               __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x.y), 0x4E, 0xF, 0xF, true)));
 }
 
-// LDS map (bytes)
+// LDS map (bytes).  The block length is a template parameter (round 5): N = 512 rows x (16 P) columns, P = 2, 4, 8 passes of 16 columns: N = 16384, 32768,
+// 65536; the channel slots are the columns N1 = 16 P.  Stage 1 does not depend on P except through the row pitch and the table sizes; G is 16 P
+// registers per lane; stage 2 is a DFT-P over the pass index in registers, one trip through LDS and the same DFT-16 over c4.  A trip holds 512 / P rows
+// ([rows][P klo][16 c4]; P = 8: 64 rows, four trips for the 256 kept rows; P = 2: all 256 in one) and a wave reads (klo = wave mod P, row block = wave div P).
 constexpr int k5ScrPts = 1084;                                   // per-wave exchange strip, as in fdc_block256.hip
 constexpr int k5OffX = 8 * k5ScrPts * 8;                         // 69376: end of the strips
-constexpr int k5Ld = 8 * 16 + 6;                                 // stage-2 trip rows: [8 klo][16 c4] + 6 (row stride 268 dwords = 12 mod 64)
-constexpr int k5Trip = 64 * k5Ld * 8;                            // 68608 <= the strips: the trip buffer lies over them
-constexpr int k5OffCt = k5OffX;                                  // [16 c4][8 klo]  W_128^(c4 klo)
-constexpr int k5OffWrow = k5OffCt + 16 * 8 * 8;                  // [16][18]  W_256^(b p)
 // W_512^(b + 16 q) for the parity-1 lanes as [16 b][18] from point k5T512Tab on; the parity-0 lanes' factor is 1: ONE row of ones at point 0, read by all
 // of them (a broadcast).  The table starts 92 dwords behind the ones (= 28 mod 64 + 64): a 16-byte read's lane group then finds the ones and its
 // four b rows on five different 4-dword windows (round 5: two tables [2 par][16][18] put (0, b) and (1, b) on the same banks — 2-way on every read)
 constexpr int k5T512Tab = 46;
-constexpr int k5OffT512 = k5OffWrow + 16 * 18 * 8;
-constexpr int k5OffB = k5OffT512 + (k5T512Tab + 16 * 18) * 8;    // [8 pass][16 c4][16]  W_N^(16 n1 q), n1 = 16 pass + c4 (rows unpadded: a wave reads two of them, broadcast)
 constexpr int k5ShPar = 16 * 16 + 4;                             // floats between the two halves of Sh: the rows (0, b) and (1, b) of a 16-byte read 4 dwords apart
-constexpr int k5OffSh = k5OffB + 8 * 16 * 16 * 8;                // [2 h][16 b][16] floats: shape[b + 16 q + 256 h] / N
-constexpr int k5OffSoff = k5OffSh + (k5ShPar + 16 * 16) * 4;     // [8 klo][16] output offsets (bytes)
-static_assert(k5OffB % 16 == 0 && k5OffSh % 16 == 0 && k5OffSoff % 16 == 0, "16-byte table reads");
-constexpr int k5Lds = k5OffSoff + 128 * 4;                       // 96256
-static_assert(k5Trip <= k5OffX, "the trip buffer lies over the strips, below the tables");
-// STAGED loads (below): the next pass's 16 columns x 512 rows as [column][row] planes.  Round 5 (the counters said a third of this kernel's LDS
+// STAGED loads: the next pass's 16 columns x 512 rows as [column][row] planes.  Round 5 (the counters said a third of this kernel's LDS
 // cycles were bank conflicts, profiles/r05/NOTES.md section 5): planes 528 points apart and the rows of column pair cp turned by 2 cp —
 //   store (16 contiguous lanes = 8 column pairs x 2 rows, 8 bytes each): dword 2 (col 528 + row + 2 cp) = 32 col + 2 row + 4 cp mod 64: the eight pairs
 //         on eight different 4-dword windows, the two columns of a pair (separate instructions) on the two bank halves: conflict-free;
 //   load  (32 lanes = 8 row groups x two columns x two parities, consecutive rows): 32 creal + 4 b + 2 par + const: all 64 banks once.
 // (516-point planes before: the pairs cp and cp + 4 of a store on the same banks, the two columns of a load 8 dwords apart: 2-way both.)
 constexpr int k5StagePlane = 512 + 16;
-constexpr int k5OffStage = k5Lds;
-constexpr int k5LdsStaged = k5OffStage + 16 * k5StagePlane * 8;   // 163840: all of it
-static_assert(k5LdsStaged <= 160 * 1024, "LDS budget");
+template <int P>
+struct B5Geom {
+    static_assert(P == 2 || P == 4 || P == 8, "passes of 16 columns: N = 16384, 32768 or 65536");
+    static constexpr int kN1 = 16 * P;                            // columns = channel slots
+    static constexpr int kN = 512 * kN1;
+    static constexpr int kTripRows = 512 / P;                     // rows of one stage-2 trip
+    static constexpr int kJT = 16 / P;                            // 32-row groups (two parities x 16 b) per trip
+    static constexpr int kLd = P * 16 + 6;                        // trip rows: [P klo][16 c4] + 6 points (row stride = 12 dwords mod 64 for P = 8, 4, 2: 268, 140, 76)
+    static constexpr int kTrip = kTripRows * kLd * 8;             // P = 8: 68608; 4: 71680; 2: 77824
+    static constexpr int kOffCt = kTrip > k5OffX ? kTrip : k5OffX;   // [16 c4][P klo]  W_N1^(c4 klo): behind the strips and the trip buffer
+    static constexpr int kOffWrow = kOffCt + 16 * P * 8;          // [16][18]  W_256^(b p)
+    static constexpr int kOffT512 = kOffWrow + 16 * 18 * 8;
+    static constexpr int kOffB = kOffT512 + (k5T512Tab + 16 * 18) * 8;   // [P pass][16 c4][16]  W_N^(16 n1 q), n1 = 16 pass + c4 (rows unpadded: a wave reads two of them, broadcast)
+    static constexpr int kOffSh = kOffB + P * 16 * 16 * 8;        // [2 h][16 b][16] floats: shape[b + 16 q + 256 h] / N
+    static constexpr int kOffSoff = kOffSh + (k5ShPar + 16 * 16) * 4;    // [P klo][16] output offsets (bytes)
+    static constexpr int kLds = kOffSoff + kN1 * 4;               // P = 8: 94336
+    static constexpr int kOffStage = kLds;
+    static constexpr int kLdsStaged = kOffStage + 16 * k5StagePlane * 8;   // P = 8: 161920
+    static_assert(kOffB % 16 == 0 && kOffSh % 16 == 0 && kOffSoff % 16 == 0 && kOffCt % 16 == 0, "16-byte table reads");
+    static_assert(kLdsStaged <= 160 * 1024, "LDS budget");
+    static_assert((kLd * 2) % 64 == 12, "trip rows 12 dwords apart mod 64: the lane groups of ds_read_b128 on all banks");
+};
+// DFT over the pass index (the register index of G): P points in place; X[k] is read through b5_pass_idx<P>(k)
+template <int P> __device__ __forceinline__ constexpr int b5_pass_idx(int k) { return P == 8 ? 4 * (k & 1) + (k >> 1) : k; }
+template <int P>
+__device__ __forceinline__ void b5_pass_dft(cf (&a)[P])
+{
+    if constexpr (P == 8) dft8<false>(a);                          // klo = k0 + 2 k1 in a[4 k0 + k1]
+    else if constexpr (P == 4) dft4<false>(a[0], a[1], a[2], a[3]);
+    else { const cf s0 = a[0] + a[1], d0 = a[0] - a[1]; a[0] = s0; a[1] = d0; }
+}
 
 // R4 = true: relinvovl = 4 (the reference's default overlap): 384 of the 512 samples of every inverse transform are kept.  The rows m >= 128 of
 // both parities stay in the G registers as for R = 2 (output rows 128 ..); the rows 64 <= m < 128 go to 128 KiB of per-workgroup scratch
@@ -83,7 +102,7 @@ static_assert(k5LdsStaged <= 160 * 1024, "LDS budget");
 // staged, wave w fetches rows 64 w .. of the pass's 16 columns in 16-byte pieces of whole 128-byte row segments (8 rows per instruction: 8 lines, half the
 // instructions), parks them in registers for a pass, writes them to [column][row] planes in LDS at the pass boundary and reads its own columns' rows back:
 // two workgroup barriers per pass for an eighth of the line requests.
-template <bool NT, bool R4, bool STAGED>
+template <bool NT, bool R4, bool STAGED, int P = 8>
 __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                       const float2 *__restrict__ tw256, const float2 *__restrict__ tw512 /* W_512^k, k < 256 */,
                                                       const float2 *__restrict__ twq /* [n1][16] W_N^(16 n1 q) */,
@@ -96,13 +115,16 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     // spectrum by half its length: the lane that holds half h of k2 holds half h ^ 1 of the modulated column.  The host swaps the halves of the
     // tables (shn, cbt) and puts W_N^(256 n1) into cbt; with the ifftshift (another swap) the inverse layer sees its halves in place, which leaves
     // one sign in the parity-1 lanes.
+    typedef B5Geom<P> GM;
+    static_assert(!R4 || P >= 4, "relinvovl 4 at N = 16384: the 128 extra rows are half a trip (not built)");
+    constexpr int kN1 = GM::kN1, k5Ld = GM::kLd;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b512);
-    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffCt);
-    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffWrow);
-    float2 *t512 = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffT512);
-    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffB);
-    float *Sh = reinterpret_cast<float *>(fdc_smem_b512 + k5OffSh);
-    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_b512 + k5OffSoff);
+    float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffCt);
+    float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffWrow);
+    float2 *t512 = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffT512);
+    float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffB);
+    float *Sh = reinterpret_cast<float *>(fdc_smem_b512 + GM::kOffSh);
+    unsigned *soff = reinterpret_cast<unsigned *>(fdc_smem_b512 + GM::kOffSoff);
     const int tid = threadIdx.x;
     // lane = vc + 4 b: vc = creal + 2 par (a quad = two columns x two parities), b = row group of the 256-point sub-transform
     const int w = tid >> 6, lane = tid & 63, vc = lane & 3, creal = vc & 1, par = vc >> 1, b = lane >> 2, c4 = 2 * w + creal;
@@ -112,22 +134,24 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (first >= nb) return;
 
-    constexpr unsigned inbytes = 65536u * 8u;
-    // row n2 = 2 (16 a + b) + par of column 16 pass + c4: 128 columns per row; a adds 32 rows = 32 KiB, a pass 16 columns = 128 B
-    const unsigned voff = (unsigned)((2 * b + par) * 128 + c4) * 8u;
-    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, 128u * 32u * 8u);
+    constexpr unsigned inbytes = (unsigned)GM::kN * 8u;
+    constexpr unsigned kRow32 = 32u * (unsigned)kN1 * 8u;          // 32 rows further on, bytes (P = 8: 32 KiB)
+    constexpr unsigned kRow8 = 8u * (unsigned)kN1 * 8u;            // 8 rows (staged loads: one instruction further on)
+    // row n2 = 2 (16 a + b) + par of column 16 pass + c4: kN1 columns per row; a adds 32 rows, a pass 16 columns = 128 B
+    const unsigned voff = (unsigned)((2 * b + par) * kN1 + c4) * 8u;
+    const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cbt, (unsigned)kN1 * 32u * 8u);
     const unsigned voffc = (unsigned)(c4 * 32 + b + 16 * par) * 8u;
     cf LA[16], LB[16], cbA, cbB;
     // staged: wave w fetches rows 64 w + 8 i + (lane >> 3), columns 2 (lane & 7), + 1 of the pass (16 bytes); instruction i adds 8 rows = 8 KiB
-    [[maybe_unused]] float2 *stg = reinterpret_cast<float2 *>(fdc_smem_b512 + k5OffStage);
-    [[maybe_unused]] const unsigned voffs = (unsigned)((64 * w + (lane >> 3)) * 128 + 2 * (lane & 7)) * 8u;
+    [[maybe_unused]] float2 *stg = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffStage);
+    [[maybe_unused]] const unsigned voffs = (unsigned)((64 * w + (lane >> 3)) * kN1 + 2 * (lane & 7)) * 8u;
     [[maybe_unused]] float2 *const stw = stg + 2 * (lane & 7) * k5StagePlane + 64 * w + (lane >> 3) + 2 * (lane & 7);   // + 8 i rows; second column: + one plane
     [[maybe_unused]] const float2 *const strd = stg + c4 * k5StagePlane + 2 * b + par + 2 * w;            // this lane's rows 32 a + 2 b + par of column c4 (pair w: turned by 2 w)
     [[maybe_unused]] u32x4 PF[8];
     [[maybe_unused]] auto stage_load = [&](int mb, int pn) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
 #pragma unroll
-        for (int i = 0; i < 8; i++) PF[i] = bld4(rin, voffs, (unsigned)i * 8192u);
+        for (int i = 0; i < 8; i++) PF[i] = bld4(rin, voffs, (unsigned)i * kRow8);
     };
     [[maybe_unused]] auto stage_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -144,7 +168,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     } else {
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)first * in_stride, inbytes);
 #pragma unroll
-        for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * 32768u);
+        for (int a = 0; a < 16; a++) LA[a] = bld2(rin, voff, (unsigned)a * kRow32);
         cbA = bld2(rcb, voffc, 0);
     }
     // ---- tables
@@ -153,11 +177,11 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
         t512[k5T512Tab + (i & 15) * 18 + (i >> 4)] = tw512[i];           // [b][q] = W_512^(b + 16 q), i = b + 16 q
         if (i < 18) t512[i] = make_float2(1.f, 0.f);                     // the parity-0 lanes' row of ones
     }
-    for (int i = tid; i < 2048; i += 512) Bt[i] = twq[i];                                 // [n1 = i >> 4][q]: twq is [n1][16] already
-    for (int i = tid; i < 128; i += 512) {
-        const long long o = slot_off[i];                                  // slot i = klo + 8 khi is entry [klo][rev16(khi)]
-        soff[(i & 7) * 16 + rev16(i >> 3)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
-        ctab[i] = tw256[(2 * (i >> 3) * (i & 7)) & 255];                  // [c4][klo] = W_128^(c4 klo)
+    for (int i = tid; i < kN1 * 16; i += 512) Bt[i] = twq[i];                             // [n1 = i >> 4][q]: twq is [n1][16] already
+    for (int i = tid; i < kN1; i += 512) {
+        const long long o = slot_off[i];                                  // slot i = klo + P khi is entry [klo][rev16(khi)]
+        soff[(i % P) * 16 + rev16(i / P)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
+        ctab[i] = tw256[((256 / kN1) * (i / P) * (i % P)) & 255];         // [c4][klo] = W_N1^(c4 klo)
     }
     for (int i = tid; i < 512; i += 512) Sh[(i >> 8) * k5ShPar + (i & 15) * 16 + ((i >> 4) & 15)] = shn[i];   // i = b + 16 q + 256 h
     __syncthreads();
@@ -176,7 +200,8 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
 
     for (int m = first; m < nb; m += grid) {
         const int mnext = m + grid < nb ? m + grid : m;
-        g8v G[8];
+        typedef unsigned long long gvec __attribute__((ext_vector_type(P)));
+        gvec G[8];
         auto one_pass = [&](const int ps, cf (&cur)[16], const cf cb, cf (&L)[16], cf &cbn) __attribute__((always_inline)) {
             if constexpr (STAGED) {
                 // the pass's rows are in the planes (written a pass ago, or by the prologue): take this lane's sixteen, then hand the planes over to
@@ -186,18 +211,18 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 for (int a = 0; a < 16; a++) cur[a] = ld2(&strd[32 * a]);
                 __syncthreads();
                 stage_write();
-                stage_load(ps < 6 ? m : mnext, (ps + 2) & 7);
-                cbn = bld2(rcb, voffc, (unsigned)((ps + 1) & 7) * 4096u);
+                stage_load(ps < P - 2 ? m : mnext, (ps + 2) & (P - 1));
+                cbn = bld2(rcb, voffc, (unsigned)((ps + 1) & (P - 1)) * 4096u);
             } else {
-                const int pn = ps < 7 ? ps + 1 : 0;
-                const int mb = ps < 7 ? m : mnext;
+                const int pn = ps < P - 1 ? ps + 1 : 0;
+                const int mb = ps < P - 1 ? m : mnext;
                 const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)mb * in_stride + 16 * pn, inbytes);
                 if (hints & 2) {
 #pragma unroll
-                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * 32768u);
+                    for (int a = 0; a < 16; a++) L[a] = bld2_nt(rin, voff, (unsigned)a * kRow32);
                 } else {
 #pragma unroll
-                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * 32768u);
+                    for (int a = 0; a < 16; a++) L[a] = bld2(rin, voff, (unsigned)a * kRow32);
                 }
                 cbn = bld2(rcb, voffc, (unsigned)pn * 4096u);
             }
@@ -272,48 +297,49 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             }
         };
 #pragma nounroll
-        for (int pp = 0; pp < 8; pp += 2) {
+        for (int pp = 0; pp < P; pp += 2) {
             one_pass(pp, LA, cbA, LB, cbB);
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
-        // ---------------- stage 2: FFT-128 over n1 = 16 pass + c4 of every row t' = rowbase + 2 (b + 16 j) + par ----------------
-        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of 64-row trips (two j each)
+        // ---------------- stage 2: FFT-N1 over n1 = 16 pass + c4 of every row t' = rowbase + 2 (b + 16 j) + par ----------------
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of trips (kJT row groups, 512 / P rows each)
         auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
-            constexpr int kNTrip = decltype(ntripc)::value;
+            constexpr int kNTrip = decltype(ntripc)::value, kJT = GM::kJT;
             __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int lane2 = t2 & 63, w2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
             const int vc2 = lane2 & 3, b_2 = lane2 >> 2, c4_2 = 2 * w2 + (vc2 & 1), par2 = vc2 >> 1;
+            const int klo2 = w2 % P, rh2 = w2 / P;                    // reader: klo, 64-row block of the trip (0 for P = 8)
             float2 *const gw = scr + (2 * b_2 + par2) * k5Ld + c4_2;             // element (row 2 b + par + 32 jj, klo) at + 32 jj kLd + 16 klo
-            const float2 *const gr = scr + lane2 * k5Ld + 16 * w2;                // row = lane, klo = wave: 16 consecutive points
-            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 16 * w2);
-            cf ct[8];
+            const float2 *const gr = scr + (64 * rh2 + lane2) * k5Ld + 16 * klo2;   // row = 64 rh + lane, klo: 16 consecutive points
+            const uint4 *const sow = reinterpret_cast<const uint4 *>(soff + 16 * klo2);
+            cf ct[P];
             {
-                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_b512 + k5OffCt) + c4_2 * 8;
+                const float2 *ctr = reinterpret_cast<const float2 *>(fdc_smem_b512 + GM::kOffCt) + c4_2 * P;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < P / 2; i++) {
                     const float4 t = ld4(&ctr[2 * i]);
                     ct[2 * i] = mk(t.x, t.y); ct[2 * i + 1] = mk(t.z, t.w);
                 }
             }
 #pragma unroll
             for (int tr = 0; tr < kNTrip; tr++) {
-                cf src[2][8];
+                cf src[kJT][P];
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++)
+                for (int jj = 0; jj < kJT; jj++)
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) src[jj][ps] = get(2 * tr + jj, ps);
+                    for (int ps = 0; ps < P; ps++) src[jj][ps] = get(kJT * tr + jj, ps);
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++) {
-                    cf a[8];
+                for (int jj = 0; jj < kJT; jj++) {
+                    cf a[P];
 #pragma unroll
-                    for (int ps = 0; ps < 8; ps++) a[ps] = src[jj][ps];
-                    dft8<false>(a);                                   // klo = k0 + 2 k1 in a[4 k0 + k1]
+                    for (int ps = 0; ps < P; ps++) a[ps] = src[jj][ps];
+                    b5_pass_dft<P>(a);
                     float2 *const g = gw + jj * 32 * k5Ld;
                     st2(&g[0], a[0]);
 #pragma unroll
-                    for (int k = 1; k < 8; k++) st2(&g[16 * k], cmul(a[4 * (k & 1) + (k >> 1)], ct[k]));
+                    for (int k = 1; k < P; k++) st2(&g[16 * k], cmul(a[b5_pass_idx<P>(k)], ct[k]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                                      // the trip is in LDS
@@ -326,7 +352,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 __syncthreads();                                      // every read of the trip is done
                 __builtin_amdgcn_sched_barrier(0);
                 dft16<false>(v);                                      // khi in v[rev16(khi)]
-                const unsigned rb = (unsigned)(m * kRows + rowbase + 64 * tr + lane2) * 8u;
+                const unsigned rb = (unsigned)(m * kRows + rowbase + GM::kTripRows * tr + 64 * rh2 + lane2) * 8u;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint4 t = sow[q];
@@ -337,12 +363,12 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        stage2([&](int j, int ps) { return unpack512(G[j][ps]); }, R4 ? 128 : 0, std::integral_constant<int, 4>{});
+        stage2([&](int j, int ps) { return unpack512(G[j][ps]); }, R4 ? 128 : 0, std::integral_constant<int, P / 2>{});
         if constexpr (R4) {
             // m = 64 .. 127 = output rows 0 .. 127: this lane's own stores, served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
-                   std::integral_constant<int, 2>{});
+                   std::integral_constant<int, P / 4>{});
         }
     }
 }
@@ -351,13 +377,20 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
 #define FDC_512_STAGED 1
 #endif
 
+bool poly_block512_supports(int N, int R)
+{
+    return (N == 65536 || N == 32768 || N == 16384) && (R == 2 || (R == 4 && N != 16384));
+}
+
 hipError_t init_block512_kernels()
 {
     hipError_t e = hipSuccess;
-#define FDC_SET5(A, B, C) \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, C ? k5LdsStaged : k5Lds);
-    FDC_SET5(true, false, false) FDC_SET5(false, false, false) FDC_SET5(true, true, false) FDC_SET5(false, true, false)
-    FDC_SET5(true, false, true) FDC_SET5(false, false, true) FDC_SET5(true, true, true) FDC_SET5(false, true, true)
+#define FDC_SET5(A, B, C, P) \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk512<A, B, C, P>), hipFuncAttributeMaxDynamicSharedMemorySize, C ? B5Geom<P>::kLdsStaged : B5Geom<P>::kLds);
+    FDC_SET5(true, false, false, 8) FDC_SET5(false, false, false, 8) FDC_SET5(true, true, false, 8) FDC_SET5(false, true, false, 8)
+    FDC_SET5(true, false, true, 8) FDC_SET5(false, false, true, 8) FDC_SET5(true, true, true, 8) FDC_SET5(false, true, true, 8)
+    FDC_SET5(true, false, true, 4) FDC_SET5(false, false, true, 4) FDC_SET5(true, true, true, 4) FDC_SET5(false, true, true, 4)
+    FDC_SET5(true, false, true, 2) FDC_SET5(false, false, true, 2)
 #undef FDC_SET5
     return e;
 }
@@ -365,19 +398,27 @@ hipError_t init_block512_kernels()
 hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int mbase, int nb_call, const float2 *tw256,
                                 const float2 *tw512, const float2 *twq, const float2 *cbt, const float *shn, const long long *slot_off,
                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int R, float2 *scratch,
-                                bool half)
+                                bool half, int N)
 {
     if (nb_chunk <= 0) return hipSuccess;
-    if ((R != 2 && R != 4) || (R == 4 && !scratch)) return hipErrorInvalidValue;
+    if (!poly_block512_supports(N, R) || (R == 4 && !scratch)) return hipErrorInvalidValue;
     int grid = ncu > 0 ? ncu : 256;
     if (grid > nb_chunk) grid = nb_chunk;
     constexpr bool kStaged = FDC_512_STAGED != 0;
-#define FDC_L512(A, B) \
-    hipExtLaunchKernelGGL((k_blk512<A, B, kStaged>), dim3((unsigned)grid), dim3(512), kStaged ? k5LdsStaged : k5Lds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
+#define FDC_L512(A, B, S, P) \
+    hipExtLaunchKernelGGL((k_blk512<A, B, S, P>), dim3((unsigned)grid), dim3(512), S ? B5Geom<P>::kLdsStaged : B5Geom<P>::kLds, s, ev_start, ev_stop, 0u, in, in_stride, out, \
                           tw256, tw512, twq, cbt, shn, slot_off, (long long)mbase * (B ? 384 : 256), (long long)nb_call, out_bytes, nb_chunk, hints, \
                           B ? scratch : (float2 *)nullptr, half ? 1 : 0)
-    if (R == 4) { if (hints & 1) FDC_L512(true, true); else FDC_L512(false, true); }
-    else { if (hints & 1) FDC_L512(true, false); else FDC_L512(false, false); }
+    const bool nt = (hints & 1) != 0;
+    if (N == 65536) {
+        if (R == 4) { if (nt) FDC_L512(true, true, kStaged, 8); else FDC_L512(false, true, kStaged, 8); }
+        else { if (nt) FDC_L512(true, false, kStaged, 8); else FDC_L512(false, false, kStaged, 8); }
+    } else if (N == 32768) {
+        if (R == 4) { if (nt) FDC_L512(true, true, true, 4); else FDC_L512(false, true, true, 4); }
+        else { if (nt) FDC_L512(true, false, true, 4); else FDC_L512(false, false, true, 4); }
+    } else {
+        if (nt) FDC_L512(true, false, true, 2); else FDC_L512(false, false, true, 2);
+    }
 #undef FDC_L512
     return hipGetLastError();
 }
