@@ -496,7 +496,7 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     switch (L) {
     case 256: return fdc::poly_block_supports(N);                                    // k_blk256: N = 16384 / 32768 / 65536, any r
     case 512: return fdc::poly_block512_supports(N, R) && (r == 0 || r == L / 2);   // k_blk512<P>: N = 16384 (R = 2) / 32768 / 65536; on the grid or half a channel off it
-    case 1024: return N == 65536 && (r == 0 || r == L / 2);                         // k_blk1024
+    case 1024: return fdc::poly_block1024_supports(N, R) && (r == 0 || r == L / 2); // k_blk1024<P>: the same
     case 128: case 64: return fdc::poly_block_narrow_supports(N, L, R) && r % (L / 4) == 0;   // k_blknar: quarters of a channel
     default: return false;
     }
@@ -1116,7 +1116,7 @@ static int launch_bank(fdc_pipeline *p, const fdc_pipeline::Bank &bk, const floa
         break;
     case 1024:
         HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, bk.d_cbt, bk.d_shn, bk.d_slot_off,
-                                          out_bytes, p->ncu, p->block_hints, s, ev0, ev1, half, p->R, p->d_fscr));
+                                          out_bytes, p->ncu, p->block_hints, s, ev0, ev1, half, p->R, p->d_fscr, p->N));
         break;
     default:
         HIPCHK(fdc::launch_poly_block_narrow(bk.L, in0, (size_t)p->H, o, nb, m0, nblocks, bk.d_tab, bk.d_cbt, bk.d_slot_off, out_bytes, p->ncu,

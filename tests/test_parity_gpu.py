@@ -1046,17 +1046,18 @@ def test_512_bin_block_kernel_at_relinvovl_4(oracle, wt):
             assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
 
 
-@pytest.mark.parametrize("N,R,off,nslots,nb", [(32768, 2, 0, 64, 7), (32768, 2, 0, 5, 261), (32768, 2, 256, 64, 9), (32768, 4, 0, 64, 7),
-                                               (32768, 4, 256, 11, 263), (16384, 2, 0, 32, 7), (16384, 2, 0, 3, 530), (16384, 2, 256, 32, 261)])
-def test_512_bin_block_kernel_at_shorter_blocks(oracle, N, R, off, nslots, nb):
-    """k_blk512<P> (round 5): the 512-bin block kernel at N = 8192 P, P = 4 and 2 passes of 16 columns (N = 32768: 64 slots, R = 2 and 4; N = 16384:
-    32 slots, R = 2) — banks on the grid and half a channel off it.  Against the oracle (head and tail), against the spectrum path on every
+@pytest.mark.parametrize("L,N,R,off,nslots,nb", [(512, 32768, 2, 0, 64, 7), (512, 32768, 2, 0, 5, 261), (512, 32768, 2, 256, 64, 9), (512, 32768, 4, 0, 64, 7),
+                                                 (512, 32768, 4, 256, 11, 263), (512, 16384, 2, 0, 32, 7), (512, 16384, 2, 0, 3, 530), (512, 16384, 2, 256, 32, 261),
+                                                 (1024, 32768, 2, 0, 32, 7), (1024, 32768, 2, 0, 5, 261), (1024, 32768, 2, 512, 32, 9), (1024, 32768, 4, 0, 32, 7),
+                                                 (1024, 32768, 4, 512, 11, 263), (1024, 16384, 2, 0, 16, 7), (1024, 16384, 2, 0, 3, 530), (1024, 16384, 2, 512, 16, 261)])
+def test_wide_block_kernels_at_shorter_blocks(oracle, L, N, R, off, nslots, nb):
+    """k_blk512<P> / k_blk1024<P> (round 5): the 512- and 1024-bin block kernels at N = 8192 P, P = 4 and 2 passes (N = 32768, R = 2 and 4;
+    N = 16384, R = 2) — banks on the grid and half a channel off it.  Against the oracle (head and tail), against the spectrum path on every
     sample, block counts below and above one round of workgroups, ragged calls bit for bit, the three window shapes."""
     if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
         pytest.skip("suite run under a forced path")
-    L = 512
     H, n1, lout = N - N // R, N // L, L - L // R
-    rng = np.random.default_rng(N // 512 + 3 * R + nb + off)
+    rng = np.random.default_rng(N // L + 3 * R + nb + off)
     slots = [int(v) for v in rng.permutation(n1 - (1 if off else 0))[:nslots]]
     wt = nb % 3
     chans = [(L * c + off, L, 0.8, 0.95) for c in slots]
@@ -1064,7 +1065,7 @@ def test_512_bin_block_kernel_at_shorter_blocks(oracle, N, R, off, nslots, nb):
     G.defaults["FDC_HOST_SUB"] = str(nb)
     try:
         p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
-        assert p.path() == 3 and "k_blk512" in p.describe()
+        assert p.path() == 3 and ("k_blk%d" % L) in p.describe()
         outs = p.work(x)
     finally:
         G.defaults.pop("FDC_HOST_SUB", None)
@@ -1074,16 +1075,16 @@ def test_512_bin_block_kernel_at_shorter_blocks(oracle, N, R, off, nslots, nb):
     ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
     for i, c in enumerate(check):
         assert outs[c].size == nb * lout
-        assert_close(outs[c][:k * lout], ref[i], "N %d slot %d head" % (N, slots[c]))
+        assert_close(outs[c][:k * lout], ref[i], "l %d N %d slot %d head" % (L, N, slots[c]))
     if nb > k:
         t0 = nb - k
         ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
         for i, c in enumerate(check):
-            assert_close(outs[c][t0 * lout:], ref2[i], "N %d slot %d tail" % (N, slots[c]))
+            assert_close(outs[c][t0 * lout:], ref2[i], "l %d N %d slot %d tail" % (L, N, slots[c]))
     q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
     assert q.path() in (0, 1)
     for c, (a, b_) in enumerate(zip(outs, q.work(x))):
-        assert_close(a, b_, "N %d slot %d vs the spectrum path" % (N, slots[c]))
+        assert_close(a, b_, "l %d N %d slot %d vs the spectrum path" % (L, N, slots[c]))
     p.reset()
     cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
     parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
