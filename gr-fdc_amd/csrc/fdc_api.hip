@@ -664,11 +664,12 @@ int build_bank_tables(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, fdc_pipeline
         // the narrow-channel block kernel (fdc_blocknarrow.hip): its LDS image, and W_N^(S V (b + r)) at [V][b], S = 256 / l
         const bool half = rb == L / 2;
         const int S = 256 / L;
-        std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L));
-        fdc::poly_block_narrow_tables(L, sn.data(), img.data(), half, half ? 0 : rb);
+        std::vector<float2> img((size_t)fdc::poly_block_narrow_table_points(L, N));
+        fdc::poly_block_narrow_tables(L, N, sn.data(), img.data(), half, half ? 0 : rb);
         UPLOAD(bk.d_tab, img);
-        cb.resize(256 * 16);
-        for (int V = 0; V < 256; V++)
+        const int NV = N / 256;                                      // virtual columns
+        cb.resize((size_t)NV * 16);
+        for (int V = 0; V < NV; V++)
             for (int b = 0; b < 16; b++) cb[(size_t)V * 16 + b] = unit(double(((long long)S * V * (b + rb)) % N) / double(N));
     }
     UPLOAD(bk.d_shn, sn);
@@ -1120,7 +1121,7 @@ static int launch_bank(fdc_pipeline *p, const fdc_pipeline::Bank &bk, const floa
         break;
     default:
         HIPCHK(fdc::launch_poly_block_narrow(bk.L, in0, (size_t)p->H, o, nb, m0, nblocks, bk.d_tab, bk.d_cbt, bk.d_slot_off, out_bytes, p->ncu,
-                                             p->block_hints, s, ev0, ev1, p->R, p->d_fscr, bk.r));
+                                             p->block_hints, s, ev0, ev1, p->R, p->d_fscr, bk.r, p->N));
     }
     return FDC_OK;
 }

@@ -1092,6 +1092,59 @@ def test_wide_block_kernels_at_shorter_blocks(oracle, L, N, R, off, nslots, nb):
         assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
 
 
+@pytest.mark.parametrize("L,N,R,off,nslots,nb", [(128, 32768, 2, 0, 256, 7), (128, 32768, 2, 64, 40, 261), (128, 32768, 2, 32, 255, 9), (128, 32768, 4, 0, 256, 7),
+                                                 (128, 32768, 4, 96, 11, 263), (128, 16384, 2, 0, 128, 7), (128, 16384, 2, 64, 3, 530), (128, 16384, 4, 0, 128, 9),
+                                                 (128, 16384, 4, 32, 17, 261),
+                                                 (64, 32768, 2, 0, 512, 7), (64, 32768, 2, 32, 40, 261), (64, 32768, 2, 16, 511, 9), (64, 32768, 4, 0, 512, 7),
+                                                 (64, 32768, 4, 48, 11, 263), (64, 16384, 2, 0, 256, 7), (64, 16384, 2, 32, 3, 530), (64, 16384, 4, 0, 256, 9),
+                                                 (64, 16384, 4, 16, 17, 261)])
+def test_narrow_block_kernel_at_shorter_blocks(oracle, L, N, R, off, nslots, nb):
+    """k_blknar<S, ..., P> (round 5): the narrow-channel block kernel at N = 8192 P, P = 4 and 2 passes of 32 virtual columns (N = 32768 and
+    16384, R = 2 and 4): banks on the grid, half and a quarter / three quarters of a channel off it.  A trip of stage 2 then holds more 64-row
+    blocks than a run has (waves without a row).  Against the oracle (head and tail; the slots at the seams of the layout), against the
+    spectrum path on every sample, several workgroup rounds, ragged calls bit for bit, the three window shapes."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    H, n1, lout = N - N // R, N // L, L - L // R
+    nv = N // 256
+    rng = np.random.default_rng(N // L + 3 * R + nb + off)
+    slots = [int(v) for v in rng.permutation(n1 - (1 if off else 0))[:nslots]]
+    wt = nb % 3
+    chans = [(L * c + off, L, 0.8, 0.95) for c in slots]
+    x = noise(nb * H, N // 100 + nb + L)
+    G.defaults["FDC_HOST_SUB"] = str(nb)
+    try:
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb)
+        assert p.path() == 3 and "k_blknar" in p.describe()
+        outs = p.work(x)
+    finally:
+        G.defaults.pop("FDC_HOST_SUB", None)
+    check = list(range(len(chans))) if len(chans) <= 12 else sorted(set([0, 1, len(chans) - 1] + [int(v) for v in rng.integers(0, len(chans), 8)]))
+    for sl in (0, 1, nv - 1, nv, nv + 1, 2 * nv - 1, 2 * nv, 3 * nv, n1 - 1):      # k and k + 32 P i sit in the lanes of one quad
+        if sl in slots and slots.index(sl) not in check:
+            check.append(slots.index(sl))
+    sub = [chans[c] for c in check]
+    k = min(nb, 3)
+    ref, _ = oracle.channelizer(N, R, wt, sub, x[:k * H], nthreads=8)
+    for i, c in enumerate(check):
+        assert outs[c].size == nb * lout
+        assert_close(outs[c][:k * lout], ref[i], "l %d N %d slot %d head" % (L, N, slots[c]))
+    if nb > k:
+        t0 = nb - k
+        ref2, _ = oracle.channelizer(N, R, wt, sub, x[t0 * H:], prefix=x[t0 * H - N // R:t0 * H], first_block=t0, nthreads=8)
+        for i, c in enumerate(check):
+            assert_close(outs[c][t0 * lout:], ref2[i], "l %d N %d slot %d tail" % (L, N, slots[c]))
+    q = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+    assert q.path() in (0, 1)
+    for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+        assert_close(a, b_, "l %d N %d slot %d vs the spectrum path" % (L, N, slots[c]))
+    p.reset()
+    cuts = [(0, 1), (1, nb // 2), (nb // 2, nb)]
+    parts = [p.work(x[a * H:b_ * H]) for a, b_ in cuts if b_ > a]
+    for c in range(len(chans)):
+        assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c])
+
+
 @pytest.mark.parametrize("L,wt", [(128, 0), (128, 1), (64, 0), (64, 2)])
 def test_narrow_block_kernel_at_relinvovl_4(oracle, L, wt):
     """l = 128 / 64 at R = 4 (the reference's default overlap): three quarters of every inverse transform are kept — the rows t >= 128 of a

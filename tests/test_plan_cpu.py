@@ -20,10 +20,10 @@ def has_block_kernel(n, R, l, r):
         return False
     if l == 256:
         return n in (16384, 32768, 65536)
-    if l in (512, 1024):
-        return n == 65536 and r in (0, l // 2)
+    if l in (512, 1024):      # k_blk512<P> / k_blk1024<P>: relinvovl 4 needs four passes
+        return (n in (32768, 65536) or (n == 16384 and R == 2)) and r in (0, l // 2)
     if l in (128, 64):
-        return n == 65536 and r % (l // 4) == 0
+        return n in (16384, 32768, 65536) and r % (l // 4) == 0
     return False
 
 
@@ -100,6 +100,17 @@ def test_the_cost_rule_at_its_thresholds():
     # other block lengths: banks of 256-bin channels only, no remainder
     assert G.plan_preview(16384, 2, bank(256, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(256, range(100), r=77))[0] == 3
     assert G.plan_preview(16384, 2, bank(256, range(60)) + [(15001, 128, 0.7, 0.9)])[0] == 0
+    # round 5: every width's block kernel at N = 16384 and 32768 too (k_blk512<P>, k_blk1024<P>, k_blknar<.., P>), banks of different widths as launches
+    for l in (64, 128, 512, 1024):
+        for n in (16384, 32768):
+            path, text, _ = G.plan_preview(n, 2, bank(l, range(n // l)))
+            assert path == 3 and ("k_blk%s" % ("nar" if l < 256 else str(l))) in text, text
+            assert G.plan_preview(n, 2, bank(l, range(n // l - 1), r=l // 2))[0] == 3
+    assert G.plan_preview(32768, 4, bank(512, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(1024, range(32)))[0] == 3
+    assert G.plan_preview(16384, 4, bank(512, range(32)))[0] == 0 and G.plan_preview(16384, 4, bank(1024, range(16)))[0] == 0     # four passes at least
+    assert G.plan_preview(16384, 4, bank(128, range(128)))[0] == 3 and G.plan_preview(16384, 4, bank(64, range(255), r=16))[0] == 3
+    path, text, asg = G.plan_preview(32768, 2, bank(256, range(64)) + bank(512, range(32, 64)))
+    assert path == 3 and "two launches" in text and set(asg) == {0, 1}, text
     assert G.plan_preview(262144, 2, bank(256, range(1024)))[0] == 2 and G.plan_preview(262144, 2, bank(256, range(1000), r=1))[0] == 0
     assert G.plan_preview(65536, 8, bank(256, range(256)))[0] == 2          # relinvovl 8: no block kernel, the two-launch form
     # the same slice twice: a copy, not a second launch
