@@ -81,6 +81,10 @@ def parse():
                          "are device pointers)")
     ap.add_argument("--sink-engine", choices=("device", "host"), default="device",
                     help="configs 3/5: where the blocks' work() loops run (FDC_SINKS_HOST_DECISIONS = the round-2 form)")
+    ap.add_argument("--lookahead", action="store_true", help="configs 3/5: the bank with two spectrum buffers (FDC_SINKS_LOOKAHEAD): the forward transform and the "
+                    "power cells of batch n + 1 run on the bank's fill stream beside the decision kernels of batch n; the block kernels leave "
+                    "--reserve-cus compute units to them and the batch is a multiple of their workgroups")
+    ap.add_argument("--reserve-cus", type=int, default=8, help="--lookahead: compute units the persistent forward-transform kernel leaves free")
     ap.add_argument("--sync-sinks", action="store_true", help="configs 3/5: fdc_sinks_work_device per step instead of the two-deep "
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "
@@ -465,6 +469,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     N, R, C, nb = a.blocklen, a.relinvovl, a.channels, a.blocks
+    if a.lookahead:
+        assert a.config in (3, 5) and not a.sync_sinks, "--lookahead applies to the sink configurations' two-deep form"
+        wgs = torch.cuda.get_device_properties(dev).multi_processor_count - a.reserve_cus
+        nb = a.blocks = max(wgs, nb // wgs * wgs)      # whole rounds of the persistent kernel's workgroups (1024 -> 992 on 248)
     H = N - N // R
     first_block, _n = G.span_for_rank(world * nb, rank, world)   # contiguous span per rank (§8e); weak scaling
     sinks, segments = None, None
@@ -525,7 +533,7 @@ def main():
         if a.config == 3:
             pac = [(((c + 0.5) / C) % 1.0, 0.8 / C, c) for c in range(C)]
             sinks = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=nb, device_id=local,
-                            host_decisions=a.sink_engine == "host", device_payload=a.payload == "device")
+                            host_decisions=a.sink_engine == "host", device_payload=a.payload == "device", lookahead=a.lookahead)
             carriers = [((c + 0.5) / C - 0.5, 1.0 / C) for c in range(C)]
             wl = "configs[2]: %d-pt FFT, 1/%d overlap-save, %d PowerActivationChannel sinks (6 dB, maxblocks 128), bursty " \
                  "carriers (8-64 blocks, 50 %% duty, 30 dB), %d blocks/step" % (N, R, C, nb)
@@ -533,7 +541,7 @@ def main():
             segments = [((0.05 + 0.5) % 1.0, (0.45 + 0.5) % 1.0), ((-0.45 + 0.5) % 1.0, (-0.05 + 0.5) % 1.0)]
             sinks = G.Sinks(N, R, segments=segments, det_thresh=10.0, det_maxblocks=128, minchandist=0.005, det_delay=1,
                             puffer=0.2, max_blocks=nb, device_id=local, host_decisions=a.sink_engine == "host",
-                            device_payload=a.payload == "device")
+                            device_payload=a.payload == "device", lookahead=a.lookahead)
             rng = np.random.default_rng(2028)
             carriers, used = [], []
             while len(carriers) < 24:                  # 24 carriers of width 0.002-0.03 at non-overlapping centres inside the segments
@@ -584,11 +592,23 @@ def main():
                 extracted[0] += int(np.frombuffer(arr, dtype=np.dtype(_lib.fdc_pdu))["nsamples"].sum())
                 extracted[1] += n
 
+        if a.lookahead:
+            # the bank's look-ahead form (include/fdc_amd.h, FDC_SINKS_LOOKAHEAD): every step transforms the NEXT batch on the fill stream —
+            # forward transform + power cells, beside this batch's decision chains — and submits the one transformed a step ago
+            fstream = sinks.fill_stream()
+            assert pipe.reserve_compute_units(a.reserve_cus) == wgs
+            pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=fstream)
+            sinks.prepare(nb, ahead=False)
+
         def step():
             # forward transform of the batch straight into the bank's spectrum buffer (the bank's stream), then the bank:
             # power cells -> decisions -> extraction of the active (block, channel) pairs -> PDUs.  Two deep: the PDUs handed
             # out by a step are those of the batch before, whose payload copy ran beside this batch's kernels.
-            pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=sstream)
+            if a.lookahead:
+                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ahead_ptr(), stream=fstream)
+                sinks.prepare(nb, ahead=True)
+            else:
+                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=sstream)
             if a.sync_sinks:
                 done = _lib.check(_lib.lib().fdc_sinks_work_device(sinks._h, nb))
             else:
@@ -791,6 +811,9 @@ def main():
         res["config"]["sink_engine"] = "device" if sinks.engine() == 1 else "host"
         res["config"]["payload"] = a.payload if sinks.engine() == 1 else "host"
         res["config"]["submission"] = "synchronous" if a.sync_sinks else "two deep (fdc_sinks_submit_device)"
+        if a.lookahead:
+            res["config"]["submission"] += ", look-ahead: forward transform + power cells of batch n + 1 on the fill stream beside batch n's decisions"
+            res["config"]["lookahead"] = {"reserved_compute_units": a.reserve_cus, "block_kernel_workgroups": wgs}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if sinks is None:
             _model, _nproc, share = host_info()

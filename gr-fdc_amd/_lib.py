@@ -56,6 +56,7 @@ class fdc_sinks_cfg(C.Structure):
 
 FDC_SINKS_HOST_DECISIONS = 1
 FDC_SINKS_DEVICE_PAYLOAD = 2
+FDC_SINKS_LOOKAHEAD = 4
 
 
 class fdc_pdu(C.Structure):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "fdc_pipeline_process_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "fdc_pipeline_synchronize": (C.c_int, [_vp]),
     "fdc_pipeline_stream": (_vp, [_vp]),
+    "fdc_pipeline_reserve_compute_units": (C.c_int, [_vp, C.c_int32]),
     "fdc_pipeline_chunk_blocks": (C.c_int32, [_vp]),
     "fdc_pipeline_path": (C.c_int32, [_vp]),
     "fdc_pipeline_describe": (C.c_int32, [_vp, C.c_char_p, C.c_int32]),
@@ -124,6 +126,9 @@ SYMBOLS = {
     "fdc_sinks_group_member_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int32)] * 5),
     "fdc_sinks_spectrum": (_vp, [_vp]),
     "fdc_sinks_stream": (_vp, [_vp]),
+    "fdc_sinks_spectrum_ahead": (_vp, [_vp]),
+    "fdc_sinks_fill_stream": (_vp, [_vp]),
+    "fdc_sinks_prepare": (C.c_int, [_vp, C.c_int, C.c_int]),
     "fdc_sinks_blocklen": (C.c_int32, [_vp]),
     "fdc_sinks_max_blocks": (C.c_int32, [_vp]),
     "fdc_sinks_work_device": (C.c_int, [_vp, C.c_int]),

@@ -240,6 +240,11 @@ class Pipeline:
     def synchronize(self):
         _lib.check(_lib.lib().fdc_pipeline_synchronize(self._h))
 
+    def reserve_compute_units(self, n):
+        """Leave n compute units out of the persistent block kernels' grids (kernels of another stream run beside them); returns the
+        number of workgroups they launch on: launch groups should hold a multiple of it in blocks."""
+        return _lib.check(_lib.lib().fdc_pipeline_reserve_compute_units(self._h, int(n)))
+
     def stream(self):
         return _lib.lib().fdc_pipeline_stream(self._h)
 

@@ -178,6 +178,7 @@ struct fdc_pipeline {
     int block_min = kBlockMinBlocks;   // FDC_BLOCK_MIN_BLOCKS (tests: 1 = the block kernels at any size)
     float2 *d_g = nullptr;                       // uniform path (two launches): stage-1 output G, chunk*lout*N/256 samples
     int ncu = 0;                                 // compute units of the handle's device
+    int reserved_cu = 0;                         // fdc_pipeline_reserve_compute_units: left out of the persistent kernels' grids
     float2 *d_twq = nullptr;                     // banks of 256-bin channels: W_N^(16 n1 q)
     // N = 65536 spectrum path: forward transform by the block kernel (fdc_block256.hip, FWD), own r = 0 tables
     bool fwd_block = false;
@@ -939,6 +940,15 @@ int32_t fdc_pipeline_channel_lout(const fdc_pipeline *p, int c)
     return p->chans[c].lout;
 }
 void *fdc_pipeline_stream(fdc_pipeline *p) { return p ? (void *)p->stream : nullptr; }
+int fdc_pipeline_reserve_compute_units(fdc_pipeline *p, int32_t n)
+{
+    FDC_ENTRY("fdc_pipeline_reserve_compute_units")
+    if (!p) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || n >= p->ncu) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "%d compute units of %d cannot be left out", (int)n, p->ncu);
+    p->reserved_cu = n;
+    return p->ncu - n;
+    FDC_ENTRY_END
+}
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk : -1; }
 int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
@@ -1086,7 +1096,7 @@ static int run_remainder(fdc_pipeline *p, const float2 *ring, int m0, int nb, in
 {
     if (p->fwd_block && !few)
         HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt, p->d_fshn,
-                                          p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, nullptr, p->d_keep));
+                                          p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, nullptr, p->d_keep));
     else
         HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, p->d_tmp, nb, p->N / 2, 1.0f / (float)p->N, p->d_tw256,
                                     p->d_twf, s, nullptr));
@@ -1108,19 +1118,19 @@ static int launch_bank(fdc_pipeline *p, const fdc_pipeline::Bank &bk, const floa
     const bool half = bk.r == bk.L / 2;
     switch (bk.L) {
     case 256:
-        HIPCHK(fdc::launch_poly_block(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, bk.d_slot_off, out_bytes, p->ncu,
+        HIPCHK(fdc::launch_poly_block(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, bk.d_slot_off, out_bytes, p->ncu - p->reserved_cu,
                                       p->block_hints, s, p->d_dbg, bk.r, first_block + m0, ev0, ev1, p->R, p->d_fscr, p->N));
         break;
     case 512:
         HIPCHK(fdc::launch_poly_block512(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw512, p->d_twq512, bk.d_cbt, bk.d_shn, bk.d_slot_off,
-                                         out_bytes, p->ncu, p->block_hints, s, ev0, ev1, p->R, p->d_fscr, half, p->N));
+                                         out_bytes, p->ncu - p->reserved_cu, p->block_hints, s, ev0, ev1, p->R, p->d_fscr, half, p->N));
         break;
     case 1024:
         HIPCHK(fdc::launch_poly_block1024(in0, (size_t)p->H, o, nb, m0, nblocks, p->d_tw256, p->d_tw1k, p->d_twq1k, bk.d_cbt, bk.d_shn, bk.d_slot_off,
-                                          out_bytes, p->ncu, p->block_hints, s, ev0, ev1, half, p->R, p->d_fscr, p->N));
+                                          out_bytes, p->ncu - p->reserved_cu, p->block_hints, s, ev0, ev1, half, p->R, p->d_fscr, p->N));
         break;
     default:
-        HIPCHK(fdc::launch_poly_block_narrow(bk.L, in0, (size_t)p->H, o, nb, m0, nblocks, bk.d_tab, bk.d_cbt, bk.d_slot_off, out_bytes, p->ncu,
+        HIPCHK(fdc::launch_poly_block_narrow(bk.L, in0, (size_t)p->H, o, nb, m0, nblocks, bk.d_tab, bk.d_cbt, bk.d_slot_off, out_bytes, p->ncu - p->reserved_cu,
                                              p->block_hints, s, ev0, ev1, p->R, p->d_fscr, bk.r, p->N));
     }
     return FDC_OK;
@@ -1190,14 +1200,14 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
             if (bk.L != 256)
                 HIPCHK(fdc::launch_poly_stage1_generic(in0, (size_t)p->H, p->d_g, p->N, bk.L, p->R, nb, bk.d_shn, p->d_tw, p->ntab, p->d_t2g, s));
             else
-                HIPCHK(fdc::launch_poly_stage1(in0, (size_t)p->H, p->d_g, p->N / 256, p->R, nb, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, p->ncu, s));
+                HIPCHK(fdc::launch_poly_stage1(in0, (size_t)p->H, p->d_g, p->N / 256, p->R, nb, p->d_tw256, p->d_twq, bk.d_cbt, bk.d_shn, p->ncu - p->reserved_cu, s));
             if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[1]; }   // the end of stage 1 IS the start of stage 2
             if (bk.L != 256)
                 HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, o, p->N / bk.L, p->R, nb, m0, nblocks, bk.d_slot_off, p->d_tw, p->ntab, s, bk.L));
             else if (p->N != 65536 && p->N != 262144)
                 HIPCHK(fdc::launch_poly_stage2_generic(p->d_g, o, p->N / 256, p->R, nb, m0, nblocks, bk.d_slot_off, p->d_tw, p->ntab, s));
             else
-                HIPCHK(fdc::launch_poly_stage2(p->d_g, o, p->N / 256, p->R, nb, m0, nblocks, p->d_tw256, p->d_tw1024, bk.d_slot_off, out_bytes, p->ncu, s));
+                HIPCHK(fdc::launch_poly_stage2(p->d_g, o, p->N / 256, p->R, nb, m0, nblocks, p->d_tw256, p->d_tw1024, bk.d_slot_off, out_bytes, p->ncu - p->reserved_cu, s));
             if (p->split) {                                     // (timing: the remainder is counted with stage 2)
                 const int rcr = run_remainder(p, ring, m0, nb, nblocks, first_block, o, few, s, nullptr, nullptr);
                 if (rcr != FDC_OK) return rcr;
@@ -1213,7 +1223,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         // spectrum buffer — writes a full spectrum into THAT buffer, d_keep is not applied.)
         if (p->fwd_block && !few)
             HIPCHK(fdc::launch_block_fft65536(in0, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
-                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
+                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
         else if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(in0, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
                                         1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));

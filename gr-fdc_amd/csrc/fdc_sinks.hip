@@ -188,10 +188,20 @@ struct fdc_sinks {
     bool poisoned = false;
     std::string poison_why;
     hipStream_t stream = nullptr;
-    float2 *d_spec = nullptr;                // (max_blocks + 1) * N: slot 0 = history block
+    float2 *d_spec = nullptr;                // (max_blocks + 1) * N: slot 0 = history block.  The buffer the NEXT batch is read from
     float2 *d_wins = nullptr, *d_tw = nullptr, *d_tw256 = nullptr;    // window pool, exp(-2 pi i k/N), exp(-2 pi i j/256)
     fdc::PowerCell *d_cells = nullptr;
-    float *d_power = nullptr;
+    float *d_power = nullptr;                // power cells of the batch in d_spec
+    // FDC_SINKS_LOOKAHEAD: a second spectrum / power buffer and a stream of its own for their producer, so that the forward transform
+    // (and the power cells) of batch n + 1 run on the device beside the decision kernels of batch n — one wave per channel or a
+    // workgroup per segment: latency-bound kernels that leave the machine idle (fdc_sinks_spectrum_ahead, fdc_sinks_prepare_ahead).
+    // d_spec / d_power always name the buffers of the batch the next submit reads; the pair swaps when a batch's extractions are enqueued.
+    float2 *d_spec_ahead = nullptr;
+    float *d_power_ahead = nullptr;
+    hipStream_t s_fill = nullptr;
+    hipEvent_t ev_fill = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_ready_ahead = nullptr;   // recorded on s_fill behind the power cells of the batch in d_spec / d_spec_ahead (fdc_sinks_prepare)
+    int prepared = -1, prepared_ahead = -1;  // blocks whose power cells are already (being) computed in d_power / d_power_ahead on s_fill; -1 = none
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
     float2 *d_ext = nullptr; size_t cap_ext = 0;
     float2 *d_wide = nullptr; size_t wide_cap = 0;  // scratch of extractions wider than 4096 points (between the two passes): wide_cap points
@@ -595,6 +605,9 @@ void fdc_sinks_destroy(fdc_sinks *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->s_fill) { (void)hipStreamSynchronize(s->s_fill); (void)hipStreamDestroy(s->s_fill); }
+    for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead}) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
@@ -790,6 +803,14 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipMemcpy(raw->d_cells, raw->cells.data(), sizeof(fdc::PowerCell) * raw->cells.size(), hipMemcpyHostToDevice));
         CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
     }
+    if (cfg->flags & FDC_SINKS_LOOKAHEAD) {
+        CHKF(hipMalloc(&raw->d_spec_ahead, sizeof(float2) * ((size_t)cfg->max_blocks + 1) * N));
+        if (!raw->cells.empty()) CHKF(hipMalloc(&raw->d_power_ahead, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
+        CHKF(hipStreamCreateWithFlags(&raw->s_fill, hipStreamNonBlocking));
+        CHKF(hipEventCreateWithFlags(&raw->ev_fill, hipEventDisableTiming));
+        CHKF(hipEventCreateWithFlags(&raw->ev_ready, hipEventDisableTiming));
+        CHKF(hipEventCreateWithFlags(&raw->ev_ready_ahead, hipEventDisableTiming));
+    }
     raw->host_threads = cfg->threads > 0 ? std::min(cfg->threads, 32) : 0;
     if (const char *t = fdc::debug_env("FDC_SINKS_THREADS")) if (atoi(t) >= 1) raw->host_threads = std::min(atoi(t), 32);   // debugging override
     {
@@ -841,6 +862,24 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
 
 void *fdc_sinks_spectrum(fdc_sinks *s) { return s ? (void *)(s->d_spec + s->N) : nullptr; }
 void *fdc_sinks_stream(fdc_sinks *s) { return s ? (void *)s->stream : nullptr; }
+void *fdc_sinks_spectrum_ahead(fdc_sinks *s) { return (s && s->d_spec_ahead) ? (void *)(s->d_spec_ahead + s->N) : nullptr; }
+void *fdc_sinks_fill_stream(fdc_sinks *s) { return s ? (void *)s->s_fill : nullptr; }
+int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead)
+{
+    FDC_ENTRY("fdc_sinks_prepare")
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
+    if (!s->s_fill) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank was created without FDC_SINKS_LOOKAHEAD");
+    if (nblocks <= 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [1, max_blocks]", nblocks);
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    float2 *const spec = ahead ? s->d_spec_ahead : s->d_spec;
+    float *const pw = ahead ? s->d_power_ahead : s->d_power;
+    if (!s->cells.empty()) HIPCHK(fdc::launch_cell_power(spec + s->N, s->N, s->d_cells, (int)s->cells.size(), nblocks, pw, s->s_fill));
+    HIPCHK(hipEventRecord(ahead ? s->ev_ready_ahead : s->ev_ready, s->s_fill));
+    (ahead ? s->prepared_ahead : s->prepared) = nblocks;
+    return FDC_OK;
+    FDC_ENTRY_END
+}
 int32_t fdc_sinks_blocklen(const fdc_sinks *s) { return s ? s->N : -1; }
 int32_t fdc_sinks_max_blocks(const fdc_sinks *s) { return s ? s->cfg.max_blocks : -1; }
 
@@ -867,6 +906,47 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
 
 // Extractions of one call, one launch (or one gather / batched transform / scatter sequence) per width class.
 // tasks: grouped by class, class k (width 2^k) = [first[k], first[k] + cnt[k])
+// ---- FDC_SINKS_LOOKAHEAD (see the struct): what a batch does at its two ends
+// start of a batch: whatever its producer enqueued on the fill stream (forward transform, power cells) comes first
+static int batch_begin(fdc_sinks *s, int nblocks, bool *have_power)
+{
+    *have_power = false;
+    if (!s->s_fill) return FDC_OK;
+    if (s->prepared == nblocks) {
+        // fdc_sinks_prepare marked the point of the fill stream where this batch is complete: what the producer has enqueued there SINCE
+        // (the next batch's transform) is not waited for — it is what runs beside this batch's decisions
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_ready, 0));
+        *have_power = true;
+    } else {
+        HIPCHK(hipEventRecord(s->ev_fill, s->s_fill));          // no mark: everything enqueued on the fill stream so far
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_fill, 0));
+    }
+    s->prepared = -1;
+    return FDC_OK;
+}
+// end of a batch (enqueued behind its last reader): history <- its last block (save_hist, PowerActivationChannel_impl.cc:173;
+// …vcm_impl.cc:571) — slot 0 of the buffer the NEXT batch is read from, which with look-ahead is the other one ...
+static int batch_end_history(fdc_sinks *s, int nblocks)
+{
+    const size_t N = (size_t)s->N;
+    float2 *const next = s->d_spec_ahead ? s->d_spec_ahead : s->d_spec;
+    HIPCHK(hipMemcpyAsync(next, s->d_spec + (size_t)nblocks * N, sizeof(float2) * N, hipMemcpyDeviceToDevice, s->stream));
+    return FDC_OK;
+}
+// ... then the buffers swap, and the fill stream may overwrite this batch's buffer once `done` (an event on the bank's stream behind the
+// history copy; null: everything enqueued on it so far) has passed
+static int batch_end_swap(fdc_sinks *s, hipEvent_t done)
+{
+    if (!s->s_fill) return FDC_OK;
+    if (done) HIPCHK(hipStreamWaitEvent(s->s_fill, done, 0));
+    else { HIPCHK(hipEventRecord(s->ev_fill, s->stream)); HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0)); }
+    std::swap(s->d_spec, s->d_spec_ahead);
+    std::swap(s->d_power, s->d_power_ahead);
+    std::swap(s->ev_ready, s->ev_ready_ahead);
+    s->prepared = s->prepared_ahead; s->prepared_ahead = -1;
+    return FDC_OK;
+}
+
 static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const size_t *first, const size_t *cnt, float2 *d_out, bool trace)
 {
     const int N = s->N;
@@ -930,8 +1010,10 @@ static int host_work_device(fdc_sinks *s, int nblocks)
     bool pool_ok = true;
     const int N = s->N, ncells = (int)s->cells.size();
     // phase 1: power of every cell of every block
+    bool have_power = false;
+    { const int rb = batch_begin(s, nblocks, &have_power); if (rb != FDC_OK) return rb; }
     if (ncells) {
-        HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
+        if (!have_power) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
         s->h_power.resize((size_t)ncells * nblocks);
         HIPCHK(hipMemcpyAsync(s->h_power.data(), s->d_power, sizeof(float) * s->h_power.size(), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -1126,8 +1208,9 @@ static int host_work_device(fdc_sinks *s, int nblocks)
         HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
     }
     // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
-    HIPCHK(hipMemcpyAsync(s->d_spec, s->d_spec + (size_t)nblocks * N, sizeof(float2) * (size_t)N, hipMemcpyDeviceToDevice, s->stream));
+    { const int rh = batch_end_history(s, nblocks); if (rh != FDC_OK) return rh; }
     HIPCHK(hipStreamSynchronize(s->stream));
+    { const int rh = batch_end_swap(s, nullptr); if (rh != FDC_OK) return rh; }
     lap("extractions + D2H");
     // phase 4: payloads; blocks still buffered in live channels become host copies
     auto resolve = [&](BlockRef &b, int len) {
@@ -1184,7 +1267,9 @@ static int dev_enqueue(fdc_sinks *s, int nblocks)
     auto &d = s->dev;
     const int N = s->N, ncells = (int)s->cells.size(), npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     const long long now = (long long)time(nullptr), bc0 = s->blockcount;
-    if (ncells) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
+    bool have_power = false;
+    { const int rb = batch_begin(s, nblocks, &have_power); if (rb != FDC_OK) return rb; }
+    if (ncells && !have_power) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
     HIPCHK(fdc::launch_pac_decide(s->d_power, ncells, nblocks, d.d_pgeom, d.d_pstate, npac, s->pac_thr, s->cfg.pac_maxblocks, s->R, bc0, now,
                                   d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners, s->stream));
     if (nseg) {
@@ -1216,7 +1301,7 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
 {
     auto &d = s->dev;
     static const bool trace = fdc::debug_env("FDC_SINKS_TRACE") != nullptr;
-    const int N = s->N, npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
+    const int npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     HIPCHK(hipEventSynchronize(d.ev_decide));
     const int b = d.cur ^ 1;                                   // this call's landing buffer; d.cur still names the previous call's
     const fdc::SinkSummary sum = *d.h_sum;
@@ -1261,9 +1346,9 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         const int rce = run_extractions(s, d.d_sorted, first, cnt, d.d_land[b], trace);
         if (rce != FDC_OK) return rce;
     }
-    // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
-    HIPCHK(hipMemcpyAsync(s->d_spec, s->d_spec + (size_t)nblocks * N, sizeof(float2) * (size_t)N, hipMemcpyDeviceToDevice, s->stream));
+    { const int rh = batch_end_history(s, nblocks); if (rh != FDC_OK) return rh; }
     HIPCHK(hipEventRecord(d.ev_extract[b], s->stream));
+    { const int rh = batch_end_swap(s, d.ev_extract[b]); if (rh != FDC_OK) return rh; }
     if (!devpay && sum.used_a) {
         HIPCHK(hipStreamWaitEvent(d.s_copy, d.ev_extract[b], 0));
         HIPCHK(hipMemcpyAsync(d.h_land[b], d.d_land[b], sizeof(float2) * (size_t)sum.used_a, hipMemcpyDeviceToHost, d.s_copy));

@@ -25,7 +25,7 @@ class Sinks:
     def __init__(self, blocklen, relinvovl, pac=(), pac_thresh=6.0, pac_maxblocks=-1, pac_delay=0,
                  segments=(), det_thresh=10.0, det_maxblocks=-1, minchandist=0.005, det_delay=1, puffer=0.2,
                  max_blocks=64, device_id=0, det_variant=0, verbose=0, det_id=-1, host_decisions=False, device_payload=False,
-                 threads=0):
+                 threads=0, lookahead=False):
         self._h = C.c_void_p()
         self.N = int(blocklen)
         pa = (_lib.fdc_pac_cfg * max(1, len(pac)))()
@@ -39,7 +39,8 @@ class Sinks:
                                  float(minchandist), int(det_delay), float(puffer), int(max_blocks), int(det_variant),
                                  int(verbose), int(det_id),
                                  (_lib.FDC_SINKS_HOST_DECISIONS if host_decisions else 0) |
-                                 (_lib.FDC_SINKS_DEVICE_PAYLOAD if device_payload else 0), int(threads))
+                                 (_lib.FDC_SINKS_DEVICE_PAYLOAD if device_payload else 0) |
+                                 (_lib.FDC_SINKS_LOOKAHEAD if lookahead else 0), int(threads))
         self.device_payload = bool(device_payload)
         rc = _lib.lib().fdc_sinks_create(C.byref(cfg), C.byref(self._h))
         if rc == -1:
@@ -60,7 +61,22 @@ class Sinks:
         return dict(zip(("start", "stop", "width", "dec", "npower"), list(v)))
 
     def spectrum_ptr(self):
+        """Where the items of the batch the NEXT submit / work call reads go (with lookahead=True: alternates, ask per batch)."""
         return _lib.lib().fdc_sinks_spectrum(self._h)
+
+    def spectrum_ahead_ptr(self):
+        """lookahead=True: where the items of the batch AFTER the next submit go; to be filled on fill_stream() (include/fdc_amd.h)."""
+        return _lib.lib().fdc_sinks_spectrum_ahead(self._h)
+
+    def stream(self):
+        return _lib.lib().fdc_sinks_stream(self._h)
+
+    def fill_stream(self):
+        return _lib.lib().fdc_sinks_fill_stream(self._h)
+
+    def prepare(self, nblocks, ahead=True):
+        """Power cells of the batch in spectrum_ahead_ptr() (or spectrum_ptr()) on the fill stream, behind whatever filled it."""
+        _lib.check(_lib.lib().fdc_sinks_prepare(self._h, int(nblocks), 1 if ahead else 0))
 
     def engine(self):
         """1 = decisions on the device (default), 0 = on host threads (verbose != 0, host_decisions, very fine segments)"""

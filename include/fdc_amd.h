@@ -164,6 +164,11 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
                                 void *d_out, void *d_spectrum, void *stream);
 int fdc_pipeline_synchronize(fdc_pipeline *p);
 void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
+/* The one-block-per-compute-unit kernels are persistent: one workgroup per unit, all of its LDS.  A consumer that wants to run other
+ * kernels BESIDE them (the sinks' look-ahead form, fdc_sinks_spectrum_ahead) asks for n units to be left out: the block kernels then
+ * launch on (units - n) workgroups.  Returns that number — launch groups should hold a multiple of it in blocks, or the last round of
+ * the persistent loop runs part of the machine — or a negative fdc_status.  n = 0 restores the default. */
+int fdc_pipeline_reserve_compute_units(fdc_pipeline *p, int32_t n);
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per internal launch group */
 /* Which kernels a process call without spectrum output runs: 0 = generic LDS Stockham kernels (any size),
  * 1 = spectrum in memory at N = 65536 (forward transform by the block kernel in one launch, ms[0]; channel kernels
@@ -292,8 +297,10 @@ typedef struct {
  * 1024 power cells, and on request.  Both engines emit the same PDUs in the same order (tests/test_sinks_gpu.py). */
 enum {
     FDC_SINKS_HOST_DECISIONS = 1,   /* use the host engine */
-    FDC_SINKS_DEVICE_PAYLOAD = 2    /* device engine: fdc_pdu.samples are DEVICE pointers (no payload copy to the host); valid like
+    FDC_SINKS_DEVICE_PAYLOAD = 2,   /* device engine: fdc_pdu.samples are DEVICE pointers (no payload copy to the host); valid like
                                        the host pointers, until the next-but-one batch is submitted */
+    FDC_SINKS_LOOKAHEAD = 4         /* a second spectrum buffer and a fill stream: the producer writes batch n + 1 while the bank decides
+                                       batch n (fdc_sinks_spectrum_ahead / fdc_sinks_fill_stream / fdc_sinks_prepare, below) */
 };
 typedef struct {
     int32_t kind;        /* 0 = PowerActivationChannel, 1 = detected channel of a segment                       */
@@ -355,6 +362,26 @@ int fdc_sinks_work_device(fdc_sinks *s, int nblocks);
 int fdc_sinks_submit_device(fdc_sinks *s, int nblocks);
 int fdc_sinks_flush(fdc_sinks *s);
 int32_t fdc_sinks_engine(const fdc_sinks *s);       /* 0 = host decisions, 1 = device decisions */
+/* Look-ahead (banks created with FDC_SINKS_LOOKAHEAD; round 5).  The decision kernels of a batch are chains — one wave per
+ * PowerActivationChannel, one workgroup per detection segment (lib/activity_detection_channelizer_vcm_impl.cc:741-841 is sequential over
+ * blocks and channels) — that leave the device idle, and the host has to see their summary before it can size the extraction launches.
+ * With two spectrum buffers the producer fills batch n + 1 beside them:
+ *     fill(fdc_sinks_spectrum(s)) on fdc_sinks_stream(s) or fdc_sinks_fill_stream(s)          batch 0
+ *     loop:  fill(fdc_sinks_spectrum_ahead(s)) on fdc_sinks_fill_stream(s)                    batch n + 1   (never on fdc_sinks_stream)
+ *            fdc_sinks_prepare(s, nblocks, 1)                          its power cells behind the fill, and the mark "batch n + 1 complete"
+ *            fdc_sinks_submit_device(s, nblocks)                       batch n; afterwards fdc_sinks_spectrum(s) names batch n + 1's buffer
+ * fdc_sinks_spectrum(s) is always the buffer the NEXT submit / work call reads; it alternates between the two, so ask again for every
+ * batch.  The bank orders the streams itself: a submit waits for the mark fdc_sinks_prepare left behind ITS batch on the fill stream (not for
+ * what the producer has enqueued there since: that is what runs beside the decisions) — without a prepare of the same block count, for
+ * everything enqueued on the fill stream so far, which is correct and overlaps nothing; work enqueued on the fill stream after a submit
+ * has returned waits until the batch before that submit's has been read for the last time.  The producer should
+ * leave a few compute units free for the chains (fdc_pipeline_reserve_compute_units): the block kernels are persistent and fill every
+ * unit's LDS.  Without the flag: spectrum_ahead and fill_stream return null, prepare refuses.
+ * fdc_sinks_prepare(s, n, ahead): power cells of the n blocks in fdc_sinks_spectrum_ahead (ahead = 1) or fdc_sinks_spectrum (0) on the
+ * fill stream; the submit of that batch then skips them if its block count is n. */
+void *fdc_sinks_spectrum_ahead(fdc_sinks *s);
+void *fdc_sinks_fill_stream(fdc_sinks *s);
+int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead);
 /* PDUs emitted by the last work call, in emission order */
 int fdc_sinks_pdu_count(const fdc_sinks *s);
 int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);

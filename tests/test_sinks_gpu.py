@@ -306,3 +306,85 @@ def test_message_ids_log_files_and_output_files(oracle, tmp_path, monkeypatch):
     os.remove(tmp_path / "gr-FDC.PowActChan.7.log")
     G.PowerActivationChannel(N, 320.0 / N, 40.0 / N, R, 6.0, 3, 0, True, False, "", 0, 7).work(spec)
     assert not os.path.exists(tmp_path / "gr-FDC.PowActChan.7.log")
+
+
+class _HipCopy:
+    """Host-to-device copies on a given stream without torch (the test process has the library's HIP runtime loaded)."""
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.h = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        self.h.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.h.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def upload(self, dst, arr, stream):
+        assert self.h.hipMemcpyAsync(dst, arr.ctypes.data, arr.nbytes, 1, stream) == 0
+        assert self.h.hipStreamSynchronize(stream) == 0      # (the source is pageable numpy memory: keep it alive until the copy is done)
+
+
+@pytest.mark.parametrize("kind,host_decisions", [("pac", False), ("vcm", False), ("vcm", True), ("pac", True)])
+def test_lookahead_bank_emits_the_same_pdus(kind, host_decisions):
+    """FDC_SINKS_LOOKAHEAD (round 5): two spectrum buffers, the producer fills batch n + 1 on the fill stream (with or without its power
+    cells) before batch n is submitted.  Same PDUs, metadata and payload bit for bit, as the one-buffer bank fed batch by batch: ragged
+    batches, bursts that cross the batch boundaries (history block, buffered blocks, live channels), both engines."""
+    N, R = 4096, 2
+    sizes = [13, 16, 5, 16, 1, 16, 9]
+    nb = sum(sizes)
+    rng = np.random.default_rng(5)
+    bursts = []
+    if kind == "pac":
+        plan = [(0.20, 0.03, 0), (0.41, 0.05, 1), (0.70, 0.011, 2), (0.9, 0.1, 7)]
+        for cf, bw, _ in plan:
+            lo, hi = int(round((cf - bw / 2) * N)), int(round((cf + bw / 2) * N))
+            t = 2
+            while t < nb - 3:
+                ln = int(rng.integers(2, 14))
+                bursts.append((lo, hi, t, min(nb - 2, t + ln), 1.0))
+                t += ln + int(rng.integers(3, 7))
+        kw = dict(pac=plan, pac_thresh=6.0, pac_maxblocks=3)
+    else:
+        segs = [(0.05, 0.45), (0.55, 0.95)]
+        for s0, s1 in segs:
+            pos = s0 + 0.02
+            while pos < s1 - 0.06:
+                wdt = float(rng.uniform(0.004, 0.03))
+                t = int(rng.integers(1, 12))
+                while t < nb - 3:
+                    ln = int(rng.integers(4, 20))
+                    bursts.append((int(pos * N), int((pos + wdt) * N), t, min(nb - 3, t + ln), 1.0))
+                    t += ln + int(rng.integers(3, 9))
+                pos += wdt + float(rng.uniform(0.03, 0.06))
+        kw = dict(segments=segs, det_thresh=10.0, det_maxblocks=3, minchandist=0.005, det_delay=1, puffer=0.2)
+    spec = burst_spectrum(N, nb, bursts, 23)
+    cuts = np.cumsum([0] + sizes)
+    batches = [np.ascontiguousarray(spec[cuts[i]:cuts[i + 1]].reshape(-1)) for i in range(len(sizes))]
+
+    plain = G.Sinks(N, R, max_blocks=16, host_decisions=host_decisions, **kw)
+    assert plain.spectrum_ahead_ptr() is None and plain.fill_stream() is None
+    with pytest.raises(G.FdcError):
+        plain.prepare(4)
+    ref = []
+    for b in batches:
+        ref += plain.work(b)
+    assert len(ref) >= 8
+
+    hip = _HipCopy()
+    bank = G.Sinks(N, R, max_blocks=16, host_decisions=host_decisions, lookahead=True, **kw)
+    fs = bank.fill_stream()
+    assert fs and bank.spectrum_ahead_ptr() and bank.spectrum_ahead_ptr() != bank.spectrum_ptr()
+    hip.upload(bank.spectrum_ptr(), batches[0], fs)
+    got = []
+    for i in range(len(batches)):
+        cur = bank.spectrum_ptr()
+        if i + 1 < len(batches):
+            hip.upload(bank.spectrum_ahead_ptr(), batches[i + 1], fs)
+            if i % 2 == 0:                                     # every other batch: its power cells too, behind the fill
+                bank.prepare(sizes[i + 1], ahead=True)
+        got += bank.submit_device(sizes[i]) if bank.engine() == 1 else bank.work_device(sizes[i])
+        assert bank.spectrum_ptr() != cur                      # the buffers have swapped
+    got += bank.flush()
+    assert len(got) == len(ref)
+    for (gm, gd), (rm, rd) in zip(got, ref):
+        assert {k: gm[k] for k in gm if k != "id"} == {k: rm[k] for k in rm if k != "id"}
+        assert unstamp(gm["id"]) == unstamp(rm["id"])
+        assert np.array_equal(gd, rd)
