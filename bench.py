@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--lookahead", action="store_true", help="configs 3/5: the bank with two spectrum buffers (FDC_SINKS_LOOKAHEAD): the forward transform and the "
                     "power cells of batch n + 1 run on the bank's fill stream beside the decision kernels of batch n; the block kernels leave "
                     "--reserve-cus compute units to them and the batch is a multiple of their workgroups")
-    ap.add_argument("--reserve-cus", type=int, default=8, help="--lookahead: compute units the persistent forward-transform kernel leaves free")
+    ap.add_argument("--reserve-cus", type=int, default=32, help="--lookahead: compute units the persistent forward-transform kernel leaves free")
     ap.add_argument("--sync-sinks", action="store_true", help="configs 3/5: fdc_sinks_work_device per step instead of the two-deep "
                                                                "fdc_sinks_submit_device")
     ap.add_argument("--mixed", action="store_true", help="diagnostics (config 2): the same centres with bandwidths cycling through "

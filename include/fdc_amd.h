@@ -102,7 +102,7 @@ enum {
     FDC_PIPE_NT_LOADS = 16,       /* block kernels: streamed (nt) input loads (not the 512- / 1024-bin kernels, which stage their loads) */
     FDC_PIPE_FULL_SPECTRUM = 32,  /* the handle's internal spectrum is written in full (default: only the 64-bin groups some channel reads) */
     FDC_PIPE_WIDE_UNIFORM = 64    /* uniform banks of ANY channel width (every channel l = L on the L-bin grid, one window) take the form without
-                                     a spectrum: the width's block kernel where there is one (N = 65536: l = 64, 128, 256, 512, 1024), else two
+                                     a spectrum: the width's block kernel where there is one (N = 16384 / 32768 / 65536: l = 64, 128, 256, 512, 1024), else two
                                      launches on generic kernels; default: only where that measured faster than the spectrum path (the block
                                      kernels; what the cost rule of csrc/fdc_plan_cost.hpp sends there: l = 1024 from 3 channels up) */
 };
@@ -179,7 +179,7 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * ms[0] = that kernel, ms[1] = ms[2] = 0).  Path 3 also takes tilings that start at any bin (f = 256*slot + r) and
  * unions of up to three tilings (different r, different windows, a slot used twice): one launch per tiling; N = 16384 and 32768
  * run the same kernel with 2 and 4 passes; uniform banks of 1024- (3 channels and more: the cost rule), 512-, 128- and 64-bin channels (R = 2 or 4) on their own grid
- * — or all half a channel higher: f = l*slot + l/2, a bank centred on multiples of l — at N = 65536 have block kernels of their own and report 3 as well.  4 = a SPLIT plan at N = 65536: the channels that form tilings take path 3 (ms[0]), the
+ * — or all half a channel higher: f = l*slot + l/2, a bank centred on multiples of l — at N = 16384 / 32768 / 65536 have block kernels of their own and report 3 as well.  4 = a SPLIT plan at N = 65536: the channels that form tilings take path 3 (ms[0]), the
  * rest — other widths, a fourth tiling — take the spectrum path on a partial spectrum that holds only what they read (forward
  * transform ms[1], channel kernels ms[2]); chosen where that is estimated cheaper than the whole plan on path 1. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);

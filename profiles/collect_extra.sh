@@ -1,10 +1,10 @@
 #!/bin/bash
 # Lines the default collection does not cover: the reference's default overlap (R = 4) at configs[1], a mixed-width
 # 256-channel plan, and PMC traffic for configs other than the headline.  Usage: profiles/collect_extra.sh <tag> [what...]
-#   what: r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5   (default: all)
+#   what: r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 shortw la3 la5 pmc1 pmc3 pmc4 pmc5   (default: all)
 set -u
 TAG=${1:-r03}; shift || true
-WHAT=${*:-r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 pmc1 pmc3 pmc4 pmc5}
+WHAT=${*:-r4 mixed twowidths n16k n32k n16kr4 n32kr4 w512 w512r4 w1024 w1024r4 w128 w64 w128r4 w64r4 shortw la3 la5 pmc1 pmc3 pmc4 pmc5}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/extra_$TAG
 mkdir -p $OUT
@@ -42,6 +42,10 @@ for w in $WHAT; do
     w64) stats w64 --width 64 --no-cpu-baseline ;;
     w128r4) stats w128r4 --width 128 --relinvovl 4 --no-cpu-baseline ;;
     w64r4) stats w64r4 --width 64 --relinvovl 4 --no-cpu-baseline ;;
+    # round 5: the other widths' block kernels at N = 32768 / 16384 (pass-count template); the sinks' look-ahead form with payloads in HBM
+    shortw) for L in 512 1024 128 64; do stats w${L}_n32k --width $L --blocklen 32768 --blocks 4096 --no-cpu-baseline; stats w${L}_n16k --width $L --blocklen 16384 --blocks 8192 --no-cpu-baseline; done ;;
+    la3) stats cfg3_lookahead --config 3 --payload device --lookahead --no-cpu-baseline ;;
+    la5) stats cfg5_lookahead --config 5 --payload device --lookahead --no-cpu-baseline ;;
     pmc1) pmc 1 16384 4096 ;;
     pmc3) pmc 3 1024 65536 ;;
     pmc4) pmc 4 256 262144 ;;
