@@ -506,6 +506,9 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
 void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
 {
     const int N = p->N, R = p->R, C = p->C;
+    // the spectrum path's forward transform is the block kernel at N = 16384 / 32768 / 65536 (fdc_pipeline_path() = 1; decided here so that
+    // fdc_pipeline_plan_preview says what create does)
+    p->fwd_block = fdc::poly_block_supports(N) && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
     p->banks.clear(); p->bank_alias.clear(); p->rem.clear();
     p->poly_ok = p->poly_block = p->split = false;
     if (C == 0 || p->cfg_generic || (flags & FDC_PIPE_NO_POLY) || N > (1 << 20) || R > 16) return;
@@ -720,9 +723,9 @@ int build_forward_tables(fdc_pipeline *p)
 {
     // twq / cbt as for a bank of 256-bin channels with r = 0, a flat "window" 1/N, and the slots of stage 2 mapped to the bins 256 c (+ k2) of
     // the shifted spectrum
-    const int N = p->N;
-    std::vector<float2> tq(256 * 16), cb(256 * 16);
-    for (int n1 = 0; n1 < 256; n1++)
+    const int N = p->N, N1 = N / 256;
+    std::vector<float2> tq((size_t)N1 * 16), cb((size_t)N1 * 16);
+    for (int n1 = 0; n1 < N1; n1++)
         for (int j = 0; j < 16; j++) {
             tq[(size_t)n1 * 16 + j] = unit(double((16ll * n1 * j) % N) / double(N));
             const float2 w = unit(double(((long long)n1 * j) % N) / double(N));
@@ -730,8 +733,8 @@ int build_forward_tables(fdc_pipeline *p)
             cb[(size_t)n1 * 16 + j] = make_float2(sg * w.x, sg * w.y);
         }
     std::vector<float> sn(256, float(1.0 / double(N)));
-    std::vector<long long> so(256);
-    for (int c = 0; c < 256; c++) so[(size_t)c] = 256ll * c;
+    std::vector<long long> so((size_t)N1);
+    for (int c = 0; c < N1; c++) so[(size_t)c] = 256ll * c;
     UPLOAD(p->d_ftwq, tq);
     UPLOAD(p->d_fcbt, cb);
     UPLOAD(p->d_fshn, sn);
@@ -758,13 +761,14 @@ int build_keep_map(fdc_pipeline *p)
         for (int b = 0; b < 64; b++) if (g64[(size_t)b]) p->keep4096 |= 1ull << b;
         return FDC_OK;
     }
-    // the block kernel's wave klo stores, per 64-row chunk q, the bins 256 c + 64 q .. + 63 of the slots c = klo + 8 khi; slot khi =
-    // k0 + 2 k1 sits in register 16 k0 + rev16(k1) (fdc_block256.hip, soff)
-    std::vector<unsigned> kw(32, 0u);
-    for (int klo = 0; klo < 8; klo++)
+    // the block kernel's wave klo stores, per 64-row chunk q, the bins 256 c + 64 q .. + 63 of the slots c = klo + P khi (P = N / 8192 passes); slot
+    // khi = k0 + 2 k1 sits in register 16 k0 + rev16(k1) (fdc_block256.hip, soff)
+    const int P = N / 8192;
+    std::vector<unsigned> kw((size_t)P * 4, 0u);
+    for (int klo = 0; klo < P; klo++)
         for (int q = 0; q < 4; q++)
             for (int r = 0; r < 32; r++) {
-                const int k0 = r >> 4, k1 = 4 * (r & 3) + ((r & 15) >> 2), c = klo + 8 * (k0 + 2 * k1);
+                const int k0 = r >> 4, k1 = 4 * (r & 3) + ((r & 15) >> 2), c = klo + P * (k0 + 2 * k1);
                 if (g64[(size_t)(4 * c + q)]) kw[(size_t)(klo * 4 + q)] |= 1u << r;
             }
     UPLOAD(p->d_keep, kw);
@@ -803,7 +807,7 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
     }
     for (auto &bk : p->banks) { const int rc = build_bank_tables(p, cfg, bk); if (rc != FDC_OK) return rc; }
     { const int rc = build_shared_bank_tables(p); if (rc != FDC_OK) return rc; }
-    p->fwd_block = N == 65536 && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
+    p->fwd_block = fdc::poly_block_supports(N) && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);      // N = 16384 / 32768 / 65536 (round 5: the forward variant has the pass-count template too)
     if (p->fwd_block) { const int rc = build_forward_tables(p); if (rc != FDC_OK) return rc; }
     {
         hipDeviceProp_t prop;
@@ -812,7 +816,7 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
     }
     // per-workgroup scratch of the block kernels: the forward-transform variant's second half of T, the R = 4 channelizers' rows 64..127
     if (p->fwd_block || (p->poly_block && R == 4)) CHK_DEV(hipMalloc(&p->d_fscr, sizeof(float2) * 32768 * (size_t)p->ncu));
-    if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || (N == 65536 && p->fwd_block))) {
+    if (p->C > 0 && !(flags & FDC_PIPE_FULL_SPECTRUM) && (N == 4096 || p->fwd_block)) {
         const int rc = build_keep_map(p);
         if (rc != FDC_OK) return rc;
     }
@@ -956,7 +960,7 @@ int32_t fdc_pipeline_path(const fdc_pipeline *p)
     if (p->poly_block && p->split) return 4;
     if (p->poly_block) return 3;
     if (p->poly_ok) return 2;
-    if (p->N == 65536 && !p->cfg_generic) return 1;
+    if (p->fwd_block || (p->N == 65536 && !p->cfg_generic)) return 1;
     return 0;
 }
 
@@ -1095,7 +1099,7 @@ static int run_remainder(fdc_pipeline *p, const float2 *ring, int m0, int nb, in
                          hipStream_t s, hipEvent_t ev2, hipEvent_t ev3)
 {
     if (p->fwd_block && !few)
-        HIPCHK(fdc::launch_block_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt, p->d_fshn,
+        HIPCHK(fdc::launch_block_fft(p->N, ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt, p->d_fshn,
                                           p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, nullptr, p->d_keep));
     else
         HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, p->d_tmp, nb, p->N / 2, 1.0f / (float)p->N, p->d_tw256,
@@ -1222,7 +1226,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         // a spectrum in memory.  (A split plan's internal spectrum holds its remainder's bins only: whoever gets here with one — a caller's
         // spectrum buffer — writes a full spectrum into THAT buffer, d_keep is not applied.)
         if (p->fwd_block && !few)
-            HIPCHK(fdc::launch_block_fft65536(in0, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
+            HIPCHK(fdc::launch_block_fft(p->N, in0, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
                                               p->d_fshn, p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
         else if (p->N == 65536 && !p->cfg_generic)
             HIPCHK(fdc::launch_fft65536(in0, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,

@@ -136,7 +136,7 @@ __device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
 // builds it for r = 128 as for any offset).  No second twiddle table, no rotated exchange, both row sets: the on-grid rate, and relinvovl 4 too
 // (128 mod 4 = 0: the window phase stays 0).
 template <int P, bool NT, bool OFF, bool FWD, bool R4 = false, bool STG = false, bool HALF = false>
-__global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
+__global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
                                                 const float2 *__restrict__ cbt, const float *__restrict__ shn,
                                                 const long long *__restrict__ slot_off, long long out_base,
@@ -145,7 +145,6 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
                                                 float2 *__restrict__ fwd_scratch, const unsigned *__restrict__ keep)
 {
     typedef BlkGeom<P> GM;
-    static_assert(!FWD || P == 8, "the forward-transform variant exists for N = 65536 only");
     static_assert(!STG || (P == 8 && !OFF && !FWD && !R4), "staged loads: the plain channelizer at N = 65536");
     static_assert(!HALF || (!OFF && !FWD && !STG), "the half-slot form is a variant of the on-grid channelizer");
     constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
@@ -162,10 +161,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
     const int w = tid >> 6, lane = tid & 63, col = lane & 3, b = lane >> 2, c5 = 4 * w + col;
     // stage-2 roles: writer = the stage-1 role (column c5, rows b + 16 j); reader: row = lane (+ 64 row half), klo = wave mod P
     // FWD with a plan that reads part of the spectrum only: which of this wave's 64-bin stores some channel reads at all
-    // ([klo = wave][k2 / 64], bit = register index of the slot); the others are dropped (offset beyond the descriptor's extent)
+    // ([klo = wave mod P][k2 / 64], bit = register index of the slot); the others are dropped (offset beyond the descriptor's extent)
     unsigned mqs[4] = {~0u, ~0u, ~0u, ~0u};
     if (FWD && keep) {
-        const int wu = __builtin_amdgcn_readfirstlane(w);
+        const int wu = __builtin_amdgcn_readfirstlane(w) % P;
 #pragma unroll
         for (int q = 0; q < 4; q++) mqs[q] = keep[wu * 4 + q];
     }
@@ -509,8 +508,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4) ? 4 : 2) 
                     // Stores: slot klo + P khi of row t' = 16 kJT tr + 64 rh + lane.  The 32 stream offsets are the same for the whole
                     // wave (table laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the
                     // store is dropped by the range check of the descriptor (no branch per store).
-                    const unsigned rb = (unsigned)(m * (FWD ? 65536 : (R4 ? 192 : 128)) + rowbase + 16 * kJT * tr + 64 * rh2 + lane2) * 8u;   // FWD: [block][65536 bins]
-                    unsigned mq = FWD ? mqs[((rowbase >> 6) + tr) & 3] : ~0u;
+                    const unsigned rb = (unsigned)(m * (FWD ? GM::kN : (R4 ? 192 : 128)) + rowbase + 16 * kJT * tr + 64 * rh2 + lane2) * 8u;   // FWD: [block][N bins]
+                    unsigned mq = FWD ? mqs[((rowbase + 16 * kJT * tr + 64 * rh2) >> 6) & 3] : ~0u;     // the 64-row chunk of k2 this wave stores
                     if constexpr (FWD) asm volatile("" : "+s"(mq));   // the 32 scalar terms below are worked out here, not held from block to block
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -572,7 +571,8 @@ hipError_t init_block_kernels()
     FDC_SETB(P, false, true, false, false) FDC_SETB(P, true, false, false, true) FDC_SETB(P, false, false, false, true) \
     FDC_SETB(P, true, true, false, true) FDC_SETB(P, false, true, false, true)
     FDC_SETP(2) FDC_SETP(4) FDC_SETP(8)
-    FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false)
+    FDC_SETB(8, true, false, true, false) FDC_SETB(8, false, false, true, false) FDC_SETB(4, true, false, true, false) FDC_SETB(4, false, false, true, false)
+    FDC_SETB(2, true, false, true, false) FDC_SETB(2, false, false, true, false)
 #undef FDC_SETP
 #undef FDC_SETB
 #define FDC_SETH(P, A, R4) \
@@ -648,24 +648,29 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 }
 
 // Forward transform of nitems blocks of 65536 samples (item m at in + m*in_stride) into the shifted, 1/N-scaled spectrum
-// out[m][65536] with the block kernel.  slot_off[c] = 256 c; shn1[k2] = 1/N; cbt0 = the r = 0 table.
+// out[m][N] with the block kernel (N = 16384 / 32768 / 65536: k_blk256<P, ..., FWD>).  slot_off[c] = 256 c, c < N / 256; shn1[k2] = 1/N; cbt0 = the r = 0 table.
 // ev: null or 3 events: start and end of the kernel (dispatch stamps), and an event recorded behind it (the 3-event protocol
 // of the two-pass transform: its second interval is empty here).
-hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
-                                 const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
-                                 float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev,
-                                 const unsigned *keep)
+hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
+                            const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
+                            float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev,
+                            const unsigned *keep)
 {
-    for (int m0 = 0; m0 < nitems; m0 += 4096) {            // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum
-        const int nb = nitems - m0 < 4096 ? nitems - m0 : 4096;
+    if (!poly_block_supports(N)) return hipErrorInvalidValue;
+    const int per = (int)(((size_t)1 << 28) / (size_t)N);  // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum (N = 65536: 4096 blocks)
+    for (int m0 = 0; m0 < nitems; m0 += per) {
+        const int nb = nitems - m0 < per ? nitems - m0 : per;
         int grid = ncu > 0 ? ncu : 256;
         if (grid > nb) grid = nb;
         hipEvent_t e0 = ev && m0 == 0 ? ev[0] : nullptr, e2 = ev && m0 + nb >= nitems ? ev[1] : nullptr;
-#define FDC_LF(A) \
-        hipExtLaunchKernelGGL((k_blk256<8, A, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<8>::kLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
-                              in_stride, out + (size_t)m0 * 65536, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
-                              (unsigned)((size_t)nb * 65536 * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep)
-        if (hints & 1) FDC_LF(true); else FDC_LF(false);
+#define FDC_LF(P, A) \
+        hipExtLaunchKernelGGL((k_blk256<P, A, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<P>::kLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
+                              in_stride, out + (size_t)m0 * (size_t)N, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
+                              (unsigned)((size_t)nb * (size_t)N * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep)
+        const bool nt = (hints & 1) != 0;
+        if (N == 65536) { if (nt) FDC_LF(8, true); else FDC_LF(8, false); }
+        else if (N == 32768) { if (nt) FDC_LF(4, true); else FDC_LF(4, false); }
+        else { if (nt) FDC_LF(2, true); else FDC_LF(2, false); }
 #undef FDC_LF
     }
     if (ev) { hipError_t e = hipEventRecord(ev[2], s); if (e != hipSuccess) return e; }

@@ -164,13 +164,13 @@ hipError_t launch_poly_block_narrow(int L, const float2 *in, size_t in_stride, f
                                     float2 *scratch = nullptr /* R = 4: ncu x 16384 points */,
                                     int r = 0 /* the bank's offset from the l-bin grid: 0, l/4, l/2, 3l/4 (tables to match) */, int N = 65536);
 
-// forward transform of 65536-sample blocks with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
-hipError_t launch_block_fft65536(const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
-                                 const float2 *twq, const float2 *cbt0 /* r = 0 */, const float *shn1 /* 256 x 1/N */,
-                                 const long long *slot_off /* [256]: 256 c */, float2 *scratch /* ncu x 32768 points */,
-                                 int ncu, int hints, hipStream_t s,
-                                 hipEvent_t *ev /* null or 3: start, end, end */,
-                                 const unsigned *keep = nullptr /* [8][4] words: 64-bin stores some channel reads (fdc_api.hip), or all */);
+// forward transform of N-sample blocks (N = 16384 / 32768 / 65536) with the block kernel (both halves of k2 in one launch): shifted, 1/N-scaled spectrum
+hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
+                            const float2 *twq, const float2 *cbt0 /* r = 0 */, const float *shn1 /* 256 x 1/N */,
+                            const long long *slot_off /* [N / 256]: 256 c */, float2 *scratch /* ncu x 32768 points */,
+                            int ncu, int hints, hipStream_t s,
+                            hipEvent_t *ev /* null or 3: start, end, end */,
+                            const unsigned *keep = nullptr /* [N / 8192][4] words: 64-bin stores some channel reads (fdc_api.hip), or all */);
 
 // real samples -> complex samples with zero imaginary part (the real-input front end)
 hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s);

@@ -171,7 +171,7 @@ void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
 int fdc_pipeline_reserve_compute_units(fdc_pipeline *p, int32_t n);
 int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per internal launch group */
 /* Which kernels a process call without spectrum output runs: 0 = generic LDS Stockham kernels (any size),
- * 1 = spectrum in memory at N = 65536 (forward transform by the block kernel in one launch, ms[0]; channel kernels
+ * 1 = spectrum in memory at N = 16384 / 32768 / 65536 (forward transform by the block kernel in one launch, ms[0]; channel kernels
  * ms[2]), 2 = uniform-plan path (all channels
  * l = 256 on the 256-bin grid: stage 1 = column FFT + window + IFFT, stage 2 = FFT across slots; timing
  * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0), 3 = the uniform plan at N = 65536, R = 2 as ONE

@@ -99,7 +99,7 @@ def test_the_cost_rule_at_its_thresholds():
     assert path in (1, 4) and len({a for a in asg if a >= 0}) <= 4
     # other block lengths: banks of 256-bin channels only, no remainder
     assert G.plan_preview(16384, 2, bank(256, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(256, range(100), r=77))[0] == 3
-    assert G.plan_preview(16384, 2, bank(256, range(60)) + [(15001, 128, 0.7, 0.9)])[0] == 0
+    assert G.plan_preview(16384, 2, bank(256, range(60)) + [(15001, 128, 0.7, 0.9)])[0] == 1     # (round 5: the spectrum path's forward transform is the block kernel at this N too)
     # round 5: every width's block kernel at N = 16384 and 32768 too (k_blk512<P>, k_blk1024<P>, k_blknar<.., P>), banks of different widths as launches
     for l in (64, 128, 512, 1024):
         for n in (16384, 32768):
@@ -107,11 +107,12 @@ def test_the_cost_rule_at_its_thresholds():
             assert path == 3 and ("k_blk%s" % ("nar" if l < 256 else str(l))) in text, text
             assert G.plan_preview(n, 2, bank(l, range(n // l - 1), r=l // 2))[0] == 3
     assert G.plan_preview(32768, 4, bank(512, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(1024, range(32)))[0] == 3
-    assert G.plan_preview(16384, 4, bank(512, range(32)))[0] == 0 and G.plan_preview(16384, 4, bank(1024, range(16)))[0] == 0     # four passes at least
+    assert G.plan_preview(16384, 4, bank(512, range(32)))[0] == 1 and G.plan_preview(16384, 4, bank(1024, range(16)))[0] == 1     # four passes at least: the spectrum path
     assert G.plan_preview(16384, 4, bank(128, range(128)))[0] == 3 and G.plan_preview(16384, 4, bank(64, range(255), r=16))[0] == 3
     path, text, asg = G.plan_preview(32768, 2, bank(256, range(64)) + bank(512, range(32, 64)))
     assert path == 3 and "two launches" in text and set(asg) == {0, 1}, text
     assert G.plan_preview(262144, 2, bank(256, range(1024)))[0] == 2 and G.plan_preview(262144, 2, bank(256, range(1000), r=1))[0] == 0
+    assert G.plan_preview(32768, 2, bank(256, range(100)) + [(777, 64, 0.7, 0.9)], flags=G.FDC_PIPE_NO_BLOCK)[0] == 0
     assert G.plan_preview(65536, 8, bank(256, range(256)))[0] == 2          # relinvovl 8: no block kernel, the two-launch form
     # the same slice twice: a copy, not a second launch
     path, text, asg = G.plan_preview(N, 2, bank(512, range(128)) + [(512 * 9, 512, 0.88, 1.0)])
