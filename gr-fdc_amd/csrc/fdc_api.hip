@@ -569,8 +569,10 @@ void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
     // (c) the cost rule (fdc_plan_cost.hpp; the numbers are measured at N = 65536, where the remainder of a split plan has its forward
     //     kernel).  Banks go back to the remainder, cheapest plan first, while that lowers the sum; then the sum must beat the whole plan on
     //     the spectrum path.  Other block lengths (banks of 256-bin channels only): no remainder, no more than kMaxBanks launches.
-    const bool may_split = N == 65536;
-    auto band = [&](const std::vector<int> &ids) { double b = 0; for (int c : ids) b += cfg->channels[c].l; return b / 65536.0; };
+    // (round 5: the forward variant of the block kernel exists at N = 16384 / 32768 too; per block everything costs N / 65536 of the table's
+    // numbers there, on both sides of every comparison)
+    const bool may_split = p->fwd_block;
+    auto band = [&](const std::vector<int> &ids) { double b = 0; for (int c : ids) b += cfg->channels[c].l; return b / double(N); };
     auto move_to_rem = [&](size_t k) {
         rem.insert(rem.end(), banks[k].chan.begin(), banks[k].chan.end());
         for (size_t i = 0; i < alias.size();) {                   // copies of a channel that is no longer computed by a bank are channels again
@@ -1101,9 +1103,12 @@ static int run_remainder(fdc_pipeline *p, const float2 *ring, int m0, int nb, in
     if (p->fwd_block && !few)
         HIPCHK(fdc::launch_block_fft(p->N, ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt, p->d_fshn,
                                           p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, nullptr, p->d_keep));
-    else
+    else if (p->N == 65536)
         HIPCHK(fdc::launch_fft65536(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, p->d_tmp, nb, p->N / 2, 1.0f / (float)p->N, p->d_tw256,
                                     p->d_twf, s, nullptr));
+    else
+        HIPCHK(fdc::launch_fft(ring + (size_t)m0 * p->H, (size_t)p->H, p->d_spec, p->d_tmp, p->N, nb, false, 0, p->N / 2, 1.0f / (float)p->N, p->d_tw, p->ntab,
+                               s, nullptr, p->d_twf, p->cfg_generic));
     if (ev2) HIPCHK(hipEventRecord(ev2, s));
     const int rc = run_channel_groups(p, true, p->d_spec, d_out, nb, m0, nblocks, first_block, s);
     if (rc != FDC_OK) return rc;

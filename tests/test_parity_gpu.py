@@ -819,12 +819,53 @@ def test_one_kernel_path_other_block_lengths_offsets_and_classes(oracle, N):
     # a 2x oversampled bank (two tilings 128 bins apart) and the same slots under two windows: one launch per class
     s0 = [int(v) for v in rng.permutation(n1 - 1)[:n1 // 2]]
     plan = [(256 * c, 256, 0.88, 1.0) for c in s0] + [(256 * c + 128, 256, 0.88, 1.0) for c in s0] + [(256 * c, 256, 0.7, 0.9) for c in s0[:5]]
-    p = G.Pipeline(N, R, plan, windowtype=2, max_blocks=nb)
+    # (round 5: the cost rule applies at these block lengths too, and prices three launches for 1.04 of the band above the spectrum path:
+    # FDC_PIPE_WIDE_UNIFORM keeps the banks)
+    assert G.Pipeline(N, R, plan, windowtype=2, max_blocks=nb).path() in (1, 3)
+    p = G.Pipeline(N, R, plan, windowtype=2, max_blocks=nb, flags=G.FDC_PIPE_WIDE_UNIFORM)
     assert p.path() == 3
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, 2, plan, x, nthreads=8)
     for c in range(len(plan)):
         assert_close(outs[c], ref[c], "N %d classes channel %d" % (N, c))
+
+
+@pytest.mark.parametrize("N,R", [(32768, 2), (16384, 2), (32768, 4), (16384, 4)])
+def test_split_plans_at_shorter_blocks(oracle, N, R):
+    """Round 5: with the forward variant of the block kernel at N = 32768 / 16384 (k_blk256<P, ..., FWD>) a plan that is almost a bank is split there
+    too (fdc_pipeline_path() = 4): banks of two widths on their block kernels, the rest on a partial spectrum.  Every channel against the oracle and
+    against the spectrum path; ragged calls bit for bit; launch groups below the block-kernel threshold (the remainder's two-pass transform)."""
+    if any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK")):
+        pytest.skip("suite run under a forced path")
+    nb = 9
+    H, n1 = N - N // R, N // 256
+    x = noise(nb * H, N // 7 + R)
+    rng = np.random.default_rng(N + R)
+    odd = [(N // 3 | 1, 512, 0.7, 0.9), (N // 2 + 33, 128, 0.88, 1.0), (2049, 1024, 0.6, 0.85), (N - 5000, 64, 0.5, 0.8), (31, 256, 0.88, 1.0)]
+    plans = {"bank + five others": [(256 * int(c), 256, 0.88, 1.0) for c in rng.permutation(n1)[:n1 - 6]] + odd,
+             "two widths + others": [(256 * c, 256, 0.88, 1.0) for c in range(n1 // 2)] + [(512 * c, 512, 0.88, 1.0) for c in range(n1 // 4, n1 // 2)] + odd[1:4]}
+    for name, plan in plans.items():
+        # (two banks + a remainder cost more than the spectrum path by the cost rule: FDC_PIPE_WIDE_UNIFORM keeps the banks, for the sake of the test)
+        fl = G.FDC_PIPE_WIDE_UNIFORM if name.startswith("two widths") else 0
+        p = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, min_block_launch=1, flags=fl)
+        assert p.path() == 4, (name, p.describe())
+        outs = p.work(x)
+        ref, _ = oracle.channelizer(N, R, 1, plan, x, nthreads=8)
+        for c in range(len(plan)):
+            if plan[c][1] != 256 or c % 7 == 0 or (plan[c][0] & 255):
+                assert_close(outs[c], ref[c], "N %d %s: channel %d %s" % (N, name, c, plan[c]))
+        q = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_NO_POLY)
+        assert q.path() == 1
+        for c, (a, b_) in enumerate(zip(outs, q.work(x))):
+            assert_close(a, b_, "N %d %s: channel %d vs the spectrum path" % (N, name, c))
+        p.reset()
+        parts = [p.work(x[a * H:b_ * H]) for a, b_ in [(0, 1), (1, 4), (4, 9)]]
+        for c in range(len(plan)):
+            assert np.array_equal(np.concatenate([pp[c] for pp in parts]), outs[c]), (name, c)
+        t = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, min_block_launch=96, flags=fl)
+        assert t.path() == 4
+        for c, (a, b_) in enumerate(zip(t.work(x), outs)):
+            assert_close(a, b_, "N %d %s: channel %d with short launch groups" % (N, name, c))
 
 
 def test_split_plans_classes_plus_remainder(oracle):
