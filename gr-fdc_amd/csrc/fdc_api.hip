@@ -496,7 +496,7 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     if ((flags & FDC_PIPE_NO_BLOCK) || (R != 2 && R != 4)) return false;
     switch (L) {
     case 256: return fdc::poly_block_supports(N);                                    // k_blk256: N = 16384 / 32768 / 65536, any r
-    case 512: return fdc::poly_block512_supports(N, R) && (r == 0 || r == L / 2);   // k_blk512<P>: N = 16384 (R = 2) / 32768 / 65536; on the grid or half a channel off it
+    case 512: return fdc::poly_block512_supports(N, R) && (r == 0 || r == L / 2);   // k_blk512<P>: N = 16384 / 32768 / 65536; on the grid or half a channel off it
     case 1024: return fdc::poly_block1024_supports(N, R) && (r == 0 || r == L / 2); // k_blk1024<P>: the same
     case 128: case 64: return fdc::poly_block_narrow_supports(N, L, R) && r % (L / 4) == 0;   // k_blknar: quarters of a channel
     default: return false;

@@ -115,7 +115,6 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
     // spectrum by half its length: the lane that holds quarter i of k2 holds quarter i ^ 2 of the modulated column (the host moves the quarters of shn
     // and cbt and puts W_N^(512 n1) into cbt), and the ifftshift — the same move again — no longer leaves a sign.
     typedef B1kGeom<P> GM;
-    static_assert(!R4 || P >= 4, "relinvovl 4 at N = 16384: the 256 extra rows are half a trip (not built)");
     constexpr int kN1 = GM::kN1, kKLd = GM::kLd;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b1k);
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b1k + GM::kOffCt);
@@ -306,9 +305,11 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
         // ---------------- stage 2: FFT-N1 over n1 = 8 pass + c3 of every row t' = rowbase + 4 (b + 16 j) + rho = rowbase + lane + 64 j ----------------
-        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of trips (kJT row groups, 1024 / P rows each)
-        auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
-            constexpr int kNTrip = decltype(ntripc)::value, kJT = GM::kJT;
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; njc: its number of 64-row groups (a trip holds kJT of them:
+        // 1024 / P rows; a run of fewer — the rows that come back from the scratch at N = 16384 — leaves the upper row blocks' waves without rows)
+        auto stage2 = [&](auto get, const int rowbase, auto njc) __attribute__((always_inline)) {
+            constexpr int kNJ = decltype(njc)::value, kJT = GM::kJT, kNTrip = (kNJ + kJT - 1) / kJT, kJA = kNJ < kJT ? kNJ : kJT;
+            static_assert(kNJ % kJA == 0, "whole trips");
             __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
@@ -328,13 +329,13 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
             }
 #pragma unroll
             for (int tr = 0; tr < kNTrip; tr++) {
-                cf src[kJT][P];
+                cf src[kJA][P];
 #pragma unroll
-                for (int jj = 0; jj < kJT; jj++)
+                for (int jj = 0; jj < kJA; jj++)
 #pragma unroll
-                    for (int ps = 0; ps < P; ps++) src[jj][ps] = get(kJT * tr + jj, ps);
+                    for (int ps = 0; ps < P; ps++) src[jj][ps] = get(kJA * tr + jj, ps);
 #pragma unroll
-                for (int jj = 0; jj < kJT; jj++) {
+                for (int jj = 0; jj < kJA; jj++) {
                     cf a[P];
 #pragma unroll
                     for (int ps = 0; ps < P; ps++) a[ps] = src[jj][ps];
@@ -346,34 +347,39 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                                      // the trip is in LDS
+                const bool active = kJA == kJT || 2 * rh2 < kJA;      // wave-uniform (kJA even): this wave's 128 rows exist in the trip
                 cf v[2][8];
+                if (active) {
 #pragma unroll
-                for (int hh = 0; hh < 2; hh++)
+                    for (int hh = 0; hh < 2; hh++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float4 t = ld4(&gr[hh * 64 * kKLd + 2 * i]);
-                        v[hh][2 * i] = mk(t.x, t.y); v[hh][2 * i + 1] = mk(t.z, t.w);
-                    }
+                        for (int i = 0; i < 4; i++) {
+                            const float4 t = ld4(&gr[hh * 64 * kKLd + 2 * i]);
+                            v[hh][2 * i] = mk(t.x, t.y); v[hh][2 * i + 1] = mk(t.z, t.w);
+                        }
+                }
                 __syncthreads();                                      // every read of the trip is done
                 __builtin_amdgcn_sched_barrier(0);
-                const uint4 s0 = sow[0], s1 = sow[1];
-                const unsigned so[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                if (active) {
+                    const uint4 s0 = sow[0], s1 = sow[1];
+                    const unsigned so[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    dft8<false>(v[hh]);                               // khi = k0 + 2 k1 in v[4 k0 + k1]
-                    const unsigned rb = (unsigned)(m * kRows + rowbase + GM::kTripRows * tr + 128 * rh2 + 64 * hh + lane2) * 8u;
+                    for (int hh = 0; hh < 2; hh++) {
+                        dft8<false>(v[hh]);                           // khi = k0 + 2 k1 in v[4 k0 + k1]
+                        const unsigned rb = (unsigned)(m * kRows + rowbase + 64 * kJA * tr + 128 * rh2 + 64 * hh + lane2) * 8u;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[hh][e]);
+                        for (int e = 0; e < 8; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[hh][e]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        stage2([&](int j, int ps) { return unpack1k(G[j][ps]); }, R4 ? 256 : 0, std::integral_constant<int, P / 2>{});
+        stage2([&](int j, int ps) { return unpack1k(G[j][ps]); }, R4 ? 256 : 0, std::integral_constant<int, 8>{});
         if constexpr (R4) {
             // m = 64 .. 127 = output rows 0 .. 255: this lane's own stores, served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
-                   std::integral_constant<int, P / 4>{});
+                   std::integral_constant<int, 4>{});
         }
     }
 }
@@ -384,7 +390,7 @@ __global__ FDC_PLAIN_DS1K __launch_bounds__(512) void k_blk1024(const float2 *__
 
 bool poly_block1024_supports(int N, int R)
 {
-    return (N == 65536 || N == 32768 || N == 16384) && (R == 2 || (R == 4 && N != 16384));
+    return (N == 65536 || N == 32768 || N == 16384) && (R == 2 || R == 4);
 }
 
 hipError_t init_block1024_kernels()
@@ -395,7 +401,7 @@ hipError_t init_block1024_kernels()
     FDC_SET1K(true, false, false, 8) FDC_SET1K(false, false, false, 8) FDC_SET1K(true, true, false, 8) FDC_SET1K(false, true, false, 8)
     FDC_SET1K(true, false, true, 8) FDC_SET1K(false, false, true, 8) FDC_SET1K(true, true, true, 8) FDC_SET1K(false, true, true, 8)
     FDC_SET1K(true, true, false, 4) FDC_SET1K(false, true, false, 4) FDC_SET1K(true, true, true, 4) FDC_SET1K(false, true, true, 4)
-    FDC_SET1K(true, true, false, 2) FDC_SET1K(false, true, false, 2)
+    FDC_SET1K(true, true, false, 2) FDC_SET1K(false, true, false, 2) FDC_SET1K(true, true, true, 2) FDC_SET1K(false, true, true, 2)
 #undef FDC_SET1K
     return e;
 }
@@ -422,7 +428,8 @@ hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out
         if (R == 4) { if (nt) FDC_L1K(true, true, true, 4); else FDC_L1K(false, true, true, 4); }
         else { if (nt) FDC_L1K(true, true, false, 4); else FDC_L1K(false, true, false, 4); }
     } else {
-        if (nt) FDC_L1K(true, true, false, 2); else FDC_L1K(false, true, false, 2);
+        if (R == 4) { if (nt) FDC_L1K(true, true, true, 2); else FDC_L1K(false, true, true, 2); }
+        else { if (nt) FDC_L1K(true, true, false, 2); else FDC_L1K(false, true, false, 2); }
     }
 #undef FDC_L1K
     return hipGetLastError();

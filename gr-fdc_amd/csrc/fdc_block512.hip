@@ -116,7 +116,6 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
     // tables (shn, cbt) and puts W_N^(256 n1) into cbt; with the ifftshift (another swap) the inverse layer sees its halves in place, which leaves
     // one sign in the parity-1 lanes.
     typedef B5Geom<P> GM;
-    static_assert(!R4 || P >= 4, "relinvovl 4 at N = 16384: the 128 extra rows are half a trip (not built)");
     constexpr int kN1 = GM::kN1, k5Ld = GM::kLd;
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_b512);
     float2 *ctab = reinterpret_cast<float2 *>(fdc_smem_b512 + GM::kOffCt);
@@ -302,9 +301,11 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             one_pass(pp + 1, LB, cbB, LA, cbA);
         }
         // ---------------- stage 2: FFT-N1 over n1 = 16 pass + c4 of every row t' = rowbase + 2 (b + 16 j) + par ----------------
-        // get(j, pass): the value of row group j; rowbase: first output row of the run; ntripc: its number of trips (kJT row groups, 512 / P rows each)
-        auto stage2 = [&](auto get, const int rowbase, auto ntripc) __attribute__((always_inline)) {
-            constexpr int kNTrip = decltype(ntripc)::value, kJT = GM::kJT;
+        // get(j, pass): the value of row group j; rowbase: first output row of the run; njc: its number of 32-row groups (a trip holds kJT of them:
+        // 512 / P rows; a run of fewer — the rows that come back from the scratch at N = 16384 — leaves the upper row blocks' waves without rows)
+        auto stage2 = [&](auto get, const int rowbase, auto njc) __attribute__((always_inline)) {
+            constexpr int kNJ = decltype(njc)::value, kJT = GM::kJT, kNTrip = (kNJ + kJT - 1) / kJT, kJA = kNJ < kJT ? kNJ : kJT;
+            static_assert(kNJ % kJA == 0 && kJA % 2 == 0, "whole trips of an even number of row groups");
             __syncthreads();                                          // every wave is done with its strip / the previous run's trip
             int t2 = tid;
             asm volatile("" : "+v"(t2));
@@ -325,13 +326,13 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
             }
 #pragma unroll
             for (int tr = 0; tr < kNTrip; tr++) {
-                cf src[kJT][P];
+                cf src[kJA][P];
 #pragma unroll
-                for (int jj = 0; jj < kJT; jj++)
+                for (int jj = 0; jj < kJA; jj++)
 #pragma unroll
-                    for (int ps = 0; ps < P; ps++) src[jj][ps] = get(kJT * tr + jj, ps);
+                    for (int ps = 0; ps < P; ps++) src[jj][ps] = get(kJA * tr + jj, ps);
 #pragma unroll
-                for (int jj = 0; jj < kJT; jj++) {
+                for (int jj = 0; jj < kJA; jj++) {
                     cf a[P];
 #pragma unroll
                     for (int ps = 0; ps < P; ps++) a[ps] = src[jj][ps];
@@ -343,32 +344,37 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                                      // the trip is in LDS
+                const bool active = kJA == kJT || 2 * rh2 < kJA;      // wave-uniform: this wave's 64 rows exist in the trip
                 cf v[16];
+                if (active) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 t = ld4(&gr[2 * i]);
-                    v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                    for (int i = 0; i < 8; i++) {
+                        const float4 t = ld4(&gr[2 * i]);
+                        v[2 * i] = mk(t.x, t.y); v[2 * i + 1] = mk(t.z, t.w);
+                    }
                 }
                 __syncthreads();                                      // every read of the trip is done
                 __builtin_amdgcn_sched_barrier(0);
-                dft16<false>(v);                                      // khi in v[rev16(khi)]
-                const unsigned rb = (unsigned)(m * kRows + rowbase + GM::kTripRows * tr + 64 * rh2 + lane2) * 8u;
+                if (active) {
+                    dft16<false>(v);                                  // khi in v[rev16(khi)]
+                    const unsigned rb = (unsigned)(m * kRows + rowbase + 32 * kJA * tr + 64 * rh2 + lane2) * 8u;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint4 t = sow[q];
-                    const unsigned so[4] = {t.x, t.y, t.z, t.w};
+                    for (int q = 0; q < 4; q++) {
+                        const uint4 t = sow[q];
+                        const unsigned so[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                    for (int e = 0; e < 4; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+                        for (int e = 0; e < 4; e++) bst2t<NT>(rout, (so[e] == 0xFFFFFFFFu ? 0xFFFFFFF0u : so[e] + rb), v[4 * q + e]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        stage2([&](int j, int ps) { return unpack512(G[j][ps]); }, R4 ? 128 : 0, std::integral_constant<int, P / 2>{});
+        stage2([&](int j, int ps) { return unpack512(G[j][ps]); }, R4 ? 128 : 0, std::integral_constant<int, 8>{});
         if constexpr (R4) {
             // m = 64 .. 127 = output rows 0 .. 127: this lane's own stores, served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 16384), 0u); }, 0,
-                   std::integral_constant<int, P / 4>{});
+                   std::integral_constant<int, 4>{});
         }
     }
 }
@@ -379,7 +385,7 @@ __global__ FDC_PLAIN_DS512 __launch_bounds__(512) void k_blk512(const float2 *__
 
 bool poly_block512_supports(int N, int R)
 {
-    return (N == 65536 || N == 32768 || N == 16384) && (R == 2 || (R == 4 && N != 16384));
+    return (N == 65536 || N == 32768 || N == 16384) && (R == 2 || R == 4);
 }
 
 hipError_t init_block512_kernels()
@@ -390,7 +396,7 @@ hipError_t init_block512_kernels()
     FDC_SET5(true, false, false, 8) FDC_SET5(false, false, false, 8) FDC_SET5(true, true, false, 8) FDC_SET5(false, true, false, 8)
     FDC_SET5(true, false, true, 8) FDC_SET5(false, false, true, 8) FDC_SET5(true, true, true, 8) FDC_SET5(false, true, true, 8)
     FDC_SET5(true, false, true, 4) FDC_SET5(false, false, true, 4) FDC_SET5(true, true, true, 4) FDC_SET5(false, true, true, 4)
-    FDC_SET5(true, false, true, 2) FDC_SET5(false, false, true, 2)
+    FDC_SET5(true, false, true, 2) FDC_SET5(false, false, true, 2) FDC_SET5(true, true, true, 2) FDC_SET5(false, true, true, 2)
 #undef FDC_SET5
     return e;
 }
@@ -417,7 +423,8 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
         if (R == 4) { if (nt) FDC_L512(true, true, true, 4); else FDC_L512(false, true, true, 4); }
         else { if (nt) FDC_L512(true, false, true, 4); else FDC_L512(false, false, true, 4); }
     } else {
-        if (nt) FDC_L512(true, false, true, 2); else FDC_L512(false, false, true, 2);
+        if (R == 4) { if (nt) FDC_L512(true, true, true, 2); else FDC_L512(false, true, true, 2); }
+        else { if (nt) FDC_L512(true, false, true, 2); else FDC_L512(false, false, true, 2); }
     }
 #undef FDC_L512
     return hipGetLastError();

@@ -134,7 +134,7 @@ hipError_t launch_poly_block512(const float2 *in, size_t in_stride, float2 *out,
                                 unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                                 int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 32768 points */,
                                 bool half = false /* the bank at f = 512 slot + 256: shn and cbt with their halves swapped, W_N^(256 n1) in cbt */,
-                                int N = 65536 /* block length: 16384 (R = 2 only), 32768 or 65536 (poly_block512_supports) */);
+                                int N = 65536 /* block length: 16384, 32768 or 65536 (poly_block512_supports) */);
 bool poly_block512_supports(int N, int R);
 
 // uniform plan of 1024-bin channels on the 1024-bin grid, N = 65536, R = 2 or 4: one kernel, one block per CU (fdc_block1024.hip): the four phases of a
@@ -147,7 +147,7 @@ hipError_t launch_poly_block1024(const float2 *in, size_t in_stride, float2 *out
                                  unsigned out_bytes, int ncu, int hints, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                                  bool half = false /* the bank at f = 1024 slot + 512: the quarters of shn and cbt moved by two, W_N^(512 n1) in cbt */,
                                  int R = 2 /* 2 or 4 */, float2 *scratch = nullptr /* R = 4: ncu x 16384 points */,
-                                 int N = 65536 /* block length: 16384 (R = 2 only), 32768 or 65536 (poly_block1024_supports) */);
+                                 int N = 65536 /* block length: 16384, 32768 or 65536 (poly_block1024_supports) */);
 bool poly_block1024_supports(int N, int R);
 
 // uniform plan of narrow channels (l = 128 or 64 bins on the l-bin grid), N = 16384 / 32768 / 65536, R = 2 or 4: one kernel, one block per CU

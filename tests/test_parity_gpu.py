@@ -1088,9 +1088,9 @@ def test_512_bin_block_kernel_at_relinvovl_4(oracle, wt):
 
 
 @pytest.mark.parametrize("L,N,R,off,nslots,nb", [(512, 32768, 2, 0, 64, 7), (512, 32768, 2, 0, 5, 261), (512, 32768, 2, 256, 64, 9), (512, 32768, 4, 0, 64, 7),
-                                                 (512, 32768, 4, 256, 11, 263), (512, 16384, 2, 0, 32, 7), (512, 16384, 2, 0, 3, 530), (512, 16384, 2, 256, 32, 261),
+                                                 (512, 32768, 4, 256, 11, 263), (512, 16384, 2, 0, 32, 7), (512, 16384, 2, 0, 3, 530), (512, 16384, 2, 256, 32, 261), (512, 16384, 4, 0, 32, 9), (512, 16384, 4, 256, 7, 263),
                                                  (1024, 32768, 2, 0, 32, 7), (1024, 32768, 2, 0, 5, 261), (1024, 32768, 2, 512, 32, 9), (1024, 32768, 4, 0, 32, 7),
-                                                 (1024, 32768, 4, 512, 11, 263), (1024, 16384, 2, 0, 16, 7), (1024, 16384, 2, 0, 3, 530), (1024, 16384, 2, 512, 16, 261)])
+                                                 (1024, 32768, 4, 512, 11, 263), (1024, 16384, 2, 0, 16, 7), (1024, 16384, 2, 0, 3, 530), (1024, 16384, 2, 512, 16, 261), (1024, 16384, 4, 0, 16, 9), (1024, 16384, 4, 512, 5, 263)])
 def test_wide_block_kernels_at_shorter_blocks(oracle, L, N, R, off, nslots, nb):
     """k_blk512<P> / k_blk1024<P> (round 5): the 512- and 1024-bin block kernels at N = 8192 P, P = 4 and 2 passes (N = 32768, R = 2 and 4;
     N = 16384, R = 2) — banks on the grid and half a channel off it.  Against the oracle (head and tail), against the spectrum path on every

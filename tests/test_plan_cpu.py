@@ -20,8 +20,8 @@ def has_block_kernel(n, R, l, r):
         return False
     if l == 256:
         return n in (16384, 32768, 65536)
-    if l in (512, 1024):      # k_blk512<P> / k_blk1024<P>: relinvovl 4 needs four passes
-        return (n in (32768, 65536) or (n == 16384 and R == 2)) and r in (0, l // 2)
+    if l in (512, 1024):      # k_blk512<P> / k_blk1024<P>
+        return n in (16384, 32768, 65536) and r in (0, l // 2)
     if l in (128, 64):
         return n in (16384, 32768, 65536) and r % (l // 4) == 0
     return False
@@ -107,7 +107,7 @@ def test_the_cost_rule_at_its_thresholds():
             assert path == 3 and ("k_blk%s" % ("nar" if l < 256 else str(l))) in text, text
             assert G.plan_preview(n, 2, bank(l, range(n // l - 1), r=l // 2))[0] == 3
     assert G.plan_preview(32768, 4, bank(512, range(64)))[0] == 3 and G.plan_preview(32768, 4, bank(1024, range(32)))[0] == 3
-    assert G.plan_preview(16384, 4, bank(512, range(32)))[0] == 1 and G.plan_preview(16384, 4, bank(1024, range(16)))[0] == 1     # four passes at least: the spectrum path
+    assert G.plan_preview(16384, 4, bank(512, range(32)))[0] == 3 and G.plan_preview(16384, 4, bank(1024, range(16)))[0] == 3     # (half a stage-2 trip comes back from the scratch)
     assert G.plan_preview(16384, 4, bank(128, range(128)))[0] == 3 and G.plan_preview(16384, 4, bank(64, range(255), r=16))[0] == 3
     path, text, asg = G.plan_preview(32768, 2, bank(256, range(64)) + bank(512, range(32, 64)))
     assert path == 3 and "two launches" in text and set(asg) == {0, 1}, text

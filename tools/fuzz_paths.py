@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box helper: randomized differential test of the kernel paths at N = 65536, R = 2 (or R = 4: third argument).  Every case draws a plan (on-grid,
+"""GPU box helper: randomized differential test of the kernel paths at N = 65536 (or 32768 / 16384: fourth argument), R = 2 (or R = 4: third argument).  Every case draws a plan (on-grid,
 offset, two or three classes, mixed widths, a split plan: tilings plus a remainder, or — round 5 — banks of several widths in one plan), a block count, a chunk size and a call pattern, runs it on the default
 dispatch and on the spectrum-in-memory path (FDC_NO_POLY=1) and compares every output sample; every fifth case is also
-compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed] [R]"""
+compared with the oracle.  Usage: python tools/fuzz_paths.py [cases] [seed] [R] [N]"""
 import os
 import sys
 
@@ -14,8 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import gr_fdc_amd as G  # noqa: E402
 import oracle as O      # noqa: E402  (checker)
 
-N, R = 65536, (int(sys.argv[3]) if len(sys.argv) > 3 else 2)
+N, R = (int(sys.argv[4]) if len(sys.argv) > 4 else 65536), (int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 H = N - N // R
+N1 = N // 256                                      # slots of the 256-bin grid
 TOL = 1e-5
 
 
@@ -58,11 +59,11 @@ def draw_plan(rng):
             two = " x2"
         return plan, "bank l=%d%s%s" % (L, "+l/2" if half else "", two)
     if kind == 0:                                     # on-grid subset
-        slots = rng.permutation(256)[:rng.integers(1, 257)]
+        slots = rng.permutation(N1)[:rng.integers(1, N1 + 1)]
         return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "grid"
     if kind == 1:                                     # one offset
         r = int(rng.integers(1, 256))
-        slots = rng.permutation(255)[:rng.integers(1, 256)]
+        slots = rng.permutation(N1 - 1)[:rng.integers(1, N1)]
         return [(256 * int(c) + r, 256, 0.88, 1.0) for c in slots], "offset %d" % r
     if kind == 2:                                     # two or three classes, enough channels for the launches to pay
         ncl = int(rng.integers(2, 4))
@@ -70,7 +71,7 @@ def draw_plan(rng):
         for k in range(ncl):
             r = int(rng.integers(0, 256))
             win = [(0.88, 1.0), (0.7, 0.9), (0.8, 0.95)][int(rng.integers(0, 3))]
-            slots = rng.permutation(255)[:rng.integers(150, 256)]
+            slots = rng.permutation(N1 - 1)[:rng.integers(150 * N1 // 256, N1)]
             plan += [(256 * int(c) + r, 256) + win for c in slots]
         order = rng.permutation(len(plan))
         return [plan[int(i)] for i in order], "%d classes" % ncl
@@ -84,14 +85,14 @@ def draw_plan(rng):
         plan = []
         for k in range(int(rng.integers(1, 4))):
             r = int(rng.integers(0, 256)) if k else 0
-            slots = rng.permutation(255)[:rng.integers(120, 256)]
+            slots = rng.permutation(N1 - 1)[:rng.integers(120 * N1 // 256, N1)]
             plan += [(256 * int(c) + r, 256, 0.88, 1.0) for c in slots]
         for _ in range(int(rng.integers(1, 9))):
             l = int(2 ** rng.integers(6, 12))
             plan.append((int(rng.integers(0, N - l + 1)), l, 0.7, 0.9))
         order = rng.permutation(len(plan))
         return [plan[int(i)] for i in order], "split"
-    slots = rng.permutation(256)[:rng.integers(1, 40)]   # few channels
+    slots = rng.permutation(N1)[:rng.integers(1, max(2, 40 * N1 // 256))]   # few channels
     return [(256 * int(c), 256, 0.88, 1.0) for c in slots], "few"
 
 
