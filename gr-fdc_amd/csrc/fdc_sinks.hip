@@ -200,6 +200,11 @@ struct fdc_sinks {
     float *d_power_ahead = nullptr;
     hipStream_t s_fill = nullptr;
     hipEvent_t ev_fill = nullptr;
+    // ... and two side streams: the width classes above 4096 points are two small launches each (a few hundred transforms); side by side
+    // they fill the device, one after the other they do not (configs[4]: 3 x (42 + 20) us).  Only with the flag: with the payload copy to the
+    // host running, more streams than hardware queues put a class behind the copy (profiles/r03/NOTES.md).
+    hipStream_t s_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     hipEvent_t ev_ready = nullptr, ev_ready_ahead = nullptr;   // recorded on s_fill behind the power cells of the batch in d_spec / d_spec_ahead (fdc_sinks_prepare)
     int prepared = -1, prepared_ahead = -1;  // blocks whose power cells are already (being) computed in d_power / d_power_ahead on s_fill; -1 = none
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
@@ -606,7 +611,8 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->s_fill) { (void)hipStreamSynchronize(s->s_fill); (void)hipStreamDestroy(s->s_fill); }
-    for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : s->s_side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead, s->ev_fork, s->ev_join[0], s->ev_join[1]}) if (e) (void)hipEventDestroy(e);
     (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
@@ -810,6 +816,11 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipEventCreateWithFlags(&raw->ev_fill, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_ready, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_ready_ahead, hipEventDisableTiming));
+        CHKF(hipEventCreateWithFlags(&raw->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) {
+            CHKF(hipStreamCreateWithFlags(&raw->s_side[i], hipStreamNonBlocking));
+            CHKF(hipEventCreateWithFlags(&raw->ev_join[i], hipEventDisableTiming));
+        }
     }
     raw->host_threads = cfg->threads > 0 ? std::min(cfg->threads, 32) : 0;
     if (const char *t = fdc::debug_env("FDC_SINKS_THREADS")) if (atoi(t) >= 1) raw->host_threads = std::min(atoi(t), 32);   // debugging override
@@ -959,13 +970,42 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
         if (cnt[k] && w <= 4096 && !(w == 256 && s->d_tw256)) { mw[nm] = w; mfirst[nm] = first[k]; mcnt[nm] = cnt[k]; nm++; }
     }
     const bool multi = nm >= 2 && nm <= fdc::kMaxExtractClasses;
-    if (multi) HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
+    // side streams (look-ahead banks): two or three classes above 4096 points, each in one piece of its own slice of the scratch
+    int nwide = 0, wk[3] = {0, 0, 0};
+    size_t wneed = 0;
+    bool side = s->s_side[0] != nullptr;
+    for (int k = 13; k < 32 && side; k++)
+        if (cnt[k]) {
+            if (nwide == 3 || cnt[k] * ((size_t)1 << k) > ((size_t)64 << 20)) { side = false; break; }
+            wk[nwide++] = k; wneed += cnt[k] * ((size_t)1 << k);
+        }
+    side = side && nwide >= 2;
+    if (side) {
+        if (s->wide_cap < wneed) {
+            (void)hipFree(s->d_wide); s->d_wide = nullptr; s->wide_cap = 0;
+            HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * (wneed + wneed / 2)));
+            s->wide_cap = wneed + wneed / 2;
+        }
+        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        size_t off = 0;
+        for (int c = 0; c < nwide; c++) {
+            const int k = wk[c], w = 1 << k;
+            hipStream_t q = c == 0 ? s->stream : s->s_side[c - 1];
+            if (c) HIPCHK(hipStreamWaitEvent(q, s->ev_fork, 0));
+            if (c == 0 && multi)        // the classes up to 4096 points go first on the bank's own stream, the widest class behind them
+                HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
+            HIPCHK(fdc::launch_extract_wide(s->d_spec, N, d_tasks + first[k], (int)cnt[k], w, w / s->R, s->d_wins, s->d_wide + off, d_out, s->d_tw, N, q));
+            off += cnt[k] * (size_t)w;
+            if (c) HIPCHK(hipEventRecord(s->ev_join[c - 1], q));
+        }
+    } else if (multi) HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
     for (int k = 0; k < 32; k++) {
         if (!cnt[k]) continue;
         const int w = 1 << k, skip = w / s->R;
         const size_t i = first[k], j = first[k] + cnt[k];
         if (trace) std::fprintf(stderr, "[fdc_sinks]     width %d: %zu tasks\n", w, j - i);
         if (multi && w <= 4096 && !(w == 256 && s->d_tw256)) continue;
+        if (side && w > 4096) continue;
         if (w == 256 && s->d_tw256) {
             HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, s->stream));
         } else if (w <= 4096) {
@@ -991,6 +1031,7 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
             }
         }
     }
+    if (side) for (int c = 1; c < nwide; c++) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join[c - 1], 0));    // the bank's stream goes on behind every class
     return FDC_OK;
 }
 

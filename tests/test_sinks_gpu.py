@@ -244,13 +244,15 @@ def test_sinks_every_width_class_in_one_call(oracle):
         pos += bw + 0.02
     assert pos < 1.0
     spec = burst_spectrum(N, nb, bursts, 77)
-    for host in (False, True):
-        bank = G.Sinks(N, R, pac=plan, pac_thresh=6.0, pac_maxblocks=3, max_blocks=16, host_decisions=host)
+    # (look-ahead banks run the classes above 4096 points side by side on streams of their own: the same PDUs)
+    for host, la in ((False, False), (True, False), (False, True)):
+        bank = G.Sinks(N, R, pac=plan, pac_thresh=6.0, pac_maxblocks=3, max_blocks=16, host_decisions=host, lookahead=la)
         assert [bank.pac_params(i)["extract_width"] for i in range(len(widths))] == widths
-        got = bank.work(spec.reshape(-1))
+        got = bank.work(spec[:4].reshape(-1)) + bank.work(spec[4:].reshape(-1)) if la else bank.work(spec.reshape(-1))
         ref = []
         for (cf, bw, ident) in plan:
-            ref.append(oracle.PowerActivationChannel(N, cf, bw, R, 6.0, 3, 0, ident).work(spec))
+            o = oracle.PowerActivationChannel(N, cf, bw, R, 6.0, 3, 0, ident)
+            ref.append(o.work(spec[:4]) + o.work(spec[4:]) if la else o.work(spec))
         assert all(len(r) >= 1 for r in ref)
         for k, (cf, bw, ident) in enumerate(plan):
             mine = [g for g in got if g[0]["source"] == ident]
