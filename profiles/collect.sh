@@ -20,6 +20,9 @@ echo "[collect] configs 1/3/4/5 done"
 for c in 3 5; do
   timeout -k 10 300 python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --payload device > $OUT/bench_cfg${c}_device_payload.json 2> /dev/null || echo "bench cfg$c device payload failed"
   timeout -k 10 300 python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --sink-engine host --sync-sinks > $OUT/bench_cfg${c}_host_engine.json 2> /dev/null || echo "bench cfg$c host engine failed"
+  # round 5: the look-ahead form (two spectrum buffers, the next batch's transform beside this batch's decisions), payloads in HBM and to the host
+  timeout -k 10 300 python3 bench.py --config $c --steps 40 --warmup 5 --no-cpu-baseline --payload device --lookahead > $OUT/bench_cfg${c}_device_payload_lookahead.json 2> /dev/null || echo "bench cfg$c look-ahead failed"
+  timeout -k 10 300 python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --lookahead > $OUT/bench_cfg${c}_lookahead.json 2> /dev/null || echo "bench cfg$c look-ahead (host payload) failed"
 done
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --input-rings 1 --blocks 1024 > $OUT/bench_one_ring_1024.json 2> /dev/null || echo "bench one ring failed"
 timeout -k 10 300 python3 bench.py --offset 37 --no-cpu-baseline > $OUT/bench_offset37.json 2> $OUT/bench_offset.err || echo "bench offset failed"
