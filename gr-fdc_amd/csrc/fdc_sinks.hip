@@ -205,6 +205,11 @@ struct fdc_sinks {
     // host running, more streams than hardware queues put a class behind the copy (profiles/r03/NOTES.md).
     hipStream_t s_side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // ... and the extraction kernels of a batch on a stream of their own (s_x), so that the NEXT batch's decision chain — enqueued on the bank's
+    // stream by the next submit — starts beside them instead of behind them (two deep as before: that submit hands out this batch's PDUs).
+    // Placement of the tasks and the buffered blocks' move stay on the bank's stream (they read what the next chain overwrites).
+    hipStream_t s_x = nullptr;
+    hipEvent_t ev_tasks = nullptr;
     hipEvent_t ev_ready = nullptr, ev_ready_ahead = nullptr;   // recorded on s_fill behind the power cells of the batch in d_spec / d_spec_ahead (fdc_sinks_prepare)
     int prepared = -1, prepared_ahead = -1;  // blocks whose power cells are already (being) computed in d_power / d_power_ahead on s_fill; -1 = none
     fdc::ExtractTask *d_tasks = nullptr; size_t cap_tasks = 0;
@@ -611,8 +616,8 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->s_fill) { (void)hipStreamSynchronize(s->s_fill); (void)hipStreamDestroy(s->s_fill); }
-    for (hipStream_t q : s->s_side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead, s->ev_fork, s->ev_join[0], s->ev_join[1]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {s->s_side[0], s->s_side[1], s->s_x}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead, s->ev_fork, s->ev_join[0], s->ev_join[1], s->ev_tasks}) if (e) (void)hipEventDestroy(e);
     (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
@@ -817,6 +822,8 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipEventCreateWithFlags(&raw->ev_ready, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_ready_ahead, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_fork, hipEventDisableTiming));
+        CHKF(hipStreamCreateWithFlags(&raw->s_x, hipStreamNonBlocking));
+        CHKF(hipEventCreateWithFlags(&raw->ev_tasks, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) {
             CHKF(hipStreamCreateWithFlags(&raw->s_side[i], hipStreamNonBlocking));
             CHKF(hipEventCreateWithFlags(&raw->ev_join[i], hipEventDisableTiming));
@@ -937,11 +944,11 @@ static int batch_begin(fdc_sinks *s, int nblocks, bool *have_power)
 }
 // end of a batch (enqueued behind its last reader): history <- its last block (save_hist, PowerActivationChannel_impl.cc:173;
 // …vcm_impl.cc:571) — slot 0 of the buffer the NEXT batch is read from, which with look-ahead is the other one ...
-static int batch_end_history(fdc_sinks *s, int nblocks)
+static int batch_end_history(fdc_sinks *s, int nblocks, hipStream_t q)
 {
     const size_t N = (size_t)s->N;
     float2 *const next = s->d_spec_ahead ? s->d_spec_ahead : s->d_spec;
-    HIPCHK(hipMemcpyAsync(next, s->d_spec + (size_t)nblocks * N, sizeof(float2) * N, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(next, s->d_spec + (size_t)nblocks * N, sizeof(float2) * N, hipMemcpyDeviceToDevice, q));
     return FDC_OK;
 }
 // ... then the buffers swap, and the fill stream may overwrite this batch's buffer once `done` (an event on the bank's stream behind the
@@ -958,9 +965,11 @@ static int batch_end_swap(fdc_sinks *s, hipEvent_t done)
     return FDC_OK;
 }
 
-static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const size_t *first, const size_t *cnt, float2 *d_out, bool trace)
+static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const size_t *first, const size_t *cnt, float2 *d_out, bool trace,
+                           hipStream_t q0 = nullptr)
 {
     const int N = s->N;
+    if (!q0) q0 = s->stream;
     // the classes that fit one workgroup's transform at 16 points per lane (w <= 4096; 256 has a kernel of its own) are independent and
     // each fills a part of the device only: two or more of them go out as ONE launch
     int mw[32], nm = 0;
@@ -986,19 +995,19 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
             HIPCHK(hipMalloc(&s->d_wide, sizeof(float2) * (wneed + wneed / 2)));
             s->wide_cap = wneed + wneed / 2;
         }
-        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        HIPCHK(hipEventRecord(s->ev_fork, q0));
         size_t off = 0;
         for (int c = 0; c < nwide; c++) {
             const int k = wk[c], w = 1 << k;
-            hipStream_t q = c == 0 ? s->stream : s->s_side[c - 1];
+            hipStream_t q = c == 0 ? q0 : s->s_side[c - 1];
             if (c) HIPCHK(hipStreamWaitEvent(q, s->ev_fork, 0));
             if (c == 0 && multi)        // the classes up to 4096 points go first on the bank's own stream, the widest class behind them
-                HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
+                HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, q0));
             HIPCHK(fdc::launch_extract_wide(s->d_spec, N, d_tasks + first[k], (int)cnt[k], w, w / s->R, s->d_wins, s->d_wide + off, d_out, s->d_tw, N, q));
             off += cnt[k] * (size_t)w;
             if (c) HIPCHK(hipEventRecord(s->ev_join[c - 1], q));
         }
-    } else if (multi) HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, s->stream));
+    } else if (multi) HIPCHK(fdc::launch_extract_multi(s->d_spec, N, d_tasks, mw, mfirst, mcnt, nm, s->R, s->d_wins, d_out, s->d_tw, N, q0));
     for (int k = 0; k < 32; k++) {
         if (!cnt[k]) continue;
         const int w = 1 << k, skip = w / s->R;
@@ -1007,9 +1016,9 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
         if (multi && w <= 4096 && !(w == 256 && s->d_tw256)) continue;
         if (side && w > 4096) continue;
         if (w == 256 && s->d_tw256) {
-            HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, s->stream));
+            HIPCHK(fdc::launch_extract256(s->d_spec, N, d_tasks + i, (int)(j - i), skip, s->d_wins, d_out, s->d_tw256, q0));
         } else if (w <= 4096) {
-            HIPCHK(fdc::launch_extract(s->d_spec, N, d_tasks + i, (int)(j - i), w, skip, s->d_wins, d_out, s->d_tw, N, s->stream));
+            HIPCHK(fdc::launch_extract(s->d_spec, N, d_tasks + i, (int)(j - i), w, skip, s->d_wins, d_out, s->d_tw, N, q0));
         } else {
             // above 4096 points (a carrier, or a run of merged carriers, over 1/16 of a 65536-bin band): the two-pass inverse transform,
             // the whole class in batches of up to 64 Mi points — pass A reads slice * window straight from the spectrum (the half swap is
@@ -1027,11 +1036,11 @@ static int run_extractions(fdc_sinks *s, const fdc::ExtractTask *d_tasks, const 
             const size_t fit = std::max<size_t>(1, s->wide_cap / (size_t)w);
             for (size_t k0 = i; k0 < j; k0 += fit) {
                 const int n = (int)std::min(fit, j - k0);
-                HIPCHK(fdc::launch_extract_wide(s->d_spec, N, d_tasks + k0, n, w, skip, s->d_wins, s->d_wide, d_out, s->d_tw, N, s->stream));
+                HIPCHK(fdc::launch_extract_wide(s->d_spec, N, d_tasks + k0, n, w, skip, s->d_wins, s->d_wide, d_out, s->d_tw, N, q0));
             }
         }
     }
-    if (side) for (int c = 1; c < nwide; c++) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join[c - 1], 0));    // the bank's stream goes on behind every class
+    if (side) for (int c = 1; c < nwide; c++) HIPCHK(hipStreamWaitEvent(q0, s->ev_join[c - 1], 0));    // the bank's stream goes on behind every class
     return FDC_OK;
 }
 
@@ -1249,7 +1258,7 @@ static int host_work_device(fdc_sinks *s, int nblocks)
         HIPCHK(hipMemcpyAsync(s->h_ext, s->d_ext, sizeof(float2) * (size_t)s->ext_used, hipMemcpyDeviceToHost, s->stream));
     }
     // history <- last block of this call (save_hist, PowerActivationChannel_impl.cc:173; …vcm_impl.cc:571)
-    { const int rh = batch_end_history(s, nblocks); if (rh != FDC_OK) return rh; }
+    { const int rh = batch_end_history(s, nblocks, s->stream); if (rh != FDC_OK) return rh; }
     HIPCHK(hipStreamSynchronize(s->stream));
     { const int rh = batch_end_swap(s, nullptr); if (rh != FDC_OK) return rh; }
     lap("extractions + D2H");
@@ -1374,6 +1383,10 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&d.h_land[b]), sizeof(cfl) * want, hipHostMallocDefault));
         d.cap_hland[b] = want;
     }
+    // look-ahead banks: the extractions run on their own stream.  The batch before's may still be at work there: its landing buffer (the
+    // buffered blocks move on from it) and the sorted task list (about to be rewritten) are its to read until it is done
+    hipStream_t qx = s->s_x ? s->s_x : s->stream;
+    if (s->s_x && d.any) HIPCHK(hipStreamWaitEvent(s->stream, d.ev_extract[d.cur], 0));
     if (sum.ntask)
         // grids from what the layout found, not from the worst case the lists were allocated for
         HIPCHK(fdc::launch_task_scatter(d.nlist, d.d_task_base, d.d_ntask, std::min<long long>(d.max_list, std::max(1, sum.max_list_tasks)), d.d_tasks,
@@ -1381,14 +1394,18 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
     if (d.any && sum.ncarry > 0)
         HIPCHK(fdc::launch_carry_copy(d.d_owners, std::min(d.carry_width, std::max(1, sum.max_region_owners)), d.d_owner_base, d.d_nowner, npac, nseg,
                                       d.d_sum, d.d_land[d.cur], d.d_land[b], s->stream));
+    if (s->s_x) {
+        HIPCHK(hipEventRecord(s->ev_tasks, s->stream));
+        HIPCHK(hipStreamWaitEvent(qx, s->ev_tasks, 0));
+    }
     if (sum.ntask) {
         size_t first[32], cnt[32];
         for (int k = 0; k < 32; k++) { first[k] = (size_t)sum.class_base[k]; cnt[k] = (size_t)sum.class_cnt[k]; }
-        const int rce = run_extractions(s, d.d_sorted, first, cnt, d.d_land[b], trace);
+        const int rce = run_extractions(s, d.d_sorted, first, cnt, d.d_land[b], trace, qx);
         if (rce != FDC_OK) return rce;
     }
-    { const int rh = batch_end_history(s, nblocks); if (rh != FDC_OK) return rh; }
-    HIPCHK(hipEventRecord(d.ev_extract[b], s->stream));
+    { const int rh = batch_end_history(s, nblocks, qx); if (rh != FDC_OK) return rh; }
+    HIPCHK(hipEventRecord(d.ev_extract[b], qx));
     { const int rh = batch_end_swap(s, d.ev_extract[b]); if (rh != FDC_OK) return rh; }
     if (!devpay && sum.used_a) {
         HIPCHK(hipStreamWaitEvent(d.s_copy, d.ev_extract[b], 0));

@@ -89,13 +89,15 @@ def run(bank, spec, cuts, max_blocks):
     return out
 
 
-def main(cases=60, seed=1, nbmax=90):
+def main(cases=60, seed=1, nbmax=90, lookahead=0):
+    """lookahead = 1 (fourth argument): the device-engine bank is a look-ahead bank (two spectrum buffers that swap per batch, the extractions on a
+    stream of their own, wide classes on side streams) — fed through work() like the other one: same PDUs."""
     rng = np.random.default_rng(seed)
     npdu = ndev = 0
     for case in range(cases):
         N, R, kw, spec, cuts = draw(rng, nbmax)
         try:
-            dev, host = G.Sinks(N, R, **kw), G.Sinks(N, R, host_decisions=True, **kw)
+            dev, host = G.Sinks(N, R, lookahead=bool(lookahead), **kw), G.Sinks(N, R, host_decisions=True, **kw)
         except ValueError:
             continue                                    # the reference's constructors refuse this geometry too
         if dev.engine() != 1:
@@ -115,4 +117,4 @@ def main(cases=60, seed=1, nbmax=90):
 
 
 if __name__ == "__main__":
-    main(*[int(v) for v in sys.argv[1:4]])
+    main(*[int(v) for v in sys.argv[1:5]])
