@@ -71,6 +71,22 @@ def test_bench_config3_and_5_sinks():
         assert d["cpu_baseline"]["value"] > 0 and d["value"] > 100.0
 
 
+def test_bench_sinks_lookahead_form():
+    """bench.py --lookahead (round 5): the sink configurations with the producer one batch ahead (FDC_SINKS_LOOKAHEAD, payloads in HBM): the same number of
+    PDUs per step as the one-buffer form on the same batch size, a batch of whole rounds of the forward kernel's workgroups, the line says what ran."""
+    for cfg in (3, 5):
+        la = _line(["--config", str(cfg), "--payload", "device", "--lookahead", "--reserve-cus", "32", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                    "--no-end-to-end"])
+        c = la["config"]
+        nb, wg = c["blocks_per_step_per_gpu"], c["lookahead"]["block_kernel_workgroups"]
+        assert c["lookahead"]["reserved_compute_units"] == 32 and nb % wg == 0 and "look-ahead" in c["submission"] and c["payload"] == "device"
+        one = _line(["--config", str(cfg), "--payload", "device", "--blocks", str(nb), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-end-to-end"])
+        assert one["config"]["blocks_per_step_per_gpu"] == nb and "lookahead" not in one["config"]
+        assert la["config"]["pdus_per_step"] == one["config"]["pdus_per_step"] > 0
+        assert la["config"]["extracted_samples_per_step"] == one["config"]["extracted_samples_per_step"]
+        assert la["value"] > 100.0
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """bench.py --gpus 2 started plainly: it spawns the two ranks itself; FDC_BENCH_REHEARSE=1 lets both use cuda:0 over gloo,
     so the HIP path runs once per rank (span sharding with halo and global block index)."""
