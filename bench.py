@@ -81,6 +81,8 @@ def parse():
                          "are device pointers)")
     ap.add_argument("--sink-engine", choices=("device", "host"), default="device",
                     help="configs 3/5: where the blocks' work() loops run (FDC_SINKS_HOST_DECISIONS = the round-2 form)")
+    ap.add_argument("--noise-input", action="store_true", help="diagnostics (configs 1/2/4): the ring is complex noise without carriers — kernel times and counters do not "
+                    "depend on the data; for rocprofv3 --pmc runs of plans whose synthesis kernels the profiler trips over (1024 carriers: it segfaults)")
     ap.add_argument("--lookahead", action="store_true", help="configs 3/5: the bank with two spectrum buffers (FDC_SINKS_LOOKAHEAD): the forward transform and the "
                     "power cells of batch n + 1 run on the bank's fill stream beside the decision kernels of batch n; the block kernels leave "
                     "--reserve-cus compute units to them and the batch is a multiple of their workgroups")
@@ -133,7 +135,7 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def synth_input(torch, dev, N, R, C, nblocks, first_block, seed):
+def synth_input(torch, dev, N, R, C, nblocks, first_block, seed, carriers=True):
     """Device-resident synthetic multicarrier ring: N/R halo samples + nblocks*H new samples (SURVEY §8d cfg2:
     one carrier per channel, random complex symbols at 0.6x the channel bandwidth, noise at -30 dB)."""
     H = N - N // R
@@ -148,7 +150,7 @@ def synth_input(torch, dev, N, R, C, nblocks, first_block, seed):
     nsym = total // sps + 2
     step = 1 << 20
     cgrp = 32
-    for c0 in range(0, C, cgrp):
+    for c0 in range(0, C if carriers else 0, cgrp):
         cc = min(cgrp, C - c0)
         sym = (torch.randint(0, 2, (cc, nsym, 2), device=dev, generator=g, dtype=torch.int32).float() * 2 - 1) * (0.5 ** 0.5)
         sym = torch.view_as_complex(sym.contiguous())
@@ -511,7 +513,7 @@ def main():
         plan = [(f, l, p, s) for (f, l, _lo, p, s) in params]
         sum_lout = sum(lo for (_f, _l, lo, _p, _s) in params)
         pipe = G.Pipeline(N, R, plan, windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk)
-        x = synth_input(torch, dev, N, R, C, nb, first_block, 2025 + rank)
+        x = synth_input(torch, dev, N, R, C, nb, first_block, 2025 + rank, carriers=not a.noise_input)
         # further rings: the same multicarrier signal with the samples rolled (distinct addresses and distinct data; the
         # generator itself takes seconds per ring)
         rings = [x] + [torch.roll(x, 7919 * (i + 1)) for i in range(max(1, a.input_rings) - 1)]
