@@ -405,6 +405,60 @@ def host_entry_leg(G, np, N, R, plan, sum_lout, devices, blocks_per_member):
     return res
 
 
+def sinks_host_entry_leg(G, np, _lib, N, R, local, x, nb, make_bank, per_call, pipelined):
+    """The sink configurations through fdc_pipeline_work_sinks from pinned HOST samples: `per_call` items per call over the bench's own
+    bursty stream (laps of its nb blocks), PDUs and payloads to host memory and counted.  pipelined: a look-ahead bank (front end of
+    call n beside the sinks of call n - 1, PDUs two calls later); otherwise the serial form (front end, then the sinks, inside the call)."""
+    import ctypes as ct
+    H = N - N // R
+    per_call = min(per_call, nb)
+    calls_per_lap = nb // per_call
+    xh = x[N // R:N // R + calls_per_lap * per_call * H].cpu().numpy()
+    pipe = G.Pipeline(N, R, [], windowtype=1, max_blocks=per_call, device_id=local, keep_spectrum=True)
+    bank = make_bank(per_call, pipelined, False)
+    none = (ct.c_void_p * 1)()
+    G.register_host(xh)
+    got = [0, 0]
+
+    def tally():
+        n = _lib.lib().fdc_sinks_pdu_count(bank._h)
+        if n > 0:
+            arr = (_lib.fdc_pdu * n)()
+            _lib.lib().fdc_sinks_pdus(bank._h, arr, n)
+            got[0] += int(np.frombuffer(arr, dtype=np.dtype(_lib.fdc_pdu))["nsamples"].sum())
+            got[1] += n
+
+    def lap():
+        for k in range(calls_per_lap):
+            pipe.work_sinks_raw(xh.ctypes.data + 8 * k * per_call * H, per_call, none, bank)
+            tally()
+    try:
+        lap()
+        while pipe.flush_sinks(bank) > 0:
+            pass
+        got[:] = [0, 0]
+        laps = max(2, (8 + calls_per_lap - 1) // calls_per_lap)
+        t0 = time.perf_counter()
+        for _ in range(laps):
+            lap()
+        while pipe.flush_sinks(bank) > 0:                    # what is still inside belongs to the region
+            tally()
+        dt = time.perf_counter() - t0
+        ncalls = laps * calls_per_lap
+        return {"value": round(ncalls * per_call * H / dt / 1e6, 3), "unit": "Msamples/s", "blocks_per_call": per_call, "calls": ncalls,
+                "ms_per_call": round(dt / ncalls * 1e3, 3), "pdus_per_call": round(got[1] / ncalls, 1),
+                "extracted_samples_per_call": round(got[0] / ncalls, 1),
+                "pdu_latency_calls": pipe.sinks_latency(bank), "sink_engine": "device" if bank.engine() == 1 else "host",
+                "entry": "fdc_pipeline_work_sinks, %s (H2D of the items from a buffer pinned with fdc_host_register + forward transform + "
+                         "sinks + PDU payloads to host memory per call)" %
+                         ("PIPELINED: look-ahead bank, front end of call n beside the sinks of call n - 1" if pipelined else
+                          "serial: front end, then the sinks, inside the call")}
+    finally:
+        G.unregister_host(xh)
+        bank.close()
+        pipe.close()
+
+
 def main():
     a = parse()
     dry = os.environ.get("FDC_BENCH_DRYRUN") == "1"      # launcher rehearsal on a CPU box: ranks, barrier, MAX — no GPU work
@@ -534,16 +588,22 @@ def main():
         pipe = G.Pipeline(N, R, [], windowtype=1, max_blocks=nb, device_id=local, chunk_blocks=a.chunk, keep_spectrum=True)
         if a.config == 3:
             pac = [(((c + 0.5) / C) % 1.0, 0.8 / C, c) for c in range(C)]
-            sinks = G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=nb, device_id=local,
-                            host_decisions=a.sink_engine == "host", device_payload=a.payload == "device", lookahead=a.lookahead)
+
+            def make_bank(max_blocks, lookahead, device_payload):
+                return G.Sinks(N, R, pac=pac, pac_thresh=6.0, pac_maxblocks=128, pac_delay=1, max_blocks=max_blocks, device_id=local,
+                               host_decisions=a.sink_engine == "host", device_payload=device_payload, lookahead=lookahead)
+            sinks = make_bank(nb, a.lookahead, a.payload == "device")
             carriers = [((c + 0.5) / C - 0.5, 1.0 / C) for c in range(C)]
             wl = "configs[2]: %d-pt FFT, 1/%d overlap-save, %d PowerActivationChannel sinks (6 dB, maxblocks 128), bursty " \
                  "carriers (8-64 blocks, 50 %% duty, 30 dB), %d blocks/step" % (N, R, C, nb)
         else:
             segments = [((0.05 + 0.5) % 1.0, (0.45 + 0.5) % 1.0), ((-0.45 + 0.5) % 1.0, (-0.05 + 0.5) % 1.0)]
-            sinks = G.Sinks(N, R, segments=segments, det_thresh=10.0, det_maxblocks=128, minchandist=0.005, det_delay=1,
-                            puffer=0.2, max_blocks=nb, device_id=local, host_decisions=a.sink_engine == "host",
-                            device_payload=a.payload == "device", lookahead=a.lookahead)
+
+            def make_bank(max_blocks, lookahead, device_payload):
+                return G.Sinks(N, R, segments=segments, det_thresh=10.0, det_maxblocks=128, minchandist=0.005, det_delay=1,
+                               puffer=0.2, max_blocks=max_blocks, device_id=local, host_decisions=a.sink_engine == "host",
+                               device_payload=device_payload, lookahead=lookahead)
+            sinks = make_bank(nb, a.lookahead, a.payload == "device")
             rng = np.random.default_rng(2028)
             carriers, used = [], []
             while len(carriers) < 24:                  # 24 carriers of width 0.002-0.03 at non-overlapping centres inside the segments
@@ -723,6 +783,12 @@ def main():
             end_to_end_group = host_entry_leg(G, np, N, R, plan, sum_lout, devs, e2e_blocks)
             if ndev == 1:
                 end_to_end_group["note"] = "one GPU visible: two VIRTUAL members on device 0 share its one PCIe link (dispatcher exercised, no gain expected)"
+    # configs[2] / configs[4] from HOST samples (round 6): the whole hier block behind ONE work()-level entry, fdc_pipeline_work_sinks on a
+    # look-ahead bank = the pipelined form (include/fdc_amd.h): H2D of 256 KiB per item, forward transform, the sinks, PDUs to host memory.
+    if sinks is not None and not a.no_end_to_end and not a.sync_sinks and world == 1:
+        fence()
+        end_to_end = [sinks_host_entry_leg(G, np, _lib, N, R, local, x, nb, make_bank, per_call, pipelined)
+                      for (per_call, pipelined) in ((256, True), (min(nb, 1024), True), (256, False))]
     msps = world * nb * H * a.steps / dt / 1e6
     chunk = pipe.chunk_blocks()
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)

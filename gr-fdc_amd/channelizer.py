@@ -197,6 +197,19 @@ class Pipeline:
                                                    spec.ctypes.data if spec is not None else None))
         return (outs, spec) if want_spectrum else outs
 
+    def flush_sinks(self, sinks):
+        """fdc_pipeline_flush_sinks: the pipelined form (a bank made with lookahead=True) hands out the oldest batch still inside;
+        returns its block count, 0 when nothing is left.  The PDUs are then the bank's current ones (sinks.pdus())."""
+        return _lib.check(_lib.lib().fdc_pipeline_flush_sinks(self._h, sinks._h))
+
+    def sinks_latency(self, sinks):
+        """Calls between an item going in and its PDUs coming out of work(..., sinks=sinks): 0 serial, 1 or 2 pipelined."""
+        return int(_lib.lib().fdc_pipeline_sinks_latency(self._h, sinks._h))
+
+    def work_sinks_raw(self, in_ptr, nblocks, out_ptrs, sinks):
+        """fdc_pipeline_work_sinks on raw addresses (timing the C entry itself; the PDUs stay with the bank)."""
+        return _lib.check(_lib.lib().fdc_pipeline_work_sinks(self._h, in_ptr, int(nblocks), out_ptrs, None, sinks._h))
+
     def work_real(self, x, want_spectrum=False):
         """Real input stream (float32 items; fdc_pipeline_work_real): the block's imaginary part is zero."""
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -390,7 +403,11 @@ class FrequencyDomainChannelizer:
                  act_det_deactivation_delay, minchanflankpuffer, verbose,
                  pow_act_deactivation_delay,
                  pow_act_maxblocks, act_det_maxblocks,
-                 debug, device_id=0, max_blocks=64, devices=None):
+                 debug, device_id=0, max_blocks=64, devices=None, pipelined=False):
+        # pipelined (not an argument of the reference): the sink blocks run beside the front end of the FOLLOWING work() calls, as the
+        # thread-per-block scheduler runs them beside the FFT in the reference (fdc_pipeline_work_sinks on a look-ahead bank,
+        # include/fdc_amd.h): same PDUs, handed out one or two work() calls later; flush() at the end of the stream
+        self.pipelined = bool(pipelined)
         self.verbose = int(verbose)
         self.itemsize = inptype
         self.debug = bool(debug)
@@ -457,7 +474,7 @@ class FrequencyDomainChannelizer:
                                minchandist=self.get_bw(minchandist) if self.activity_detection_segments else 0.005,
                                det_delay=add, puffer=puf, max_blocks=max_blocks, device_id=device_id,
                                det_variant=1,      # the hier block instantiates SegmentDetection (:25, :261-278)
-                               verbose=self.verbose)
+                               verbose=self.verbose, lookahead=self.pipelined and self.inpveclen == 1)
         # devices = [ordinals]: the throughput chain of one work() call spread over several GPUs (fdc_pipeline_group); the sink
         # blocks stay on ONE device's spectrum, so a hier block with sinks keeps the single-device handle
         if devices is not None and len(devices) > 1 and self.sinks is None and self.inpveclen == 1:
@@ -527,16 +544,29 @@ class FrequencyDomainChannelizer:
             res = self.pipeline.work_spectrum(samples, want_spectrum=self.debug, sinks=self.sinks)
         self.messages = []
         if self.sinks is not None:
-            from .sinks import _pac_pdu, _det_pdu, _write_files
-            raw = self.sinks._collect()
-            pac = [_pac_pdu(m, d) for (m, d) in raw if m["kind"] == 0]
-            det = [_det_pdu(m, d) for (m, d) in raw if m["kind"] == 1]
-            if self.fileoutput:
-                _write_files(self.outputpath, pac, True)
-                _write_files(self.outputpath, det, False)
-            if self.msgoutput:
-                self.messages = pac + det
+            self._publish()
         if self.debug:
             outs, spec = res
             return [spec] + outs
         return res
+
+    def _publish(self):
+        """The bank's current PDUs -> files and self.messages (appended)"""
+        from .sinks import _pac_pdu, _det_pdu, _write_files
+        raw = self.sinks._collect()
+        pac = [_pac_pdu(m, d) for (m, d) in raw if m["kind"] == 0]
+        det = [_det_pdu(m, d) for (m, d) in raw if m["kind"] == 1]
+        if self.fileoutput:
+            _write_files(self.outputpath, pac, True)
+            _write_files(self.outputpath, det, False)
+        if self.msgoutput:
+            self.messages += pac + det
+
+    def flush(self):
+        """End of the stream (what the block's stop() does): the pipelined form still holds the PDUs of the last one or two work()
+        calls; they are published here, batch by batch in stream order, and left in self.messages.  Serial form: nothing to do."""
+        self.messages = []
+        if self.sinks is not None and self.pipelined and self.inpveclen == 1:
+            while self.pipeline.flush_sinks(self.sinks) > 0:
+                self._publish()
+        return self.messages

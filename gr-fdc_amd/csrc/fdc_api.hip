@@ -199,6 +199,7 @@ struct fdc_pipeline {
     float2 *d_tmp = nullptr;     // two-pass intermediate, chunk*N
     float2 *d_spec = nullptr;    // spectrum, chunk*N (or max_blocks*N with keep_spectrum)
     float2 *d_ring = nullptr;    // work(): ovl + max_blocks*H
+    float2 *d_specfull = nullptr; // work() with a host spectrum (debug port) and no bank to put it in: max_blocks*N, allocated at the first such call
     float *d_real = nullptr;     // work_real(): max_blocks*H real samples
     float2 *d_out = nullptr;     // work(): max_blocks*sum_lout
     int64_t blockcount = 0;      // work(): blocks consumed so far
@@ -208,6 +209,13 @@ struct fdc_pipeline {
     float2 *pin_out[2] = {nullptr, nullptr};                                     // staging for unregistered output buffers
     fdc::ScatterEnt *pin_tab = nullptr, *d_tab = nullptr;                        // registered outputs: scatter table
     int sub = 0;                 // blocks per sub-batch
+    // fdc_pipeline_work_sinks on a look-ahead bank (the pipelined hier block): the batch of the last call sits transformed in the bank's
+    // next-batch buffer and is submitted by the NEXT call, beside that call's input copy and forward transform
+    int hier_filled = 0;         // its block count (0 = none)
+    fdc_sinks *hier_bank = nullptr;
+    hipEvent_t ev_hier = nullptr;   // on the bank's fill stream behind the last call's transform and history copy: the ring may be overwritten
+    bool hier_ring_busy = false;
+    bool reserve_user = false;   // fdc_pipeline_reserve_compute_units was called: the pipelined entry leaves the reservation alone
     bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
     // timing
     bool timing = false;
@@ -368,7 +376,8 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
 {
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_dbg); (void)hipFree(p->d_g);
+    if (p->ev_hier) { (void)hipEventSynchronize(p->ev_hier); (void)hipEventDestroy(p->ev_hier); }   // kernels of the pipelined entry ran on the bank's stream
+    (void)hipFree(p->d_dbg); (void)hipFree(p->d_g); (void)hipFree(p->d_specfull);
     for (auto e : p->events) (void)hipEventDestroy(e);
     for (auto st : {p->s_in, p->s_out}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) {
@@ -952,6 +961,7 @@ int fdc_pipeline_reserve_compute_units(fdc_pipeline *p, int32_t n)
     if (!p) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || n >= p->ncu) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "%d compute units of %d cannot be left out", (int)n, p->ncu);
     p->reserved_cu = n;
+    p->reserve_user = n > 0;
     return p->ncu - n;
     FDC_ENTRY_END
 }
@@ -1279,11 +1289,22 @@ void fdc_pipeline_reset(fdc_pipeline *p)
 {
     if (!p) return;
     p->blockcount = 0;
+    p->hier_filled = 0;                         // a batch of the pipelined hier entry that was not submitted yet is dropped with the stream
+    if (p->ev_hier && p->hier_ring_busy) (void)hipEventSynchronize(p->ev_hier);
     if (p->d_ring) {
         (void)hipSetDevice(p->cfg.device_id);
         (void)hipMemsetAsync(p->d_ring, 0, sizeof(float2) * (size_t)p->ovl, p->stream);
         (void)hipStreamSynchronize(p->stream);
     }
+}
+
+// The whole-call spectrum of a work() that hands it to the host (debug port, python/FrequencyDomainChannelizer.py:152-158, :314-315) when
+// no bank's buffer takes it: allocated at the first such call, kept (no hipMalloc / hipFree in the steady state of any entry).
+static int spec_staging(fdc_pipeline *p, float2 **out)
+{
+    if (!p->d_specfull) HIPCHK(hipMalloc(&p->d_specfull, sizeof(float2) * (size_t)p->cfg.max_blocks * p->N));
+    *out = p->d_specfull;
+    return FDC_OK;
 }
 
 static int work_io_setup(fdc_pipeline *p)
@@ -1344,9 +1365,8 @@ static int pipeline_work_impl(fdc_pipeline *p, const void *in, int nblocks, void
     }
 
     // spectrum wanted (debug port / sinks): every sub-batch writes its part of one whole-call buffer
-    float2 *d_specfull = d_spec_dst, *d_owned = nullptr;
-    if (spectrum && !d_specfull) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_specfull = d_owned; }
-    struct OwnedGuard { float2 *p; ~OwnedGuard() { if (p) (void)hipFree(p); } } owned_guard{d_owned};
+    float2 *d_specfull = d_spec_dst;
+    if (spectrum && !d_specfull && (rc = spec_staging(p, &d_specfull)) != FDC_OK) return rc;
 
     const bool in_reg = host_registered(in, sizeof(float2) * nin);
     bool out_reg = p->C > 0;
@@ -1490,8 +1510,7 @@ static int pipeline_work_real_impl(fdc_pipeline *p, const void *in, int nblocks,
     // d_real: [N/R history samples of a span call][max_blocks*H new samples]
     if (!p->d_real) HIPCHK(hipMalloc(&p->d_real, sizeof(float) * ((size_t)p->ovl + (size_t)p->cfg.max_blocks * p->H)));
     float2 *d_specfull = nullptr;
-    if (spectrum) HIPCHK(hipMalloc(&d_specfull, sizeof(float2) * (size_t)nblocks * p->N));
-    struct Guard { float2 *p; ~Guard() { if (p) (void)hipFree(p); } } guard{d_specfull};
+    if (spectrum && (rc = spec_staging(p, &d_specfull)) != FDC_OK) return rc;
     HIPCHK(hipMemcpyAsync(p->d_real + p->ovl, in, sizeof(float) * nin, hipMemcpyHostToDevice, s));
     if (span) {
         if (halo) HIPCHK(hipMemcpyAsync(p->d_real, halo, sizeof(float) * (size_t)p->ovl, hipMemcpyHostToDevice, s));
@@ -1530,20 +1549,119 @@ int fdc_pipeline_work_span_real(fdc_pipeline *p, const void *halo, const void *i
     FDC_ENTRY_END
 }
 
+// fdc_pipeline_work_sinks on a bank created with FDC_SINKS_LOOKAHEAD: the pipelined hier block.  What one call does:
+//   - the items' copy to the device (own stream), their forward transform (+ channel kernels) into the bank's NEXT-batch buffer and its
+//     power cells (fdc_sinks_prepare) — all on the bank's fill stream, behind the copy;
+//   - fdc_sinks_submit_device for the batch the call BEFORE left there: its decision chains, the host's one wait for their summary, its
+//     extractions — beside this call's copy and transform — and the hand-out of the batch before that one (its payload copy ran meanwhile);
+//   - the wait for this call's input copy (the caller's buffer is not retained), and for the channel outputs / the debug spectrum if any.
+// So the items of call n come back as PDUs from call n + 2 (device engine; n + 1 on the host engine, whose submit is synchronous), and
+// fdc_pipeline_flush_sinks hands out what is still inside at stop().  Nothing here waits for the transform of the call's own items unless
+// the call has stream outputs: with pinned input the call costs what its input copy costs.
+static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum, fdc_sinks *sinks)
+{
+    if (nblocks < 0) return fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
+    if (nblocks == 0) return 0;
+    if (nblocks > p->cfg.max_blocks) return fail(FDC_ERR_INVALID_ARGUMENT, "nblocks %d above max_blocks %d", nblocks, p->cfg.max_blocks);
+    if (!in || (p->C > 0 && !outs)) return fail(FDC_ERR_INVALID_ARGUMENT, "null host buffer");
+    if (!p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
+    if (p->hier_bank && p->hier_bank != sinks && p->hier_filled > 0)
+        return fail(FDC_ERR_INVALID_ARGUMENT, "a batch of another bank is still inside this pipeline: fdc_pipeline_flush_sinks() with that bank first");
+    HIPCHK(hipSetDevice(p->cfg.device_id));
+    int rc = work_io_setup(p);
+    if (rc != FDC_OK) return rc;
+    if (!p->ev_hier) HIPCHK(hipEventCreateWithFlags(&p->ev_hier, hipEventDisableTiming));
+    p->hier_bank = sinks;
+    hipStream_t fs = static_cast<hipStream_t>(fdc_sinks_fill_stream(sinks));
+    const bool first = p->hier_filled == 0;                       // stream start, or everything was flushed: the bank's current buffer is free
+    float2 *dst = static_cast<float2 *>(first ? fdc_sinks_spectrum(sinks) : fdc_sinks_spectrum_ahead(sinks));
+    // the persistent block kernels take every compute unit; the decision chains of the batch before run beside them on a few units left free
+    // (long launch groups only: a group of one round is over before a chain would notice)
+    if (!p->reserve_user) p->reserved_cu = std::min(nblocks, p->chunk) >= 2 * p->ncu ? p->ncu / 8 : 0;
+
+    const size_t nin = (size_t)nblocks * p->H;
+    // input: one copy on s_in.  The ring is read by the transform of the call before (fill stream) until ev_hier.
+    if (p->hier_ring_busy) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_hier, 0));
+    HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, p->s_in));
+    HIPCHK(hipEventRecord(p->ev_in[0], p->s_in));
+    HIPCHK(hipStreamWaitEvent(fs, p->ev_in[0], 0));
+    rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, dst, fs);
+    if (rc != FDC_OK) return rc;
+    // history <- last ovl samples of this call (overlap_save_impl.cc:78)
+    HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, fs));
+    HIPCHK(hipEventRecord(p->ev_hier, fs));
+    p->hier_ring_busy = true;
+    p->blockcount += nblocks;
+    // from here on the call has happened as far as the stream state goes: a failure below must not invite a retry with the same items
+    rc = fdc_sinks_prepare(sinks, nblocks, first ? 0 : 1);
+    if (rc != FDC_OK) return rc;
+    bool out_reg = p->C > 0;
+    if (p->C > 0) {
+        for (int c = 0; c < p->C && out_reg; c++) {
+            fdc::ScatterEnt &e = p->pin_tab[c];
+            e.dst = nullptr; e.out_off = p->chans[c].out_off; e.lout = p->chans[c].lout; e.pad = 0;
+            if (outs[c] && !host_registered(outs[c], sizeof(float2) * (size_t)nblocks * p->chans[c].lout, reinterpret_cast<void **>(&e.dst)))
+                out_reg = false;
+        }
+        if (out_reg) HIPCHK(fdc::launch_scatter_out(p->d_out, p->d_tab, p->C, nblocks, 0, fs));
+        else
+            for (int c = 0; c < p->C; c++)
+                if (outs[c])
+                    HIPCHK(hipMemcpyAsync(outs[c], p->d_out + (size_t)nblocks * p->chans[c].out_off,
+                                          sizeof(float2) * (size_t)nblocks * p->chans[c].lout, hipMemcpyDeviceToHost, fs));
+    }
+    if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, dst, sizeof(float2) * (size_t)nblocks * p->N, hipMemcpyDeviceToHost, fs));
+    const int before = p->hier_filled;
+    p->hier_filled = nblocks;
+    if (before > 0) {
+        const int rs = fdc_sinks_submit_device(sinks, before);
+        if (rs < 0) return rs;
+    } else {
+        const int rs = fdc_sinks_submit_device(sinks, 0);          // nothing to submit yet: hands out a batch still in flight, or no PDUs
+        if (rs < 0) return rs;
+    }
+    HIPCHK(hipEventSynchronize(p->ev_in[0]));
+    if (p->C > 0 || spectrum) HIPCHK(hipStreamSynchronize(fs));
+    return nblocks;
+}
+
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                             fdc_sinks *sinks)
 {
     FDC_ENTRY("fdc_pipeline_work_sinks")
     if (!sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null sinks handle");
-    if (p && (fdc_sinks_blocklen(sinks) != p->N || nblocks > fdc_sinks_max_blocks(sinks)))
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (fdc_sinks_blocklen(sinks) != p->N || nblocks > fdc_sinks_max_blocks(sinks))
         return fail(FDC_ERR_INVALID_ARGUMENT, "sinks were created for blocklen %d / %d blocks per call, pipeline call has %d / %d",
                     fdc_sinks_blocklen(sinks), fdc_sinks_max_blocks(sinks), p->N, nblocks);
+    if (fdc_sinks_fill_stream(sinks)) return work_sinks_pipelined(p, in, nblocks, outs, spectrum, sinks);
     // the spectrum goes straight into the sinks' device buffer (no PCIe round trip), then the sinks run on it
     int rc = pipeline_work_impl(p, in, nblocks, outs, spectrum, static_cast<float2 *>(fdc_sinks_spectrum(sinks)));
     if (rc < 0) return rc;
     const int rs = fdc_sinks_work_device(sinks, nblocks);
     return rs < 0 ? rs : rc;
     FDC_ENTRY_END
+}
+
+int fdc_pipeline_flush_sinks(fdc_pipeline *p, fdc_sinks *sinks)
+{
+    FDC_ENTRY("fdc_pipeline_flush_sinks")
+    if (!p || !sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (p->hier_bank == sinks && p->hier_filled > 0) {
+        const int n = p->hier_filled;
+        p->hier_filled = 0;
+        const int rs = fdc_sinks_submit_device(sinks, n);
+        if (rs != 0) return rs;                                    // an older batch's PDUs (or the host engine's: this batch's), or a failure
+    }
+    return fdc_sinks_flush(sinks);
+    FDC_ENTRY_END
+}
+
+int32_t fdc_pipeline_sinks_latency(const fdc_pipeline *p, const fdc_sinks *sinks)
+{
+    if (!p || !sinks) return -1;
+    if (!fdc_sinks_fill_stream(const_cast<fdc_sinks *>(sinks))) return 0;
+    return fdc_sinks_engine(sinks) == 1 ? 2 : 1;
 }
 
 int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
@@ -1562,8 +1680,8 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
                     fdc_sinks_blocklen(sinks), fdc_sinks_max_blocks(sinks), p->N, nblocks);
     HIPCHK(hipSetDevice(p->cfg.device_id));
     hipStream_t s = p->stream;
-    float2 *d_full = sinks ? static_cast<float2 *>(fdc_sinks_spectrum(sinks)) : nullptr, *d_owned = nullptr;
-    if (!d_full) { HIPCHK(hipMalloc(&d_owned, sizeof(float2) * (size_t)nblocks * p->N)); d_full = d_owned; }
+    float2 *d_full = sinks ? static_cast<float2 *>(fdc_sinks_spectrum(sinks)) : nullptr;
+    if (!d_full) { const int rcs = spec_staging(p, &d_full); if (rcs != FDC_OK) return rcs; }
     if (p->sum_lout > 0 && !p->d_out) HIPCHK(hipMalloc(&p->d_out, sizeof(float2) * (size_t)p->cfg.max_blocks * p->sum_lout));
     const size_t n = (size_t)nblocks * p->N;
     HIPCHK(hipMemcpyAsync(d_full, in, sizeof(float2) * n, hipMemcpyHostToDevice, s));
@@ -1573,7 +1691,7 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
         if (l > 4096) {
             const int rcw = channels_wide(p, d_full, p->d_out, p->d_groups + p->group_off[g], (int)p->groups[g].second.size(), l, nblocks, 0, nblocks,
                                           p->blockcount, s);
-            if (rcw != FDC_OK) { if (d_owned) (void)hipFree(d_owned); return rcw; }
+            if (rcw != FDC_OK) return rcw;
         } else if (l == 256 && ((256 / p->R) & 1) == 0 && !p->cfg_generic)
             HIPCHK(fdc::launch_channels256(d_full, p->d_out, p->d_chans, p->d_groups + p->group_off[g],
                                            (int)p->groups[g].second.size(), p->g_aligned[g] != 0, p->g_out_aligned[g] != 0,
@@ -1590,7 +1708,6 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
     }
     if (spectrum) HIPCHK(hipMemcpyAsync(spectrum, d_full, sizeof(float2) * n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (d_owned) HIPCHK(hipFree(d_owned));
     p->blockcount += nblocks;
     if (sinks) {
         const int rs = fdc_sinks_work_device(sinks, nblocks);
@@ -1761,6 +1878,51 @@ void fdc_phase_window_destroy(fdc_phase_window *b)
     delete b;
 }
 
+// fdc_fft_vcc keeps what a transform size needs — twiddle table, device buffers, a stream — in a small per-(device, n) cache: a flowgraph
+// calls it item batch after item batch with the same n, and the first form (four hipMalloc, a table rebuilt and uploaded, hipDeviceSynchronize,
+// four hipFree per call) stalled every other stream of the device each time.  Buffers grow to the largest batch seen; at most kFftPlans sizes
+// stay cached (the least recently used one goes).
+}  // extern "C"
+namespace {
+struct FftPlan {
+    int dev = 0, n = 0;
+    float2 *d_in = nullptr, *d_out = nullptr, *d_tmp = nullptr, *d_tw = nullptr;
+    size_t cap_items = 0;
+    hipStream_t s = nullptr;
+    unsigned long long used = 0;
+    std::mutex mu;                               // one caller at a time per plan
+    void release()
+    {
+        (void)hipSetDevice(dev);
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_tmp); (void)hipFree(d_tw);
+    }
+};
+constexpr size_t kFftPlans = 8;
+std::mutex g_fft_mu;
+std::vector<std::shared_ptr<FftPlan>> g_fft_plans;
+unsigned long long g_fft_tick = 0;
+
+std::shared_ptr<FftPlan> fft_plan(int dev, int n)
+{
+    std::lock_guard<std::mutex> g(g_fft_mu);
+    for (auto &q : g_fft_plans)
+        if (q->dev == dev && q->n == n) { q->used = ++g_fft_tick; return q; }
+    if (g_fft_plans.size() >= kFftPlans) {
+        auto lru = std::min_element(g_fft_plans.begin(), g_fft_plans.end(), [](const auto &a, const auto &b) { return a->used < b->used; });
+        std::shared_ptr<FftPlan> old = *lru;
+        g_fft_plans.erase(lru);
+        std::lock_guard<std::mutex> busy(old->mu);   // a caller still inside it finishes first
+        old->release();
+    }
+    auto q = std::make_shared<FftPlan>();
+    q->dev = dev; q->n = n; q->used = ++g_fft_tick;
+    g_fft_plans.push_back(q);
+    return q;
+}
+}  // namespace
+extern "C" {
+
 int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, int nitems, void *out)
 {
     FDC_ENTRY("fdc_fft_vcc")
@@ -1768,24 +1930,31 @@ int fdc_fft_vcc(int device_id, int n, int forward, int shift, const void *in, in
     if (nitems <= 0) return nitems == 0 ? 0 : fail(FDC_ERR_INVALID_ARGUMENT, "negative item count");
     if (!in || !out) return fail(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     int rc = select_device(device_id); if (rc) return rc;
+    std::shared_ptr<FftPlan> q = fft_plan(device_id, n);
+    std::lock_guard<std::mutex> g(q->mu);
+    HIPCHK(hipSetDevice(device_id));
+    if (!q->s) HIPCHK(hipStreamCreateWithFlags(&q->s, hipStreamNonBlocking));
+    if (!q->d_tw) {
+        const std::vector<float2> tw = make_twiddles(n);
+        HIPCHK(hipMalloc(&q->d_tw, sizeof(float2) * (size_t)n));
+        HIPCHK(hipMemcpy(q->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    }
     const size_t nb = sizeof(float2) * (size_t)n * nitems;
-    float2 *d_in = nullptr, *d_out = nullptr, *d_tmp = nullptr, *d_tw = nullptr;
-    auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_tmp); (void)hipFree(d_tw); };
-#define CHK2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(FDC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-    CHK2(hipMalloc(&d_in, nb));
-    CHK2(hipMalloc(&d_out, nb));
-    if (n > fdc::kMaxLdsFft) CHK2(hipMalloc(&d_tmp, nb));
-    const std::vector<float2> tw = make_twiddles(n);
-    CHK2(hipMalloc(&d_tw, sizeof(float2) * (size_t)n));
-    CHK2(hipMemcpy(d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-    CHK2(hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice));
+    if ((size_t)nitems > q->cap_items) {
+        HIPCHK(hipStreamSynchronize(q->s));
+        (void)hipFree(q->d_in); (void)hipFree(q->d_out); (void)hipFree(q->d_tmp);
+        q->d_in = q->d_out = q->d_tmp = nullptr; q->cap_items = 0;
+        HIPCHK(hipMalloc(&q->d_in, nb));
+        HIPCHK(hipMalloc(&q->d_out, nb));
+        if (n > fdc::kMaxLdsFft) HIPCHK(hipMalloc(&q->d_tmp, nb));
+        q->cap_items = (size_t)nitems;
+    }
+    HIPCHK(hipMemcpyAsync(q->d_in, in, nb, hipMemcpyHostToDevice, q->s));
     // forward+shift: halves of the output swapped; inverse+shift: halves of the input swapped
     const int in_rot = (!forward && shift) ? n / 2 : 0, out_rot = (forward && shift) ? n / 2 : 0;
-    CHK2(fdc::launch_fft(d_in, (size_t)n, d_out, d_tmp, n, nitems, !forward, in_rot, out_rot, 1.0f, d_tw, n, nullptr, nullptr));
-    CHK2(hipDeviceSynchronize());
-    CHK2(hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost));
-#undef CHK2
-    cleanup();
+    HIPCHK(fdc::launch_fft(q->d_in, (size_t)n, q->d_out, q->d_tmp, n, nitems, !forward, in_rot, out_rot, 1.0f, q->d_tw, n, q->s, nullptr));
+    HIPCHK(hipMemcpyAsync(out, q->d_out, nb, hipMemcpyDeviceToHost, q->s));
+    HIPCHK(hipStreamSynchronize(q->s));
     return nitems;
     FDC_ENTRY_END
 }

@@ -892,6 +892,11 @@ int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead)
     HIPCHK(hipSetDevice(s->cfg.device_id));
     float2 *const spec = ahead ? s->d_spec_ahead : s->d_spec;
     float *const pw = ahead ? s->d_power_ahead : s->d_power;
+    if (!ahead) {
+        // the current buffer may have been filled on the bank's own stream (a batch 0 written there, fdc_sinks_work's copy): the cells wait for it
+        HIPCHK(hipEventRecord(s->ev_fill, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0));
+    }
     if (!s->cells.empty()) HIPCHK(fdc::launch_cell_power(spec + s->N, s->N, s->d_cells, (int)s->cells.size(), nblocks, pw, s->s_fill));
     HIPCHK(hipEventRecord(ahead ? s->ev_ready_ahead : s->ev_ready, s->s_fill));
     (ahead ? s->prepared_ahead : s->prepared) = nblocks;
@@ -1597,6 +1602,7 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     if (nitems == 0) { s->pdus.clear(); return 0; }
     if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     HIPCHK(hipSetDevice(s->cfg.device_id));
+    s->prepared = -1;                                          // the buffer is overwritten: power cells an earlier fdc_sinks_prepare left for it are stale
     HIPCHK(hipMemcpyAsync(s->d_spec + s->N, spectrum, sizeof(float2) * (size_t)nitems * s->N, hipMemcpyHostToDevice, s->stream));
     return fdc_sinks_work_device(s, nitems);
     FDC_ENTRY_END
@@ -1639,6 +1645,7 @@ int fdc_sinks_work_band(fdc_sinks *s, const void *spectrum, int nitems, int32_t 
     if (nitems == 0) { s->pdus.clear(); return 0; }
     if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     HIPCHK(hipSetDevice(s->cfg.device_id));
+    s->prepared = -1;                                          // as in fdc_sinks_work
     if (bin_hi > bin_lo) {
         const size_t pitch = sizeof(float2) * (size_t)s->N;
         HIPCHK(hipMemcpy2DAsync(s->d_spec + s->N + bin_lo, pitch, static_cast<const float2 *>(spectrum) + bin_lo, pitch,

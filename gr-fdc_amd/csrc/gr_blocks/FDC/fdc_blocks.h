@@ -57,8 +57,11 @@ public:
     virtual std::vector<int> devices() const = 0;
     virtual int max_items() const = 0;
     // Items per work() call the block asks of the scheduler (set_output_multiple + set_min_output_buffer, fdc_blocks.cc):
-    // 0 = the default — one device batch (max_items) for fdc_pipeline_vcc and the three sink blocks, 1 for the single-block
-    // faces.  Latency and the unprocessed tail of a finite stream are one batch; 1 = the reference's item-by-item behaviour.
+    // 0 or 1 = the default, the reference's item-by-item behaviour: every item of a finite stream is processed, whatever the
+    // scheduler offers.  n > 1 (typically max_items()) is the OPT-IN for device-sized batches: the scheduler then hands work()
+    // whole multiples of n and sizes the buffers for two of them (0.7 -> 4.1 Gsample/s at 256-KiB items) — at the price every block
+    // with an output multiple pays: one batch of latency, and when a FINITE stream drains its last partial batch (up to n - 1
+    // items, and any PDU of a burst in them) is never offered to work().  For flowgraphs that run without end.
     // Before the flowgraph starts (GNU Radio reads output_multiple when it allocates the buffers).
     virtual void set_scheduler_batch(int items) = 0;
     virtual int scheduler_batch() const = 0;
@@ -124,6 +127,37 @@ public:
     virtual int output_item_len(int port) const = 0;
     // which kernels the plan was given, in words (fdc_pipeline_describe; the first member of a group)
     virtual std::string kernel_plan() const = 0;
+
+    // The hier block's sink blocks on THIS block's spectrum (python/FrequencyDomainChannelizer.py:237-278 connects one
+    // PowerActivationChannel per activity-controlled channel and one SegmentDetection per segment to the normalised spectrum;
+    // here the spectrum never leaves the device: fdc_pipeline_work_sinks, include/fdc_amd.h).  Frequencies in the hier block's
+    // INTERNAL units ([0, 1), DC at 0.5: what its get_freq / get_bw lambdas return, :70-91); the other fields are the hier block's
+    // constructor arguments of the same names.  PDUs leave on this block's "msgout" port (and / or as files under `path`) exactly as
+    // the reference's blocks publish them.
+    //   pipelined = false: the PDUs of a work() call's items are published inside that call (the reference's behaviour);
+    //   pipelined = true : the sinks of one call run beside the input copy and forward transform of the next — what GNU Radio's
+    //                      thread-per-block scheduler does for the reference's separate blocks; PDUs are published sinks_latency()
+    //                      work() calls later (2; 1 with verbose != 0), the rest at stop().  One device (set_devices of one entry).
+    struct sink_setup {
+        std::vector<std::vector<float>> activity_controlled_channels;   // rows (cfreq, bw); ID = row index
+        float pac_thresh = 6.0f;            // act_contr_threshold, dB
+        int pac_maxblocks = -1;             // pow_act_maxblocks
+        int pac_deactivation_delay = 0;     // pow_act_deactivation_delay
+        std::vector<std::vector<float>> activity_detection_segments;    // rows (start, stop)
+        float det_thresh = 10.0f;           // act_det_threshold, dB
+        int det_maxblocks = -1;             // act_det_maxblocks
+        float minchandist = 0.005f;
+        int det_deactivation_delay = 1;     // act_det_deactivation_delay
+        double window_flank_puffer = 0.2;   // minchanflankpuffer
+        bool msgoutput = true, fileoutput = false;
+        std::string path;
+        int verbose = 0;
+        bool pipelined = false;
+    };
+    virtual void attach_sinks(const sink_setup &s) = 0;     // before the flowgraph starts; throws what the sink blocks' make() throws
+    virtual int sinks_latency() const = 0;                  // work() calls between an item and its PDUs (0 serial, 1 or 2 pipelined)
+    // publishes what the pipelined sinks still hold (stop() calls it); returns the number of batches handed out, -1 on failure
+    virtual int flush_sinks() = 0;
 };
 
 }  // namespace FDC

@@ -12,6 +12,7 @@
 #include "compat/gnuradio/stock_scheduler.h"
 #endif
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -95,11 +96,13 @@ static int stock_main(int argc, char **argv)
         std::printf("{\"mode\": \"stock scheduler stand-in\", \"blocklen\": %d, \"relinvovl\": %d, \"channels\": %d, \"max_items\": %d, "
                     "\"scheduler_batch\": %d, \"in_buffer_items\": %ld, \"out_buffer_items\": %ld, \"pinned\": %s, \"items\": %ld, \"calls\": %ld, "
                     "\"items_per_call_min\": %ld, \"items_per_call_max\": %ld, \"wall_s\": %.6f, \"work_s\": %.6f, "
-                    "\"gsamples_per_s_wall\": %.4f, \"gsamples_per_s_in_work\": %.4f, \"status\": %d, \"channels_mismatched\": %ld, \"plan\": \"%s\"}\n",
+                    "\"gsamples_per_s_wall\": %.4f, \"gsamples_per_s_in_work\": %.4f, \"status\": %d, \"channels_mismatched\": %ld, "
+                    "\"items_offered\": %ld, \"items_left_unprocessed\": %ld, \"plan\": \"%s\"}\n",
                     N, R, C, pipe->max_items(), pipe->scheduler_batch(), r.in_buffer_items, r.out_buffer_items.empty() ? 0L : r.out_buffer_items[0],
                     r.pinned ? "true" : "false", r.items, r.calls, r.min_call, r.max_call, r.wall_seconds, r.work_seconds,
                     r.wall_seconds > 0 ? (double)r.items * H / r.wall_seconds / 1e9 : 0.0, r.work_seconds > 0 ? (double)r.items * H / r.work_seconds / 1e9 : 0.0,
-                    r.status, mismatched, pipe->kernel_plan().c_str());
+                    r.status, mismatched, total, total - r.items /* the tail an output multiple leaves behind when a finite stream drains */,
+                    pipe->kernel_plan().c_str());
         return (r.status == 0 && mismatched <= 0) ? 0 : 1;
     } catch (const std::exception &e) {
         std::cerr << "blocks_demo stock: " << e.what() << std::endl;
@@ -185,6 +188,65 @@ int main(int argc, char **argv)
             bool threw2 = false;
             try { fdc_pipeline_vcc::make(N, R, {{0.f, 64.f, 0.9f, 0.5f}}, 1, 4); } catch (const std::invalid_argument &) { threw2 = true; }
             if (!threw2) throw std::runtime_error("fdc_pipeline_vcc: bad channel did not throw");
+        }
+
+        // The hier block as ONE block: fdc_pipeline_vcc with the sink blocks attached to its device-resident spectrum, the stream handed
+        // over in ragged work() calls; once serial (PDUs inside the call), once pipelined (PDUs two calls later, the rest at stop()):
+        // the same messages in the same order, payloads bit for bit.  <dir>/xb.c64 -> hier_pdus.txt / hier_pdus.out / hier_pipe0.out
+        {
+            std::ifstream probe(dir + "/xb.c64", std::ios::binary);
+            if (probe.good()) {
+                const auto xb = slurp(dir + "/xb.c64");
+                const int nbb = (int)(xb.size() / (size_t)H);
+                const std::vector<std::vector<float>> chans = {{128.f, 256.f, 0.8f, 1.0f}};
+                fdc_pipeline_vcc::sink_setup ss;
+                ss.activity_controlled_channels = {{0.3f, 0.04f}};
+                ss.pac_thresh = 6.0f; ss.pac_maxblocks = 3; ss.pac_deactivation_delay = 0;
+                ss.activity_detection_segments = {{0.55f, 0.9f}};
+                ss.det_thresh = 10.0f; ss.det_maxblocks = 3; ss.minchandist = 0.01f; ss.det_deactivation_delay = 1;
+                std::vector<std::vector<gr::fdc_message>> msgs(2);
+                std::vector<std::vector<gr_complex>> outs(2);
+                for (int form = 0; form < 2; form++) {
+                    auto hb = fdc_pipeline_vcc::make(N, R, chans, 1, 5);
+                    ss.pipelined = form == 1;
+                    hb->attach_sinks(ss);
+                    if (hb->sinks_latency() != (form ? 2 : 0)) throw std::runtime_error("hier block: unexpected PDU latency");
+                    outs[(size_t)form].resize((size_t)nbb * hb->output_item_len(0));
+                    const int sizes[] = {3, 5, 1, 4, 5, 2};
+                    int a = 0, k = 0;
+                    size_t before = 0;
+                    while (a < nbb) {
+                        const int n = std::min(sizes[k++ % 6], nbb - a);
+                        gr_vector_const_void_star pi{xb.data() + (size_t)a * H};
+                        gr_vector_void_star pv{outs[(size_t)form].data() + (size_t)a * hb->output_item_len(0)};
+                        if (hb->work(n, pi, pv) != n) throw std::runtime_error("hier block: work() failed");
+                        if (form == 1 && k <= 2 && hb->published().size() != before) throw std::runtime_error("hier block: PDUs before their latency");
+                        before = hb->published().size();
+                        a += n;
+                    }
+                    hb->stop();
+                    msgs[(size_t)form] = hb->published();
+                }
+                if (msgs[0].size() < 2 || msgs[0].size() != msgs[1].size()) throw std::runtime_error("hier block: pipelined form publishes another number of PDUs");
+                for (size_t i = 0; i < msgs[0].size(); i++) {
+                    gr::fdc_message &u = msgs[0][i], &v = msgs[1][i];
+                    if (u.str["ID"].substr(20) != v.str["ID"].substr(20) || u.num != v.num || u.real != v.real || u.flag != v.flag ||
+                        u.samples.size() != v.samples.size() ||
+                        std::memcmp(u.samples.data(), v.samples.data(), u.samples.size() * sizeof(gr_complex)) != 0)
+                        throw std::runtime_error("hier block: PDU " + std::to_string(i) + " of the pipelined form differs from the serial form");
+                }
+                if (std::memcmp(outs[0].data(), outs[1].data(), outs[0].size() * sizeof(gr_complex)) != 0)
+                    throw std::runtime_error("hier block: stream output of the pipelined form differs");
+                std::vector<gr_complex> all;
+                FILE *meta = std::fopen((dir + "/hier_pdus.txt").c_str(), "w");
+                for (auto &m : msgs[0]) {
+                    std::fprintf(meta, "%s %ld %ld %zu\n", m.str["ID"].c_str(), m.num["blockstart"], m.num["blockend"], m.samples.size());
+                    all.insert(all.end(), m.samples.begin(), m.samples.end());
+                }
+                std::fclose(meta);
+                dump(dir + "/hier_pdus.out", all);
+                dump(dir + "/hier_pipe0.out", outs[0]);
+            }
         }
 
         const auto spec = slurp(dir + "/spec.c64");

@@ -39,7 +39,9 @@ int report(const char *who, int n)
 // 4.5 at 256 items).  output_multiple = batch makes (i) every upstream buffer hold >= 2 batches (the
 // reader's multiple counts), (ii) this block's buffers hold >= 2 batches, (iii) every call a whole number of batches.
 // The price, as for every block with an output multiple: latency of one batch, and the last partial batch of a finite stream is
-// not processed when the flowgraph drains.  set_scheduler_batch(1) is the reference's item-by-item behaviour.
+// NOT PROCESSED when the flowgraph drains (up to batch - 1 items, and any PDU of a burst in that tail).  The reference's blocks process
+// every item, so the default is batch = 1 for every face (round 6); a flowgraph that runs without end — a receiver — opts in with
+// set_scheduler_batch(max_items()) and gets 0.7 -> 4.1 Gsample/s.
 template <class Blk>
 void apply_scheduler_hints(Blk *blk, int batch, int max_items, int nout)
 {
@@ -53,9 +55,9 @@ class device_state {
 protected:
     std::vector<int> d_devices{0};
     int d_max_items = 64;
-    int d_batch = 0;                       // items per work() call asked of the scheduler; 0 = the class default (sched_batch())
-    bool d_batch_follows = true;           // fused chain and sinks: one device batch; single-block faces: 1
-    int sched_batch() const { return d_batch > 0 ? std::min(d_batch, d_max_items) : d_batch_follows ? d_max_items : 1; }
+    int d_batch = 0;                       // items per work() call asked of the scheduler; 0 = the default: 1, the reference's item-by-item
+                                           // behaviour (every item of a finite stream is processed); device-sized batches are opt-in
+    int sched_batch() const { return d_batch > 0 ? std::min(d_batch, d_max_items) : 1; }
     virtual ~device_state() {}
     virtual void rebuild() = 0;            // destroy the handle(s), create them again from d_devices / d_max_items; throws like make()
     void assign_devices(const std::vector<int> &devices)
@@ -103,7 +105,6 @@ public:
                          gr::io_signature::make(1, 1, itemsize * outputlen)),
           d_itemsize(itemsize), d_outputlen(outputlen), d_overlaplen(overlaplen)
     {
-        d_batch_follows = false;           // a byte copy per item: no batch asked for unless set_scheduler_batch() does
         rebuild();
     }
     ~overlap_save_impl() override { fdc_overlap_save_destroy(d_h); }
@@ -129,7 +130,6 @@ public:
                          gr::io_signature::make(1, 1, itemsize * blocklen)),
           d_itemsize(itemsize), d_veclen(veclen), d_offset(offset), d_blocklen(blocklen)
     {
-        d_batch_follows = false;
         rebuild();
     }
     ~vector_cut_vxx_impl() override { fdc_vector_cut_destroy(d_h); }
@@ -156,7 +156,6 @@ public:
                          gr::io_signature::make(1, 1, sizeof(gr_complex) * blocklen)),
           d_blocklen(blocklen), d_states(numphasestates), d_shifts(shifts), d_windowtype(windowtype), d_passbw(passbw), d_stopbw(stopbw)
     {
-        d_batch_follows = false;
         rebuild();
     }
     ~phase_shifting_windowing_vcc_impl() override { fdc_phase_window_destroy(d_h); }
@@ -166,6 +165,56 @@ public:
     }
 };
 
+// PDU records -> messages on "msgout" and raw files, as the reference's blocks publish them (a PowerActivationChannel's PDU is kind 0)
+void publish_pdus(gr::sync_block *blk, const std::vector<fdc_pdu> &all, bool d_msg, bool d_file, const std::string &d_path)
+{
+    for (const fdc_pdu &p : all) {
+        const bool pac = p.kind == 0;
+        const std::string id(p.id);          // "<time>.PowActChan.<ID>.<n>" / "<time>.DETECTED.<seg>.<n>", fixed at activation
+        const gr_complex *d = static_cast<const gr_complex *>(p.samples);
+        if (d_msg) {
+#ifdef FDC_HAVE_GNURADIO
+            // the reference's PDU: pmt::cons(dict, c32vector), keys in its order (PowerActivationChannel_impl.cc:222-232,
+            // activity_detection_channelizer_vcm_impl.cc:415-429)
+            pmt::pmt_t dict = pmt::make_dict();
+            dict = pmt::dict_add(dict, pmt::intern("ID"), pmt::intern(pac ? id + (p.finalized ? ".fin" : ".part") : id));
+            dict = pmt::dict_add(dict, pmt::intern("finalized"), pmt::from_bool(p.finalized != 0));
+            if (p.has_part) dict = pmt::dict_add(dict, pmt::intern("part"), pmt::from_long(p.part));
+            if (pac) {
+                dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
+                dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
+            } else {
+                dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
+                dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
+            }
+            dict = pmt::dict_add(dict, pmt::intern("blockstart"), pmt::from_long((long)p.blockstart));
+            dict = pmt::dict_add(dict, pmt::intern("blockend"), pmt::from_long((long)p.blockend));
+            if (!pac) {
+                dict = pmt::dict_add(dict, pmt::intern("vectorstart"), pmt::from_long((long)p.vectorstart));
+                dict = pmt::dict_add(dict, pmt::intern("vectorend"), pmt::from_long((long)p.vectorend));
+            }
+            blk->message_port_pub(pmt::intern("msgout"), pmt::cons(dict, pmt::init_c32vector((size_t)p.nsamples, d)));
+#else
+            gr::fdc_message m;               // the same PDU without pmt (compat build)
+            m.str["ID"] = pac ? id + (p.finalized ? ".fin" : ".part") : id;
+            m.flag["finalized"] = p.finalized != 0;
+            if (p.has_part) m.num["part"] = p.part;
+            m.real["rel_bw"] = p.rel_bw; m.real["rel_cfreq"] = p.rel_cfreq;
+            m.num["blockstart"] = (long)p.blockstart; m.num["blockend"] = (long)p.blockend;
+            if (!pac) { m.num["vectorstart"] = (long)p.vectorstart; m.num["vectorend"] = (long)p.vectorend; }
+            m.samples.assign(d, d + p.nsamples);
+            blk->message_port_pub("msgout", m);
+#endif
+        }
+        if (d_file) {
+            const std::string fn = d_path + "/" + id + (p.finalized ? std::string(".fin") : ".parted." + std::to_string(p.part));
+            FILE *fh = std::fopen(fn.c_str(), "wb");
+            if (!fh) std::cerr << "Cannot write to file " << fn << std::endl;
+            else { std::fwrite(d, sizeof(gr_complex), (size_t)p.nsamples, fh); std::fclose(fh); }
+        }
+    }
+}
+
 class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
     fdc_pipeline *d_p = nullptr;               // one device
     fdc_pipeline_group *d_g = nullptr;         // several devices: one work() call cut into spans (include/fdc_amd.h)
@@ -174,6 +223,12 @@ class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
     size_t d_in_item = 0;
     std::vector<int> d_lout;
     std::vector<void *> d_pinned;
+    // attach_sinks(): the hier block's sink blocks on this block's device-resident spectrum
+    bool d_has_sinks = false;
+    sink_setup d_ss;
+    fdc_sinks *d_s = nullptr;
+    std::vector<fdc_pac_cfg> d_pacs;
+    std::vector<fdc_segment_cfg> d_segs;
     static std::vector<int> out_sizes(int relinvovl, const std::vector<std::vector<float>> &ch)
     {
         std::vector<int> v;
@@ -186,9 +241,13 @@ class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
     }
     void rebuild() override
     {
+        drop_sinks();
         fdc_pipeline_destroy(d_p); d_p = nullptr;
         fdc_pipeline_group_destroy(d_g); d_g = nullptr;
-        fdc_pipeline_cfg cfg{d_devices[0], d_blocklen, d_relinvovl, d_windowtype, (int32_t)d_ch.size(), d_ch.data(), d_max_items, 0, 0};
+        fdc_pipeline_cfg cfg{d_devices[0], d_blocklen, d_relinvovl, d_windowtype, (int32_t)d_ch.size(), d_ch.data(), d_max_items, 0,
+                             d_has_sinks ? 1 : 0 /* keep_spectrum: the sinks read it */};
+        if (d_has_sinks && d_devices.size() > 1)
+            throw std::invalid_argument("fdc_pipeline_vcc: the sink blocks read ONE device's spectrum; a block with sinks runs on one device");
         if (d_devices.size() > 1) {
             std::vector<int32_t> dv(d_devices.begin(), d_devices.end());
             check_create(fdc_pipeline_group_create(&cfg, dv.data(), (int)dv.size(), 0, &d_g));
@@ -200,9 +259,72 @@ class fdc_pipeline_vcc_impl : public fdc_pipeline_vcc, device_state {
         for (size_t i = 0; i < d_ch.size(); i++) d_lout.push_back(fdc_pipeline_channel_lout(p0, (int)i));
         // the scheduler offers whole device batches and sizes this block's and its upstream buffers for two of them
         apply_scheduler_hints(this, sched_batch(), d_max_items, (int)d_ch.size());
+        if (d_has_sinks) {
+            fdc_sinks_cfg c{};
+            c.device_id = d_devices[0]; c.blocklen = d_blocklen; c.relinvovl = d_relinvovl;
+            c.npac = (int32_t)d_pacs.size(); c.pac = d_pacs.data();
+            c.pac_thresh_db = d_ss.pac_thresh; c.pac_maxblocks = d_ss.pac_maxblocks; c.pac_deactivation_delay = d_ss.pac_deactivation_delay;
+            c.nseg = (int32_t)d_segs.size(); c.seg = d_segs.data();
+            c.det_thresh_db = d_ss.det_thresh; c.det_maxblocks = d_ss.det_maxblocks; c.minchandist = d_ss.minchandist;
+            c.det_deactivation_delay = d_ss.det_deactivation_delay; c.window_flank_puffer = d_ss.window_flank_puffer;
+            c.max_blocks = d_max_items;
+            c.det_variant = 1;                 // the hier block instantiates SegmentDetection (python/FrequencyDomainChannelizer.py:261-278)
+            c.verbose = d_ss.verbose; c.det_id = -1;
+            c.flags = d_ss.pipelined ? FDC_SINKS_LOOKAHEAD : 0;
+            check_create(fdc_sinks_create(&c, &d_s));
+        }
+    }
+    void drop_sinks()
+    {
+        if (d_s && d_p) while (fdc_pipeline_flush_sinks(d_p, d_s) > 0) {}      // nothing of the bank may be in flight when it goes
+        fdc_sinks_destroy(d_s); d_s = nullptr;
+    }
+    void publish_current()
+    {
+        std::vector<fdc_pdu> all((size_t)fdc_sinks_pdu_count(d_s));
+        fdc_sinks_pdus(d_s, all.data(), (int)all.size());
+        publish_pdus(this, all, d_ss.msgoutput, d_ss.fileoutput, d_ss.path);
     }
 public:
     FDC_DEVICE_CONFIG
+    void attach_sinks(const sink_setup &ss) override
+    {
+        for (const auto &v : ss.activity_controlled_channels)
+            if (v.size() != 2) throw std::invalid_argument("attach_sinks: activity-controlled channels are rows (cfreq, bw)");
+        for (const auto &v : ss.activity_detection_segments)
+            if (v.size() != 2) throw std::invalid_argument("Segment is incorrect. must be of size 2");
+        const bool had = d_has_sinks;
+        const sink_setup before = d_ss;
+        const std::vector<fdc_pac_cfg> pacs0 = d_pacs;
+        const std::vector<fdc_segment_cfg> segs0 = d_segs;
+        d_ss = ss; d_pacs.clear(); d_segs.clear();
+        for (size_t i = 0; i < ss.activity_controlled_channels.size(); i++)      // ID = index in the list (:239-250)
+            d_pacs.push_back(fdc_pac_cfg{ss.activity_controlled_channels[i][0], ss.activity_controlled_channels[i][1], (int32_t)i});
+        for (const auto &v : ss.activity_detection_segments) d_segs.push_back(fdc_segment_cfg{v[0], v[1]});
+        d_has_sinks = !d_pacs.empty() || !d_segs.empty();
+        try { rebuild(); }
+        catch (...) { d_has_sinks = had; d_ss = before; d_pacs = pacs0; d_segs = segs0; try { rebuild(); } catch (...) {} throw; }
+        if (d_has_sinks && ss.msgoutput) {
+#ifdef FDC_HAVE_GNURADIO
+            message_port_register_out(pmt::intern("msgout"));
+#else
+            message_port_register_out("msgout");
+#endif
+        }
+    }
+    int sinks_latency() const override { return d_s && d_p ? fdc_pipeline_sinks_latency(d_p, d_s) : 0; }
+    int flush_sinks() override
+    {
+        int batches = 0;
+        if (!d_s || !d_p) return 0;
+        for (;;) {
+            const int r = fdc_pipeline_flush_sinks(d_p, d_s);
+            if (r < 0) { std::cerr << "fdc_pipeline_vcc: " << fdc_last_error() << std::endl; return -1; }
+            if (r == 0) return batches;
+            publish_current();
+            batches++;
+        }
+    }
     fdc_pipeline_vcc_impl(int blocklen, int relinvovl, const std::vector<std::vector<float>> &channels, int windowtype, int max_items)
         : gr::sync_block("fdc_pipeline_vcc",
                          gr::io_signature::make(1, 1, (int)sizeof(gr_complex) * (blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1))),
@@ -216,7 +338,7 @@ public:
         d_in_item = sizeof(gr_complex) * (size_t)(blocklen - blocklen / (relinvovl > 0 ? relinvovl : 1));
         rebuild();
     }
-    ~fdc_pipeline_vcc_impl() override { unpin_buffers(); fdc_pipeline_destroy(d_p); fdc_pipeline_group_destroy(d_g); }
+    ~fdc_pipeline_vcc_impl() override { unpin_buffers(); drop_sinks(); fdc_pipeline_destroy(d_p); fdc_pipeline_group_destroy(d_g); }
 #ifdef FDC_HAVE_GNURADIO
     // the flowgraph has allocated this block's port buffers (flat_flowgraph::setup_connections runs before start()): pin both
     // mappings of every circular buffer once, so that work() DMAs in place.  A buffer that cannot be pinned stays pageable.
@@ -235,7 +357,10 @@ public:
         }
         return true;
     }
-    bool stop() override { unpin_buffers(); return true; }
+    // the pipelined sinks still hold the PDUs of the last one or two work() calls: they go out before the flowgraph is torn down
+    bool stop() override { flush_sinks(); unpin_buffers(); return true; }
+#else
+    bool stop() override { flush_sinks(); return true; }
 #endif
     int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
@@ -247,8 +372,10 @@ public:
                 o[c] = static_cast<char *>(out[c]) + (size_t)a * (size_t)d_lout[c] * sizeof(gr_complex);
             const char *src = static_cast<const char *>(in[0]) + (size_t)a * d_in_item;
             const int r = report("fdc_pipeline_vcc", d_g ? fdc_pipeline_group_work(d_g, src, k, o.data(), nullptr)
-                                                         : fdc_pipeline_work(d_p, src, k, o.data(), nullptr));
+                                                     : d_s ? fdc_pipeline_work_sinks(d_p, src, k, o.data(), nullptr, d_s)
+                                                           : fdc_pipeline_work(d_p, src, k, o.data(), nullptr));
             if (r != k) return a > 0 ? a : r;
+            if (d_s) publish_current();          // serial bank: this piece's PDUs; pipelined: those of one or two pieces ago
         }
         return n;
     }
@@ -303,54 +430,11 @@ protected:
     virtual void apply_hints() = 0;            // the block face applies the scheduler hints (it is the gr::sync_block)
     ~sink_base() override { fdc_sinks_destroy(d_s); fdc_sinks_group_destroy(d_sg); }
     int sink_work(const void *items, int n) { return d_sg ? fdc_sinks_group_work(d_sg, items, n) : fdc_sinks_work(d_s, items, n); }
-    void publish(gr::sync_block *blk, bool pac)
+    void publish(gr::sync_block *blk, bool)
     {
         std::vector<fdc_pdu> all((size_t)(d_sg ? fdc_sinks_group_pdu_count(d_sg) : fdc_sinks_pdu_count(d_s)));
         if (d_sg) fdc_sinks_group_pdus(d_sg, all.data(), (int)all.size()); else fdc_sinks_pdus(d_s, all.data(), (int)all.size());
-        for (const fdc_pdu &p : all) {
-            const std::string id(p.id);          // "<time>.PowActChan.<ID>.<n>" / "<time>.DETECTED.<seg>.<n>", fixed at activation
-            const gr_complex *d = static_cast<const gr_complex *>(p.samples);
-            if (d_msg) {
-#ifdef FDC_HAVE_GNURADIO
-                // the reference's PDU: pmt::cons(dict, c32vector), keys in its order (PowerActivationChannel_impl.cc:222-232,
-                // activity_detection_channelizer_vcm_impl.cc:415-429)
-                pmt::pmt_t dict = pmt::make_dict();
-                dict = pmt::dict_add(dict, pmt::intern("ID"), pmt::intern(pac ? id + (p.finalized ? ".fin" : ".part") : id));
-                dict = pmt::dict_add(dict, pmt::intern("finalized"), pmt::from_bool(p.finalized != 0));
-                if (p.has_part) dict = pmt::dict_add(dict, pmt::intern("part"), pmt::from_long(p.part));
-                if (pac) {
-                    dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
-                    dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
-                } else {
-                    dict = pmt::dict_add(dict, pmt::intern("rel_bw"), pmt::from_double(p.rel_bw));
-                    dict = pmt::dict_add(dict, pmt::intern("rel_cfreq"), pmt::from_double(p.rel_cfreq));
-                }
-                dict = pmt::dict_add(dict, pmt::intern("blockstart"), pmt::from_long((long)p.blockstart));
-                dict = pmt::dict_add(dict, pmt::intern("blockend"), pmt::from_long((long)p.blockend));
-                if (!pac) {
-                    dict = pmt::dict_add(dict, pmt::intern("vectorstart"), pmt::from_long((long)p.vectorstart));
-                    dict = pmt::dict_add(dict, pmt::intern("vectorend"), pmt::from_long((long)p.vectorend));
-                }
-                blk->message_port_pub(pmt::intern("msgout"), pmt::cons(dict, pmt::init_c32vector((size_t)p.nsamples, d)));
-#else
-                gr::fdc_message m;               // the same PDU without pmt (compat build)
-                m.str["ID"] = pac ? id + (p.finalized ? ".fin" : ".part") : id;
-                m.flag["finalized"] = p.finalized != 0;
-                if (p.has_part) m.num["part"] = p.part;
-                m.real["rel_bw"] = p.rel_bw; m.real["rel_cfreq"] = p.rel_cfreq;
-                m.num["blockstart"] = (long)p.blockstart; m.num["blockend"] = (long)p.blockend;
-                if (!pac) { m.num["vectorstart"] = (long)p.vectorstart; m.num["vectorend"] = (long)p.vectorend; }
-                m.samples.assign(d, d + p.nsamples);
-                blk->message_port_pub("msgout", m);
-#endif
-            }
-            if (d_file) {
-                const std::string fn = d_path + "/" + id + (p.finalized ? std::string(".fin") : ".parted." + std::to_string(p.part));
-                FILE *fh = std::fopen(fn.c_str(), "wb");
-                if (!fh) std::cerr << "Cannot write to file " << fn << std::endl;
-                else { std::fwrite(d, sizeof(gr_complex), (size_t)p.nsamples, fh); std::fclose(fh); }
-            }
-        }
+        publish_pdus(blk, all, d_msg, d_file, d_path);
     }
     void register_port(gr::sync_block *blk)
     {

@@ -331,9 +331,30 @@ int fdc_pipeline_work_spectrum(fdc_pipeline *p, const void *in, int nblocks, voi
 int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
 /* The whole hier block in one call: fdc_pipeline_work() whose spectrum lands directly in the sinks' device buffer,
  * followed by the sinks' work on it (python/FrequencyDomainChannelizer.py:283-312).  The pipeline needs keep_spectrum,
- * the same blocklen/device as the sinks and nblocks <= the sinks' max_blocks. */
+ * the same blocklen/device as the sinks and nblocks <= the sinks' max_blocks.
+ * Two forms, chosen by the BANK:
+ *  - a bank without FDC_SINKS_LOOKAHEAD (default): front end, then the sinks, inside the call; fdc_sinks_pdu*() afterwards give the PDUs
+ *    the reference's blocks would have published for exactly these items (the reference's item-by-item behaviour, whatever the batch);
+ *  - a bank created with FDC_SINKS_LOOKAHEAD: PIPELINED (round 6).  In the reference the front end and every sink are blocks of one
+ *    flowgraph that GNU Radio's thread-per-block scheduler runs side by side (python/FrequencyDomainChannelizer.py:237-278); here one call
+ *    copies and transforms ITS items into the bank's next-batch buffer on the bank's fill stream (power cells behind them), submits the
+ *    batch the call BEFORE left there (fdc_sinks_submit_device: decision chains beside this call's copy and transform, then extractions)
+ *    and hands out the PDUs of the batch before that one, whose payload copy ran meanwhile.  The call returns when its input has left the
+ *    caller's buffer (and its stream outputs / debug spectrum, if any, have arrived): with pinned input and no stream outputs it costs what
+ *    its input copy costs.  fdc_sinks_pdu*() after call n give the PDUs of the items of call n - fdc_pipeline_sinks_latency() (2 on the
+ *    device engine, 1 on the host engine; none for the first calls) — same PDUs, same order, same bits as the serial form, later.
+ *    fdc_pipeline_flush_sinks() hands out what is still inside: call it until it returns 0 when the stream ends (the block's stop()).
+ *    The persistent forward kernel leaves ncu/8 compute units to the bank's chains when a call is long enough to take it through two
+ *    rounds (fdc_pipeline_reserve_compute_units overrides).  Between the first pipelined call and the last flush the bank belongs to the
+ *    pipeline: no fdc_sinks_work*() / submit / prepare on it from elsewhere; flush before destroying either handle or resetting the
+ *    pipeline (fdc_pipeline_reset drops a batch that was not submitted yet). */
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                             fdc_sinks *sinks);
+/* Pipelined form: submits / finishes the oldest batch still inside and makes its PDUs the bank's current ones; returns its block count,
+ * 0 when nothing is left (serial form: always 0), or a negative fdc_status. */
+int fdc_pipeline_flush_sinks(fdc_pipeline *p, fdc_sinks *sinks);
+/* How many calls later the PDUs of a call's items are handed out: 0 (serial form), 1 or 2 (pipelined; see above); -1 for a null handle. */
+int32_t fdc_pipeline_sinks_latency(const fdc_pipeline *p, const fdc_sinks *sinks);
 void fdc_sinks_destroy(fdc_sinks *s);
 /* work()-shaped: nitems normalised-spectrum items of blocklen samples each on the host; returns nitems */
 int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems);
@@ -366,7 +387,7 @@ int32_t fdc_sinks_engine(const fdc_sinks *s);       /* 0 = host decisions, 1 = d
  * PowerActivationChannel, one workgroup per detection segment (lib/activity_detection_channelizer_vcm_impl.cc:741-841 is sequential over
  * blocks and channels) — that leave the device idle, and the host has to see their summary before it can size the extraction launches.
  * With two spectrum buffers the producer fills batch n + 1 beside them:
- *     fill(fdc_sinks_spectrum(s)) on fdc_sinks_stream(s) or fdc_sinks_fill_stream(s)          batch 0
+ *     fill(fdc_sinks_spectrum(s)) on fdc_sinks_fill_stream(s)                                 batch 0   (a look-ahead bank is filled on the fill stream only)
  *     loop:  fill(fdc_sinks_spectrum_ahead(s)) on fdc_sinks_fill_stream(s)                    batch n + 1   (never on fdc_sinks_stream)
  *            fdc_sinks_prepare(s, nblocks, 1)                          its power cells behind the fill, and the mark "batch n + 1 complete"
  *            fdc_sinks_submit_device(s, nblocks)                       batch n; afterwards fdc_sinks_spectrum(s) names batch n + 1's buffer

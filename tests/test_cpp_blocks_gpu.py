@@ -22,6 +22,17 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     spec[3:8, 300:340] += (rng.standard_normal((5, 40)) + 1j * rng.standard_normal((5, 40))).astype(np.complex64)
     spec[5:11, 700:760] += (rng.standard_normal((6, 60)) + 1j * rng.standard_normal((6, 60))).astype(np.complex64)
     x.tofile(tmp_path / "x.c64"); spec.tofile(tmp_path / "spec.c64")
+    # the hier block as one C++ block (fdc_pipeline_vcc::attach_sinks, round 6): a bursty stream with a carrier inside the
+    # activity-controlled channel (0.3) and one inside the detection segment [0.55, 0.9]
+    nbb = 26
+    n = np.arange(nbb * H)
+    xb = 0.01 * (rng.standard_normal(nbb * H) + 1j * rng.standard_normal(nbb * H))
+    for fc, t0, t1 in [(0.3 - 0.5, 3, 9), (0.7 - 0.5, 6, 15), (0.3 - 0.5, 14, 19), (0.74 - 0.5, 18, 24)]:
+        env = np.zeros(nbb * H); env[t0 * H:t1 * H] = 1.0
+        sym = (rng.integers(0, 2, nbb * H // 64 + 1) * 2 - 1) + 1j * (rng.integers(0, 2, nbb * H // 64 + 1) * 2 - 1)
+        xb += env * np.repeat(sym, 64)[:nbb * H] * np.exp(2j * np.pi * fc * n)
+    xb = xb.astype(np.complex64)
+    xb.tofile(tmp_path / "xb.c64")
     subprocess.check_call([DEMO, str(tmp_path)], cwd=str(tmp_path))
     rd = lambda n: np.fromfile(tmp_path / n, dtype=np.complex64)   # noqa: E731
     blocks = oracle.OverlapSave(8, N, N // R).work(x)
@@ -59,6 +70,27 @@ def test_cpp_block_faces_against_oracle(oracle, tmp_path):
     allref = np.concatenate([r["samples"] for r in ref])
     got = rd("pdus.out")
     assert got.size == allref.size and np.abs(got - allref).max() <= 1e-5 * np.abs(allref).max()
+    # hier block (blocks_demo has already checked: pipelined == serial, bit for bit): the serial form against the oracle
+    href, hspec = oracle.channelizer(N, R, 1, [(128, 256, 0.8, 1.0)], xb, want_spectrum=True, nthreads=2)
+    got = rd("hier_pipe0.out")
+    assert got.size == href[0].size and np.abs(got - href[0]).max() <= 1e-5 * np.abs(href[0]).max()
+    hspec = hspec.reshape(nbb, N)
+    pref = oracle.PowerActivationChannel(N, 0.3, 0.04, R, 6.0, 3, 0, 0).work(hspec)
+    dref = oracle.SegmentDetection(0, N, R, 0.55, 0.9, 10.0, 0.01, 0.2, 3, 1).work(hspec)
+    lines = [ln.split() for ln in open(tmp_path / "hier_pdus.txt").read().split("\n")[:-1]]
+    gp = [ln for ln in lines if ".PowActChan." in ln[0]]
+    gd = [ln for ln in lines if ".DETECTED." in ln[0]]
+    assert len(pref) >= 2 and len(dref) >= 2 and len(gp) == len(pref) and len(gd) == len(dref)
+    for ln, r in zip(gp + gd, pref + dref):
+        assert (int(ln[1]), int(ln[2]), int(ln[3])) == (r["blockstart"], r["blockend"], r["samples"].size)
+    # payloads: the file holds them in publication order (per work() call: PowerActivationChannels, then the segments)
+    got = rd("hier_pdus.out")
+    off, by_kind = 0, {"P": [], "D": []}
+    for ln in lines:
+        by_kind["P" if ".PowActChan." in ln[0] else "D"].append(got[off:off + int(ln[3])]); off += int(ln[3])
+    for g, r in zip(by_kind["P"] + by_kind["D"], pref + dref):
+        if r["samples"].size:
+            assert np.abs(g - r["samples"]).max() <= 1e-5 * np.abs(r["samples"]).max()
 
 
 def test_plain_c_example_runs(tmp_path):
@@ -76,20 +108,23 @@ def test_plain_c_example_runs(tmp_path):
 def test_stock_scheduler_gets_device_sized_batches():
     """VERDICT r04 missing #1: fdc_pipeline_vcc behind the stock-scheduler stand-in (compat/gnuradio/stock_scheduler.h: buffers sized by
     GNU Radio's allocate_buffer rule, at most half a buffer per call).  What the block asks for (set_output_multiple = one device
-    batch, set_min_output_buffer = two) must reach work(): calls of exactly max_items items, both mappings of the circular buffers
+    batch, set_min_output_buffer = two) (round 6: OPT-IN, set_scheduler_batch) must reach work(): calls of exactly max_items items, both mappings of the circular buffers
     pinned, the outputs bit-identical to ONE work() over the same stream; without the request (scheduler batch 1, the reference's
     item-by-item behaviour) a 256-KiB item leaves 1 - 3 items per call."""
     import json
     demo = DEMO
     if not os.path.exists(demo):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "gr-fdc_amd", "csrc")])
-    r = subprocess.run([demo, "stock", "65536", "2", "256", "64", "300", "0", "verify"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([demo, "stock", "65536", "2", "256", "64", "300", "64", "verify"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads(r.stdout)
     assert d["pinned"] and d["scheduler_batch"] == 64 and d["in_buffer_items"] >= 128 and d["out_buffer_items"] >= 128
-    assert d["items_per_call_min"] == 64 and d["items_per_call_max"] == 64 and d["items"] == 256 and d["calls"] == 4     # the tail of 44 items stays behind
+    assert d["items_per_call_min"] == 64 and d["items_per_call_max"] == 64 and d["items"] == 256 and d["calls"] == 4
+    assert d["items_left_unprocessed"] == 44                  # the price of the opt-in: the tail of a FINITE stream stays behind, and the run says so
     assert d["channels_mismatched"] == 0 and "path 3" in d["plan"]
-    r = subprocess.run([demo, "stock", "65536", "2", "256", "64", "60", "1", "verify"], capture_output=True, text=True, timeout=300)
+    # the default (round 6, ADVICE r05): scheduler batch 1, the reference's item-by-item behaviour: every item is processed
+    r = subprocess.run([demo, "stock", "65536", "2", "256", "64", "60", "0", "verify"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads(r.stdout)
     assert d["scheduler_batch"] == 1 and d["in_buffer_items"] == 4 and d["items_per_call_max"] <= 3 and d["items"] == 60 and d["channels_mismatched"] == 0
+    assert d["items_left_unprocessed"] == 0

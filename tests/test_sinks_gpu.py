@@ -390,3 +390,67 @@ def test_lookahead_bank_emits_the_same_pdus(kind, host_decisions):
         assert {k: gm[k] for k in gm if k != "id"} == {k: rm[k] for k in rm if k != "id"}
         assert unstamp(gm["id"]) == unstamp(rm["id"])
         assert np.array_equal(gd, rd)
+
+
+def _bursty_stream(N, R, nb, seed, carriers):
+    """nb items of (N - N/R) samples: noise floor plus QPSK-like bursty carriers (fc, first_block, last_block)"""
+    H = N - N // R
+    rng = np.random.default_rng(seed)
+    n = np.arange(nb * H)
+    x = 0.01 * (rng.standard_normal(nb * H) + 1j * rng.standard_normal(nb * H))
+    for fc, t0, t1 in carriers:
+        env = np.zeros(nb * H); env[t0 * H:t1 * H] = 1.0
+        sym = (rng.integers(0, 2, nb * H // 64 + 1) * 2 - 1) + 1j * (rng.integers(0, 2, nb * H // 64 + 1) * 2 - 1)
+        x += env * np.repeat(sym, 64)[:nb * H] * np.exp(2j * np.pi * fc * n)
+    return x.astype(np.complex64)
+
+
+def _same_messages(got, ref):
+    assert len(got) == len(ref), (len(got), len(ref))
+    for (gd, gs), (rd, rs) in zip(got, ref):
+        assert {k: gd[k] for k in gd if k != "ID"} == {k: rd[k] for k in rd if k != "ID"}
+        assert unstamp(gd["ID"]) == unstamp(rd["ID"])
+        assert np.array_equal(gs, rs)
+
+
+@pytest.mark.parametrize("N,R,sizes,verbose", [(4096, 4, [5, 8, 1, 8, 2, 7, 8, 3], 0), (65536, 2, [24, 7, 24, 1, 16], 0), (4096, 2, [6, 6, 6, 6], 1)])
+def test_hier_block_pipelined_emits_the_same_pdus(N, R, sizes, verbose, capfd):
+    """fdc_pipeline_work_sinks on a look-ahead bank (round 6: the pipelined hier block — copy and forward transform of call n beside the
+    sinks of call n - 1, PDUs handed out one or two calls later, fdc_pipeline_flush_sinks at the end) against the serial form: the same
+    messages in the same order, payloads bit for bit; stream outputs and the debug spectrum of every call identical; ragged calls; a
+    flush in mid-stream after which the stream goes on.  verbose = 1: the host engine (its submit is synchronous: one call late)."""
+    nb = sum(sizes)
+    H = N - N // R
+    x = _bursty_stream(N, R, nb, 8, [(-0.2, 3, 9), (0.31, 6, 15), (-0.2, 17, 22), (0.33, 20, nb - 2)])
+    args = (8, 1, N, R, [[0.1, 0.05]], [[-0.2, 0.04]], 6.0, 1.0, 0.0, 'normalized', 1,
+            True, False, "", False, [[0.25, 0.4]], 10.0, 0.005, 1, 0.2, verbose, 0, 3, 3, True)
+    cuts = np.cumsum([0] + sizes)
+    serial = G.FrequencyDomainChannelizer(*args, max_blocks=max(sizes))
+    piped = G.FrequencyDomainChannelizer(*args, max_blocks=max(sizes), pipelined=True)
+    assert serial.pipeline.sinks_latency(serial.sinks) == 0
+    lat = piped.pipeline.sinks_latency(piped.sinks)
+    assert lat == (1 if verbose else 2) and piped.sinks.engine() == (0 if verbose else 1)
+    ref_msgs, got_msgs = [], []
+    halves = [range(0, len(sizes) // 2), range(len(sizes) // 2, len(sizes))]
+    for part in halves:                                       # a flush in mid-stream, then the stream goes on through the same handles
+        per_call = []
+        for k, i in enumerate(part):
+            xi = x[cuts[i] * H:cuts[i + 1] * H]
+            rp = serial.work(xi)
+            gp = piped.work(xi)
+            for a, b in zip(gp, rp):                          # debug spectrum + the throughput channel: this call's items, now
+                assert np.array_equal(a, b)
+            ref_msgs += serial.messages
+            per_call.append(len(serial.messages))
+            n_before = len(got_msgs)
+            got_msgs += piped.messages
+            # the pipelined block hands out exactly the PDUs of the call `lat` calls ago
+            assert len(got_msgs) - n_before == (per_call[k - lat] if k >= lat else 0)
+        assert serial.flush() == []
+        tail = piped.flush()
+        assert len(tail) == sum(per_call[max(0, len(per_call) - lat):])
+        got_msgs += tail
+        assert piped.flush() == []
+        _same_messages(got_msgs, ref_msgs)
+    assert len(ref_msgs) >= 4
+    capfd.readouterr()
