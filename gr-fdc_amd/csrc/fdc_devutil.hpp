@@ -79,9 +79,14 @@ __device__ __forceinline__ srd_t make_srd(const void *base, unsigned bytes)
     r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = 0x00020000;   // as make_rsrc: stride 0, raw
     return r;
 }
-// -DFDC_AUTO_WAITS=1 (A/B builds, tools/build_variant.sh): the same kernels with compiler-visible loads and the compiler's own waits
+// ROUND 6: the SHIPPED build is -DFDC_AUTO_WAITS=1 — compiler-visible loads, the compiler's own waits.  The hand-stated waits are correct only
+// while two things hold that nothing checks: the register allocator never copies or spills an asm "=v" result between the load and the
+// vm_wait (it believes the value is ready when the asm statement ends), and the number of vector-memory instructions issued behind the loads
+// is at least the N of the wait (vm_wait<16 - KEEP> relies on the run-time row skip equalling the template KEEP, vm_wait<16> on exactly 16
+// unconditional stores).  A compiler update or a small edit of a kernel would corrupt data silently, for 1.2 % on one path that is not the
+// headline.  -DFDC_AUTO_WAITS=0 (tools/build_variant.sh) builds the exact-wait form for A/B runs.
 #ifndef FDC_AUTO_WAITS
-#define FDC_AUTO_WAITS 0
+#define FDC_AUTO_WAITS 1
 #endif
 template <bool NT>
 __device__ __forceinline__ cf ald2(srd_t r, unsigned voff, unsigned soff)
