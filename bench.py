@@ -135,6 +135,35 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+def gpu_numa_cpus(ordinal):
+    """CPUs of the NUMA node GPU `ordinal` hangs off, from sysfs alone (nothing here touches the GPU: it runs before the first HIP call).
+    HIP lists the KFD topology's GPU nodes in order (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES given as plain indices are applied);
+    node properties carry the PCI domain and location_id = bus << 8 | devfn.  None when anything is missing (containers, one-node hosts)."""
+    try:
+        gpus = []
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for nd in sorted(os.listdir(base), key=int):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, nd, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+                gpus.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v:
+                gpus = [gpus[int(i)] for i in v.split(",")]
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % gpus[ordinal]).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus |= set(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return (node, cpus) if cpus else None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def synth_input(torch, dev, N, R, C, nblocks, first_block, seed, carriers=True):
     """Device-resident synthetic multicarrier ring: N/R halo samples + nblocks*H new samples (SURVEY §8d cfg2:
     one carrier per channel, random complex symbols at 0.6x the channel bandwidth, noise at -30 dB)."""
@@ -470,6 +499,12 @@ def main():
     if a.gpus != world:
         raise SystemExit("--gpus %d but %d rank(s) are running" % (a.gpus, world))
 
+    # every rank on the CPUs of its GPU's NUMA node, before anything touches the GPU (the host-buffer legs copy from this process's memory)
+    placed = None
+    if world > 1 and not dry and os.environ.get("FDC_BENCH_REHEARSE") != "1":
+        placed = gpu_numa_cpus(local)
+        if placed:
+            os.sched_setaffinity(0, placed[1])
     import torch                      # first: my library then binds to the same libamdhip64 torch loaded
     import numpy as np
     # rehearsal on a one-GPU box (FDC_BENCH_REHEARSE=1): all ranks share cuda:0 and talk over gloo; the driver's real
@@ -849,7 +884,8 @@ def main():
                    # N > 1: what the process group reports (not what the command line asked for) and every rank's own step time
                    "ranks_seen": dist.get_world_size() if dist is not None else 1,
                    "backend": dist.get_backend() if dist is not None else None,
-                   "per_rank_ms": per_rank_ms},
+                   "per_rank_ms": per_rank_ms,
+                   "rank0_numa_node": placed[0] if placed else None},
         # frac: the contract's definition (all algorithmic bytes of a launch over the dominant kernel's launch time);
         # pipeline_frac: SURVEY.md §8d's headline, algorithmic bytes over the WHOLE step.  With the one-kernel path (3) the
         # dominant kernel IS the step, and the two coincide up to the launch gaps.

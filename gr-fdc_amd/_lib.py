@@ -111,6 +111,8 @@ SYMBOLS = {
     "fdc_sinks_destroy": (None, [_vp]),
     "fdc_pipeline_work_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_pipeline_work_sinks": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
+    "fdc_device_numa_node": (C.c_int, [C.c_int]),
+    "fdc_selftest_worker_placement": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "fdc_pipeline_flush_sinks": (C.c_int, [_vp, _vp]),
     "fdc_pipeline_sinks_latency": (C.c_int32, [_vp, _vp]),
     "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),

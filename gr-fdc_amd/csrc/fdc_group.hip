@@ -30,6 +30,8 @@
 #include <thread>
 #include <vector>
 
+#include "fdc_hostplace.hpp"
+
 namespace {
 
 #define FDC_ENTRY(name) return fdc::guarded(name, [&]() -> int {
@@ -46,6 +48,8 @@ struct SpanJob {
 
 // one worker thread per member beyond the first (the first member's share runs on the calling thread)
 struct Worker {
+    int node = -1;               // NUMA node of the member's device (-1: unknown — the thread stays where the system puts it)
+    int pinned = 0;              // what pin_this_thread_to_node said (1 pinned, 0 left alone, -1 failed)
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -63,6 +67,9 @@ int run_span(fdc_pipeline *p, const SpanJob &j)
 
 void worker_main(Worker *w)
 {
+    // the thread that feeds member i's device over PCIe runs on that device's NUMA node (its pinned staging is allocated by the HIP runtime
+    // from the host pool closest to the device, whatever thread asks: hipHostMalloc without hipHostMallocNumaUser)
+    w->pinned = fdc::pin_this_thread_to_node(w->node);
     for (;;) {
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [w] { return w->state == 1 || w->state == 3; });
@@ -275,6 +282,7 @@ int fdc_pipeline_group_create(const fdc_pipeline_cfg *cfg, const int32_t *device
     for (int i = 1; i < ndevices; i++) {
         g->workers.emplace_back(new Worker());
         Worker *w = g->workers.back().get();
+        w->node = fdc_device_numa_node(devices[i]);
         w->th = std::thread(worker_main, w);
     }
     *out = g.release();
@@ -315,6 +323,55 @@ int32_t fdc_pipeline_group_device(const fdc_pipeline_group *g, int i)
     return g && i >= 0 && i < (int)g->dev.size() ? g->dev[(size_t)i] : -1;
 }
 int32_t fdc_pipeline_group_member_max_blocks(const fdc_pipeline_group *g) { return g ? g->member_max : -1; }
+
+int fdc_device_numa_node(int device_id)
+{
+    int n = 0;
+    if (device_id < 0 || hipGetDeviceCount(&n) != hipSuccess || device_id >= n) { (void)hipGetLastError(); return -1; }
+    char bdf[64] = "";
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device_id) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return fdc::pci_numa_node(bdf);
+}
+
+int fdc_selftest_worker_placement(int node, int32_t *cpus_of_node, int32_t *cpus_of_worker)
+{
+    FDC_ENTRY("fdc_selftest_worker_placement")
+    // exactly what a group does for a member on `node`: a Worker whose thread pins itself, then reports the mask it runs under
+    cpu_set_t want, have, both;
+    const bool known = fdc::node_cpuset(node, &want);
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return fdc::set_error(FDC_ERR_HIP, "sched_getaffinity failed");
+    CPU_AND(&both, &want, &have);
+    if (cpus_of_node) *cpus_of_node = known ? CPU_COUNT(&both) : 0;
+    std::vector<std::unique_ptr<Worker>> ws;
+    ws.emplace_back(new Worker());
+    Worker *w = ws[0].get();
+    w->node = node;
+    w->th = std::thread(worker_main, w);
+    cpu_set_t got;
+    CPU_ZERO(&got);
+    int rcw;
+    {
+        Join join(ws);
+        join.post(0, [&got]() -> int { return sched_getaffinity(0, sizeof got, &got) == 0 ? FDC_OK : FDC_ERR_HIP; });
+        join.wait();
+        rcw = w->rc;
+    }
+    const int pinned = w->pinned;
+    stop_workers(ws);
+    if (rcw != FDC_OK) return fdc::set_error(FDC_ERR_HIP, "the worker could not read its affinity mask");
+    if (cpus_of_worker) *cpus_of_worker = CPU_COUNT(&got);
+    if (pinned < 0) return fdc::set_error(FDC_ERR_HIP, "pthread_setaffinity_np failed for node %d", node);
+    if (pinned == 0) {
+        // left alone: the worker must run under the process's own mask
+        return CPU_EQUAL(&got, &have) ? 0 : fdc::set_error(FDC_ERR_HIP, "an unpinned worker does not run under the process's mask");
+    }
+    cpu_set_t inside;
+    CPU_AND(&inside, &got, &both);
+    if (CPU_COUNT(&got) == 0 || !CPU_EQUAL(&inside, &got))
+        return fdc::set_error(FDC_ERR_HIP, "worker for node %d runs on CPUs outside the node", node);
+    return 1;
+    FDC_ENTRY_END
+}
 
 int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_block, int32_t *nblocks, int cap)
 {
@@ -399,6 +456,7 @@ int fdc_sinks_group_create(const fdc_sinks_cfg *cfg, const int32_t *devices, int
     }
     for (int i = 0; i < ndevices; i++) {
         g->workers.emplace_back(new Worker());
+        g->workers.back()->node = fdc_device_numa_node(g->mem[(size_t)i].dev);
         if (i > 0 && g->mem[(size_t)i].s) g->workers.back()->th = std::thread(worker_main, g->workers.back().get());
     }
     *out = g.release();

@@ -234,6 +234,18 @@ int32_t fdc_pipeline_group_size(const fdc_pipeline_group *g);
 fdc_pipeline *fdc_pipeline_group_member(fdc_pipeline_group *g, int i);   /* owned by the group (fdc_pipeline_path, sizes, timing) */
 int32_t fdc_pipeline_group_device(const fdc_pipeline_group *g, int i);
 int32_t fdc_pipeline_group_member_max_blocks(const fdc_pipeline_group *g);   /* the longest span a member can be given */
+/* Host placement (round 6).  A group's worker thread for member i — the thread that copies the member's span over its PCIe link — pins itself
+ * to the CPUs of the NUMA node its device hangs off (/sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/node<k>/cpulist,
+ * intersected with the process's own mask; member 0 runs on the calling thread, which is never touched: pin the scheduler thread of the
+ * block yourself if you want it placed).  Pinned staging comes from the host pool closest to the member's device whatever thread asks
+ * (hipHostMalloc without hipHostMallocNumaUser).  Best effort: unknown node (-1: single-node machines, most containers) = left alone.
+ *   fdc_device_numa_node(d)                 the node of HIP device d, -1 if unknown or no such device
+ *   fdc_selftest_worker_placement(node,..)  starts a worker exactly as a group would for a member on `node` and checks the mask it runs
+ *                                           under: 1 = pinned inside the node's CPUs, 0 = left alone under the process's mask (node unknown
+ *                                           or none of its CPUs usable), negative = failure; the two counts are the node's usable CPUs and the
+ *                                           worker's.  Needs no device (tests/test_abi_cpu.py). */
+int fdc_device_numa_node(int device_id);
+int fdc_selftest_worker_placement(int node, int32_t *cpus_of_node, int32_t *cpus_of_worker);
 /* the spans of the last call: first_block[i] (global index) and nblocks[i] (0 = member idle) for i < min(size, cap); returns size */
 int fdc_pipeline_group_last_spans(const fdc_pipeline_group *g, int64_t *first_block, int32_t *nblocks, int cap);
 

@@ -190,3 +190,41 @@ def test_a_call_may_not_produce_4_gib_of_output():
     cfg = _lib.fdc_pipeline_cfg(0, 65536, 2, 1, 256, chans, 16384, 0, 0, 0, 0, 0)
     assert G.lib().fdc_pipeline_create(C.byref(cfg), C.byref(h)) == -1
     assert b"4 GiB" in G.lib().fdc_last_error() and b"16383" in G.lib().fdc_last_error()
+
+
+def test_group_workers_are_pinned_to_their_devices_numa_node():
+    """the worker thread of a group member runs on the CPUs of the NUMA node its device hangs off.  The placement code
+    needs no device: fdc_selftest_worker_placement starts a worker exactly as a group does for a member on `node` and reports the mask it
+    runs under.  Every online node: pinned inside the node's CPUs (or left alone when none of them is in this process's cpuset); an unknown
+    node (-1, 4095): left alone under the process's own mask.  Skips where sysfs lists no nodes."""
+    import ctypes as C
+    import gr_fdc_amd as G
+    lib = G.lib()
+    mine = os.sched_getaffinity(0)
+    for bogus in (-1, 4095):
+        a, b = C.c_int32(-1), C.c_int32(-1)
+        assert lib.fdc_selftest_worker_placement(bogus, C.byref(a), C.byref(b)) == 0 and a.value == 0 and b.value == len(mine)
+    assert lib.fdc_device_numa_node(-1) == -1 and lib.fdc_device_numa_node(10 ** 6) == -1
+    try:
+        online = open("/sys/devices/system/node/online").read().strip()
+    except OSError:
+        pytest.skip("no NUMA nodes in sysfs")
+    nodes = []
+    for part in online.split(","):
+        lo, _, hi = part.partition("-")
+        nodes += list(range(int(lo), int(hi or lo) + 1))
+    checked = 0
+    for node in nodes:
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus |= set(range(int(lo), int(hi or lo) + 1))
+        a, b = C.c_int32(-1), C.c_int32(-1)
+        rc = lib.fdc_selftest_worker_placement(node, C.byref(a), C.byref(b))
+        usable = cpus & mine
+        assert rc == (1 if usable else 0), (node, rc, lib.fdc_last_error())
+        assert a.value == len(usable) and b.value == (len(usable) if usable else len(mine))
+        checked += 1
+    assert checked >= 1
+    assert os.sched_getaffinity(0) == mine            # the calling thread was never touched

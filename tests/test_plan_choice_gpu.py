@@ -162,7 +162,17 @@ class _Hip:
 
 
 def time_the_forms(n, plan, nb, name):
-    """The chosen form and every forced alternative over nb blocks: HIP events on the launch stream; fails when the choice is > 10 % off the best."""
+    """The chosen form and every forced alternative over nb blocks: HIP events on the launch stream; fails when the choice is > 10 % off the best.
+    A timing assertion inside a suite the driver runs with -x: the file is collected LAST (tests/conftest.py), and a case
+    that misses its 10 % is timed once more over four times the blocks before it fails — a noisy box does not stop the run in front of a parity test."""
+    try:
+        _time_the_forms(n, plan, nb, name)
+    except AssertionError as first:
+        print("\nPLANCHOICE %s: missed at %d blocks (%s); once more over %d" % (name, nb, str(first)[:200], 4 * nb), file=sys.stderr)
+        _time_the_forms(n, plan, 4 * nb, name + " [re-timed x4]")
+
+
+def _time_the_forms(n, plan, nb, name):
     R = 2
     h = n - n // R
     hip = _Hip()
