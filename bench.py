@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--lookahead", action="store_true", help="configs 3/5: the bank with two spectrum buffers (FDC_SINKS_LOOKAHEAD): the forward transform and the "
                     "power cells of batch n + 1 run on the bank's fill stream beside the decision kernels of batch n; the block kernels leave "
                     "--reserve-cus compute units to them and the batch is a multiple of their workgroups")
+    ap.add_argument("--no-fused-cells", action="store_true", help="configs 3 / 5: power cells by a pass over the spectrum (k_cell_power, the round-5 form) instead of "
+                                                                   "from the group sums of the forward kernel's epilogue")
     ap.add_argument("--reserve-cus", type=int, default=32, help="--lookahead: compute units the persistent forward-transform kernel leaves free")
     ap.add_argument("--sync-sinks", action="store_true", help="configs 3/5: fdc_sinks_work_device per step instead of the two-deep "
                                                                "fdc_sinks_submit_device")
@@ -680,6 +682,7 @@ def main():
         from gr_fdc_amd import _lib
         sstream = _lib.lib().fdc_sinks_stream(sinks._h)
         count = [False]
+        fused = not a.no_fused_cells
 
         def tally():
             n = _lib.lib().fdc_sinks_pdu_count(sinks._h)
@@ -694,18 +697,25 @@ def main():
             # forward transform + power cells, beside this batch's decision chains — and submits the one transformed a step ago
             fstream = sinks.fill_stream()
             assert pipe.reserve_compute_units(a.reserve_cus) == wgs
-            pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=fstream)
-            sinks.prepare(nb, ahead=False)
+            pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=fstream,
+                                d_group_power=sinks.group_power_ptr() if fused else None)
+            sinks.prepare(nb, ahead=False, from_groups=fused)
 
         def step():
             # forward transform of the batch straight into the bank's spectrum buffer (the bank's stream), then the bank:
             # power cells -> decisions -> extraction of the active (block, channel) pairs -> PDUs.  Two deep: the PDUs handed
             # out by a step are those of the batch before, whose payload copy ran beside this batch's kernels.
+            # round 6 (fused): the forward kernel leaves the power of the spectrum's 16-bin groups beside the spectrum and the bank sums its cells
+            # from them (fdc_sinks_prepare_from_groups) instead of reading the spectrum back (k_cell_power); --no-fused-cells: the round-5 form
             if a.lookahead:
-                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ahead_ptr(), stream=fstream)
-                sinks.prepare(nb, ahead=True)
+                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ahead_ptr(), stream=fstream,
+                                    d_group_power=sinks.group_power_ahead_ptr() if fused else None)
+                sinks.prepare(nb, ahead=True, from_groups=fused)
             else:
-                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=sstream)
+                pipe.process_device(x.data_ptr(), first_block, nb, None, d_spectrum=sinks.spectrum_ptr(), stream=sstream,
+                                    d_group_power=sinks.group_power_ptr() if fused else None)
+                if fused:
+                    sinks.prepare(nb, ahead=False, from_groups=True)
             if a.sync_sinks:
                 done = _lib.check(_lib.lib().fdc_sinks_work_device(sinks._h, nb))
             else:
@@ -915,6 +925,7 @@ def main():
         res["config"]["sink_engine"] = "device" if sinks.engine() == 1 else "host"
         res["config"]["payload"] = a.payload if sinks.engine() == 1 else "host"
         res["config"]["submission"] = "synchronous" if a.sync_sinks else "two deep (fdc_sinks_submit_device)"
+        res["config"]["power_cells"] = "from the forward kernel's 16-bin group sums (fdc_sinks_prepare_from_groups)" if fused else "pass over the spectrum (k_cell_power)"
         if a.lookahead:
             res["config"]["submission"] += ", look-ahead: forward transform + power cells of batch n + 1 on the fill stream beside batch n's decisions"
             res["config"]["lookahead"] = {"reserved_compute_units": a.reserve_cus, "block_kernel_workgroups": wgs}

@@ -113,6 +113,10 @@ SYMBOLS = {
     "fdc_pipeline_work_sinks": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _vp, _vp]),
     "fdc_device_numa_node": (C.c_int, [C.c_int]),
     "fdc_selftest_worker_placement": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "fdc_pipeline_process_device_power": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
+    "fdc_sinks_group_power": (_vp, [_vp]),
+    "fdc_sinks_group_power_ahead": (_vp, [_vp]),
+    "fdc_sinks_prepare_from_groups": (C.c_int, [_vp, C.c_int, C.c_int]),
     "fdc_pipeline_flush_sinks": (C.c_int, [_vp, _vp]),
     "fdc_pipeline_sinks_latency": (C.c_int32, [_vp, _vp]),
     "fdc_sinks_work": (C.c_int, [_vp, _vp, C.c_int]),

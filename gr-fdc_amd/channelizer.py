@@ -246,9 +246,15 @@ class Pipeline:
         _lib.lib().fdc_pipeline_reset(self._h)
 
     # -- device path
-    def process_device(self, d_ring, first_block, nblocks, d_out, d_spectrum=None, stream=None):
-        _lib.check(_lib.lib().fdc_pipeline_process_device(self._h, d_ring, int(first_block), int(nblocks), d_out,
-                                                         d_spectrum, stream))
+    def process_device(self, d_ring, first_block, nblocks, d_out, d_spectrum=None, stream=None, d_group_power=None):
+        """d_group_power: device buffer of nblocks * N/16 float32 for the power of the spectrum's 16-bin groups (fdc_pipeline_process_device_power:
+        what Sinks.prepare(..., from_groups=True) sums a bank's power cells from)."""
+        if d_group_power:
+            _lib.check(_lib.lib().fdc_pipeline_process_device_power(self._h, d_ring, int(first_block), int(nblocks), d_out, d_spectrum,
+                                                                   d_group_power, stream))
+        else:
+            _lib.check(_lib.lib().fdc_pipeline_process_device(self._h, d_ring, int(first_block), int(nblocks), d_out,
+                                                             d_spectrum, stream))
 
     def synchronize(self):
         _lib.check(_lib.lib().fdc_pipeline_synchronize(self._h))

@@ -216,6 +216,10 @@ struct fdc_pipeline {
     hipEvent_t ev_hier = nullptr;   // on the bank's fill stream behind the last call's transform and history copy: the ring may be overwritten
     bool hier_ring_busy = false;
     bool reserve_user = false;   // fdc_pipeline_reserve_compute_units was called: the pipelined entry leaves the reservation alone
+    // fdc_pipeline_process_device_power: where the power of the spectrum's 16-bin groups goes (the sinks' cells are summed from it): group sums of
+    // the block whose spectrum starts at gpow_spec + k N go to gpow_base + k N / 16.  Set for the duration of one call.
+    float *gpow_base = nullptr;
+    const float2 *gpow_spec = nullptr;
     bool cfg_generic = false;    // FDC_FORCE_GENERIC=1: bypass the size-specialised kernels (A/B testing)
     // timing
     bool timing = false;
@@ -1240,15 +1244,21 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
         // a spectrum in memory.  (A split plan's internal spectrum holds its remainder's bins only: whoever gets here with one — a caller's
         // spectrum buffer — writes a full spectrum into THAT buffer, d_keep is not applied.)
+        // the power of the 16-bin groups of the caller's spectrum (fdc_pipeline_process_device_power): summed by the block kernel while the bins are in
+        // its registers; by a pass over the spectrum where another transform ran
+        float *const gp = (p->gpow_base && d_spectrum) ? p->gpow_base + (size_t)(spec - p->gpow_spec) / 16 : nullptr;
         if (p->fwd_block && !few)
             HIPCHK(fdc::launch_block_fft(p->N, in0, (size_t)p->H, spec, nb, p->d_tw256, p->d_ftwq, p->d_fcbt,
-                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep));
-        else if (p->N == 65536 && !p->cfg_generic)
-            HIPCHK(fdc::launch_fft65536(in0, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
-                                        1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
-        else
-            HIPCHK(fdc::launch_fft(in0, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
-                                   1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
+                                              p->d_fshn, p->d_fslot, p->d_fscr, p->ncu - p->reserved_cu, p->block_hints, s, evp, d_spectrum ? nullptr : p->d_keep, gp));
+        else {
+            if (p->N == 65536 && !p->cfg_generic)
+                HIPCHK(fdc::launch_fft65536(in0, (size_t)p->H, spec, p->d_tmp, nb, p->N / 2,
+                                            1.0f / (float)p->N, p->d_tw256, p->d_twf, s, evp));
+            else
+                HIPCHK(fdc::launch_fft(in0, (size_t)p->H, spec, p->d_tmp, p->N, nb, false, 0, p->N / 2,
+                                       1.0f / (float)p->N, p->d_tw, p->ntab, s, evp, p->d_twf, p->cfg_generic, d_spectrum ? ~0ull : p->keep4096));
+            if (gp) HIPCHK(fdc::launch_group_power(spec, p->N, nb, gp, s));
+        }
         { const int rcc = run_channel_groups(p, false, spec, o, nb, m0, nblocks, first_block, s); if (rcc != FDC_OK) return rcc; }
         if (tg) {
             HIPCHK(hipEventRecord(p->events[span[3]], s));
@@ -1257,6 +1267,20 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         }
     }
     return FDC_OK;
+    FDC_ENTRY_END
+}
+
+int fdc_pipeline_process_device_power(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks, void *d_out, void *d_spectrum,
+                                      void *d_group_power, void *stream)
+{
+    FDC_ENTRY("fdc_pipeline_process_device_power")
+    if (!p) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (d_group_power && (!d_spectrum || (p->N & 15))) return fail(FDC_ERR_INVALID_ARGUMENT, "group powers go with a spectrum output of a block length that is a multiple of 16");
+    p->gpow_base = static_cast<float *>(d_group_power);
+    p->gpow_spec = static_cast<const float2 *>(d_spectrum);
+    const int rc = fdc_pipeline_process_device(p, d_ring, first_block, nblocks, d_out, d_spectrum, stream);
+    p->gpow_base = nullptr; p->gpow_spec = nullptr;
+    return rc;
     FDC_ENTRY_END
 }
 
@@ -1570,7 +1594,10 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     HIPCHK(hipSetDevice(p->cfg.device_id));
     int rc = work_io_setup(p);
     if (rc != FDC_OK) return rc;
-    if (!p->ev_hier) HIPCHK(hipEventCreateWithFlags(&p->ev_hier, hipEventDisableTiming));
+    if (!p->ev_hier) {
+        HIPCHK(hipEventCreateWithFlags(&p->ev_hier, hipEventDisableTiming));
+        HIPCHK(hipStreamSynchronize(p->stream));                  // work_io_setup zeroes the history on the handle's own stream; this entry runs on others
+    }
     p->hier_bank = sinks;
     hipStream_t fs = static_cast<hipStream_t>(fdc_sinks_fill_stream(sinks));
     const bool first = p->hier_filled == 0;                       // stream start, or everything was flushed: the bank's current buffer is free
@@ -1585,7 +1612,9 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     HIPCHK(hipMemcpyAsync(p->d_ring + p->ovl, in, sizeof(float2) * nin, hipMemcpyHostToDevice, p->s_in));
     HIPCHK(hipEventRecord(p->ev_in[0], p->s_in));
     HIPCHK(hipStreamWaitEvent(fs, p->ev_in[0], 0));
-    rc = fdc_pipeline_process_device(p, p->d_ring, p->blockcount, nblocks, p->d_out, dst, fs);
+    // the power of the spectrum's 16-bin groups comes out of the forward kernel's epilogue: the bank's cells are summed from it (no pass over the spectrum)
+    float *const gpw = static_cast<float *>(first ? fdc_sinks_group_power(sinks) : fdc_sinks_group_power_ahead(sinks));
+    rc = fdc_pipeline_process_device_power(p, p->d_ring, p->blockcount, nblocks, p->d_out, dst, gpw, fs);
     if (rc != FDC_OK) return rc;
     // history <- last ovl samples of this call (overlap_save_impl.cc:78)
     HIPCHK(hipMemcpyAsync(p->d_ring, p->d_ring + nin, sizeof(float2) * (size_t)p->ovl, hipMemcpyDeviceToDevice, fs));
@@ -1593,7 +1622,7 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     p->hier_ring_busy = true;
     p->blockcount += nblocks;
     // from here on the call has happened as far as the stream state goes: a failure below must not invite a retry with the same items
-    rc = fdc_sinks_prepare(sinks, nblocks, first ? 0 : 1);
+    rc = gpw ? fdc_sinks_prepare_from_groups(sinks, nblocks, first ? 0 : 1) : fdc_sinks_prepare(sinks, nblocks, first ? 0 : 1);
     if (rc != FDC_OK) return rc;
     bool out_reg = p->C > 0;
     if (p->C > 0) {
@@ -1635,9 +1664,14 @@ int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *
         return fail(FDC_ERR_INVALID_ARGUMENT, "sinks were created for blocklen %d / %d blocks per call, pipeline call has %d / %d",
                     fdc_sinks_blocklen(sinks), fdc_sinks_max_blocks(sinks), p->N, nblocks);
     if (fdc_sinks_fill_stream(sinks)) return work_sinks_pipelined(p, in, nblocks, outs, spectrum, sinks);
-    // the spectrum goes straight into the sinks' device buffer (no PCIe round trip), then the sinks run on it
+    // the spectrum goes straight into the sinks' device buffer (no PCIe round trip), then the sinks run on it; their power cells are summed from
+    // the group powers the forward kernel leaves beside the spectrum
+    float *const gpw = static_cast<float *>(fdc_sinks_group_power(sinks));
+    p->gpow_base = gpw; p->gpow_spec = static_cast<const float2 *>(fdc_sinks_spectrum(sinks));
     int rc = pipeline_work_impl(p, in, nblocks, outs, spectrum, static_cast<float2 *>(fdc_sinks_spectrum(sinks)));
+    p->gpow_base = nullptr; p->gpow_spec = nullptr;
     if (rc < 0) return rc;
+    if (gpw && rc > 0) { const int rp = fdc_sinks_prepare_from_groups(sinks, nblocks, 0); if (rp != FDC_OK) return rp; }
     const int rs = fdc_sinks_work_device(sinks, nblocks);
     return rs < 0 ? rs : rc;
     FDC_ENTRY_END
@@ -1750,8 +1784,11 @@ int fdc_overlap_save_work(fdc_overlap_save *b, const void *in, int nitems, void 
         unsigned char *nr = nullptr, *no = nullptr;
         HIPCHK(hipMalloc(&nr, ovb + inb * nitems + 16));
         HIPCHK(hipMalloc(&no, outb * nitems));
-        if (b->d_ring) HIPCHK(hipMemcpy(nr, b->d_ring, ovb, hipMemcpyDeviceToDevice));
-        else HIPCHK(hipMemset(nr, 0, ovb + 16));
+        // on the block's OWN stream: it is non-blocking, so the null stream's memset would not be ordered in front of the copies and the
+        // kernel below (round 6: the first item's history came out as whatever the allocation held, now and then)
+        if (b->d_ring) HIPCHK(hipMemcpyAsync(nr, b->d_ring, ovb, hipMemcpyDeviceToDevice, b->s));
+        else HIPCHK(hipMemsetAsync(nr, 0, ovb + 16, b->s));
+        HIPCHK(hipStreamSynchronize(b->s));
         (void)hipFree(b->d_ring); (void)hipFree(b->d_out);
         b->d_ring = nr; b->d_out = no; b->cap = nitems;
     }

@@ -100,12 +100,21 @@ struct BlkGeom {
 };
 
 // FWD = false: the channelizer (above).  FWD = true: the same machinery as a plain forward transform of the block (no window,
-// no inverse transform; P = 8 only).  Stage 1 stops after the forward FFT-256 of a column: T[k2][n1] = A[k2] W_N^(n1 k2) / N.  The half
-// k2 < 128 stays in the G registers, the other half goes to 256 KiB of per-workgroup scratch (it stays in the L2 / the
-// memory-side cache) and is read back into the G registers after the first run of stage 2; stage 2 is unchanged and runs
-// twice, its "slots" are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the (-1)^n1 of cbt moves k1 by 128 =
-// fftshift), 64 consecutive bins per wave store.  This is what plans that need a spectrum in memory (mixed channel plans,
-// the sinks, the debug port) use instead of two passes through a scratch buffer of the whole batch.
+// no inverse transform).  Stage 1 stops after the forward FFT-256 of a column: T[k2][n1] = A[k2] W_N^(n1 k2) / N, 512 KiB per block —
+// twice what the G registers hold.  Rounds 2-5 kept the half k2 < 128 in G and sent the other half through 256 KiB of per-workgroup
+// scratch: the counters (profiles/r06/pmc_summary_fwd.txt) say that trip is real traffic — WRITE 807 MB + FETCH 560 MB per 1024 blocks
+// for 805 MB of work, at 5.5 TB/s: the kernel was bound by the memory system on bytes of which 39 % were its own scratch.
+// Round 6 built the alternative (-DFDC_FWD_TWO_WG=1; not shipped, it measured 5 % slower — see the macro below): TWO WORKGROUPS PER BLOCK,
+// no scratch.  A work item is (block, half h): the workgroup computes the columns' forward
+// FFT-256 for the rows k2 = b + 16 q with q = 2 r + h only — bit 4 of k2, so that a half is every other 16-bin run = every other
+// 128-byte line of the spectrum: both halves store whole lines — 128 rows, exactly G.  The split is a decimation in frequency of
+// the SECOND DFT-16 (over the exchanged index bb): q even: DFT-8 of v[bb] + v[bb + 8]; q odd: DFT-8 of (v[bb] - v[bb + 8]) W_16^bb;
+// first DFT-16, twiddle and exchange are done in full by both halves (stage-1 arithmetic per half: 0.7 of the whole).  The two
+// halves of a block are neighbouring slots of ONE XCD in the same round (h = slot & 1 is a constant of the workgroup): the input
+// rows are fetched from memory once and the second reader hits that XCD's L2, as the overlap half of the next block always did.
+// Stage 2 is unchanged and runs once per item; its "slots" are the k1 of the spectrum: bins 256 c + k2 of the SHIFTED spectrum (the
+// (-1)^n1 of cbt moves k1 by 128 = fftshift); a wave store is four 16-bin runs 32 bins apart.  This is what plans that need a
+// spectrum in memory (mixed channel plans, the sinks, the debug port) use instead of two passes through a scratch of the whole batch.
 // R4 = true: the channelizer at relinvovl = 4 (the reference's default overlap, grc/FDC_FrequencyDomainChannelizer.xml:61): three
 // quarters of every inverse transform are kept, G is 192 rows x N1 columns.  The rows t >= 128 stay in the G registers
 // as for R = 2; the rows 64 <= t < 128 take the route of the forward-transform variant: per-workgroup scratch (L2),
@@ -135,6 +144,14 @@ __device__ __forceinline__ void blk_pass_dft(cf (&a)[P])
 // ifftshift of the inverse is the identity — the value stays in its register, the tables are read at k2 ^ 128 (q ^ 8), W_N^(128 n1) is in cbt (the host
 // builds it for r = 128 as for any offset).  No second twiddle table, no rotated exchange, both row sets: the on-grid rate, and relinvovl 4 too
 // (128 mod 4 = 0: the window phase stays 0).
+// -DFDC_FWD_TWO_WG=1 builds the forward-transform variant as TWO WORKGROUPS PER BLOCK without scratch (round 6, tools/build_variant.sh); the
+// shipped form is the round-2..5 one (one workgroup per block, the half k2 >= 128 through per-workgroup scratch).  Measured on one box,
+// alternating (profiles/r06/fwd_ab.txt): full band 0.2525 against 0.2405 ms per 1024 blocks, nothing written 0.2017 against 0.188 — the
+// two-workgroup form moves 805 MB instead of 1367 and is SLOWER: its passes are a third of the channelizer's (no inverse transform), so the
+// rows requested one pass ahead are not there when the pass starts, and it asks for every row twice (16 cache lines per load instruction).
+#ifndef FDC_FWD_TWO_WG
+#define FDC_FWD_TWO_WG 0
+#endif
 template <int P, bool NT, bool OFF, bool FWD, bool R4 = false, bool STG = false, bool HALF = false>
 __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ? 4 : 2) void k_blk256(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out,
                                                 const float2 *__restrict__ tw256, const float2 *__restrict__ twq,
@@ -142,12 +159,14 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                                                 const long long *__restrict__ slot_off, long long out_base,
                                                 long long nb_call, unsigned out_bytes, int nb, int hints,
                                                 unsigned long long *__restrict__ dbg, int roff, long long first_block,
-                                                float2 *__restrict__ fwd_scratch, const unsigned *__restrict__ keep)
+                                                float2 *__restrict__ fwd_scratch, const unsigned *__restrict__ keep,
+                                                float *__restrict__ gpow)
 {
     typedef BlkGeom<P> GM;
     static_assert(!STG || (P == 8 && !OFF && !FWD && !R4), "staged loads: the plain channelizer at N = 65536");
     static_assert(!HALF || (!OFF && !FWD && !STG), "the half-slot form is a variant of the on-grid channelizer");
     constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
+    constexpr bool FW2 = FWD && FDC_FWD_TWO_WG;                                  // forward transform, two workgroups per block
     float2 *scr = reinterpret_cast<float2 *>(fdc_smem_blk);                     // stage 1: 8 wave scratches; stage 2: the trip buffer
     float2 *wrow = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffWrowS : GM::kOffWrow));     // [b][p] = W256^(b p), rows of 18
     float2 *Bt = reinterpret_cast<float2 *>(fdc_smem_blk + (STG ? GM::kOffBS : GM::kOffB));             // [c5][q] = W_N^(16 c5 q)
@@ -172,8 +191,13 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
     // block order: round rho, XCD x = workgroup mod 8 (round-robin dispatch), slot = workgroup / 8:
     // block = rho*grid + x*(grid/8) + slot, i.e. one XCD works on grid/8 consecutive blocks at a time
     const int grid = gridDim.x, per = grid >> 3;
-    const bool xmap = (grid & 7) == 0;
-    const int first = xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // FWD: the work items are (block, half); neighbouring slots of an XCD share a block (the launcher makes the grid even), so a round is
+    // grid / 2 blocks and an XCD still walks a contiguous run of them
+    const bool xmap = FW2 ? (grid & 15) == 0 : (grid & 7) == 0;
+    const int fhalf = FW2 ? (xmap ? (int)(blockIdx.x >> 3) & 1 : (int)blockIdx.x & 1) : 0;      // which rows this workgroup computes: k2 bit 4
+    const int mstride = FW2 ? grid >> 1 : grid;
+    const int first = FW2 ? (xmap ? (int)(blockIdx.x & 7) * (per >> 1) + (int)(blockIdx.x >> 4) : (int)(blockIdx.x >> 1))
+                          : (xmap ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
     if (first >= nb) return;
 #ifdef FDC_BLK_WGTIMES
     // diagnostics (tools/wg_times.py): when every workgroup starts and ends, 100 MHz clock: [0..255] starts, [256..511] ends
@@ -230,9 +254,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
         soff[(i % P) * 32 + ((i / P) & 1) * 16 + rev16((i / P) >> 1)] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
     for (int i = tid; i < 32 * P; i += 512) ctab[i] = tw256[((i / P) * (i % P) * (8 / P)) & 255];     // [c5][klo] = W_N1^(c5 klo)
-    Bt[(tid >> 4) * 18 + (tid & 15)] = twq[HALF ? tid ^ 8 : tid];               // c5 = tid >> 4 < 32, q = tid & 15 (HALF: the entry of q ^ 8)
+    // FWD: entry r < 8 of a row is the one of q = 2 r + h (the rows this workgroup computes); entries 8 .. 15 are not read
+    Bt[(tid >> 4) * 18 + (tid & 15)] = twq[HALF ? tid ^ 8 : FW2 ? (tid & ~15) + ((2 * (tid & 15) + fhalf) & 15) : tid];   // c5 = tid >> 4 < 32, q = tid & 15 (HALF: the entry of q ^ 8)
     for (int i = tid; i < 256 * P; i += 512) {
-        const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15, qt = HALF ? q ^ 8 : q;
+        const int ps = i >> 8, bb = (i >> 4) & 15, q = i & 15, qt = HALF ? q ^ 8 : FW2 ? (2 * q + fhalf) & 15 : q;
         const float2 t = twq[(size_t)(32 * ps) * 16 + qt];                       // W_N^(16 * 32 ps * q)
         const float s = shn[bb + 16 * qt];
         SA[(ps * 16 + bb) * kSaLd + q] = make_float2(t.x * s, t.y * s);
@@ -246,7 +271,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
     const float2 *const btr = Bt + c5 * 18;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
     // FWD / R4: this workgroup's scratch, [pass][j][thread]
-    const __amdgpu_buffer_rsrc_t rscr = make_rsrc((FWD || R4) ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, (FWD || R4) ? 32768u * 8u : 0u);
+    constexpr bool kScr = (FWD && !FW2) || R4;
+    const __amdgpu_buffer_rsrc_t rscr = make_rsrc(kScr ? fwd_scratch + (size_t)blockIdx.x * 32768 : fwd_scratch, kScr ? 32768u * 8u : 0u);
 
     // Two waves share a SIMD (waves w and w + 4).  The older one wins the issue arbitration and finishes stage 1 ~10 k cycles
     // earlier; s_setprio (either half favoured, or alternating per pass) changes nothing about that (profiles/r02/NOTES.md).
@@ -263,8 +289,8 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
 #ifdef FDC_BLK_L2PF
     unsigned pfd = 0;
 #endif
-    for (int m = first; m < nb; m += grid) {
-        const int mnext = m + grid < nb ? m + grid : m;
+    for (int m = first; m < nb; m += mstride) {
+        const int mnext = m + mstride < nb ? m + mstride : m;
 #ifdef FDC_BLK_STAMPS
         unsigned long long st[32] = {};
 #endif
@@ -354,11 +380,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
             cf v[16];
 #pragma unroll
             for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&scrr[4 * bb]);
-            dft16<false>(v);                                      // A[k2 = b + 16 q] in v[rev16(q)]
-            if constexpr (FWD) {
-                // forward only: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N.  The half q < 8 stays in the G registers, the
-                // half q >= 8 goes to this workgroup's 256 KiB of scratch ([pass][j][thread]: every wave store is 512
-                // contiguous bytes) and comes back into the G registers for the second run of stage 2.
+            if constexpr (FWD && !FW2) {
+                // round-2..5 form: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N.  The half q < 8 stays in the G registers, the half q >= 8 goes to this
+                // workgroup's 256 KiB of scratch ([pass][j][thread]: 512-byte wave stores) and comes back for the second run of stage 2
+                dft16<false>(v);
                 const float2 *sar = SA + (ps * 16 + b) * kSaLd;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -371,7 +396,34 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                         bst2(rscr, (unsigned)tid * 8u + (unsigned)(2 * i - 7) * 4096u, (unsigned)ps * 32768u, y1);
                     }
                 }
+            } else if constexpr (FW2) {
+                // forward only: T[k2 = b + 16 q][n1] = A[k2] W_N^(n1 k2) / N for this workgroup's rows q = 2 r + h: the second DFT-16 decimated
+                // in frequency — a fold of v[bb] with v[bb + 8] and ONE DFT-8 (h is uniform: a scalar branch)
+                cf e[8];
+                if (fhalf) {
+                    e[0] = v[0] - v[8];
+                    e[1] = mul_w16<false, 1>(v[1] - v[9]);
+                    e[2] = mul_w16<false, 2>(v[2] - v[10]);
+                    e[3] = mul_w16<false, 3>(v[3] - v[11]);
+                    e[4] = mul_w16<false, 4>(v[4] - v[12]);
+                    e[5] = mul_w16<false, 5>(v[5] - v[13]);
+                    e[6] = mul_w16<false, 6>(v[6] - v[14]);
+                    e[7] = mul_w16<false, 7>(v[7] - v[15]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) e[i] = v[i] + v[i + 8];
+                }
+                dft8<false>(e);                                   // A[b + 16 (2 r + h)], r = k0 + 2 k1, in e[4 k0 + k1]
+                const float2 *sar = SA + (ps * 16 + b) * kSaLd;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 t0 = ld4(&btr[2 * i]), t1 = ld4(&sar[2 * i]);
+                    constexpr int kRev8[8] = {0, 4, 1, 5, 2, 6, 3, 7};          // r -> 4 (r & 1) + (r >> 1)
+                    FDC_GPUT(2 * i, ps, cmul(cmul(cmul(e[kRev8[2 * i]], mk(t0.x, t0.y)), mk(t1.x, t1.y)), cb));
+                    FDC_GPUT(2 * i + 1, ps, cmul(cmul(cmul(e[kRev8[2 * i + 1]], mk(t0.z, t0.w)), mk(t1.z, t1.w)), cb));
+                }
             } else {
+                dft16<false>(v);                                  // A[k2 = b + 16 q] in v[rev16(q)]
                 cf u[16];
                 {
                     const float2 *sar = SA + (ps * 16 + b) * kSaLd;
@@ -508,8 +560,13 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                     // Stores: slot klo + P khi of row t' = 16 kJT tr + 64 rh + lane.  The 32 stream offsets are the same for the whole
                     // wave (table laid out [klo][register]).  Unused slots: the byte offset is pushed beyond the buffer's extent and the
                     // store is dropped by the range check of the descriptor (no branch per store).
-                    const unsigned rb = (unsigned)(m * (FWD ? GM::kN : (R4 ? 192 : 128)) + rowbase + 16 * kJT * tr + 64 * rh2 + lane2) * 8u;   // FWD: [block][N bins]
-                    unsigned mq = FWD ? mqs[((rowbase + 16 * kJT * tr + 64 * rh2) >> 6) & 3] : ~0u;     // the 64-row chunk of k2 this wave stores
+                    // FWD: [block][N bins]; row t' = b + 16 j of the run is bin k2 = b + 16 (2 j + h): four 16-bin runs per wave store, 32 bins apart
+                    const int trow0 = 16 * kJT * tr + 64 * rh2, trow = trow0 + lane2;
+                    const unsigned rb = FW2 ? (unsigned)(m * GM::kN + (trow & 15) + 32 * (trow >> 4) + 16 * fhalf) * 8u
+                                            : (unsigned)(m * (FWD ? GM::kN : (R4 ? 192 : 128)) + rowbase + trow) * 8u;
+                    // two workgroups per block: the two 64-bin groups of k2 a wave's store touches (lanes 0-31 / 32-63): kept if some channel reads either
+                    unsigned mq = FW2 ? (mqs[(trow0 >> 5) & 3] | mqs[((trow0 >> 5) + 1) & 3])
+                                      : FWD ? mqs[((rowbase + trow0) >> 6) & 3] : ~0u;
                     if constexpr (FWD) asm volatile("" : "+s"(mq));   // the 32 scalar terms below are worked out here, not held from block to block
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -522,13 +579,66 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                             bst2t<NT>(rout, (o == 0xFFFFFFFFu ? 0xFFFFFFF0u : o + rb), v[4 * q + e]);
                         }
                     }
+                    if constexpr (FWD && !FW2) {
+                        // Power of every 16-bin group of the spectrum while it is in the registers (round 6: what the sinks' power cells are summed from —
+                        // k_cell_power used to read the whole spectrum back, 444-472 MB per 1024 blocks).  This lane holds bins 256 slot + k2 of 32
+                        // slots, its row of 16 lanes is one 16-bin group of each: 32 sums over 16 lanes as ONE transposed reduction — every step
+                        // halves the registers and pairs the lanes of one bit (bits 3 and 2 of the lane: DPP row rotations / shifts whose bank mask
+                        // picks which half of the lanes writes; bits 1 and 0: quad permutations) — 66 additions instead of 128, and lane j of the
+                        // row ends with the sums of registers 2 j and 2 j + 1.
+                        if (gpow) {
+                            float t16[16];
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const float s0 = __builtin_fmaf(v[i].y, v[i].y, v[i].x * v[i].x);
+                                const float s1 = __builtin_fmaf(v[i + 16].y, v[i + 16].y, v[i + 16].x * v[i + 16].x);
+                                asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                                    "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc" : "=&v"(t16[i]) : "v"(s0), "v"(s1));
+                            }
+                            float t8[8];
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                asm("v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                                    "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(t8[i]) : "v"(t16[i]), "v"(t16[i + 8]));
+                            const bool b1 = (lane2 & 2) != 0, b0 = (lane2 & 1) != 0;
+                            float t4[4], t2[2];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const float keepv = b1 ? t8[i + 4] : t8[i], send = b1 ? t8[i] : t8[i + 4];
+                                t4[i] = keepv + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+                            }
+#pragma unroll
+                            for (int i = 0; i < 2; i++) {
+                                const float keepv = b0 ? t4[i + 2] : t4[i], send = b0 ? t4[i] : t4[i + 2];
+                                t2[i] = keepv + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                            }
+                            // Lane (row g, j) now holds the sums of registers 2 j, 2 j + 1 over row g = group g of this trip's four.  Stored from there a
+                            // wave's 128 values would be 128 separate 4-byte write requests (the four groups of a slot sit in four different rows of the
+                            // wave; measured: + 31 us per 896 blocks, the request rate, not the bytes).  One hop through the LDS crossbar (ds_bpermute: no
+                            // LDS memory) first: lane (rho, i) takes register R = 8 rho + (i >> 1), groups 2 (i & 1) and + 1, so that two NEIGHBOURING lanes
+                            // write the 16 contiguous bytes of a slot's four groups: 32 requests per wave and trip.
+                            const int i16 = lane2 & 15, rho = lane2 >> 4, gsrc = 2 * (i16 & 1);
+                            const int a0 = (16 * gsrc + 4 * rho + (i16 >> 2)) * 4, a1 = a0 + 64;
+                            const int z0 = __builtin_bit_cast(int, t2[0]), z1 = __builtin_bit_cast(int, t2[1]);
+                            const int f0a = __builtin_amdgcn_ds_bpermute(a0, z0), f0b = __builtin_amdgcn_ds_bpermute(a0, z1);
+                            const int f1a = __builtin_amdgcn_ds_bpermute(a1, z0), f1b = __builtin_amdgcn_ds_bpermute(a1, z1);
+                            const bool odd = (i16 & 2) != 0;                      // R & 1: which of the source lane's two registers
+                            float2 pr;
+                            pr.x = __builtin_bit_cast(float, odd ? f0b : f0a);
+                            pr.y = __builtin_bit_cast(float, odd ? f1b : f1a);
+                            // register R -> slot (soff is laid out [klo][register]: register R is khi = (R >> 4) + 2 rev16(R & 15), slot klo + P khi);
+                            // gpow is [block][slot][16 groups of the slot's 256 bins]
+                            const int reg = 8 * rho + (i16 >> 1), slot = klo2 + P * ((reg >> 4) + 2 * (4 * (reg & 3) + ((reg & 15) >> 2)));
+                            *reinterpret_cast<float2 *>(gpow + (size_t)m * (GM::kN / 16) + 16 * slot + (rowbase + trow0) / 16 + gsrc) = pr;
+                        }
+                    }
                 }
                 FDC_STAMP(14 + 5 * tr);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         stage2([&](int j, int ps) { return FDC_GGET(j, ps); }, R4 ? 64 : 0, std::integral_constant<int, 8>{});
-        if constexpr (FWD) {
+        if constexpr (FWD && !FW2) {
             // second half of k2: the values stage 1 put aside are this lane's own stores; sc1 loads are served by the L2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage2([&](int j, int ps) { return bld2_sc1(rscr, (unsigned)tid * 8u + (unsigned)(j * 4096 + ps * 32768), 0u); }, 128,
@@ -614,11 +724,11 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 #define FDC_LB(P, A, B, R4) \
     hipExtLaunchKernelGGL((k_blk256<P, A, B, false, R4>), dim3((unsigned)grid), dim3(512), B ? BlkGeom<P>::kLdsOff : BlkGeom<P>::kLds, s, ev_start, \
                           ev_stop, 0u, in, in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * (R4 ? 192 : 128), (long long)nb_call, \
-                          out_bytes, nb_chunk, hints, dbg, r & 255, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr)
+                          out_bytes, nb_chunk, hints, dbg, r & 255, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr, (float *)nullptr)
 #define FDC_LH(P, A, R4) \
     hipExtLaunchKernelGGL((k_blk256<P, A, false, false, R4, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<P>::kLds, s, ev_start, \
                           ev_stop, 0u, in, in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * (R4 ? 192 : 128), (long long)nb_call, \
-                          out_bytes, nb_chunk, hints, dbg, 0, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr)
+                          out_bytes, nb_chunk, hints, dbg, 0, first_block, R4 ? scratch : (float2 *)nullptr, (const unsigned *)nullptr, (float *)nullptr)
 #define FDC_LP(P) \
     do { \
         if (halfslot) { \
@@ -635,7 +745,7 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 #define FDC_LS(A) \
         hipExtLaunchKernelGGL((k_blk256<8, A, false, false, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<8>::kLdsS, s, ev_start, ev_stop, 0u, in, \
                               in_stride, out, tw256, twq, cbt, shn, slot_off, (long long)mbase * 128, (long long)nb_call, out_bytes, nb_chunk, hints, dbg, 0, \
-                              first_block, (float2 *)nullptr, (const unsigned *)nullptr)
+                              first_block, (float2 *)nullptr, (const unsigned *)nullptr, (float *)nullptr)
         if (hints & 1) FDC_LS(true); else FDC_LS(false);
 #undef FDC_LS
     } else
@@ -654,19 +764,25 @@ hipError_t launch_poly_block(const float2 *in, size_t in_stride, float2 *out, in
 hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *out, int nitems, const float2 *tw256,
                             const float2 *twq, const float2 *cbt0, const float *shn1, const long long *slot_off,
                             float2 *scratch /* ncu x 32768 points */, int ncu, int hints, hipStream_t s, hipEvent_t *ev,
-                            const unsigned *keep)
+                            const unsigned *keep, float *gpow /* null, or nitems x N/16 floats: the power of every 16-bin group of the spectrum */)
 {
     if (!poly_block_supports(N)) return hipErrorInvalidValue;
     const int per = (int)(((size_t)1 << 28) / (size_t)N);  // 32-bit byte offsets inside one launch: at most 2 GiB of spectrum (N = 65536: 4096 blocks)
     for (int m0 = 0; m0 < nitems; m0 += per) {
         const int nb = nitems - m0 < per ? nitems - m0 : per;
         int grid = ncu > 0 ? ncu : 256;
+#if FDC_FWD_TWO_WG
+        grid &= ~1;                                        // two workgroups per block (the halves of k2): an even grid, at most two per block
+        if (grid > 2 * nb) grid = 2 * nb;
+#else
         if (grid > nb) grid = nb;
+#endif
         hipEvent_t e0 = ev && m0 == 0 ? ev[0] : nullptr, e2 = ev && m0 + nb >= nitems ? ev[1] : nullptr;
 #define FDC_LF(P, A) \
         hipExtLaunchKernelGGL((k_blk256<P, A, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<P>::kLds, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
                               in_stride, out + (size_t)m0 * (size_t)N, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
-                              (unsigned)((size_t)nb * (size_t)N * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep)
+                              (unsigned)((size_t)nb * (size_t)N * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep, \
+                              gpow ? gpow + (size_t)m0 * (size_t)(N / 16) : (float *)nullptr)
         const bool nt = (hints & 1) != 0;
         if (N == 65536) { if (nt) FDC_LF(8, true); else FDC_LF(8, false); }
         else if (N == 32768) { if (nt) FDC_LF(4, true); else FDC_LF(4, false); }

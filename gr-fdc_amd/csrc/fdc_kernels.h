@@ -170,7 +170,11 @@ hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *o
                             const long long *slot_off /* [N / 256]: 256 c */, float2 *scratch /* ncu x 32768 points */,
                             int ncu, int hints, hipStream_t s,
                             hipEvent_t *ev /* null or 3: start, end, end */,
-                            const unsigned *keep = nullptr /* [N / 8192][4] words: 64-bin stores some channel reads (fdc_api.hip), or all */);
+                            const unsigned *keep = nullptr /* [N / 8192][4] words: 64-bin stores some channel reads (fdc_api.hip), or all */,
+                            float *gpow = nullptr /* nitems x N / 16 floats: the power of every 16-bin group of the spectrum, summed in the epilogue */);
+// the sinks' power cells from those group sums + the bins of the groups a cell cuts; the group sums of a spectrum in memory (launch groups the block kernel did not transform)
+hipError_t launch_cell_power_groups(const float2 *spec, const float *gpow, int N, const PowerCell *cells, int ncells, int nblocks, float *out, hipStream_t s);
+hipError_t launch_group_power(const float2 *spec, int N, int nblocks, float *gpow, hipStream_t s);
 
 // real samples -> complex samples with zero imaginary part (the real-input front end)
 hipError_t launch_real_to_complex(const float *in, float2 *out, size_t n, hipStream_t s);

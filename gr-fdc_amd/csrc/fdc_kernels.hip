@@ -483,6 +483,50 @@ __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restric
     }
 }
 
+// Power cells from the sums of the spectrum's 16-bin groups (round 6): gpow[m][N / 16] is written by the forward transform while the spectrum is in its
+// registers (fdc_block256.hip), so a cell is the groups that lie inside it plus the bins of the two groups it cuts — one or two cache lines of the
+// spectrum per cell and block instead of all of it (a detector's cells tile 80 % of the band: k_cell_power read 444-472 MB per 1024 blocks back).
+// Summation order differs from k_cell_power's in the last bits (the blocks' thresholds sit 6-10 dB above what they compare).
+__global__ __launch_bounds__(kThreads) void k_cell_power_groups(const float2 *__restrict__ spec, const float *__restrict__ gpow, int N,
+                                                                const PowerCell *__restrict__ cells, int ncells, int nblocks, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cell = blockIdx.x * (kThreads / 64) + wave;
+    const int mb = blockIdx.y * kCellBlocks;
+    if (cell >= ncells) return;
+    const PowerCell pc = cells[cell];
+    const int end = pc.start + pc.len, g0 = (pc.start + 15) >> 4, g1 = end >> 4;
+    const bool any = g1 >= g0;                                     // a group boundary inside the cell
+    const int hc = any ? 16 * g0 - pc.start : pc.len, tc = any ? end - 16 * g1 : 0, ng = any ? g1 - g0 : 0;    // hc < 31, tc < 16
+    const int ngrp = N >> 4;
+#pragma unroll
+    for (int j = 0; j < kCellBlocks; j++) {
+        const int m = mb + j;
+        if (m >= nblocks) break;
+        const float2 *x = spec + (size_t)m * N;
+        float acc = 0.f;
+        if (lane < hc) { const float2 v = x[pc.start + lane]; acc = v.x * v.x + v.y * v.y; }
+        if (lane < tc) { const float2 v = x[16 * g1 + lane]; acc += v.x * v.x + v.y * v.y; }
+        const float *gp = gpow + (size_t)m * ngrp + g0;
+        for (int g = lane; g < ng; g += 64) acc += gp[g];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) out[(size_t)m * ncells + cell] = acc * pc.scale;
+    }
+}
+
+// the same group sums from a spectrum in memory: launch groups the block kernel did not transform (short calls on the two-pass transform, block
+// lengths without a block kernel)
+__global__ __launch_bounds__(256) void k_group_power(const float4 *__restrict__ spec2, size_t ngroups, float *__restrict__ gpow)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ngroups * 8; i += (size_t)gridDim.x * 256) {
+        const float4 v = spec2[i];                                 // two bins; eight lanes per group
+        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if ((i & 7) == 0) gpow[i >> 3] = s;
+    }
+}
+
 // Extraction of one width class: out = IFFT_w( halfswap( X[slot][start .. start+w) * win ) )[skip .. w)
 //   lib/PowerActivationChannel_impl.cc:260-284, lib/activity_detection_channelizer_vcm_impl.cc:373-397
 template <int NB>
@@ -935,6 +979,28 @@ hipError_t launch_cell_power(const float2 *spec, int N, const PowerCell *cells, 
         hipLaunchKernelGGL(k_cell_power, dim3((ncells + 3) / 4, (nb + kCellBlocks - 1) / kCellBlocks), dim3(kThreads), 0, s, spec + (size_t)m0 * N, N, cells,
                            ncells, nb, out + (size_t)m0 * ncells);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_cell_power_groups(const float2 *spec, const float *gpow, int N, const PowerCell *cells, int ncells, int nblocks, float *out, hipStream_t s)
+{
+    if (ncells <= 0 || nblocks <= 0) return hipSuccess;
+    if (N & 15) return hipErrorInvalidValue;
+    for (int m0 = 0; m0 < nblocks; m0 += 32768) {
+        const int nb = nblocks - m0 < 32768 ? nblocks - m0 : 32768;
+        hipLaunchKernelGGL(k_cell_power_groups, dim3((ncells + 3) / 4, (nb + kCellBlocks - 1) / kCellBlocks), dim3(kThreads), 0, s, spec + (size_t)m0 * N,
+                           gpow + (size_t)m0 * (N >> 4), N, cells, ncells, nb, out + (size_t)m0 * ncells);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_group_power(const float2 *spec, int N, int nblocks, float *gpow, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    if (N & 15) return hipErrorInvalidValue;
+    const size_t ngroups = (size_t)nblocks * (size_t)(N >> 4);
+    size_t g = (ngroups * 8 + 255) / 256; if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_group_power, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const float4 *>(spec), ngroups, gpow);
     return hipGetLastError();
 }
 

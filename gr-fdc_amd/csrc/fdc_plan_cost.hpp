@@ -28,8 +28,10 @@ inline double bank_launch(int width)
 }
 
 // The spectrum path for channels that read `band` of the 65536 bins (sum of their widths / 65536; may exceed 1 for overlapping slices):
-// forward transform by the block kernel 0.20 (nothing written; bound by its arithmetic) ... 0.25 (every 64-bin group written), channel
-// kernels 0.19 per 65536 bins read.
+// forward transform by the block kernel 0.20 (nothing written) ... 0.25 (every 64-bin group written), channel kernels 0.19 per 65536 bins read.
+// (What bounds the forward kernel — round 6, profiles/r06/pmc_summary_fwd.txt: the memory system on its OWN traffic, 1368 MB per 1024 blocks at
+// 5.5 TB/s, 39 % of it the scratch trip of the half of T that does not fit the registers; VALU 28 % of the issue slots.  With nothing written it
+// still moves the 537 MB of scratch and waits for it: 0.19-0.20.  Not "bound by its arithmetic", as this line said until round 5.)
 //   forward  0.477 ms / 2048 blocks, full band    profiles/r04/NOTES.md section 4 (bench_extra4_spectrum_path.json: 0.8246 = 0.477 + 0.364)
 //            0.377 ms / 2048, 4 channels read     profiles/r04/bench_extra4.json (split plan: bank 0.321 + forward 0.377 + channels 0.043)
 //   channels 0.364 ms / 2048 for 1.03 of the band profiles/r04/bench_extra4_spectrum_path.json; 0.43 for the mixed plan (bench_mixed.json)

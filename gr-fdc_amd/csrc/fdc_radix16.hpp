@@ -72,13 +72,13 @@ __device__ __forceinline__ cf mul_w16(cf v)
 {
     constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
     constexpr int e = E & 15;
-    static_assert(e == 0 || e == 1 || e == 2 || e == 3 || e == 4 || e == 6 || e == 9, "unused twiddle");
+    static_assert(e == 0 || e == 1 || e == 2 || e == 3 || e == 4 || e == 5 || e == 6 || e == 7 || e == 9, "unused twiddle");
     if constexpr (e == 0) return v;
     else if constexpr (e == 4) return mulj<INV>(v);
     else {
         // forward twiddle = (c, -s0); inverse = (c, +s0)
-        constexpr float c = e == 1 ? C1 : e == 2 ? H : e == 3 ? S1 : e == 6 ? -H : -C1;
-        constexpr float s0 = e == 1 ? S1 : e == 2 ? H : e == 3 ? C1 : e == 6 ? H : -S1;
+        constexpr float c = e == 1 ? C1 : e == 2 ? H : e == 3 ? S1 : e == 5 ? -S1 : e == 6 ? -H : -C1;          // cos(2 pi e / 16); e = 7, 9: -C1
+        constexpr float s0 = e == 1 ? S1 : e == 2 ? H : e == 3 ? C1 : e == 5 ? C1 : e == 6 ? H : e == 7 ? S1 : -S1;   // sin(2 pi e / 16)
         constexpr float s = INV ? s0 : -s0;
         return __builtin_elementwise_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
     }

@@ -198,6 +198,9 @@ struct fdc_sinks {
     // d_spec / d_power always name the buffers of the batch the next submit reads; the pair swaps when a batch's extractions are enqueued.
     float2 *d_spec_ahead = nullptr;
     float *d_power_ahead = nullptr;
+    // round 6: the power of every 16-bin group of the spectra in d_spec (slot 1 on) / d_spec_ahead, written by the producer's forward kernel
+    // (fdc_pipeline_process_device_power) beside the spectrum: fdc_sinks_prepare_from_groups sums the cells from it instead of reading the spectrum back
+    float *d_gpow = nullptr, *d_gpow_ahead = nullptr;
     hipStream_t s_fill = nullptr;
     hipEvent_t ev_fill = nullptr;
     // ... and two side streams: the width classes above 4096 points are two small launches each (a few hundred transforms); side by side
@@ -618,7 +621,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (s->s_fill) { (void)hipStreamSynchronize(s->s_fill); (void)hipStreamDestroy(s->s_fill); }
     for (hipStream_t q : {s->s_side[0], s->s_side[1], s->s_x}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead, s->ev_fork, s->ev_join[0], s->ev_join[1], s->ev_tasks}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead);
+    (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead); (void)hipFree(s->d_gpow); (void)hipFree(s->d_gpow_ahead);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
@@ -814,7 +817,9 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipMemcpy(raw->d_cells, raw->cells.data(), sizeof(fdc::PowerCell) * raw->cells.size(), hipMemcpyHostToDevice));
         CHKF(hipMalloc(&raw->d_power, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
     }
+    if (!raw->cells.empty() && N >= 16) CHKF(hipMalloc(&raw->d_gpow, sizeof(float) * (size_t)cfg->max_blocks * (size_t)(N / 16)));
     if (cfg->flags & FDC_SINKS_LOOKAHEAD) {
+        if (raw->d_gpow) CHKF(hipMalloc(&raw->d_gpow_ahead, sizeof(float) * (size_t)cfg->max_blocks * (size_t)(N / 16)));
         CHKF(hipMalloc(&raw->d_spec_ahead, sizeof(float2) * ((size_t)cfg->max_blocks + 1) * N));
         if (!raw->cells.empty()) CHKF(hipMalloc(&raw->d_power_ahead, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
         CHKF(hipStreamCreateWithFlags(&raw->s_fill, hipStreamNonBlocking));
@@ -836,6 +841,8 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         if (rcd != FDC_OK) { fdc_sinks_destroy(raw); return rcd; }
     }
 #undef CHKF
+    // the tables and zeroed buffers above went through the null stream; the bank works on non-blocking streams of its own, which do not wait for it
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); fdc_sinks_destroy(raw); return fdc::set_error(FDC_ERR_HIP, "device synchronisation failed"); }
     // ---- logs of the constructors (verbose != 0)
     if (cfg->verbose) {
         fdc_sinks *const sp = raw;
@@ -903,6 +910,33 @@ int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead)
     return FDC_OK;
     FDC_ENTRY_END
 }
+void *fdc_sinks_group_power(fdc_sinks *s) { return s ? (void *)s->d_gpow : nullptr; }
+void *fdc_sinks_group_power_ahead(fdc_sinks *s) { return s ? (void *)s->d_gpow_ahead : nullptr; }
+int fdc_sinks_prepare_from_groups(fdc_sinks *s, int nblocks, int ahead)
+{
+    FDC_ENTRY("fdc_sinks_prepare_from_groups")
+    if (!s) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    FDC_DEAD_CHECK(s);
+    if (nblocks <= 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [1, max_blocks]", nblocks);
+    if (ahead && !s->s_fill) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank was created without FDC_SINKS_LOOKAHEAD");
+    float *const gp = ahead ? s->d_gpow_ahead : s->d_gpow;
+    if (!s->cells.empty() && !gp) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank has no group-power buffer (block length below 16)");
+    HIPCHK(hipSetDevice(s->cfg.device_id));
+    float2 *const spec = ahead ? s->d_spec_ahead : s->d_spec;
+    float *const pw = ahead ? s->d_power_ahead : s->d_power;
+    // look-ahead banks: on the fill stream, behind what the producer enqueued there; other banks: on the bank's own stream (the producer
+    // wrote spectrum and group powers on a stream it has synchronised, or on this one: fdc_sinks_spectrum's contract)
+    hipStream_t q = s->s_fill ? s->s_fill : s->stream;
+    if (s->s_fill && !ahead) {
+        HIPCHK(hipEventRecord(s->ev_fill, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0));
+    }
+    if (!s->cells.empty()) HIPCHK(fdc::launch_cell_power_groups(spec + s->N, gp, s->N, s->d_cells, (int)s->cells.size(), nblocks, pw, q));
+    if (s->s_fill) HIPCHK(hipEventRecord(ahead ? s->ev_ready_ahead : s->ev_ready, s->s_fill));
+    (ahead ? s->prepared_ahead : s->prepared) = nblocks;
+    return FDC_OK;
+    FDC_ENTRY_END
+}
 int32_t fdc_sinks_blocklen(const fdc_sinks *s) { return s ? s->N : -1; }
 int32_t fdc_sinks_max_blocks(const fdc_sinks *s) { return s ? s->cfg.max_blocks : -1; }
 
@@ -934,7 +968,12 @@ int fdc_sinks_segment_params(const fdc_sinks *s, int i, int32_t *v)
 static int batch_begin(fdc_sinks *s, int nblocks, bool *have_power)
 {
     *have_power = false;
-    if (!s->s_fill) return FDC_OK;
+    if (!s->s_fill) {
+        // one-buffer bank: fdc_sinks_prepare_from_groups has (enqueued, on this stream) the cells of exactly this batch
+        *have_power = s->prepared == nblocks;
+        s->prepared = -1;
+        return FDC_OK;
+    }
     if (s->prepared == nblocks) {
         // fdc_sinks_prepare marked the point of the fill stream where this batch is complete: what the producer has enqueued there SINCE
         // (the next batch's transform) is not waited for — it is what runs beside this batch's decisions
@@ -965,6 +1004,7 @@ static int batch_end_swap(fdc_sinks *s, hipEvent_t done)
     else { HIPCHK(hipEventRecord(s->ev_fill, s->stream)); HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0)); }
     std::swap(s->d_spec, s->d_spec_ahead);
     std::swap(s->d_power, s->d_power_ahead);
+    std::swap(s->d_gpow, s->d_gpow_ahead);
     std::swap(s->ev_ready, s->ev_ready_ahead);
     s->prepared = s->prepared_ahead; s->prepared_ahead = -1;
     return FDC_OK;

@@ -74,9 +74,21 @@ class Sinks:
     def fill_stream(self):
         return _lib.lib().fdc_sinks_fill_stream(self._h)
 
-    def prepare(self, nblocks, ahead=True):
-        """Power cells of the batch in spectrum_ahead_ptr() (or spectrum_ptr()) on the fill stream, behind whatever filled it."""
-        _lib.check(_lib.lib().fdc_sinks_prepare(self._h, int(nblocks), 1 if ahead else 0))
+    def group_power_ptr(self):
+        """Device buffer (max_blocks * N/16 float32) for the group powers that go with spectrum_ptr(): Pipeline.process_device(..., d_group_power=)."""
+        return _lib.lib().fdc_sinks_group_power(self._h)
+
+    def group_power_ahead_ptr(self):
+        return _lib.lib().fdc_sinks_group_power_ahead(self._h)
+
+    def prepare(self, nblocks, ahead=True, from_groups=False):
+        """Power cells of the batch in spectrum_ahead_ptr() (or spectrum_ptr()) on the fill stream, behind whatever filled it.
+        from_groups: summed from the group powers the forward kernel left in group_power(_ahead)_ptr() instead of from the spectrum
+        (ahead=False then also works on a bank without lookahead, on its own stream)."""
+        if from_groups:
+            _lib.check(_lib.lib().fdc_sinks_prepare_from_groups(self._h, int(nblocks), 1 if ahead else 0))
+        else:
+            _lib.check(_lib.lib().fdc_sinks_prepare(self._h, int(nblocks), 1 if ahead else 0))
 
     def engine(self):
         """1 = decisions on the device (default), 0 = on host threads (verbose != 0, host_decisions, very fine segments)"""

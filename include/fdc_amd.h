@@ -162,6 +162,14 @@ void fdc_pipeline_reset(fdc_pipeline *p);    /* history <- zeros, block counter 
  *   stream      hipStream_t (NULL = the handle's own stream).  Asynchronous: returns after enqueue. */
 int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks,
                                 void *d_out, void *d_spectrum, void *stream);
+/* The same, and beside the spectrum the POWER OF ITS 16-BIN GROUPS (round 6): d_group_power receives nblocks x N/16 float32, entry [m][g] = the sum
+ * of |S|^2 over bins 16 g .. 16 g + 15 of block m's normalised, shifted spectrum.  At N = 16384 / 32768 / 65536 the forward kernel sums them in its
+ * epilogue, while the bins are in its registers; elsewhere (other block lengths, launch groups too short for the block kernel) a pass over the
+ * spectrum does.  What a sink bank's power cells are summed from (fdc_sinks_group_power / fdc_sinks_prepare_from_groups below) instead of reading the
+ * spectrum back: lib/PowerActivationChannel_impl.cc:286-306, lib/activity_detection_channelizer_vcm_impl.cc:630-650 sum |X|^2 over a bin range per
+ * block.  Needs d_spectrum and N a multiple of 16; d_group_power = NULL is fdc_pipeline_process_device. */
+int fdc_pipeline_process_device_power(fdc_pipeline *p, const void *d_ring, int64_t first_block, int nblocks, void *d_out, void *d_spectrum,
+                                      void *d_group_power, void *stream);
 int fdc_pipeline_synchronize(fdc_pipeline *p);
 void *fdc_pipeline_stream(fdc_pipeline *p);  /* the handle's hipStream_t */
 /* The one-block-per-compute-unit kernels are persistent: one workgroup per unit, all of its LDS.  A consumer that wants to run other
@@ -415,6 +423,15 @@ int32_t fdc_sinks_engine(const fdc_sinks *s);       /* 0 = host decisions, 1 = d
 void *fdc_sinks_spectrum_ahead(fdc_sinks *s);
 void *fdc_sinks_fill_stream(fdc_sinks *s);
 int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead);
+/* Power cells WITHOUT a pass over the spectrum (round 6).  fdc_sinks_group_power(s) / fdc_sinks_group_power_ahead(s): device buffers of max_blocks x N/16
+ * float32 that go with fdc_sinks_spectrum(s) / fdc_sinks_spectrum_ahead(s) (they swap together; NULL for a bank without cells or N < 16): the producer
+ * hands them to fdc_pipeline_process_device_power as d_group_power.  fdc_sinks_prepare_from_groups(s, n, ahead) then sums every cell from the groups
+ * inside it plus the bins of the (at most two) groups it cuts, and marks the batch like fdc_sinks_prepare: the submit / work call of n blocks that follows
+ * skips its own power pass.  ahead = 0 also on banks without FDC_SINKS_LOOKAHEAD (on the bank's stream).  The cells' float sums are formed in another
+ * order than k_cell_power forms them (last bits); the PDUs' payloads do not depend on them.  fdc_pipeline_work_sinks does all of this itself. */
+void *fdc_sinks_group_power(fdc_sinks *s);
+void *fdc_sinks_group_power_ahead(fdc_sinks *s);
+int fdc_sinks_prepare_from_groups(fdc_sinks *s, int nblocks, int ahead);
 /* PDUs emitted by the last work call, in emission order */
 int fdc_sinks_pdu_count(const fdc_sinks *s);
 int fdc_sinks_pdu(const fdc_sinks *s, int i, fdc_pdu *out);

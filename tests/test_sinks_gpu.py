@@ -454,3 +454,67 @@ def test_hier_block_pipelined_emits_the_same_pdus(N, R, sizes, verbose, capfd):
         _same_messages(got_msgs, ref_msgs)
     assert len(ref_msgs) >= 4
     capfd.readouterr()
+
+
+@pytest.mark.parametrize("N,min_block_launch,lookahead", [(65536, 1, False), (65536, 1, True), (32768, 1, False), (16384, 1, True),
+                                                          (65536, None, False), (4096, None, False)])
+def test_power_cells_from_the_forward_kernels_group_sums(oracle, N, min_block_launch, lookahead):
+    """Round 6: the forward kernel leaves the power of every 16-bin group of the spectrum beside the spectrum (fdc_pipeline_process_device_power) and
+    the bank sums its cells from them plus the bins of the groups a cell cuts (fdc_sinks_prepare_from_groups) instead of reading the spectrum back.
+    The block kernel's epilogue at N = 65536 / 32768 / 16384, the pass over the spectrum where another transform ran (short launch groups at the
+    default threshold, N = 4096); cells that start and end anywhere inside a group (PowerActivationChannels) and cells of dec bins on the
+    detector's grid; a bank fed through the spectrum pass gives the same PDUs (metadata equal, payloads bit for bit: the extractions do not
+    depend on the cells), and both match the oracle."""
+    R, sizes = 2, [9, 16, 3, 16]
+    nb = sum(sizes)
+    H = N - N // R
+    carriers = [(-0.2, 3, 11), (0.31, 6, 17), (-0.2, 20, 30), (0.33, 25, nb - 3), (0.12, 2, 40)]
+    x = _bursty_stream(N, R, nb, 8, carriers)
+    pac = [((-0.2 + 0.5) % 1.0, 0.04, 0), ((0.12 + 0.5) % 1.0, 37.0 / N + 0.011, 1)]
+    segs = [(0.75, 0.9)]
+    kw = dict(pac=pac, pac_thresh=6.0, pac_maxblocks=3, segments=segs, det_thresh=10.0, det_maxblocks=3, minchandist=0.005, det_delay=1,
+              puffer=0.2, max_blocks=16)
+    hip = _HipCopy()
+    hip.h.hipMalloc.argtypes = [hip.C.POINTER(hip.C.c_void_p), hip.C.c_size_t]
+    ring = hip.C.c_void_p()
+    assert hip.h.hipMalloc(hip.C.byref(ring), (N // R + nb * H) * 8) == 0
+    pipe = G.Pipeline(N, R, [], windowtype=1, max_blocks=16, keep_spectrum=True, min_block_launch=min_block_launch)
+    xr = np.concatenate([np.zeros(N // R, np.complex64), x])
+    hip.upload(ring, xr, pipe.stream())
+    cuts = np.cumsum([0] + sizes)
+    results = []
+    for from_groups in (True, False):
+        bank = G.Sinks(N, R, lookahead=lookahead, **kw)
+        assert bank.group_power_ptr() and (bool(bank.group_power_ahead_ptr()) == lookahead)
+        got = []
+        q = bank.fill_stream() if lookahead else bank.stream()
+
+        def fill(i, ahead):
+            pipe.process_device(int(ring.value) + 8 * int(cuts[i]) * H, int(cuts[i]), sizes[i], None,
+                                d_spectrum=bank.spectrum_ahead_ptr() if ahead else bank.spectrum_ptr(), stream=q,
+                                d_group_power=(bank.group_power_ahead_ptr() if ahead else bank.group_power_ptr()) if from_groups else None)
+            if from_groups or lookahead:
+                bank.prepare(sizes[i], ahead=ahead, from_groups=from_groups)
+        if lookahead:
+            fill(0, False)
+        for i in range(len(sizes)):
+            if lookahead:
+                if i + 1 < len(sizes):
+                    fill(i + 1, True)
+            else:
+                fill(i, False)
+            got += bank.submit_device(sizes[i])
+        got += bank.flush()
+        results.append(got)
+        bank.close()
+    assert len(results[0]) == len(results[1]) >= 6
+    for (gm, gd), (rm, rd) in zip(*results):
+        assert {k: gm[k] for k in gm if k != "id"} == {k: rm[k] for k in rm if k != "id"}
+        assert np.array_equal(gd, rd)
+    _, spec = oracle.channelizer(N, R, 1, [], x, want_spectrum=True, nthreads=4)
+    spec = spec.reshape(nb, N)
+    for i, (cf, bw, ident) in enumerate(pac):
+        compare([g for g in results[0] if g[0]["kind"] == 0 and g[0]["source"] == ident], oracle.PowerActivationChannel(N, cf, bw, R, 6.0, 3, 0, ident).work(spec), vec=False)
+    compare([g for g in results[0] if g[0]["kind"] == 1], oracle.ActivityDetectionVcm(N, [list(segs[0])], 10.0, R, 3, 0.005, 1, 0.2).work(spec))
+    hip.h.hipFree.argtypes = [hip.C.c_void_p]
+    hip.h.hipFree(ring)
