@@ -866,6 +866,22 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
 
 extern "C" {
 
+// fdc_pipeline_cfg.flags as create AND plan_preview read them: under FDC_DEBUG_ENV=1 the debugging variables override the fields (one place, so
+// that what the preview describes is what create builds)
+static int effective_flags(int flags)
+{
+    auto on = [](const char *n) { const char *v = fdc::debug_env(n); return v && v[0] == '1'; };
+    if (on("FDC_FORCE_GENERIC")) flags |= FDC_PIPE_FORCE_GENERIC;
+    if (on("FDC_NO_POLY")) flags |= FDC_PIPE_NO_POLY;
+    if (on("FDC_NO_BLOCK")) flags |= FDC_PIPE_NO_BLOCK;
+    if (const char *bh = fdc::debug_env("FDC_BLOCK_HINTS")) {
+        flags &= ~(FDC_PIPE_PLAIN_STORES | FDC_PIPE_NT_LOADS);
+        if (!(atoi(bh) & 1)) flags |= FDC_PIPE_PLAIN_STORES;
+        if (atoi(bh) & 2) flags |= FDC_PIPE_NT_LOADS;
+    }
+    return flags;
+}
+
 int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
 {
     FDC_ENTRY("fdc_pipeline_create")
@@ -884,18 +900,7 @@ int fdc_pipeline_create(const fdc_pipeline_cfg *cfg, fdc_pipeline **out)
     std::vector<std::complex<float>> pool;
     build_channel_records(p, cfg, pool);
 
-    int flags = cfg->flags;
-    {
-        auto on = [](const char *n) { const char *v = fdc::debug_env(n); return v && v[0] == '1'; };
-        if (on("FDC_FORCE_GENERIC")) flags |= FDC_PIPE_FORCE_GENERIC;
-        if (on("FDC_NO_POLY")) flags |= FDC_PIPE_NO_POLY;
-        if (on("FDC_NO_BLOCK")) flags |= FDC_PIPE_NO_BLOCK;
-        if (const char *bh = fdc::debug_env("FDC_BLOCK_HINTS")) {
-            flags &= ~(FDC_PIPE_PLAIN_STORES | FDC_PIPE_NT_LOADS);
-            if (!(atoi(bh) & 1)) flags |= FDC_PIPE_PLAIN_STORES;
-            if (atoi(bh) & 2) flags |= FDC_PIPE_NT_LOADS;
-        }
-    }
+    const int flags = effective_flags(cfg->flags);
     p->cfg.flags = flags;
     p->cfg_generic = (flags & FDC_PIPE_FORCE_GENERIC) != 0;
     p->block_hints = ((flags & FDC_PIPE_PLAIN_STORES) ? 0 : 1) | ((flags & FDC_PIPE_NT_LOADS) ? 2 : 0);
@@ -934,8 +939,10 @@ int fdc_pipeline_plan_preview(const fdc_pipeline_cfg *cfg, char *buf, int32_t n,
     p->N = cfg->blocklen; p->R = cfg->relinvovl; p->ovl = p->N / p->R; p->H = p->N - p->ovl; p->C = cfg->nchannels;
     std::vector<std::complex<float>> pool;
     build_channel_records(p.get(), cfg, pool);
-    p->cfg_generic = (cfg->flags & FDC_PIPE_FORCE_GENERIC) != 0;
-    classify_plan(p.get(), cfg, cfg->flags);
+    const int flags = effective_flags(cfg->flags);
+    p->cfg.flags = flags;
+    p->cfg_generic = (flags & FDC_PIPE_FORCE_GENERIC) != 0;
+    classify_plan(p.get(), cfg, flags);
     if (assignment) {
         for (int c = 0; c < p->C; c++) assignment[c] = -1;
         for (size_t k = 0; k < p->banks.size(); k++) for (int c : p->banks[k].chan) assignment[c] = (int32_t)k;

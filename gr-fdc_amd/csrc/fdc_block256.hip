@@ -592,13 +592,15 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                             for (int i = 0; i < 16; i++) {
                                 const float s0 = __builtin_fmaf(v[i].y, v[i].y, v[i].x * v[i].x);
                                 const float s1 = __builtin_fmaf(v[i + 16].y, v[i + 16].y, v[i + 16].x * v[i + 16].x);
-                                asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                                // (s_nop 1: a DPP operand written by the VALU instruction just before needs two wait states; the compiler's hazard
+                                // recogniser does not look into inline assembly)
+                                asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
                                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc" : "=&v"(t16[i]) : "v"(s0), "v"(s1));
                             }
                             float t8[8];
 #pragma unroll
                             for (int i = 0; i < 8; i++)
-                                asm("v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                                asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
                                     "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(t8[i]) : "v"(t16[i]), "v"(t16[i + 8]));
                             const bool b1 = (lane2 & 2) != 0, b0 = (lane2 & 1) != 0;
                             float t4[4], t2[2];

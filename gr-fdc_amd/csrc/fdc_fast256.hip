@@ -539,6 +539,25 @@ __global__ __launch_bounds__(TR * 16, 4) void k_p2(const float2 *__restrict__ g,
 // LDS exchange layouts (both conflict-free for b64 accesses, rows on the fast lanes at the store end):
 //   exchange 1: (r, p, b')    at (p*64 + b')*16 + ((r ^ b') & 15)
 //   exchange 2: (r, p, d, s)  at ((p*4 + d)*16 + (s ^ (d & 1)))*16 + r
+// Round 6: 16-BYTE ACCESSES at both ends as a build variant (-DFDC_P2K_WIDE=1; the shipped form is the 8-byte one of rounds 2-5, see below).  The memory pattern alone runs at 6.3-6.6 TB/s
+// with 16 bytes per lane where the 8-byte form of this kernel moved its 537 MB at 5.76 (profiles/r05/NOTES.md section 1), and what kept the wide shape
+// out of k_p1 — lane pairs must trade halves so that a lane ends up with ONE column (loads) / one slot's TWO rows (stores) — costs one
+// instruction per dword here: v_permlane16_swap_b32 (gfx950) trades the odd rows of one register with the even rows of another, so the lane bit
+// that pairs two lanes is made bit 4 of the lane at both ends.
+//   loads : lane (c8, rlo, ah, rmid) of wave (rhi, j) asks for columns 2 c8, 2 c8 + 1 of row r at a = 8 ah + i, i < 8 (sixteen bytes); after eight
+//           swaps per component it holds column col = 2 c8 + ah at all sixteen a: the layer-1 roles with another lane numbering
+//   stores: layer-2/3 roles numbered so that bit 4 of the lane is bit 0 of the row: lanes l and l ^ 16 hold rows r2, r2 ^ 1 of the same sixteen slots;
+//           after the swaps the even row's lane has slots 0-7 of BOTH rows and the odd row's lane slots 8-15: eight 16-byte stores each.
+// The exchanges stay conflict-free under the new lane numberings (worked out against the bank rules as in the comment above: exchange 2's row
+// position is r2 ^ (d & 1) now, so that the two d of a 16-lane store group do not fall on the same 32 banks).
+// MEASURED (profiles/r06/ab_p2k_wide.txt, same box, three alternations, N = 262144): 0.0990 / 0.1001 / 0.1010 ms per 256 blocks against 0.0956 / 0.0980 /
+// 0.1062 for the 8-byte form: nothing.  Halving the instructions does not change what the memory system sees: G's column tiles are 16 columns wide
+// (k_p1's layout) and a tile has 16 rows per slot (LDS: 128 KiB), so both ends stay at 128-byte pieces; the pattern bench's gain came with 256-byte
+// pieces.  The 32 swaps per lane and tile cost nothing either.  Shipped: the 8-byte form (FDC_P2K_WIDE=0); the wide form passes the same parity tests.
+#ifndef FDC_P2K_WIDE
+#define FDC_P2K_WIDE 0
+#endif
+typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, float2 *__restrict__ out,
                                                   const float2 *__restrict__ tw1024,
                                                   const long long *__restrict__ slot_off, long long nrows,
@@ -561,27 +580,50 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
         const long long o = slot_off[tid];
         soff[tid] = o >= 0 ? (unsigned)((o * nb_call + out_base) * 8) : 0xFFFFFFFFu;
     }
+#if FDC_P2K_WIDE
+    const int ah = (tid >> 4) & 1;                                   // which half of a the lane loads; afterwards bit 0 of its column
+    const int col = 2 * (tid & 7) + ah, r = ((tid >> 3) & 1) + 2 * ((tid >> 5) & 1) + 4 * ((tid >> 6) & 3), j = tid >> 8;
+    const int bp = 16 * j + col;
+    const int r2 = 2 * ((tid >> 1) & 7) + ((tid >> 4) & 1), d = (tid & 1) + 2 * ((tid >> 5) & 1), p2 = tid >> 6;
+#else
     const int col = tid & 15, r = (tid >> 4) & 15, j = tid >> 8;     // layer 1: row r, b' = 16j + col
     const int bp = 16 * j + col;
     const int r2 = tid & 15, d = (tid >> 4) & 3, p2 = tid >> 6;      // layer 2: row r2, (p2, d); layer 3: (p2, e = d)
+#endif
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
     const int tpb = lout / TR;                                       // tiles per block
     // G[m][ct][t'][16]: point n1 = 64a + b' sits in column tile ct = 4a + j at column col
-    const unsigned voff = (unsigned)((j * lout + r) * 16 + col) * 8u;
     const unsigned astep = 4u * (unsigned)lout * 16u * 8u;
+#if FDC_P2K_WIDE
+    const unsigned voff = (unsigned)((j * lout + r) * 16 + (col & ~1)) * 8u + 8u * (unsigned)ah * astep;
+#else
+    const unsigned voff = (unsigned)((j * lout + r) * 16 + col) * 8u;
+#endif
     // LDS addresses with the swizzles folded into a few base pointers (everything else is an immediate offset)
     float2 *const wr1 = tile + bp * 16 + ((r ^ bp) & 15);                          // + p*1024
     const float2 *rd1[4];                                                          // + c*64, base by c & 3
 #pragma unroll
     for (int k = 0; k < 4; k++) rd1[k] = tile + (p2 * 64 + d) * 16 + ((r2 ^ d ^ (4 * k)) & 15);
     float2 *wr2[2];                                                                // s even / odd: + (s>>1)*32
-    wr2[0] = tile + ((p2 * 4 + d) * 16 + (d & 1)) * 16 + r2;
-    wr2[1] = tile + ((p2 * 4 + d) * 16 + 1 - (d & 1)) * 16 + r2;
+    constexpr int kPosSw = FDC_P2K_WIDE ? 1 : 0;                                   // wide form: row position r2 ^ (d & 1)
+    wr2[0] = tile + ((p2 * 4 + d) * 16 + (d & 1)) * 16 + (r2 ^ (kPosSw & d));
+    wr2[1] = tile + ((p2 * 4 + d) * 16 + 1 - (d & 1)) * 16 + (r2 ^ (kPosSw & d));
     const float2 *rd2[2];                                                          // d' even / odd: + (d'*16 + 4f)*16
     rd2[0] = tile + (p2 * 64 + d) * 16 + r2;
-    rd2[1] = tile + (p2 * 64 + (d ^ 1)) * 16 + r2;
+    rd2[1] = tile + (p2 * 64 + (d ^ 1)) * 16 + (r2 ^ kPosSw);
     // the tile loads are inline assembly and waited for behind the tile's stores (vm_wait, fdc_devutil.hpp): the compiler's own wait at
     // the loop latch was vmcnt(0) — every wave of the one workgroup a compute unit has sat out the completion of its sixteen stores
+#if FDC_P2K_WIDE
+    u32x4 L4[8];
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const size_t m = t / tpb;
+        const int t0 = (t - (int)m * tpb) * TR;
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g + m * (size_t)lout * 1024 + (size_t)t0 * 16, (unsigned)lout * 1024u * 8u);
+#pragma unroll
+        for (int i = 0; i < 8; i++) L4[i] = bld4(rg, voff, (unsigned)i * astep);
+    };
+    issue(tl);
+#else
     cf L[16];
     auto issue = [&](int t) __attribute__((always_inline)) {
         const size_t m = t / tpb;
@@ -592,10 +634,23 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
     };
     issue(tl);
     vm_wait<0>(L);
+#endif
     for (;;) {
         cf v[16];
+#if FDC_P2K_WIDE
+        // (columns 2 c8, 2 c8 + 1 at a = 8 ah + i) -> (column 2 c8 + ah at a = i and at a = 8 + i): the even row of a pair keeps its first column and
+        // gets it at the other eight a from the odd row, which keeps its second column
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u32x2p sx = __builtin_amdgcn_permlane16_swap(L4[i].x, L4[i].z, false, false);
+            const u32x2p sy = __builtin_amdgcn_permlane16_swap(L4[i].y, L4[i].w, false, false);
+            v[i] = mk(__uint_as_float(sx.x), __uint_as_float(sy.x));
+            v[8 + i] = mk(__uint_as_float(sx.y), __uint_as_float(sy.y));
+        }
+#else
 #pragma unroll
         for (int a = 0; a < 16; a++) v[a] = L[a];
+#endif
         const int nxt = tl + gridDim.x;
         if (nxt < ntiles) issue(nxt);
         dft16<false>(v);                                            // Y_b'[p] in v[rev16(p)]
@@ -641,6 +696,26 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
         for (int f = 0; f < 4; f++) dft4<false>(v[4 * f], v[4 * f + 1], v[4 * f + 2], v[4 * f + 3]);
         // Always sixteen stores per lane: a slot the plan does not use, or a row beyond the call, gets an offset beyond the descriptor's
         // extent and is dropped by its range check (no branch per store; the count is what the wait below is stated in)
+#if FDC_P2K_WIDE
+        // rows r2 (even) and r2 + 1 of a slot are 16 contiguous bytes of its stream: the even row's lane takes slots v[0..7] of both rows, the odd
+        // row's lane slots v[8..15]; always eight stores per lane (unused slots / rows beyond the call: beyond the descriptor's extent)
+        const int odd = r2 & 1;
+        const long long rho = (long long)tl * TR + (r2 & ~1);
+        const bool live = rho < nrows;
+        const unsigned rbytes = (unsigned)rho * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int f = i >> 2, u = i & 3;
+            const unsigned off = soff[p2 + 16 * (4 * (f + 2 * odd) + d) + 256 * u];
+            const unsigned o = (off == 0xFFFFFFFFu || !live) ? 0xFFFFFFF0u : off + rbytes;
+            const u32x2p sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i].x), __float_as_uint(v[i + 8].x), false, false);
+            const u32x2p sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i].y), __float_as_uint(v[i + 8].y), false, false);
+            const cf lo = mk(__uint_as_float(sx.x), __uint_as_float(sy.x)), hi = mk(__uint_as_float(sx.y), __uint_as_float(sy.y));
+            if (hints & 1) bst4<true>(rout, o, lo, hi); else bst4<false>(rout, o, lo, hi);
+        }
+        if (nxt >= ntiles) break;
+        tl = nxt;
+#else
         const long long rho = (long long)tl * TR + r2;
         const bool live = rho < nrows;
         const unsigned rbytes = (unsigned)rho * 8u;
@@ -662,6 +737,7 @@ __global__ __launch_bounds__(1024, 1) void k_p2k(const float2 *__restrict__ g, f
         if (nxt >= ntiles) break;
         vm_wait<16>(L);                                              // the next tile has landed; this tile's stores are not waited for
         tl = nxt;
+#endif
     }
 }
 

@@ -512,7 +512,7 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
     // the channels in FREQUENCY order: a PowerActivationChannel PDU is put back by the place of its channel in the bank's own list (bank_pos);
     // the segments are runs of the bank order: member 0's detections, member 1's, ...  Inside one channel / one member's detections the PDUs are
     // in emission order already: the sort is stable on (item, kind, place).
-    struct Key { int32_t item, kind, member; uint32_t seq; };
+    struct Key { int32_t item, kind, member; int32_t from, idx; };      // from / idx: which member's list, which entry (no packing: any member or PDU count)
     std::vector<Key> keys;
     std::vector<std::vector<fdc_pdu>> got(g->mem.size());
     std::vector<int32_t> items, pacs;
@@ -530,7 +530,7 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
             const int32_t kind = got[(size_t)i][(size_t)k].kind, pc = pacs[(size_t)k];
             // place: a PowerActivationChannel's index in cfg->pac[]; a detection's member (members own runs of the segment list)
             const int32_t place = (kind == 0 && pc >= 0 && (size_t)pc < bp.size()) ? bp[(size_t)pc] : i;
-            keys.push_back(Key{items[(size_t)k], kind, place, (uint32_t)(((uint32_t)i << 24) | (uint32_t)k)});
+            keys.push_back(Key{items[(size_t)k], kind, place, i, k});
         }
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
@@ -539,7 +539,7 @@ int fdc_sinks_group_work(fdc_sinks_group *g, const void *spectrum, int nitems)
         return a.member < b.member;
     });
     g->pdus.reserve(keys.size());
-    for (const Key &k : keys) g->pdus.push_back(got[(size_t)(k.seq >> 24)][k.seq & 0xFFFFFFu]);
+    for (const Key &k : keys) g->pdus.push_back(got[(size_t)k.from][(size_t)k.idx]);
     guard.done = true;
     return nitems;
     FDC_ENTRY_END

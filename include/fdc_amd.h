@@ -184,12 +184,13 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * l = 256 on the 256-bin grid: stage 1 = column FFT + window + IFFT, stage 2 = FFT across slots; timing
  * slots ms[0], ms[1] then hold stage 1 and stage 2 and ms[2] = 0), 3 = the uniform plan at N = 65536, R = 2 as ONE
  * kernel (one block per compute unit, nothing between the input rows and the output samples touches memory;
- * ms[0] = that kernel, ms[1] = ms[2] = 0).  Path 3 also takes tilings that start at any bin (f = 256*slot + r) and
- * unions of up to three tilings (different r, different windows, a slot used twice): one launch per tiling; N = 16384 and 32768
- * run the same kernel with 2 and 4 passes; uniform banks of 1024- (3 channels and more: the cost rule), 512-, 128- and 64-bin channels (R = 2 or 4) on their own grid
- * — or all half a channel higher: f = l*slot + l/2, a bank centred on multiples of l — at N = 16384 / 32768 / 65536 have block kernels of their own and report 3 as well.  4 = a SPLIT plan at N = 65536: the channels that form tilings take path 3 (ms[0]), the
- * rest — other widths, a fourth tiling — take the spectrum path on a partial spectrum that holds only what they read (forward
- * transform ms[1], channel kernels ms[2]); chosen where that is estimated cheaper than the whole plan on path 1. */
+ * ms[0] = that kernel, ms[1] = ms[2] = 0).  Path 3 is every plan that is a line-up of up to FOUR BANKS, one block-kernel launch each: a bank is a
+ * set of channels of one width l in {64, 128, 256, 512, 1024} on one grid f = l*slot + r with one window (l = 256: any r; 512 / 1024: r = 0 or l/2; 128 /
+ * 64: r a multiple of l/4), banks of different widths may stand side by side (round 5), at N = 16384 / 32768 / 65536 (2 / 4 / 8 passes of the same kernels),
+ * R = 2 or 4.  4 = a SPLIT plan at any of those three block lengths: the banks take path 3 (ms[0]), the rest — widths without a block kernel, odd offsets,
+ * a fifth bank, banks the cost rule sends back — take the spectrum path on a partial spectrum that holds only what they read (forward transform ms[1], channel
+ * kernels ms[2]).  Which it is, the cost rule decides (csrc/fdc_plan_cost.hpp: measured constants per launch and per band read; a plan goes to path 1 whole
+ * when the sum says so); fdc_pipeline_describe / fdc_pipeline_plan_preview say what was chosen. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 /* The same in words, for logs: which kernels the handle's plan was given ("N = 65536, R = 2, 512 channels; path 3: k_blknar, l = 128, bank of 511 half a
  * channel off the grid + bank of 1 on the grid (two launches)").  Writes at most n bytes including the terminator; returns the untruncated length, -1 for
