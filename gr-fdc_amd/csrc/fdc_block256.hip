@@ -163,7 +163,7 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
                                                 float *__restrict__ gpow)
 {
     typedef BlkGeom<P> GM;
-    static_assert(!STG || (P == 8 && !OFF && !FWD && !R4), "staged loads: the plain channelizer at N = 65536");
+    static_assert(!STG || (P == 8 && !OFF && !R4), "staged loads: the plain channelizer and the forward transform at N = 65536");
     static_assert(!HALF || (!OFF && !FWD && !STG), "the half-slot form is a variant of the on-grid channelizer");
     constexpr int kN1 = GM::kN1, kLd = GM::kLd, kJT = GM::kJT, kJB = GM::kJB;
     constexpr bool FW2 = FWD && FDC_FWD_TWO_WG;                                  // forward transform, two workgroups per block
@@ -670,6 +670,10 @@ __global__ FDC_PLAIN_DS __launch_bounds__(512, (P == 2 && !OFF && !R4 && !FWD) ?
 #ifndef FDC_BLK_STAGED
 #define FDC_BLK_STAGED 0
 #endif
+// -DFDC_FWD_STAGED=1: the forward-transform variant at N = 65536 with its loads staged through LDS (experiment, round 6)
+#ifndef FDC_FWD_STAGED
+#define FDC_FWD_STAGED 0
+#endif
 
 hipError_t init_block_kernels()
 {
@@ -694,6 +698,12 @@ hipError_t init_block_kernels()
     FDC_SETHP(2) FDC_SETHP(4) FDC_SETHP(8)
 #undef FDC_SETHP
 #undef FDC_SETH
+#if FDC_FWD_STAGED
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
+    if (e != hipSuccess) return e;
+#endif
 #if FDC_BLK_STAGED
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk256<8, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::kLdsS);
     if (e != hipSuccess) return e;
@@ -786,6 +796,15 @@ hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *o
                               (unsigned)((size_t)nb * (size_t)N * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep, \
                               gpow ? gpow + (size_t)m0 * (size_t)(N / 16) : (float *)nullptr)
         const bool nt = (hints & 1) != 0;
+#if FDC_FWD_STAGED
+#define FDC_LFS(A) \
+        hipExtLaunchKernelGGL((k_blk256<8, A, false, true, false, true>), dim3((unsigned)grid), dim3(512), BlkGeom<8>::kLdsS, s, e0, e2, 0u, in + (size_t)m0 * in_stride, \
+                              in_stride, out + (size_t)m0 * (size_t)N, tw256, twq, cbt0, shn1, slot_off, 0ll, 1ll, \
+                              (unsigned)((size_t)nb * (size_t)N * 8), nb, hints, (unsigned long long *)nullptr, 0, 0ll, scratch, keep, \
+                              gpow ? gpow + (size_t)m0 * (size_t)(N / 16) : (float *)nullptr)
+        if (N == 65536) { if (nt) FDC_LFS(true); else FDC_LFS(false); } else
+#undef FDC_LFS
+#endif
         if (N == 65536) { if (nt) FDC_LF(8, true); else FDC_LF(8, false); }
         else if (N == 32768) { if (nt) FDC_LF(4, true); else FDC_LF(4, false); }
         else { if (nt) FDC_LF(2, true); else FDC_LF(2, false); }

@@ -487,31 +487,48 @@ __global__ __launch_bounds__(kThreads) void k_cell_power(const float2 *__restric
 // registers (fdc_block256.hip), so a cell is the groups that lie inside it plus the bins of the two groups it cuts — one or two cache lines of the
 // spectrum per cell and block instead of all of it (a detector's cells tile 80 % of the band: k_cell_power read 444-472 MB per 1024 blocks back).
 // Summation order differs from k_cell_power's in the last bits (the blocks' thresholds sit 6-10 dB above what they compare).
+// Sixteen lanes per (cell, block) and kGrpBlocks blocks per lane group, all loads of a lane issued before the first sum: the first form (a wave per
+// cell, its four blocks one after the other, a 64-lane reduction each) was a chain of dependent loads with a quarter of the lanes busy — 62-71 us
+// per 1024 blocks, as long as the pass over the spectrum it replaced (profiles/r06/rocprof_kernel_stats_cfg3.csv, first collection).
+constexpr int kGrpBlocks = 8;
 __global__ __launch_bounds__(kThreads) void k_cell_power_groups(const float2 *__restrict__ spec, const float *__restrict__ gpow, int N,
                                                                 const PowerCell *__restrict__ cells, int ncells, int nblocks, float *__restrict__ out)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cell = blockIdx.x * (kThreads / 64) + wave;
-    const int mb = blockIdx.y * kCellBlocks;
-    if (cell >= ncells) return;
-    const PowerCell pc = cells[cell];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 lane groups per workgroup: 16 cells
+    const int cell = blockIdx.x * (kThreads / 16) + grp;
+    const int mb = blockIdx.y * kGrpBlocks;
+    const bool on = cell < ncells;
+    const PowerCell pc = cells[on ? cell : 0];
     const int end = pc.start + pc.len, g0 = (pc.start + 15) >> 4, g1 = end >> 4;
     const bool any = g1 >= g0;                                     // a group boundary inside the cell
     const int hc = any ? 16 * g0 - pc.start : pc.len, tc = any ? end - 16 * g1 : 0, ng = any ? g1 - g0 : 0;    // hc < 31, tc < 16
     const int ngrp = N >> 4;
+    float acc[kGrpBlocks];
+    float2 h0[kGrpBlocks], h1[kGrpBlocks], t0[kGrpBlocks];
+    float gq[kGrpBlocks];
 #pragma unroll
-    for (int j = 0; j < kCellBlocks; j++) {
-        const int m = mb + j;
-        if (m >= nblocks) break;
+    for (int j = 0; j < kGrpBlocks; j++) {
+        const int m = mb + j < nblocks ? mb + j : nblocks - 1;
         const float2 *x = spec + (size_t)m * N;
-        float acc = 0.f;
-        if (lane < hc) { const float2 v = x[pc.start + lane]; acc = v.x * v.x + v.y * v.y; }
-        if (lane < tc) { const float2 v = x[16 * g1 + lane]; acc += v.x * v.x + v.y * v.y; }
-        const float *gp = gpow + (size_t)m * ngrp + g0;
-        for (int g = lane; g < ng; g += 64) acc += gp[g];
+        h0[j] = (on && sub < hc) ? x[pc.start + sub] : make_float2(0.f, 0.f);
+        h1[j] = (on && sub + 16 < hc) ? x[pc.start + sub + 16] : make_float2(0.f, 0.f);
+        t0[j] = (on && sub < tc) ? x[16 * g1 + sub] : make_float2(0.f, 0.f);
+        gq[j] = (on && sub < ng) ? gpow[(size_t)m * ngrp + g0 + sub] : 0.f;
+    }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) out[(size_t)m * ncells + cell] = acc * pc.scale;
+    for (int j = 0; j < kGrpBlocks; j++) {
+        acc[j] = h0[j].x * h0[j].x + h0[j].y * h0[j].y + h1[j].x * h1[j].x + h1[j].y * h1[j].y + t0[j].x * t0[j].x + t0[j].y * t0[j].y + gq[j];
+        if (ng > 16) {                                            // wide cells (a PowerActivationChannel's measure range can be any width)
+            const int m = mb + j < nblocks ? mb + j : nblocks - 1;
+            const float *gp = gpow + (size_t)m * ngrp + g0;
+            for (int g = sub + 16; g < ng; g += 16) acc[j] += gp[g];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kGrpBlocks; j++) {
+        float t = acc[j];
+        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+        if (on && sub == 0 && mb + j < nblocks) out[(size_t)(mb + j) * ncells + cell] = t * pc.scale;
     }
 }
 
@@ -988,7 +1005,7 @@ hipError_t launch_cell_power_groups(const float2 *spec, const float *gpow, int N
     if (N & 15) return hipErrorInvalidValue;
     for (int m0 = 0; m0 < nblocks; m0 += 32768) {
         const int nb = nblocks - m0 < 32768 ? nblocks - m0 : 32768;
-        hipLaunchKernelGGL(k_cell_power_groups, dim3((ncells + 3) / 4, (nb + kCellBlocks - 1) / kCellBlocks), dim3(kThreads), 0, s, spec + (size_t)m0 * N,
+        hipLaunchKernelGGL(k_cell_power_groups, dim3((ncells + kThreads / 16 - 1) / (kThreads / 16), (nb + kGrpBlocks - 1) / kGrpBlocks), dim3(kThreads), 0, s, spec + (size_t)m0 * N,
                            gpow + (size_t)m0 * (N >> 4), N, cells, ncells, nb, out + (size_t)m0 * ncells);
     }
     return hipGetLastError();
