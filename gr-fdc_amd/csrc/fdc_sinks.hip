@@ -263,6 +263,7 @@ struct fdc_sinks {
         int cur = 1;                          // landing buffer of the newest batch
         bool inflight = false;                // some batch is pending
         bool any = false;                     // a batch has run: d_land[cur] holds buffered blocks
+        int eager_n = 0;                      // look-ahead: the decision chain of the NEXT batch (prepared, this many blocks) is already enqueued
     } dev;
 };
 
@@ -600,7 +601,16 @@ int dev_setup(fdc_sinks *s)
     }
 #undef DUP
 #undef DALLOC
-    HIPCHK(hipStreamCreateWithFlags(&d.s_copy, hipStreamNonBlocking));
+    {
+        // the payload copy's stream at the highest priority (its own hardware-queue pool: see the extraction streams in fdc_sinks_create): all it ever
+        // carries are a wait, a copy and a mark, and behind a 250-us forward kernel on a shared queue they start a kernel late
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+#ifdef FDC_SINKS_NO_PRIO
+        hi = 0;
+#endif
+        HIPCHK(hipStreamCreateWithPriority(&d.s_copy, hipStreamNonBlocking, hi));
+    }
     HIPCHK(hipEventCreateWithFlags(&d.ev_decide, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipEventCreateWithFlags(&d.ev_extract[i], hipEventDisableTiming));
@@ -827,10 +837,23 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipEventCreateWithFlags(&raw->ev_ready, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_ready_ahead, hipEventDisableTiming));
         CHKF(hipEventCreateWithFlags(&raw->ev_fork, hipEventDisableTiming));
-        CHKF(hipStreamCreateWithFlags(&raw->s_x, hipStreamNonBlocking));
+        // The extraction streams get the HIGHEST priority: the runtime maps streams onto a few hardware queues PER PRIORITY LEVEL, and at equal
+        // priority the extraction stream shared one with the fill stream — a batch's extractions sat behind the NEXT batch's 250-us forward
+        // kernel, whose successor in turn waits for those extractions to release the spectrum buffer (round 6, gpurun_out/timeline_cfg3.txt:
+        // k_x256 started the moment the forward kernel ended; configs[2] 0.373 ms per 896 blocks for 0.27 of fill-stream work).  They are also the
+        // work the buffer hand-over waits for: first in line is right.
+        int prio_lo = 0, prio_hi = 0;
+        CHKF(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        // (The payload copy's stream too, dev_setup: with the extraction stream gone from the normal pool the round robin put THAT one on the fill
+        // stream's queue, and every step's copy started one forward kernel late: configs[2] 2.29 -> 2.55 ms, configs[4] 1.27 -> 1.53 per 896 blocks with
+        // PDUs to host memory, profiles/r06/sched_ab.txt.)
+#ifdef FDC_SINKS_NO_PRIO                      // A/B builds
+        prio_hi = 0;
+#endif
+        CHKF(hipStreamCreateWithPriority(&raw->s_x, hipStreamNonBlocking, prio_hi));
         CHKF(hipEventCreateWithFlags(&raw->ev_tasks, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) {
-            CHKF(hipStreamCreateWithFlags(&raw->s_side[i], hipStreamNonBlocking));
+            CHKF(hipStreamCreateWithPriority(&raw->s_side[i], hipStreamNonBlocking, prio_hi));
             CHKF(hipEventCreateWithFlags(&raw->ev_join[i], hipEventDisableTiming));
         }
     }
@@ -896,6 +919,7 @@ int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead)
     FDC_DEAD_CHECK(s);
     if (!s->s_fill) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank was created without FDC_SINKS_LOOKAHEAD");
     if (nblocks <= 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [1, max_blocks]", nblocks);
+    if (!ahead && s->dev.eager_n > 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the batch in the current buffer was prepared before and its decisions are enqueued: submit it");
     HIPCHK(hipSetDevice(s->cfg.device_id));
     float2 *const spec = ahead ? s->d_spec_ahead : s->d_spec;
     float *const pw = ahead ? s->d_power_ahead : s->d_power;
@@ -919,6 +943,7 @@ int fdc_sinks_prepare_from_groups(fdc_sinks *s, int nblocks, int ahead)
     FDC_DEAD_CHECK(s);
     if (nblocks <= 0 || nblocks > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nblocks %d outside [1, max_blocks]", nblocks);
     if (ahead && !s->s_fill) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank was created without FDC_SINKS_LOOKAHEAD");
+    if (!ahead && s->dev.eager_n > 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the batch in the current buffer was prepared before and its decisions are enqueued: submit it");
     float *const gp = ahead ? s->d_gpow_ahead : s->d_gpow;
     if (!s->cells.empty() && !gp) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "the bank has no group-power buffer (block length below 16)");
     HIPCHK(hipSetDevice(s->cfg.device_id));
@@ -1357,19 +1382,26 @@ static int host_work_device(fdc_sinks *s, int nblocks)
 // the summary of the layout kernel (buffer sizes, tasks per width class) on the host, then enqueues the rest: placement of the
 // tasks, blocks buffered from the call before, extraction kernels, history block, and the copy of the emitted runs to the host
 // on a stream of its own.  dev_complete(): waits for that copy and turns the emission records into fdc_pdu.
-static int dev_enqueue(fdc_sinks *s, int nblocks)
+// ahead: the chain of the batch that sits PREPARED in the ahead buffer (look-ahead banks, enqueued by the submit in front of it): its power cells are
+// marked by ev_ready_ahead
+static int dev_enqueue(fdc_sinks *s, int nblocks, bool ahead = false)
 {
     auto &d = s->dev;
     const int N = s->N, ncells = (int)s->cells.size(), npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     const long long now = (long long)time(nullptr), bc0 = s->blockcount;
     bool have_power = false;
-    { const int rb = batch_begin(s, nblocks, &have_power); if (rb != FDC_OK) return rb; }
-    if (ncells && !have_power) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, s->d_power, s->stream));
-    HIPCHK(fdc::launch_pac_decide(s->d_power, ncells, nblocks, d.d_pgeom, d.d_pstate, npac, s->pac_thr, s->cfg.pac_maxblocks, s->R, bc0, now,
+    float *const d_power = ahead ? s->d_power_ahead : s->d_power;
+    if (ahead) {
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_ready_ahead, 0));
+        s->prepared_ahead = -1;                                    // consumed: after the swap the batch is no longer "prepared", its chain is out
+        have_power = true;
+    } else { const int rb = batch_begin(s, nblocks, &have_power); if (rb != FDC_OK) return rb; }
+    if (ncells && !have_power) HIPCHK(fdc::launch_cell_power(s->d_spec + N, N, s->d_cells, ncells, nblocks, d_power, s->stream));
+    HIPCHK(fdc::launch_pac_decide(d_power, ncells, nblocks, d.d_pgeom, d.d_pstate, npac, s->pac_thr, s->cfg.pac_maxblocks, s->R, bc0, now,
                                   d.d_tasks, d.d_pdus, d.d_task_base, d.d_pdu_base, d.d_ntask, d.d_npdu, d.d_owners, s->stream));
     if (nseg) {
         const int sd = s->cfg.det_variant == 1;
-        HIPCHK(fdc::launch_det_cands(s->d_power, ncells, nblocks, d.d_dgeom, nseg, s->dec, s->det_thr, sd, d.d_cand, d.d_cand_base,
+        HIPCHK(fdc::launch_det_cands(d_power, ncells, nblocks, d.d_dgeom, nseg, s->dec, s->det_thr, sd, d.d_cand, d.d_cand_base,
                                      d.d_ncand, s->cfg.max_blocks, s->stream));
         fdc::DetParams dp{};
         dp.N = N; dp.R = s->R; dp.dec = s->dec; dp.variant = sd; dp.maxblocks = s->cfg.det_maxblocks; dp.delay = s->cfg.det_deactivation_delay;
@@ -1398,6 +1430,7 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
     static const bool trace = fdc::debug_env("FDC_SINKS_TRACE") != nullptr;
     const int npac = (int)s->pacs.size(), nseg = (int)s->segs.size();
     HIPCHK(hipEventSynchronize(d.ev_decide));
+    const int64_t bc0_this = s->blockcount - nblocks;          // block counter at the start of THIS batch (the next batch's chain may advance it below)
     const int b = d.cur ^ 1;                                   // this call's landing buffer; d.cur still names the previous call's
     const fdc::SinkSummary sum = *d.h_sum;
     if (sum.error) {
@@ -1443,6 +1476,20 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         HIPCHK(hipEventRecord(s->ev_tasks, s->stream));
         HIPCHK(hipStreamWaitEvent(qx, s->ev_tasks, 0));
     }
+    // Look-ahead banks: the NEXT batch is already transformed and its power cells are (being) summed (fdc_sinks_prepare(.., ahead) came before this
+    // submit): its decision chain goes out NOW, behind this batch's task placement on the bank's stream — the decision arrays are free from there on, the
+    // host has its copy of this batch's summary and records — instead of when the caller comes back with the next submit, and in front of this batch's
+    // extraction launches: the chain is the long pole of a detector's step (k_det_track: 0.3 ms on two compute units) and used to start a host lap late
+    // (profiles/r06/timeline_cfg5_before.txt: 220 us between the end of one k_det_track and the start of the next).  The submit that follows must be
+    // for exactly that batch.
+#ifndef FDC_SINKS_NO_EAGER                    // (A/B builds)
+    if (s->s_fill && s->prepared_ahead > 0) {
+        const int n_next = s->prepared_ahead;
+        const int re = dev_enqueue(s, n_next, true);
+        if (re != FDC_OK) return re;
+        d.eager_n = n_next;
+    }
+#endif
     if (sum.ntask) {
         size_t first[32], cnt[32];
         for (int k = 0; k < 32; k++) { first[k] = (size_t)sum.class_base[k]; cnt[k] = (size_t)sum.class_cnt[k]; }
@@ -1457,7 +1504,7 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
         HIPCHK(hipMemcpyAsync(d.h_land[b], d.d_land[b], sizeof(float2) * (size_t)sum.used_a, hipMemcpyDeviceToHost, d.s_copy));
         HIPCHK(hipEventRecord(d.ev_copied[b], d.s_copy));
     }
-    d.cur = b; d.any = true; d.inflight = true; d.pend[b] = true; d.nb_of[b] = nblocks; d.bc0[b] = s->blockcount - nblocks;
+    d.cur = b; d.any = true; d.inflight = true; d.pend[b] = true; d.nb_of[b] = nblocks; d.bc0[b] = bc0_this;
     if (trace) std::fprintf(stderr, "[fdc_sinks dev] %d tasks, %d PDUs, %lld samples emitted, %lld buffered\n", sum.ntask, sum.npdu,
                             (long long)sum.used_a, (long long)(sum.used_total - sum.b_start));
     return FDC_OK;
@@ -1590,8 +1637,18 @@ int fdc_sinks_submit_device(fdc_sinks *s, int nblocks)
     // From the first launch of dev_enqueue on, the channel state on the device, the block counter and the layout of this batch's
     // landing buffer have moved on: a failure anywhere below leaves them ahead of the host's bookkeeping (d.cur, d.pend), so it
     // poisons the handle instead of returning an error that invites a retry.
-    int rc = poison(s, dev_enqueue(s, nblocks));
-    if (rc != FDC_OK) return rc;
+    int rc;
+    if (d.eager_n > 0) {
+        // the chain of this batch went out at the end of the submit before (dev_launch_extractions): the state has advanced for exactly eager_n blocks
+        if (nblocks != d.eager_n) {
+            fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a batch of %d blocks was prepared ahead and its decisions are enqueued: the submit must be for it, not for %d blocks", d.eager_n, nblocks);
+            return poison(s, FDC_ERR_INVALID_ARGUMENT);
+        }
+        d.eager_n = 0;
+    } else {
+        rc = poison(s, dev_enqueue(s, nblocks));
+        if (rc != FDC_OK) return rc;
+    }
     const int before = d.cur;
     const bool had = d.pend[before];
     if (had) { rc = poison(s, dev_build(s, before)); if (rc < 0) return rc; }
@@ -1639,6 +1696,7 @@ int fdc_sinks_work(fdc_sinks *s, const void *spectrum, int nitems)
     FDC_DEAD_CHECK(s);
     if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
+    if (s->dev.eager_n > 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a batch prepared ahead has its decisions enqueued: submit it before feeding the bank from the host");
     if (nitems == 0) { s->pdus.clear(); return 0; }
     if (!spectrum) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "null buffer");
     HIPCHK(hipSetDevice(s->cfg.device_id));
@@ -1677,6 +1735,7 @@ int fdc_sinks_work_band(fdc_sinks *s, const void *spectrum, int nitems, int32_t 
     FDC_DEAD_CHECK(s);
     if (nitems < 0 || nitems > s->cfg.max_blocks) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "nitems %d outside [0, max_blocks]", nitems);
     if (s->dev.on && s->dev.inflight) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a submitted batch is in flight: fdc_sinks_flush() first");
+    if (s->dev.eager_n > 0) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "a batch prepared ahead has its decisions enqueued: submit it before feeding the bank from the host");
     if (bin_lo < 0 || bin_hi > s->N || bin_lo > bin_hi) return fdc::set_error(FDC_ERR_INVALID_ARGUMENT, "band [%d, %d) outside the block", bin_lo, bin_hi);
     int32_t need_lo = 0, need_hi = 0;
     fdc_sinks_read_band(s, &need_lo, &need_hi);

@@ -420,7 +420,13 @@ int32_t fdc_sinks_engine(const fdc_sinks *s);       /* 0 = host decisions, 1 = d
  * leave a few compute units free for the chains (fdc_pipeline_reserve_compute_units): the block kernels are persistent and fill every
  * unit's LDS.  Without the flag: spectrum_ahead and fill_stream return null, prepare refuses.
  * fdc_sinks_prepare(s, n, ahead): power cells of the n blocks in fdc_sinks_spectrum_ahead (ahead = 1) or fdc_sinks_spectrum (0) on the
- * fill stream; the submit of that batch then skips them if its block count is n. */
+ * fill stream; the submit of that batch then skips them if its block count is n.
+ * Round 6: a batch prepared AHEAD is committed.  The submit in front of it, once it has placed its own tasks, enqueues the prepared batch's decision
+ * chain at once (device engine) instead of when the caller returns with the next submit — the chain is the long pole of a detector's step and used
+ * to start a host lap late — so the next submit / work_device call must be for exactly that batch (another block count: FDC_ERR_INVALID_ARGUMENT and the
+ * handle is dead); fdc_sinks_work / work_band / a second prepare of the current buffer are refused until it has been submitted.  The extraction
+ * streams run at the device's highest stream priority (own hardware queues: at equal priority they shared one with the fill stream and sat behind the
+ * next batch's forward kernel). */
 void *fdc_sinks_spectrum_ahead(fdc_sinks *s);
 void *fdc_sinks_fill_stream(fdc_sinks *s);
 int fdc_sinks_prepare(fdc_sinks *s, int nblocks, int ahead);
