@@ -198,6 +198,14 @@ struct fdc_sinks {
     // d_spec / d_power always name the buffers of the batch the next submit reads; the pair swaps when a batch's extractions are enqueued.
     float2 *d_spec_ahead = nullptr;
     float *d_power_ahead = nullptr;
+    // ... and, only under -DFDC_SINKS_THREE_BUFFERS, a THIRD spectrum buffer (round 6, measured and not shipped).  With two, the forward transform of
+    // batch n + 2 waits for the extractions of batch n to release their buffer, and a batch's whole chain (transform, cells, decisions, the host's look at
+    // the summary, task placement, extractions: 0.65 ms at configs[2]) runs two deep: 0.34 ms per step for 0.29 ms of fill-stream work
+    // (profiles/r06/timeline_cfg3_two_buffers.txt).  With three (current <- ahead <- spare <- current; the fill stream waits for the extractions of the
+    // batch BEFORE the one just submitted) the transform does run beside the extractions — and both slow down: they are the two bandwidth-heavy
+    // kernels of the step (configs[2] 0.340 -> 0.335 ms, forward kernel 0.25 -> 0.28; configs[4] 0.49 -> 0.53, forward kernel 0.40 beside k_det_track
+    // and the extractions; profiles/r06/sched_three_buffers.txt).  The step is the memory system's, not the schedule's.
+    float2 *d_spec_spare = nullptr;
     // round 6: the power of every 16-bin group of the spectra in d_spec (slot 1 on) / d_spec_ahead, written by the producer's forward kernel
     // (fdc_pipeline_process_device_power) beside the spectrum: fdc_sinks_prepare_from_groups sums the cells from it instead of reading the spectrum back
     float *d_gpow = nullptr, *d_gpow_ahead = nullptr;
@@ -631,7 +639,7 @@ void fdc_sinks_destroy(fdc_sinks *s)
     if (s->s_fill) { (void)hipStreamSynchronize(s->s_fill); (void)hipStreamDestroy(s->s_fill); }
     for (hipStream_t q : {s->s_side[0], s->s_side[1], s->s_x}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : {s->ev_fill, s->ev_ready, s->ev_ready_ahead, s->ev_fork, s->ev_join[0], s->ev_join[1], s->ev_tasks}) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_power_ahead); (void)hipFree(s->d_gpow); (void)hipFree(s->d_gpow_ahead);
+    (void)hipFree(s->d_spec_ahead); (void)hipFree(s->d_spec_spare); (void)hipFree(s->d_power_ahead); (void)hipFree(s->d_gpow); (void)hipFree(s->d_gpow_ahead);
     (void)hipFree(s->d_spec); (void)hipFree(s->d_wins); (void)hipFree(s->d_tw); (void)hipFree(s->d_tw256); (void)hipFree(s->d_cells);
     (void)hipFree(s->d_power); (void)hipFree(s->d_tasks); (void)hipFree(s->d_ext); (void)hipFree(s->d_wide);
     if (s->h_ext) (void)hipHostFree(s->h_ext);
@@ -831,6 +839,10 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
     if (cfg->flags & FDC_SINKS_LOOKAHEAD) {
         if (raw->d_gpow) CHKF(hipMalloc(&raw->d_gpow_ahead, sizeof(float) * (size_t)cfg->max_blocks * (size_t)(N / 16)));
         CHKF(hipMalloc(&raw->d_spec_ahead, sizeof(float2) * ((size_t)cfg->max_blocks + 1) * N));
+#ifdef FDC_SINKS_THREE_BUFFERS                // (A/B builds; measured, not shipped: see the struct)
+        if (!(cfg->flags & FDC_SINKS_HOST_DECISIONS) && cfg->verbose == 0)
+            CHKF(hipMalloc(&raw->d_spec_spare, sizeof(float2) * ((size_t)cfg->max_blocks + 1) * N));
+#endif
         if (!raw->cells.empty()) CHKF(hipMalloc(&raw->d_power_ahead, sizeof(float) * raw->cells.size() * (size_t)cfg->max_blocks));
         CHKF(hipStreamCreateWithFlags(&raw->s_fill, hipStreamNonBlocking));
         CHKF(hipEventCreateWithFlags(&raw->ev_fill, hipEventDisableTiming));
@@ -1022,12 +1034,21 @@ static int batch_end_history(fdc_sinks *s, int nblocks, hipStream_t q)
 }
 // ... then the buffers swap, and the fill stream may overwrite this batch's buffer once `done` (an event on the bank's stream behind the
 // history copy; null: everything enqueued on it so far) has passed
-static int batch_end_swap(fdc_sinks *s, hipEvent_t done)
+// Three spectrum buffers (device engine): the buffer that becomes "ahead" is the one of the batch BEFORE this one; its last reader is `prev_done`
+// (have_prev: there was such a batch).  The power and group-power buffers stay a pair: this batch's were last read by its decision chain, which the
+// host has seen finish (the summary), and by its cell kernel on the fill stream itself.
+static int batch_end_swap(fdc_sinks *s, hipEvent_t done, hipEvent_t prev_done = nullptr, bool have_prev = false)
 {
     if (!s->s_fill) return FDC_OK;
-    if (done) HIPCHK(hipStreamWaitEvent(s->s_fill, done, 0));
-    else { HIPCHK(hipEventRecord(s->ev_fill, s->stream)); HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0)); }
-    std::swap(s->d_spec, s->d_spec_ahead);
+    if (s->d_spec_spare && done) {
+        if (have_prev) HIPCHK(hipStreamWaitEvent(s->s_fill, prev_done, 0));
+        float2 *const cur = s->d_spec;
+        s->d_spec = s->d_spec_ahead; s->d_spec_ahead = s->d_spec_spare; s->d_spec_spare = cur;
+    } else {
+        if (done) HIPCHK(hipStreamWaitEvent(s->s_fill, done, 0));
+        else { HIPCHK(hipEventRecord(s->ev_fill, s->stream)); HIPCHK(hipStreamWaitEvent(s->s_fill, s->ev_fill, 0)); }
+        std::swap(s->d_spec, s->d_spec_ahead);
+    }
     std::swap(s->d_power, s->d_power_ahead);
     std::swap(s->d_gpow, s->d_gpow_ahead);
     std::swap(s->ev_ready, s->ev_ready_ahead);
@@ -1498,7 +1519,7 @@ static int dev_launch_extractions(fdc_sinks *s, int nblocks)
     }
     { const int rh = batch_end_history(s, nblocks, qx); if (rh != FDC_OK) return rh; }
     HIPCHK(hipEventRecord(d.ev_extract[b], qx));
-    { const int rh = batch_end_swap(s, d.ev_extract[b]); if (rh != FDC_OK) return rh; }
+    { const int rh = batch_end_swap(s, d.ev_extract[b], d.ev_extract[b ^ 1], d.any); if (rh != FDC_OK) return rh; }
     if (!devpay && sum.used_a) {
         HIPCHK(hipStreamWaitEvent(d.s_copy, d.ev_extract[b], 0));
         HIPCHK(hipMemcpyAsync(d.h_land[b], d.d_land[b], sizeof(float2) * (size_t)sum.used_a, hipMemcpyDeviceToHost, d.s_copy));
