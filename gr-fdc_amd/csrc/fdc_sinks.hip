@@ -201,7 +201,7 @@ struct fdc_sinks {
     // ... and, only under -DFDC_SINKS_THREE_BUFFERS, a THIRD spectrum buffer (round 6, measured and not shipped).  With two, the forward transform of
     // batch n + 2 waits for the extractions of batch n to release their buffer, and a batch's whole chain (transform, cells, decisions, the host's look at
     // the summary, task placement, extractions: 0.65 ms at configs[2]) runs two deep: 0.34 ms per step for 0.29 ms of fill-stream work
-    // (profiles/r06/timeline_cfg3_two_buffers.txt).  With three (current <- ahead <- spare <- current; the fill stream waits for the extractions of the
+    // (profiles/r06/timeline_cfg3_shipped.txt).  With three (current <- ahead <- spare <- current; the fill stream waits for the extractions of the
     // batch BEFORE the one just submitted) the transform does run beside the extractions — and both slow down: they are the two bandwidth-heavy
     // kernels of the step (configs[2] 0.340 -> 0.335 ms, forward kernel 0.25 -> 0.28; configs[4] 0.49 -> 0.53, forward kernel 0.40 beside k_det_track
     // and the extractions; profiles/r06/sched_three_buffers.txt).  The step is the memory system's, not the schedule's.
@@ -851,7 +851,7 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out)
         CHKF(hipEventCreateWithFlags(&raw->ev_fork, hipEventDisableTiming));
         // The extraction streams get the HIGHEST priority: the runtime maps streams onto a few hardware queues PER PRIORITY LEVEL, and at equal
         // priority the extraction stream shared one with the fill stream — a batch's extractions sat behind the NEXT batch's 250-us forward
-        // kernel, whose successor in turn waits for those extractions to release the spectrum buffer (round 6, gpurun_out/timeline_cfg3.txt:
+        // kernel, whose successor in turn waits for those extractions to release the spectrum buffer (round 6, profiles/r06/timeline_cfg3_before.txt:
         // k_x256 started the moment the forward kernel ended; configs[2] 0.373 ms per 896 blocks for 0.27 of fill-stream work).  They are also the
         // work the buffer hand-over waits for: first in line is right.
         int prio_lo = 0, prio_hi = 0;
