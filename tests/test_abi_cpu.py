@@ -228,3 +228,14 @@ def test_group_workers_are_pinned_to_their_devices_numa_node():
         checked += 1
     assert checked >= 1
     assert os.sched_getaffinity(0) == mine            # the calling thread was never touched
+
+
+def test_round6_entry_points_validate_without_a_device():
+    """The entries added in round 6 refuse null handles before anything touches a device (and say so in fdc_last_error)."""
+    lib = G.lib()
+    assert lib.fdc_pipeline_flush_sinks(None, None) == -1 and b"null" in lib.fdc_last_error()
+    assert lib.fdc_pipeline_sinks_latency(None, None) == -1
+    assert lib.fdc_pipeline_process_device_power(None, None, 0, 1, None, None, None, None) == -1
+    assert lib.fdc_sinks_prepare_from_groups(None, 1, 0) == -1
+    assert not lib.fdc_sinks_group_power(None) and not lib.fdc_sinks_group_power_ahead(None)
+    assert lib.fdc_pipeline_work_sinks(None, None, 1, None, None, None) == -1
