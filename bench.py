@@ -506,7 +506,10 @@ def main():
     if world > 1 and not dry and os.environ.get("FDC_BENCH_REHEARSE") != "1":
         placed = gpu_numa_cpus(local)
         if placed:
-            os.sched_setaffinity(0, placed[1])
+            try:
+                os.sched_setaffinity(0, placed[1])
+            except OSError:                       # best effort: a cpuset that refuses the mask leaves the rank where it is
+                placed = None
     import torch                      # first: my library then binds to the same libamdhip64 torch loaded
     import numpy as np
     # rehearsal on a one-GPU box (FDC_BENCH_REHEARSE=1): all ranks share cuda:0 and talk over gloo; the driver's real

@@ -518,3 +518,48 @@ def test_power_cells_from_the_forward_kernels_group_sums(oracle, N, min_block_la
     compare([g for g in results[0] if g[0]["kind"] == 1], oracle.ActivityDetectionVcm(N, [list(segs[0])], 10.0, R, 3, 0.005, 1, 0.2).work(spec))
     hip.h.hipFree.argtypes = [hip.C.c_void_p]
     hip.h.hipFree(ring)
+
+
+def test_a_batch_prepared_ahead_is_committed():
+    """Round 6: on a look-ahead bank the submit in front of a batch that was prepared AHEAD enqueues that batch's decision chain at once.  From then
+    on the batch is committed: feeding the bank from the host or preparing the current buffer again is refused (handle stays usable), the submit that
+    follows must be for exactly that batch — another block count kills the handle instead of advancing the state machines twice."""
+    N, R = 4096, 2
+    spec = burst_spectrum(N, 24, [(1200, 1300, 3, 9, 1.0), (1200, 1300, 14, 20, 1.0)], 4)
+    kw = dict(pac=[(1250 / N, 100 / N, 0)], pac_thresh=6.0, pac_maxblocks=3, max_blocks=8)
+    ref = G.Sinks(N, R, **kw)
+    want = []
+    for a in (0, 8, 16):
+        want += ref.work(spec[a:a + 8].reshape(-1))
+    hip = _HipCopy()
+    bank = G.Sinks(N, R, lookahead=True, **kw)
+    fs = bank.fill_stream()
+    b = [np.ascontiguousarray(spec[a:a + 8].reshape(-1)) for a in (0, 8, 16)]
+    hip.upload(bank.spectrum_ptr(), b[0], fs)
+    bank.prepare(8, ahead=False)
+    hip.upload(bank.spectrum_ahead_ptr(), b[1], fs)
+    bank.prepare(8, ahead=True)
+    got = bank.submit_device(8)                            # batch 0; batch 1's chain goes out inside this call
+    with pytest.raises(G.FdcError):
+        bank.work(b[2])                                    # the committed batch first
+    with pytest.raises(G.FdcError):
+        bank.prepare(8, ahead=False)
+    hip.upload(bank.spectrum_ahead_ptr(), b[2], fs)        # the ahead buffer is free for batch 2 meanwhile
+    bank.prepare(8, ahead=True)
+    got += bank.submit_device(8)                           # batch 1, as promised
+    got += bank.submit_device(8)                           # batch 2
+    got += bank.flush()
+    assert len(got) == len(want) >= 2
+    for (gm, gd), (rm, rd) in zip(got, want):
+        assert {k: gm[k] for k in gm if k != "id"} == {k: rm[k] for k in rm if k != "id"} and np.array_equal(gd, rd)
+    # the other block count: dead handle
+    bank2 = G.Sinks(N, R, lookahead=True, **kw)
+    hip.upload(bank2.spectrum_ptr(), b[0], bank2.fill_stream())
+    bank2.prepare(8, ahead=False)
+    hip.upload(bank2.spectrum_ahead_ptr(), b[1][:5 * N], bank2.fill_stream())
+    bank2.prepare(5, ahead=True)
+    bank2.submit_device(8)
+    with pytest.raises(G.FdcError):
+        bank2.submit_device(8)                             # 5 were prepared and are on their way
+    with pytest.raises(G.FdcError):
+        bank2.submit_device(5)                             # dead from the first wrong call on
