@@ -810,6 +810,10 @@ hipError_t launch_block_fft(int N, const float2 *in, size_t in_stride, float2 *o
         else { if (nt) FDC_LF(2, true); else FDC_LF(2, false); }
 #undef FDC_LF
     }
+#if FDC_FWD_TWO_WG
+    // (variant build: the epilogue reduction exists in the shipped form only)
+    if (gpow) { hipError_t e = launch_group_power(out, N, nitems, gpow, s); if (e != hipSuccess) return e; }
+#endif
     if (ev) { hipError_t e = hipEventRecord(ev[2], s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
