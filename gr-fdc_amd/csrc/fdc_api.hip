@@ -1320,7 +1320,8 @@ void fdc_pipeline_reset(fdc_pipeline *p)
 {
     if (!p) return;
     p->blockcount = 0;
-    p->hier_filled = 0;                         // a batch of the pipelined hier entry that was not submitted yet is dropped with the stream
+    // (a batch of the pipelined hier entry that sits transformed in the bank stays there: the sink blocks are blocks of their own with their own
+    // state, its PDUs come out with the next call or fdc_pipeline_flush_sinks)
     if (p->ev_hier && p->hier_ring_busy) (void)hipEventSynchronize(p->ev_hier);
     if (p->d_ring) {
         (void)hipSetDevice(p->cfg.device_id);

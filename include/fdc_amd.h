@@ -367,8 +367,9 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
  *    fdc_pipeline_flush_sinks() hands out what is still inside: call it until it returns 0 when the stream ends (the block's stop()).
  *    The persistent forward kernel leaves ncu/8 compute units to the bank's chains when a call is long enough to take it through two
  *    rounds (fdc_pipeline_reserve_compute_units overrides).  Between the first pipelined call and the last flush the bank belongs to the
- *    pipeline: no fdc_sinks_work*() / submit / prepare on it from elsewhere; flush before destroying either handle or resetting the
- *    pipeline (fdc_pipeline_reset drops a batch that was not submitted yet). */
+ *    pipeline: no fdc_sinks_work*() / submit / prepare on it from elsewhere; flush before destroying either handle
+ *    (fdc_pipeline_reset resets the front end only — history and block counter; a batch already transformed into the bank stays there and its PDUs
+ *    come out with the next call or a flush: the sink blocks keep their own state, as separate blocks do). */
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                             fdc_sinks *sinks);
 /* Pipelined form: submits / finishes the oldest batch still inside and makes its PDUs the bank's current ones; returns its block count,
