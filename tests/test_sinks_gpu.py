@@ -563,3 +563,18 @@ def test_a_batch_prepared_ahead_is_committed():
         bank2.submit_device(8)                             # 5 were prepared and are on their way
     with pytest.raises(G.FdcError):
         bank2.submit_device(5)                             # dead from the first wrong call on
+
+
+def test_randomised_hier_block_pipelined_equals_serial(monkeypatch, capsys):
+    """tools/fuzz_hier.py, twelve seeded cases inside the suite: random block lengths, overlaps, throughput / activity-controlled channels, detection
+    segments, maxblocks, delays, call cuts and flushes in mid-stream — the pipelined hier block (group sums, early decision chains, PDUs two calls late)
+    against the serial form bit for bit, and both against a bank fed the debug spectrum (cells by the pass over the spectrum)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_hier", os.path.join(root, "tools", "fuzz_hier.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["fuzz_hier.py", "12", "2026"])
+    mod.main()
+    assert "12 cases" in capsys.readouterr().out
