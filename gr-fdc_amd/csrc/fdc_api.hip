@@ -215,6 +215,7 @@ struct fdc_pipeline {
     fdc_sinks *hier_bank = nullptr;
     hipEvent_t ev_hier = nullptr;   // on the bank's fill stream behind the last call's transform and history copy: the ring may be overwritten
     bool hier_ring_busy = false;
+    bool hier_broken = false;    // a pipelined call failed after it had advanced the stream state: the pair of handles cannot go on (see work_sinks_pipelined)
     bool reserve_user = false;   // fdc_pipeline_reserve_compute_units was called: the pipelined entry leaves the reservation alone
     // fdc_pipeline_process_device_power: where the power of the spectrum's 16-bin groups goes (the sinks' cells are summed from it): group sums of
     // the block whose spectrum starts at gpow_spec + k N go to gpow_base + k N / 16.  Set for the duration of one call.
@@ -1599,6 +1600,7 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     if (!p->cfg.keep_spectrum) return fail(FDC_ERR_INVALID_ARGUMENT, "spectrum output needs keep_spectrum");
     if (p->hier_bank && p->hier_bank != sinks && p->hier_filled > 0)
         return fail(FDC_ERR_INVALID_ARGUMENT, "a batch of another bank is still inside this pipeline: fdc_pipeline_flush_sinks() with that bank first");
+    if (p->hier_broken) return fail(FDC_ERR_HIP, "an earlier pipelined call failed after it had advanced the stream state: destroy the pipeline and the bank");
     HIPCHK(hipSetDevice(p->cfg.device_id));
     int rc = work_io_setup(p);
     if (rc != FDC_OK) return rc;
@@ -1629,7 +1631,9 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     HIPCHK(hipEventRecord(p->ev_hier, fs));
     p->hier_ring_busy = true;
     p->blockcount += nblocks;
-    // from here on the call has happened as far as the stream state goes: a failure below must not invite a retry with the same items
+    // from here on the call has happened as far as the stream state goes (history, block counter, the bank's buffer): a failure below cannot be
+    // retried with the same items nor skipped — the pair is marked broken and every later call says so
+    struct Broken { fdc_pipeline *p; bool ok = false; ~Broken() { if (!ok) p->hier_broken = true; } } guard{p};
     rc = gpw ? fdc_sinks_prepare_from_groups(sinks, nblocks, first ? 0 : 1) : fdc_sinks_prepare(sinks, nblocks, first ? 0 : 1);
     if (rc != FDC_OK) return rc;
     bool out_reg = p->C > 0;
@@ -1659,6 +1663,7 @@ static int work_sinks_pipelined(fdc_pipeline *p, const void *in, int nblocks, vo
     }
     HIPCHK(hipEventSynchronize(p->ev_in[0]));
     if (p->C > 0 || spectrum) HIPCHK(hipStreamSynchronize(fs));
+    guard.ok = true;
     return nblocks;
 }
 
@@ -1689,6 +1694,7 @@ int fdc_pipeline_flush_sinks(fdc_pipeline *p, fdc_sinks *sinks)
 {
     FDC_ENTRY("fdc_pipeline_flush_sinks")
     if (!p || !sinks) return fail(FDC_ERR_INVALID_ARGUMENT, "null handle");
+    if (p->hier_broken) return fail(FDC_ERR_HIP, "an earlier pipelined call failed after it had advanced the stream state: destroy the pipeline and the bank");
     if (p->hier_bank == sinks && p->hier_filled > 0) {
         const int n = p->hier_filled;
         p->hier_filled = 0;

@@ -369,7 +369,9 @@ int fdc_sinks_create(const fdc_sinks_cfg *cfg, fdc_sinks **out);
  *    rounds (fdc_pipeline_reserve_compute_units overrides).  Between the first pipelined call and the last flush the bank belongs to the
  *    pipeline: no fdc_sinks_work*() / submit / prepare on it from elsewhere; flush before destroying either handle
  *    (fdc_pipeline_reset resets the front end only — history and block counter; a batch already transformed into the bank stays there and its PDUs
- *    come out with the next call or a flush: the sink blocks keep their own state, as separate blocks do). */
+ *    come out with the next call or a flush: the sink blocks keep their own state, as separate blocks do).  A pipelined call that fails after it has
+ *    advanced the stream state (history, block counter, the bank's buffers: a HIP error, a dead bank) cannot be repeated or skipped: every later
+ *    fdc_pipeline_work_sinks / fdc_pipeline_flush_sinks on that pipeline returns FDC_ERR_HIP — destroy both handles (as for a dead bank, below). */
 int fdc_pipeline_work_sinks(fdc_pipeline *p, const void *in, int nblocks, void *const *outs, void *spectrum,
                             fdc_sinks *sinks);
 /* Pipelined form: submits / finishes the oldest batch still inside and makes its PDUs the bank's current ones; returns its block count,
