@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify a few blocks against the oracle first")
     ap.add_argument("--offset", type=int, default=0, help="diagnostics (configs 2/4): every channel r bins higher (the last one "
                                                              "dropped): a tiling that does not start at bin 0")
-    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum", "wide-uniform"), default=None,
+    ap.add_argument("--force-path", choices=("no-block", "no-poly", "generic", "full-spectrum", "wide-uniform", "no-fused"), default=None,
                     help="diagnostics: fdc_pipeline_cfg.flags FDC_PIPE_NO_BLOCK / NO_POLY / FORCE_GENERIC (the slower forms of the path)")
     ap.add_argument("--block-hints", type=int, default=None, metavar="H",
                     help="diagnostics: memory hints of the block kernels (bit 0: streamed output stores, bit 1: streamed input loads; default 1)")
@@ -545,7 +545,7 @@ def main():
     import gr_fdc_amd as G
     if a.force_path:
         G.defaults[{"no-block": "FDC_NO_BLOCK", "no-poly": "FDC_NO_POLY", "generic": "FDC_FORCE_GENERIC",
-                    "full-spectrum": "FDC_FULL_SPECTRUM", "wide-uniform": "FDC_WIDE_UNIFORM"}[a.force_path]] = "1"
+                    "full-spectrum": "FDC_FULL_SPECTRUM", "wide-uniform": "FDC_WIDE_UNIFORM", "no-fused": "FDC_NO_FUSED"}[a.force_path]] = "1"
     if a.block_hints is not None:
         G.defaults["FDC_BLOCK_HINTS"] = str(a.block_hints)
     if not torch.cuda.is_available():
@@ -842,7 +842,8 @@ def main():
     ngroups = max(1, int(last[3]))              # launch groups that carried events (every timing_stride-th of the region)
     nlaunch = (nb + chunk - 1) // chunk         # launch groups per step
     path = pipe.path()
-    names = ["poly_stage1_generic(colFFT+window+IFFT, any width)", "poly_stage2_generic(slotFFT)", "unused"] if path == 2 and sinks is None and a.width else \
+    names = ["fused4096(FFT+cut+window+IFFTs, spectrum in LDS)", "unused", "unused2"] if path == 5 and sinks is None else \
+            ["poly_stage1_generic(colFFT+window+IFFT, any width)", "poly_stage2_generic(slotFFT)", "unused"] if path == 2 and sinks is None and a.width else \
             ["block_kernel(the tilings of a split plan)", "block_fft(forward, partial spectrum)", "channels(remainder)"] if path == 4 and sinks is None else \
             ["block_kernel(colFFT+window+IFFT+slotFFT)", "unused", "unused2"] if path == 3 and sinks is None else \
             ["poly_stage1(colFFT+window+IFFT)", "poly_stage2(slotFFT)", "unused"] if path == 2 and sinks is None else \

@@ -9,7 +9,7 @@ from .blocks import overlap_save, vector_cut_vxx, phase_shifting_windowing_vcc, 
 from .channelizer import (FrequencyDomainChannelizer, Pipeline, PipelineGroup, plan_preview, FREQMODE, VERBOSEMODE, WINDOWTYPES,   # noqa: F401
                           nextpow2, get_opt_channelparams, freq_converters, register_host, unregister_host, defaults)
 from ._lib import (FDC_PIPE_FORCE_GENERIC, FDC_PIPE_NO_POLY, FDC_PIPE_NO_BLOCK, FDC_PIPE_PLAIN_STORES, FDC_PIPE_NT_LOADS,   # noqa: F401
-                   FDC_PIPE_FULL_SPECTRUM, FDC_PIPE_WIDE_UNIFORM,
+                   FDC_PIPE_FULL_SPECTRUM, FDC_PIPE_WIDE_UNIFORM, FDC_PIPE_NO_FUSED,
                    FDC_SINKS_HOST_DECISIONS, FDC_SINKS_DEVICE_PAYLOAD, FDC_SINKS_LOOKAHEAD)
 from .sharding import span_for_rank, ring_bounds, ring_for_span                       # noqa: F401
 from .sinks import Sinks, SinksGroup, PowerActivationChannel, activity_detection_channelizer_vcm, SegmentDetection      # noqa: F401

@@ -33,6 +33,7 @@ class fdc_pipeline_cfg(C.Structure):
 FDC_PIPE_FORCE_GENERIC, FDC_PIPE_NO_POLY, FDC_PIPE_NO_BLOCK, FDC_PIPE_PLAIN_STORES, FDC_PIPE_NT_LOADS = 1, 2, 4, 8, 16
 FDC_PIPE_FULL_SPECTRUM = 32
 FDC_PIPE_WIDE_UNIFORM = 64
+FDC_PIPE_NO_FUSED = 128
 
 
 class fdc_pac_cfg(C.Structure):

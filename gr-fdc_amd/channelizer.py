@@ -97,7 +97,7 @@ def unregister_host(arr):
 
 # Process-wide defaults for the kernel-choice fields of fdc_pipeline_cfg (flags, min_block_launch, host_sub_blocks) of pipelines
 # created without them: how tests and A/B tools force a path.  Keys (the library itself reads no environment variable):
-#   "FDC_FORCE_GENERIC" / "FDC_NO_POLY" / "FDC_NO_BLOCK" / "FDC_FULL_SPECTRUM" -> FDC_PIPE_* flags, "FDC_BLOCK_MIN_BLOCKS" -> min_block_launch,
+#   "FDC_FORCE_GENERIC" / "FDC_NO_POLY" / "FDC_NO_BLOCK" / "FDC_NO_FUSED" / "FDC_FULL_SPECTRUM" -> FDC_PIPE_* flags, "FDC_BLOCK_MIN_BLOCKS" -> min_block_launch,
 #   "FDC_HOST_SUB" -> host_sub_blocks, "FDC_BLOCK_HINTS" (bit 0 nt stores, bit 1 nt loads)
 defaults = {}
 
@@ -114,6 +114,8 @@ def _default_cfg_fields():
         flags |= _lib.FDC_PIPE_FULL_SPECTRUM
     if defaults.get("FDC_WIDE_UNIFORM"):
         flags |= _lib.FDC_PIPE_WIDE_UNIFORM
+    if defaults.get("FDC_NO_FUSED"):
+        flags |= _lib.FDC_PIPE_NO_FUSED
     if "FDC_BLOCK_HINTS" in defaults:
         h = int(defaults["FDC_BLOCK_HINTS"])
         flags |= (0 if h & 1 else _lib.FDC_PIPE_PLAIN_STORES) | (_lib.FDC_PIPE_NT_LOADS if h & 2 else 0)

@@ -182,6 +182,13 @@ struct fdc_pipeline {
     float2 *d_twq = nullptr;                     // banks of 256-bin channels: W_N^(16 n1 q)
     // N = 65536 spectrum path: forward transform by the block kernel (fdc_block256.hip, FWD), own r = 0 tables
     bool fwd_block = false;
+    // N = 4096 in one launch (fdc_fused4096.hip; fdc_pipeline_path() = 5): the spectrum of a block stays in LDS.  A workgroup takes two blocks; f4_wave[w]:
+    // the rows wave w of its eight runs (2 channel + block of the pair; one width per wave), f4_cls the kernel's class nibble per wave; the device
+    // schedule is made in build_device_state
+    bool fused = false;
+    std::vector<int> f4_wave[8];
+    unsigned f4_cls = 0;
+    fdc::F4Row *d_f4rows = nullptr;
     float2 *d_ftwq = nullptr, *d_fcbt = nullptr;
     float *d_fshn = nullptr;
     long long *d_fslot = nullptr;
@@ -393,7 +400,7 @@ void fdc_pipeline_destroy(fdc_pipeline *p)
     (void)hipFree(p->d_tw256); (void)hipFree(p->d_tw1024); (void)hipFree(p->d_twf); (void)hipFree(p->d_twq);
     for (auto &c : p->banks) { (void)hipFree(c.d_cbt); (void)hipFree(c.d_shn); (void)hipFree(c.d_slot_off); (void)hipFree(c.d_tab); }
     (void)hipFree(p->d_ftwq); (void)hipFree(p->d_fcbt); (void)hipFree(p->d_fshn); (void)hipFree(p->d_fslot); (void)hipFree(p->d_fscr);
-    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep);
+    (void)hipFree(p->d_tw); (void)hipFree(p->d_wins); (void)hipFree(p->d_chans); (void)hipFree(p->d_groups); (void)hipFree(p->d_rgroups); (void)hipFree(p->d_keep); (void)hipFree(p->d_f4rows);
     (void)hipFree(p->d_tw512); (void)hipFree(p->d_twq512); (void)hipFree(p->d_t2g);
     (void)hipFree(p->d_tw1k); (void)hipFree(p->d_twq1k);
     (void)hipFree(p->d_big); (void)hipFree(p->d_wtasks); (void)hipFree(p->d_tmp); (void)hipFree(p->d_spec); (void)hipFree(p->d_ring); (void)hipFree(p->d_out); (void)hipFree(p->d_real);
@@ -517,6 +524,39 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     }
 }
 
+// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 256, 512 or 1024 bins wide.  A workgroup takes a pair of blocks; its
+// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256; their exchange areas
+// must fit the two tiles the spectra leave behind.  Always true for plans of up to 4096 bins in total; plans of channels that overlap to more stay on the
+// spectrum path.
+bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
+{
+    for (auto &w : p->f4_wave) w.clear();
+    p->f4_cls = 0;
+    if (p->N != 4096 || p->C == 0 || p->cfg_generic || (flags & (FDC_PIPE_NO_POLY | FDC_PIPE_NO_FUSED))) return false;
+    std::vector<int> by[3];                                       // rows of 1024, 512, 256 bins: the two blocks' rows of a channel side by side
+    for (int c = 0; c < p->C; c++) {
+        const int l = cfg->channels[c].l;
+        if ((l != 256 && l != 512 && l != 1024) || l % p->R) return false;
+        for (int k = 0; k < 2; k++) by[l == 1024 ? 0 : l == 512 ? 1 : 2].push_back(2 * c + k);
+    }
+    const int w1k = ((int)by[0].size() + 1) / 2, w512 = ((int)by[1].size() + 3) / 4, avail = 8 - w1k - w512, n256 = (int)by[2].size();
+    if (avail < 0 || n256 > 8 * avail) return false;
+    const long long pts = 1056ll * (long long)by[0].size() + 513ll * (long long)by[1].size() + 272ll * n256;   // the row pitches of k_c1024 / k_c512 / k_c256
+    if (pts > 2 * fdc::fused4096_tile_points()) return false;
+    int w = 0;
+    unsigned cls = 0;
+    for (size_t i = 0; i < by[0].size(); i += 2, w++) { for (size_t j = i; j < std::min(i + 2, by[0].size()); j++) p->f4_wave[w].push_back(by[0][j]); cls |= 4u << (4 * w); }
+    for (size_t i = 0; i < by[1].size(); i += 4, w++) { for (size_t j = i; j < std::min(i + 4, by[1].size()); j++) p->f4_wave[w].push_back(by[1][j]); cls |= 3u << (4 * w); }
+    if (n256) {
+        // as few waves as one set of four rows each allows (a wave's instructions cost the same for one row as for four); two sets where that is not enough
+        const int nw = n256 <= 4 * avail ? (n256 + 3) / 4 : avail;
+        for (int i = 0; i < n256; i++) p->f4_wave[w + i % nw].push_back(by[2][(size_t)i]);
+        for (int k = 0; k < nw; k++) cls |= (p->f4_wave[w + k].size() > 4 ? 2u : 1u) << (4 * (w + k));
+    }
+    p->f4_cls = cls;
+    return true;
+}
+
 void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
 {
     const int N = p->N, R = p->R, C = p->C;
@@ -525,6 +565,8 @@ void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
     p->fwd_block = fdc::poly_block_supports(N) && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);
     p->banks.clear(); p->bank_alias.clear(); p->rem.clear();
     p->poly_ok = p->poly_block = p->split = false;
+    p->fused = plan_fused4096(p, cfg, flags);
+    if (p->fused) return;
     if (C == 0 || p->cfg_generic || (flags & FDC_PIPE_NO_POLY) || N > (1 << 20) || R > 16) return;
     auto same_window = [&](const fdc_pipeline::Bank &b, const fdc_channel &ch) { return b.passbw == ch.passbw && b.stopbw == ch.stopbw; };
 
@@ -822,6 +864,24 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
         UPLOAD(p->d_twf, tf);
     }
     for (auto &bk : p->banks) { const int rc = build_bank_tables(p, cfg, bk); if (rc != FDC_OK) return rc; }
+    if (p->fused) {
+        std::vector<fdc::F4Row> rows(64);
+        int xch = 0;
+        for (int w = 0; w < 8; w++) {
+            const unsigned cls = (p->f4_cls >> (4 * w)) & 0xfu;
+            const int L = cls == 4 ? 1024 : cls == 3 ? 512 : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : 272;
+            for (int k = 0; k < 8; k++) {
+                fdc::F4Row &r = rows[(size_t)(8 * w + k)];
+                r = fdc::F4Row{0, 0, 0, 0, L - L / R, 0, 0};
+                if (k >= (int)p->f4_wave[w].size()) continue;
+                const int code = p->f4_wave[w][(size_t)k];
+                const fdc::ChanDev &ch = p->chans[(size_t)(code >> 1)];
+                r = fdc::F4Row{ch.f, ch.win_off, ch.shift, xch, ch.lout, 1 + (code & 1), (long long)ch.out_off};
+                xch += pitch;
+            }
+        }
+        UPLOAD(p->d_f4rows, rows);
+    }
     { const int rc = build_shared_bank_tables(p); if (rc != FDC_OK) return rc; }
     p->fwd_block = fdc::poly_block_supports(N) && !p->cfg_generic && !(flags & FDC_PIPE_NO_BLOCK);      // N = 16384 / 32768 / 65536 (round 5: the forward variant has the pass-count template too)
     if (p->fwd_block) { const int rc = build_forward_tables(p); if (rc != FDC_OK) return rc; }
@@ -875,6 +935,7 @@ static int effective_flags(int flags)
     if (on("FDC_FORCE_GENERIC")) flags |= FDC_PIPE_FORCE_GENERIC;
     if (on("FDC_NO_POLY")) flags |= FDC_PIPE_NO_POLY;
     if (on("FDC_NO_BLOCK")) flags |= FDC_PIPE_NO_BLOCK;
+    if (on("FDC_NO_FUSED")) flags |= FDC_PIPE_NO_FUSED;
     if (const char *bh = fdc::debug_env("FDC_BLOCK_HINTS")) {
         flags &= ~(FDC_PIPE_PLAIN_STORES | FDC_PIPE_NT_LOADS);
         if (!(atoi(bh) & 1)) flags |= FDC_PIPE_PLAIN_STORES;
@@ -981,6 +1042,7 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p) { return p ? p->chunk :
 int32_t fdc_pipeline_path(const fdc_pipeline *p)
 {
     if (!p) return -1;
+    if (p->fused) return 5;
     if (p->poly_block && p->split) return 4;
     if (p->poly_block) return 3;
     if (p->poly_ok) return 2;
@@ -997,7 +1059,11 @@ int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
     auto add = [&](const char *fmt, auto... a) { if (k < (int)sizeof(t)) k += std::snprintf(t + k, sizeof(t) - (size_t)k, fmt, a...); };
     auto kernel = [](int L) { return L == 256 ? "k_blk256" : L == 512 ? "k_blk512" : L == 1024 ? "k_blk1024" : "k_blknar"; };
     auto where = [](int L, int r) { return r == 0 ? "on the grid" : 2 * r == L ? "half a channel off the grid" : 4 * r == L ? "a quarter of a channel off the grid" : "three quarters of a channel off the grid"; };
-    if (p->poly_block) {
+    if (p->fused) {
+        int nw = 0;
+        for (const auto &w : p->f4_wave) nw += !w.empty();
+        add("k_f4096, transform + %d channel transforms in one launch (spectrum in LDS, rows on %d wave%s)", p->C, nw, nw == 1 ? "" : "s");
+    } else if (p->poly_block) {
         bool one_width = true, all256 = true;
         for (const auto &b : p->banks) { one_width = one_width && b.L == p->banks[0].L; all256 = all256 && b.L == 256; }
         if (all256) {
@@ -1204,6 +1270,13 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         // units leaves the rest idle (one block takes ~42 us there, however few there are).  Short calls — a scheduler handing
         // over a few items — take the two-launch form where the plan has one (ONE bank on its grid), which spreads every block over the device.
         const bool few = nb < p->block_min;
+        if (p->fused && !d_spectrum) {
+            // N = 4096: one launch, nothing but the input samples and the output samples crosses the memory interface
+            if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
+            HIPCHK(fdc::launch_fused4096(in0, (size_t)p->H, o, nb, p->R, m0, nblocks, first_block, p->d_tw, p->ntab, p->d_wins, p->d_f4rows, p->f4_cls, s));
+            if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[3] = span[1]; span[4] = kSpanBanks; p->ev_spans.push_back(span); }
+            continue;
+        }
         if (use_poly && p->poly_block && !(few && two_launch_possible(p))) {
             // one launch per bank: nothing but the input rows and the output samples crosses the memory interface.
             // timing: the first launch's begin and the last one's end are the dispatches' own stamps, no packets around the kernels

@@ -749,6 +749,8 @@ hipError_t init_fast_kernels()
     if (e != hipSuccess) return e;
     e = init_wide_kernels();
     if (e != hipSuccess) return e;
+    e = init_fused4096_kernels();
+    if (e != hipSuccess) return e;
     const int a = kTileBytes + 8192, c = kCTileBytes + 2304;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_a256), hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;

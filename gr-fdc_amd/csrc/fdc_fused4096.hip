@@ -1,0 +1,297 @@
+// N = 4096 in ONE launch (round 6): overlap-save gather + forward transform + every channel's slice, phase / window, ifftshift,
+// inverse transform, overlap discard and * l — the spectrum of a block never leaves its compute unit.  This is the block length of the
+// reference's own example flowgraph (examples/FDC_example.grc: l = 256 / 512 / 1024 / 512 at N = 4096) and of BASELINE configs[0]; the
+// two-launch spectrum path it replaces there (k_fft4096 + k_c256 / k_c512 / k_c1024) writes the bins some channel reads to memory and reads
+// them back: python/FrequencyDomainChannelizer.py:206 (fft_vcc) -> :214-216 (vector_cut_vxx, phase_shifting_windowing_vcc) -> :218-226
+// (ifft, vector_cut_vxx, multiply_const) per channel.
+//
+//   one 512-thread workgroup per PAIR of input blocks: each team of four waves transforms one block (4096 points = 32 KiB, the same three
+//   DFT-16 layers as k_fft4096, fdc_chanwide.hip) and stores the shifted, 1/N-scaled spectrum to LDS over its exchange tile (32 KiB);
+//   every one of the eight WAVES then owns rows — (block of the pair, channel) — of ONE channel width: the plan's schedule, made by the
+//   host (fdc_api.hip, plan_fused4096).  Two blocks per workgroup because a wave's instructions cost the same for one row as for a full
+//   wave of them: the reference's example plan fills its 1024- and 512-bin waves only with the rows of two blocks.
+//       l =  256: 16 lanes x 16 points per row, up to eight rows (two sets of four) per wave   (the row machinery of k_c256)
+//       l =  512: 16 lanes x 32 points, up to four rows                                        (k_c512)
+//       l = 1024: 32 lanes x 32 points, up to two rows                                         (k_c1024)
+//     a row reads its slice from the LDS spectrum and its window row (phase counter in closed form) from memory, runs its first DFT
+//     layer in registers; ONE workgroup barrier (every slice has been read) and the tile is free for the rows' own exchanges, which stay
+//     inside a wave: no further barrier.  Sum of the rows' exchange areas <= the two tiles, at most eight waves of rows: plans with more
+//     (channels that overlap to more than 4096 bins in total) stay on the spectrum path.
+// Bytes per block: H = N - N/R new input samples + sum(lout) output samples, nothing else (the window rows and tables are cache hits).
+#include "fdc_kernels.h"
+#include "fdc_radix16.hpp"
+#include "fdc_devutil.hpp"
+
+namespace fdc {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_f4[];
+
+namespace {
+constexpr int kF4TilePts = 16 * 272;                         // exchange tile of one block's forward transform; then its spectrum; then rows' exchanges
+constexpr int kF4Tiles = 2 * kF4TilePts * 8;                 // two blocks per workgroup
+constexpr int kF4OffT256 = kF4Tiles;                         // [x][y] = W_256^(x y), 16 x 18
+constexpr int kF4OffT4k = kF4OffT256 + 16 * 18 * 8;          // [x][y] = W_4096^(x y), 16 x 18
+constexpr int kF4OffRows = kF4OffT4k + 16 * 18 * 8;          // the schedule: [8 waves][8 slots] F4Row
+constexpr int kF4Lds = kF4OffRows + 64 * 32;                 // 76288
+constexpr int kF4OffW1k = kF4Lds;                            // [x][p] = W_1024^(x p), 16 x 34
+constexpr int kF4OffW64 = kF4OffW1k + 16 * 34 * 8;           // [c][p] = W_64^(c p), 2 x 34
+constexpr int kF4LdsWide = kF4OffW64 + 2 * 34 * 8;           // 81184: two 512-thread workgroups per compute unit, sixteen waves
+static_assert(sizeof(F4Row) == 32, "schedule rows are copied 16 bytes at a time");
+static_assert(2 * kF4LdsWide <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ constexpr int pos32(int k) { return 16 * (k & 1) + rev16(k >> 1); }   // dft32 leaves X[k0 + 2 k1] in v[16 k0 + rev16(k1)]
+
+// stores of some lanes of a wave, then loads of others of the SAME wave: LDS serves a wave's accesses in order, the compiler is told not to move them
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct RowAt { const float2 *win; const float2 *spec; long long dst; bool on; };
+// ri.valid: 0 = no row, 1 + k = a row of the workgroup's block k
+__device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, int mbase, long long first_block, int R, const float2 *wins,
+                                        long long nb_call, const float2 *tiles)
+{
+    const int k = ri.valid ? ri.valid - 1 : 0, m = m0 + k;
+    const int cnt = (int)((((first_block + mbase + m) % R) * ri.shift) % R);     // phase counter in closed form (lib/phase_shifting_windowing_vcc_impl.cc:58,83-89)
+    return RowAt{wins + ri.win_off + cnt * L, tiles + k * kF4TilePts + ri.f, nb_call * ri.out_off + ((long long)mbase + m) * ri.lout - (L - ri.lout),
+                 ri.valid != 0 && m < nb};
+}
+}  // namespace
+
+// 512 threads: two teams of four waves, team t transforms block 2 pair + t; then wave w of the eight runs the rows the schedule gives it.
+// wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1)
+template <bool WIDE>
+__global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
+                                                  int mbase, int nb_call, long long first_block, const float2 *__restrict__ tw,
+                                                  int twstride /* ntab / 4096 */, const float2 *__restrict__ wins,
+                                                  const F4Row *__restrict__ rows, unsigned wcls)
+{
+    float2 *tiles = reinterpret_cast<float2 *>(fdc_smem_f4);
+    float2 *t256 = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffT256);
+    float2 *t4k = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffT4k);
+    const F4Row *srows = reinterpret_cast<const F4Row *>(fdc_smem_f4 + kF4OffRows);
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, lo = tid & 15, hi = tid >> 4;
+    // neighbouring blocks share R - 1 of R input samples: workgroup ids go round the eight XCDs, so XCD x takes the x-th eighth of the launch
+    // and the shared samples are hits in ITS L2
+    const int npairs = (nb + 1) >> 1, per = (npairs + 7) >> 3;
+    const int pair = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (pair >= npairs) return;
+    const int m0 = 2 * pair, m = m0 + team;
+    float2 *tile = tiles + team * kF4TilePts;
+    if (team == 0) {
+        t256[hi * 18 + lo] = tw[((16 * hi * lo) & 4095) * twstride];
+        t4k[hi * 18 + lo] = tw[(hi * lo) * twstride];
+    } else {
+        if (tid < 128) reinterpret_cast<float4 *>(fdc_smem_f4 + kF4OffRows)[tid] = reinterpret_cast<const float4 *>(rows)[tid];
+        if constexpr (WIDE) {
+            float2 *w1k = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffW1k), *w64 = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffW64);
+            for (int i = tid; i < 512; i += 256) w1k[(i >> 5) * 34 + (i & 31)] = tw[((i >> 5) * (i & 31)) * (4 * twstride)];
+            if (tid < 64) w64[(tid >> 5) * 34 + (tid & 31)] = tid < 32 ? make_float2(1.0f, 0.0f) : tw[(tid & 31) * (64 * twstride)];
+        }
+    }
+    // ---- forward transform: n = a + 16 b + 256 c, k = k0 + 16 k1 + 256 k2 (k_fft4096, fdc_chanwide.hip) ---------------------------------
+    cf v[32];
+    {
+        cf (&u)[16] = reinterpret_cast<cf (&)[16]>(v[0]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) u[c] = m < nb ? ld2(in + (size_t)m * in_stride + (tid + 256 * c)) : mk(0.f, 0.f);
+        __syncthreads();
+        dft16<false>(u);                                             // layer 1 over c: k0 in u[rev16(k0)]; thread = (a = lo, b = hi)
+        {
+            cf w[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 t = ld4(&t256[hi * 18 + 2 * i]);
+                w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0++) st2(&tile[k0 * 272 + tid], k0 == 0 ? u[rev16(0)] : cmul(u[rev16(k0)], w[k0]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; b++) u[b] = ld2(&tile[hi * 272 + b * 16 + lo]);      // thread = (a = lo, k0 = hi)
+        dft16<false>(u);                                             // layer 2 over b: k1 in u[rev16(k1)]
+        __syncthreads();                                             // every read of exchange 1 is done
+        {
+            const cf s = ld2(&t4k[lo * 18 + hi]);                    // W_4096^(a k0)
+            cf w[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 t = ld4(&t256[lo * 18 + 2 * i]);        // W_256^(a k1)
+                w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) st2(&tile[k1 * 257 + hi * 16 + (lo ^ hi)], cmul(u[rev16(k1)], k1 == 0 ? s : cmul(s, w[k1])));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 16; a++) u[a] = ld2(&tile[hi * 257 + lo * 16 + (a ^ lo)]);   // thread = (k0 = lo, k1 = hi)
+        dft16<false>(u);                                             // layer 3 over a: bin k0 + 16 k1 + 256 k2 in u[rev16(k2)]
+        __syncthreads();                                             // every read of exchange 2 is done
+        // the shifted spectrum (fftshift: bin k at k + N/2; python/FrequencyDomainChannelizer.py:206 fft_vcc(..., shift = True)), times 1/N
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) st2(&tile[tid + 256 * (k2 ^ 8)], u[rev16(k2)] * (1.0f / 4096.0f));
+    }
+    __syncthreads();
+    // ---- the rows of this wave ---------------------------------------------------------------------------------------------------------
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const unsigned cls = (wcls >> (4 * wave)) & 0xfu;
+    const F4Row *wr = srows + 8 * wave;
+    F4Row r0{}, r1{};
+    RowAt a0{}, a1{};
+    if (cls == 1 || cls == 2) {
+        const int b = lane & 15;
+        r0 = wr[lane >> 4];
+        a0 = row_at(r0, 256, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+        {
+            cf w[16];
+#pragma unroll
+            for (int a = 0; a < 16; a++) w[a] = ld2(a0.win + 16 * a + b);
+#pragma unroll
+            for (int a = 0; a < 16; a++) v[a ^ 8] = cmul(ld2(a0.spec + 16 * a + b), w[a]);      // ifftshift of the slice: i -> i + l/2
+        }
+        if (cls == 2) {
+            r1 = wr[4 + (lane >> 4)];
+            a1 = row_at(r1, 256, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+            cf w[16];
+#pragma unroll
+            for (int a = 0; a < 16; a++) w[a] = ld2(a1.win + 16 * a + b);
+#pragma unroll
+            for (int a = 0; a < 16; a++) v[16 + (a ^ 8)] = cmul(ld2(a1.spec + 16 * a + b), w[a]);
+        }
+        dft16<true>(reinterpret_cast<cf (&)[16]>(v[0]));
+        if (cls == 2) dft16<true>(reinterpret_cast<cf (&)[16]>(v[16]));
+    }
+    if constexpr (WIDE) {
+        if (cls == 3 || cls == 4) {
+            const int L = cls == 3 ? 512 : 1024, lg = cls == 3 ? 4 : 5;
+            const int b = lane & ((1 << lg) - 1);
+            r0 = wr[lane >> lg];
+            a0 = row_at(r0, L, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+            cf w[32];
+#pragma unroll
+            for (int a = 0; a < 32; a++) w[a] = ld2(a0.win + (a << lg) + b);
+#pragma unroll
+            for (int a = 0; a < 32; a++) v[a ^ 16] = cmul(ld2(a0.spec + (a << lg) + b), w[a]);
+            dft32<true>(v);                                          // over a: index p in v[pos32(p)]
+        }
+    }
+    __syncthreads();                                                 // every slice has been read: the tiles belong to the rows' exchanges
+    if (cls == 1 || cls == 2) {
+        const int b = lane & 15;
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&t256[b * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
+        // element (b, p) of a row at p * 16 + (b ^ p): stores of one p and loads of one b are conflict-free (k_c256)
+        float2 *row0 = tiles + r0.xch, *row1 = tiles + r1.xch;
+        if (a0.on) {
+#pragma unroll
+            for (int p = 0; p < 16; p++) st2(&row0[p * 16 + (b ^ p)], cmulc(v[rev16(p)], w[p]));
+        }
+        if (cls == 2 && a1.on) {
+#pragma unroll
+            for (int p = 0; p < 16; p++) st2(&row1[p * 16 + (b ^ p)], cmulc(v[16 + rev16(p)], w[p]));
+        }
+        wave_sync();
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) v[bb] = ld2(&row0[b * 16 + (bb ^ b)]);
+        if (cls == 2) {
+#pragma unroll
+            for (int bb = 0; bb < 16; bb++) v[16 + bb] = ld2(&row1[b * 16 + (bb ^ b)]);
+        }
+        dft16<true>(reinterpret_cast<cf (&)[16]>(v[0]));
+        if (cls == 2) dft16<true>(reinterpret_cast<cf (&)[16]>(v[16]));
+        // y[t], t = b + 16 q; keep t >= l/R (vector_cut_vxx(l, l - lout, lout)), times l (multiply_const_cc)
+        const int skip = 256 - r0.lout;
+        if (a0.on) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) st2(out + a0.dst + b + 16 * q, v[rev16(q)] * 256.f);
+        }
+        if (cls == 2 && a1.on) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) st2(out + a1.dst + b + 16 * q, v[16 + rev16(q)] * 256.f);
+        }
+    }
+    if constexpr (WIDE) {
+        // the inter-layer twiddles of both wide forms from ONE table: W_1024^(x p) = W_1024^((x & 15) p) W_64^((x >> 4) p), x < 32;
+        // l = 1024: x = b; l = 512: W_512^(b p) = W_1024^(2 b p), x = 2 b
+        if (cls == 3 || cls == 4) {
+            const int lg = cls == 3 ? 4 : 5, b = lane & ((1 << lg) - 1), x = cls == 3 ? 2 * b : b;
+            const float2 *wa = reinterpret_cast<const float2 *>(fdc_smem_f4 + kF4OffW1k) + (x & 15) * 34;
+            const float2 *wb = reinterpret_cast<const float2 *>(fdc_smem_f4 + kF4OffW64) + (x >> 4) * 34;
+            float2 *row = tiles + r0.xch;
+            // element (b, p) of a row at p * lanes + (b ^ (p mod lanes)) (k_c1024, k_c512)
+            if (a0.on) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float4 t = ld4(&wa[2 * i]), c = ld4(&wb[2 * i]);
+                    st2(&row[((2 * i) << lg) + (b ^ ((2 * i) & ((1 << lg) - 1)))], cmulc(v[pos32(2 * i)], cmul(mk(t.x, t.y), mk(c.x, c.y))));
+                    st2(&row[((2 * i + 1) << lg) + (b ^ ((2 * i + 1) & ((1 << lg) - 1)))], cmulc(v[pos32(2 * i + 1)], cmul(mk(t.z, t.w), mk(c.z, c.w))));
+                }
+            }
+            wave_sync();
+            if (cls == 4) {
+#pragma unroll
+                for (int bb = 0; bb < 32; bb++) v[bb] = ld2(&row[b * 32 + (bb ^ b)]);
+                dft32<true>(v);                                      // y[t = b + 32 q] in v[pos32(q)]
+                const int skip = 1024 - r0.lout;
+                if (a0.on) {
+#pragma unroll
+                    for (int q = 0; q < 32; q++) if (b + 32 * q >= skip) st2(out + a0.dst + b + 32 * q, v[pos32(q)] * 1024.f);
+                }
+            } else {
+                // l = 512 = 32 x 16: DFT-16 over b for p = lane and p = lane + 16; y[t = p + 32 q]
+#pragma unroll
+                for (int bb = 0; bb < 16; bb++) {
+                    v[bb] = ld2(&row[b * 16 + (bb ^ b)]);
+                    v[16 + bb] = ld2(&row[(b + 16) * 16 + (bb ^ b)]);
+                }
+                dft16<true>(reinterpret_cast<cf (&)[16]>(v[0]));
+                dft16<true>(reinterpret_cast<cf (&)[16]>(v[16]));
+                const int skip = 512 - r0.lout;
+                if (a0.on) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int t0 = b + 32 * q, t1 = t0 + 16;
+                        if (t0 >= skip) st2(out + a0.dst + t0, v[rev16(q)] * 512.f);
+                        if (t1 >= skip) st2(out + a0.dst + t1, v[16 + rev16(q)] * 512.f);
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t init_fused4096_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kF4Lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kF4LdsWide);
+}
+
+int fused4096_tile_points() { return kF4TilePts; }
+
+hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int R, int mbase, int nb_call, int64_t first_block,
+                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, hipStream_t s)
+{
+    if (nb_chunk <= 0) return hipSuccess;
+    bool wide = false;
+    for (int w = 0; w < 8; w++) wide = wide || ((wcls >> (4 * w)) & 0xfu) >= 3;
+    const int npairs = (nb_chunk + 1) / 2;
+    const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
+    if (wide)
+        hipLaunchKernelGGL(k_f4096<true>, grid, dim3(512), kF4LdsWide, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (long long)first_block, tw,
+                           ntab / 4096, wins, rows, wcls);
+    else
+        hipLaunchKernelGGL(k_f4096<false>, grid, dim3(512), kF4Lds, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (long long)first_block, tw,
+                           ntab / 4096, wins, rows, wcls);
+    return hipGetLastError();
+}
+
+}  // namespace fdc

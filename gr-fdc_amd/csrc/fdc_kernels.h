@@ -82,6 +82,17 @@ hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int n
                           float scale, const float2 *tw, int ntab, hipStream_t s,
                           unsigned long long keep = ~0ull /* 64-bin groups of the output some reader wants */);
 
+// N = 4096 in one launch (fdc_fused4096.hip): forward transform + every channel's slice / window / inverse transform, the spectrum stays in LDS.
+// A 512-thread workgroup takes a pair of blocks.  The schedule is the host's (fdc_api.hip plan_fused4096): rows[8 waves][8 slots], four bits per
+// wave in wcls (0 = no rows, 1 = l = 256 slots 0..3, 2 = l = 256 slots 0..7, 3 = l = 512 slots 0..3, 4 = l = 1024 slots 0..1); valid = 0: no row,
+// 1 + k: a row of the pair's block k; xch = the row's exchange area in the two tiles (points), rows disjoint, all inside 2 fused4096_tile_points().
+// Unused slots: everything 0 except lout.
+struct F4Row { int32_t f, win_off, shift, xch, lout, valid; long long out_off; };
+hipError_t init_fused4096_kernels();
+int fused4096_tile_points();
+hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int R, int mbase, int nb_call, int64_t first_block,
+                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, hipStream_t s);
+
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;
 //   slot_off[c] = per-block sample offset of the channel sitting in slot c, or -1;  g: nb_chunk*lout*N1 scratch

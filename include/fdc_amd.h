@@ -101,6 +101,7 @@ enum {
     FDC_PIPE_PLAIN_STORES = 8,    /* block kernels: ordinary instead of streamed (nt) output stores                 */
     FDC_PIPE_NT_LOADS = 16,       /* block kernels: streamed (nt) input loads (not the 512- / 1024-bin kernels, which stage their loads) */
     FDC_PIPE_FULL_SPECTRUM = 32,  /* the handle's internal spectrum is written in full (default: only the 64-bin groups some channel reads) */
+    FDC_PIPE_NO_FUSED = 128,      /* N = 4096: not the one-launch kernel that keeps the spectrum in LDS (A/B, tests); also off under FDC_PIPE_NO_POLY */
     FDC_PIPE_WIDE_UNIFORM = 64    /* uniform banks of ANY channel width (every channel l = L on the L-bin grid, one window) take the form without
                                      a spectrum: the width's block kernel where there is one (N = 16384 / 32768 / 65536: l = 64, 128, 256, 512, 1024), else two
                                      launches on generic kernels; default: only where that measured faster than the spectrum path (the block

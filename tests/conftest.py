@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # they run with the threshold at 1; test_short_calls_take_the_tiled_kernels checks the default.
 import gr_fdc_amd as _G                                # noqa: E402  (does not load the library yet)
 _G.defaults.setdefault("FDC_BLOCK_MIN_BLOCKS", "1")     # -> fdc_pipeline_cfg.min_block_launch of every pipeline the tests create
-for _k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK"):     # the whole suite under a forced path: FDC_TEST_FORCE=FDC_NO_POLY pytest ...
+for _k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK", "FDC_NO_FUSED"):     # the whole suite under a forced path: FDC_TEST_FORCE=FDC_NO_POLY pytest ...
     if os.environ.get("FDC_TEST_FORCE") == _k:
         _G.defaults[_k] = "1"
 

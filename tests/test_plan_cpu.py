@@ -58,10 +58,14 @@ def check_structure(n, R, plan, flags=0):
         assert not rem and list(banks) == [0] and all(plan[c][0] % plan[c][1] == 0 for c in banks[0]) and not any(a <= -2 for a in asg)
     else:
         assert len(rem) == len(plan)
+    if path == 5:     # the one-launch form of N = 4096 (fdc_fused4096.hip): every width has a row form, the rows fit four waves and the tile
+        n1k, n512, n256 = (sum(1 for c in plan if c[1] == l) for l in (1024, 512, 256))
+        assert n == 4096 and n1k + n512 + n256 == len(plan) and not flags & (G.FDC_PIPE_NO_POLY | G.FDC_PIPE_NO_FUSED | G.FDC_PIPE_FORCE_GENERIC)
+        assert n1k + (n512 + 1) // 2 + (n256 + 3) // 4 <= 8 and 1056 * n1k + 513 * n512 + 272 * n256 <= 4352, text      # a workgroup = two blocks, eight waves
     if flags & G.FDC_PIPE_NO_POLY:
         assert path in (0, 1)
     if flags & G.FDC_PIPE_NO_BLOCK:
-        assert path in (0, 1, 2)
+        assert path in (0, 1, 2, 5)
     return path, text, asg
 
 
@@ -78,6 +82,42 @@ def test_the_seventeen_plans_of_the_choice_test_have_the_expected_paths():
         for flags in (G.FDC_PIPE_NO_POLY, G.FDC_PIPE_NO_BLOCK, G.FDC_PIPE_WIDE_UNIFORM):
             check_structure(N, 2, plan, flags)
             check_structure(N, 4, plan, flags)
+
+
+def test_the_one_launch_form_at_n_4096():
+    """N = 4096 (the reference's example flowgraph, BASELINE configs[0]): plans of 256- / 512- / 1024-bin channels run as ONE launch (path 5) whenever their
+    rows fit four waves and the tile; anything else keeps the spectrum path (or the two-launch form of a uniform 256-bin bank under FDC_PIPE_NO_FUSED)."""
+    example = [(100, 256, 0.8, 1.0), (700, 512, 0.8, 1.0), (1500, 1024, 0.8, 1.0), (3000, 512, 0.8, 1.0)]     # examples/FDC_example.grc: l = 256 / 512 / 1024 / 512
+    for R in (2, 4, 8):
+        path, text, asg = check_structure(4096, R, example)
+        assert path == 5 and "k_f4096" in text and "3 waves" in text and asg == [-1] * 4, text
+    assert check_structure(4096, 2, example, G.FDC_PIPE_NO_FUSED)[0] == 0 and check_structure(4096, 2, example, G.FDC_PIPE_NO_POLY)[0] == 0
+    assert check_structure(4096, 2, example, G.FDC_PIPE_FORCE_GENERIC)[0] == 0 and check_structure(4096, 2, example, G.FDC_PIPE_NO_BLOCK)[0] == 5
+    # a full band of 256-bin channels: the two blocks of a workgroup fill its eight waves with four rows each; on its grid it was the two-launch form before
+    full = bank(256, range(16))
+    path, text, _ = check_structure(4096, 2, full)
+    assert path == 5 and "8 waves" in text, text
+    assert check_structure(4096, 2, full, G.FDC_PIPE_NO_FUSED)[0] == 2
+    assert check_structure(4096, 2, bank(256, range(4)))[0] == 5 and "2 waves)" in check_structure(4096, 2, bank(256, range(4)))[1]
+    assert "1 wave)" in check_structure(4096, 2, bank(256, range(2)))[1]
+    # widths without a row form, too many bins (channels that overlap), other block lengths: not this form
+    assert check_structure(4096, 2, example + [(2000, 128, 0.8, 1.0)])[0] == 0
+    assert check_structure(4096, 2, example + [(0, 2048, 0.8, 1.0)])[0] == 0
+    assert check_structure(4096, 2, [(c * 200, 1024, 0.8, 1.0) for c in range(5)])[0] == 0          # 5120 bins of rows
+    assert check_structure(4096, 2, [(c * 230, 256, 0.8, 1.0) for c in range(16)])[0] == 5           # overlapping slices are fine while the rows fit
+    assert check_structure(4096, 2, [(c * 200, 256, 0.8, 1.0) for c in range(17)])[0] == 0
+    assert check_structure(8192, 2, example)[0] == 0
+    # every mixture of up to 4096 bins of rows fits
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        plan, left = [], 4096
+        while left >= 256:
+            l = int(rng.choice([w for w in (256, 512, 1024) if w <= left]))
+            plan.append((int(rng.integers(0, 4096 - l + 1)), l, 0.8, 1.0))
+            left -= l
+            if rng.random() < 0.15:
+                break
+        assert check_structure(4096, int(rng.choice([2, 4])), plan)[0] == 5, plan
 
 
 def test_the_cost_rule_at_its_thresholds():
@@ -156,7 +196,7 @@ def test_every_plan_the_selector_makes_is_well_formed():
         flags = int(rng.choice([0, 0, 0, G.FDC_PIPE_WIDE_UNIFORM, G.FDC_PIPE_NO_BLOCK, G.FDC_PIPE_NO_POLY, G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK]))
         path, _text, _asg = check_structure(n, R, plan, flags)
         seen.add(path)
-    assert seen == {0, 1, 2, 3, 4}, seen
+    assert seen == {0, 1, 2, 3, 4, 5}, seen
 
 
 def test_argument_errors_are_those_of_create():
