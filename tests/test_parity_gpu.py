@@ -211,6 +211,10 @@ def test_uniform_plan_two_stage_path(oracle, N, R, wt):
     x = noise(nb * (N - N // R), 31 + R)
     p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2)
     forced = any(G.defaults.get(k) for k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY"))   # the suite run under a forced path
+    if N == 4096 and not forced and not G.defaults.get("FDC_NO_FUSED"):
+        # round 6: N = 4096 runs in ONE launch with the spectrum in LDS (path 5, tests/test_fused4096_gpu.py); the two-stage form is what FDC_PIPE_NO_FUSED leaves
+        assert p.path() == 5
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=2, flags=G.FDC_PIPE_NO_FUSED)
     assert forced or p.path() == (3 if N in (16384, 32768, 65536) and R in (2, 4) and not G.defaults.get("FDC_NO_BLOCK") else 2)   # N = 16384 / 32768 / 65536, R = 2 or 4: the one-kernel form
     outs = p.work(x)
     ref, _ = oracle.channelizer(N, R, wt, chans, x, nthreads=4)
