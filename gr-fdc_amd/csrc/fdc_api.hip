@@ -534,11 +534,16 @@ bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
     p->f4_cls = 0;
     if (p->N != 4096 || p->C == 0 || p->cfg_generic || (flags & (FDC_PIPE_NO_POLY | FDC_PIPE_NO_FUSED))) return false;
     std::vector<int> by[3];                                       // rows of 1024, 512, 256 bins: the two blocks' rows of a channel side by side
+    long long bins = 0;
     for (int c = 0; c < p->C; c++) {
         const int l = cfg->channels[c].l;
         if ((l != 256 && l != 512 && l != 1024) || l % p->R) return false;
         for (int k = 0; k < 2; k++) by[l == 1024 ? 0 : l == 512 ? 1 : 2].push_back(2 * c + k);
+        bins += l;
     }
+    // ONE 256-bin channel: the two launches are 9 % faster (0.063 against 0.069 ms per 8192 blocks; four such channels: 0.076 / 0.073; everything wider:
+    // 1.3 - 1.6 x for this form, profiles/r06/plan_choice_4096.txt) — the forward transform alone is what both cost, and k_fft4096 has four workgroups per unit
+    if (bins < 512 && !(flags & FDC_PIPE_WIDE_UNIFORM)) return false;
     const int w1k = ((int)by[0].size() + 1) / 2, w512 = ((int)by[1].size() + 3) / 4, avail = 8 - w1k - w512, n256 = (int)by[2].size();
     if (avail < 0 || n256 > 8 * avail) return false;
     const long long pts = 1056ll * (long long)by[0].size() + 513ll * (long long)by[1].size() + 272ll * n256;   // the row pitches of k_c1024 / k_c512 / k_c256

@@ -26,6 +26,11 @@ namespace fdc {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_f4[];
 
+// diagnostics (tools/build_variant.sh -DF4_EXP=bits): 1 = every input load from one cached line, 2 = every window load from one cached line,
+// 4 = no output stores (unless a value the data never takes): what each stream's latency costs the kernel (profiles/r06/NOTES.md section 8)
+#ifndef F4_EXP
+#define F4_EXP 0
+#endif
 namespace {
 constexpr int kF4TilePts = 16 * 272;                         // exchange tile of one block's forward transform; then its spectrum; then rows' exchanges
 constexpr int kF4Tiles = 2 * kF4TilePts * 8;                 // two blocks per workgroup
@@ -49,14 +54,20 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ void out_st(float2 *p, cf v)
+{
+    if (!(F4_EXP & 4) || v.x == 1.2345e30f) st2(p, v);
+}
+
 struct RowAt { const float2 *win; const float2 *spec; long long dst; bool on; };
 // ri.valid: 0 = no row, 1 + k = a row of the workgroup's block k
-__device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, int mbase, long long first_block, int R, const float2 *wins,
+// fbm = (first block of the call + first block of the launch) mod R
+__device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, int mbase, int fbm, int R, const float2 *wins,
                                         long long nb_call, const float2 *tiles)
 {
     const int k = ri.valid ? ri.valid - 1 : 0, m = m0 + k;
-    const int cnt = (int)((((first_block + mbase + m) % R) * ri.shift) % R);     // phase counter in closed form (lib/phase_shifting_windowing_vcc_impl.cc:58,83-89)
-    return RowAt{wins + ri.win_off + cnt * L, tiles + k * kF4TilePts + ri.f, nb_call * ri.out_off + ((long long)mbase + m) * ri.lout - (L - ri.lout),
+    const int cnt = (int)(((unsigned)(fbm + m) % (unsigned)R) * (unsigned)ri.shift % (unsigned)R);     // phase counter in closed form (lib/phase_shifting_windowing_vcc_impl.cc:58,83-89)
+    return RowAt{wins + ((F4_EXP & 2) ? 0 : ri.win_off + cnt * L), tiles + k * kF4TilePts + ri.f, nb_call * ri.out_off + ((long long)mbase + m) * ri.lout - (L - ri.lout),
                  ri.valid != 0 && m < nb};
 }
 }  // namespace
@@ -64,8 +75,8 @@ __device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, 
 // 512 threads: two teams of four waves, team t transforms block 2 pair + t; then wave w of the eight runs the rows the schedule gives it.
 // wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1)
 template <bool WIDE>
-__global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
-                                                  int mbase, int nb_call, long long first_block, const float2 *__restrict__ tw,
+__global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per compute unit */) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
+                                                  int mbase, int nb_call, int fbm /* (first block of the call + mbase) mod R */, const float2 *__restrict__ tw,
                                                   int twstride /* ntab / 4096 */, const float2 *__restrict__ wins,
                                                   const F4Row *__restrict__ rows, unsigned wcls)
 {
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
     {
         cf (&u)[16] = reinterpret_cast<cf (&)[16]>(v[0]);
 #pragma unroll
-        for (int c = 0; c < 16; c++) u[c] = m < nb ? ld2(in + (size_t)m * in_stride + (tid + 256 * c)) : mk(0.f, 0.f);
+        for (int c = 0; c < 16; c++) u[c] = m < nb ? ld2(in + ((F4_EXP & 1) ? (size_t)(tid & 15) + 16 * c : (size_t)m * in_stride + (tid + 256 * c))) : mk(0.f, 0.f);
         __syncthreads();
         dft16<false>(u);                                             // layer 1 over c: k0 in u[rev16(k0)]; thread = (a = lo, b = hi)
         {
@@ -145,20 +156,20 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
     if (cls == 1 || cls == 2) {
         const int b = lane & 15;
         r0 = wr[lane >> 4];
-        a0 = row_at(r0, 256, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+        a0 = row_at(r0, 256, m0, nb, mbase, fbm, R, wins, nb_call, tiles);
         {
             cf w[16];
 #pragma unroll
-            for (int a = 0; a < 16; a++) w[a] = ld2(a0.win + 16 * a + b);
+            for (int a = 0; a < 16; a++) w[a] = ld2(a0.win + ((F4_EXP & 2) ? 0 : 16 * a) + b);
 #pragma unroll
             for (int a = 0; a < 16; a++) v[a ^ 8] = cmul(ld2(a0.spec + 16 * a + b), w[a]);      // ifftshift of the slice: i -> i + l/2
         }
         if (cls == 2) {
             r1 = wr[4 + (lane >> 4)];
-            a1 = row_at(r1, 256, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+            a1 = row_at(r1, 256, m0, nb, mbase, fbm, R, wins, nb_call, tiles);
             cf w[16];
 #pragma unroll
-            for (int a = 0; a < 16; a++) w[a] = ld2(a1.win + 16 * a + b);
+            for (int a = 0; a < 16; a++) w[a] = ld2(a1.win + ((F4_EXP & 2) ? 0 : 16 * a) + b);
 #pragma unroll
             for (int a = 0; a < 16; a++) v[16 + (a ^ 8)] = cmul(ld2(a1.spec + 16 * a + b), w[a]);
         }
@@ -170,10 +181,10 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
             const int L = cls == 3 ? 512 : 1024, lg = cls == 3 ? 4 : 5;
             const int b = lane & ((1 << lg) - 1);
             r0 = wr[lane >> lg];
-            a0 = row_at(r0, L, m0, nb, mbase, first_block, R, wins, nb_call, tiles);
+            a0 = row_at(r0, L, m0, nb, mbase, fbm, R, wins, nb_call, tiles);
             cf w[32];
 #pragma unroll
-            for (int a = 0; a < 32; a++) w[a] = ld2(a0.win + (a << lg) + b);
+            for (int a = 0; a < 32; a++) w[a] = ld2(a0.win + ((F4_EXP & 2) ? 0 : (a << lg)) + b);
 #pragma unroll
             for (int a = 0; a < 32; a++) v[a ^ 16] = cmul(ld2(a0.spec + (a << lg) + b), w[a]);
             dft32<true>(v);                                          // over a: index p in v[pos32(p)]
@@ -211,11 +222,11 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
         const int skip = 256 - r0.lout;
         if (a0.on) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) st2(out + a0.dst + b + 16 * q, v[rev16(q)] * 256.f);
+            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) out_st(out + a0.dst + b + 16 * q, v[rev16(q)] * 256.f);
         }
         if (cls == 2 && a1.on) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) st2(out + a1.dst + b + 16 * q, v[16 + rev16(q)] * 256.f);
+            for (int q = 0; q < 16; q++) if (b + 16 * q >= skip) out_st(out + a1.dst + b + 16 * q, v[16 + rev16(q)] * 256.f);
         }
     }
     if constexpr (WIDE) {
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
                 const int skip = 1024 - r0.lout;
                 if (a0.on) {
 #pragma unroll
-                    for (int q = 0; q < 32; q++) if (b + 32 * q >= skip) st2(out + a0.dst + b + 32 * q, v[pos32(q)] * 1024.f);
+                    for (int q = 0; q < 32; q++) if (b + 32 * q >= skip) out_st(out + a0.dst + b + 32 * q, v[pos32(q)] * 1024.f);
                 }
             } else {
                 // l = 512 = 32 x 16: DFT-16 over b for p = lane and p = lane + 16; y[t = p + 32 q]
@@ -259,8 +270,8 @@ __global__ __launch_bounds__(512, 2) void k_f4096(const float2 *__restrict__ in,
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const int t0 = b + 32 * q, t1 = t0 + 16;
-                        if (t0 >= skip) st2(out + a0.dst + t0, v[rev16(q)] * 512.f);
-                        if (t1 >= skip) st2(out + a0.dst + t1, v[16 + rev16(q)] * 512.f);
+                        if (t0 >= skip) out_st(out + a0.dst + t0, v[rev16(q)] * 512.f);
+                        if (t1 >= skip) out_st(out + a0.dst + t1, v[16 + rev16(q)] * 512.f);
                     }
                 }
             }
@@ -286,10 +297,10 @@ hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int
     const int npairs = (nb_chunk + 1) / 2;
     const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
     if (wide)
-        hipLaunchKernelGGL(k_f4096<true>, grid, dim3(512), kF4LdsWide, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (long long)first_block, tw,
+        hipLaunchKernelGGL(k_f4096<true>, grid, dim3(512), kF4LdsWide, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (int)((first_block + mbase) % R), tw,
                            ntab / 4096, wins, rows, wcls);
     else
-        hipLaunchKernelGGL(k_f4096<false>, grid, dim3(512), kF4Lds, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (long long)first_block, tw,
+        hipLaunchKernelGGL(k_f4096<false>, grid, dim3(512), kF4Lds, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (int)((first_block + mbase) % R), tw,
                            ntab / 4096, wins, rows, wcls);
     return hipGetLastError();
 }

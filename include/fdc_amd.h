@@ -191,7 +191,11 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * R = 2 or 4.  4 = a SPLIT plan at any of those three block lengths: the banks take path 3 (ms[0]), the rest — widths without a block kernel, odd offsets,
  * a fifth bank, banks the cost rule sends back — take the spectrum path on a partial spectrum that holds only what they read (forward transform ms[1], channel
  * kernels ms[2]).  Which it is, the cost rule decides (csrc/fdc_plan_cost.hpp: measured constants per launch and per band read; a plan goes to path 1 whole
- * when the sum says so); fdc_pipeline_describe / fdc_pipeline_plan_preview say what was chosen. */
+ * when the sum says so); fdc_pipeline_describe / fdc_pipeline_plan_preview say what was chosen.
+ * 5 (round 6) = N = 4096 — the block length of the reference's example flowgraph — in ONE launch (csrc/fdc_fused4096.hip; ms[0]): forward transform, channel
+ * slices, windows and inverse transforms with the spectrum in LDS, nothing but the new input samples and the output samples crosses the memory interface.
+ * Every plan of 256- / 512- / 1024-bin channels (any offsets, windows, overlaps between them) of at least 512 and — about — at most 4096 bins in total; a call
+ * that asks for the spectrum runs path 0 on the same handle.  FDC_PIPE_NO_FUSED / FDC_PIPE_NO_POLY: paths 0 / 2 as before.  plan_preview: every channel -1. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 /* The same in words, for logs: which kernels the handle's plan was given ("N = 65536, R = 2, 512 channels; path 3: k_blknar, l = 128, bank of 511 half a
  * channel off the grid + bank of 1 on the grid (two launches)").  Writes at most n bytes including the terminator; returns the untruncated length, -1 for

@@ -29,7 +29,8 @@ for k in sorted(acc):
 import json
 names = {"fdc::k_blk256": "block_kernel(colFFT+window+IFFT+slotFFT)", "fdc::k_p1": "poly_stage1(colFFT+window+IFFT)", "fdc::k_p2": "poly_stage2(slotFFT)",
          "fdc::k_p2k": "poly_stage2(slotFFT)", "fdc::k_a256": "fft_pass_a", "fdc::k_b256": "fft_pass_b", "fdc::k_c256": "channels",
-         "fdc::k_fft4096": "fft_pass_b", "fdc::k_channels": "channels", "fdc::k_c512": "channels", "fdc::k_c1024": "channels"}
+         "fdc::k_fft4096": "fft_pass_b", "fdc::k_channels": "channels", "fdc::k_c512": "channels", "fdc::k_c1024": "channels",
+         "fdc::k_f4096": "fused4096(FFT+cut+window+IFFTs, spectrum in LDS)"}
 cfg = int(os.environ.get("PMC_CONFIG", "2"))
 tag = os.environ.get("PMC_TAG", "")
 out, allk = {}, {}

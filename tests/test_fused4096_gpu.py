@@ -22,7 +22,7 @@ def plans():
     return {
         "example flowgraph": EXAMPLE,
         "configs[0]: four 256-bin channels": [(300 + 900 * c + c, 256, 0.8, 1.0) for c in range(4)],
-        "one 256-bin channel": [(1234, 256, 0.5, 0.7)],
+        "one 512-bin channel": [(1234, 512, 0.5, 0.7)],
         "one 1024-bin channel at the band edge": [(3072, 1024, 0.9, 1.0)],
         "full band of 256-bin channels (four waves of four rows)": full256,
         "1024 + 512 + ten 256 (two waves of two sets)": [(5, 1024, 0.8, 1.0), (1111, 512, 0.8, 1.0)] + [(int(rng.integers(0, N - 255)), 256, 0.8, 1.0) for _ in range(10)],

@@ -179,7 +179,8 @@ def _time_the_forms(n, plan, nb, name):
     ring = hip.alloc((n // R + nb * h) * 8, fill=0x3F000000)          # 0.5 + 0.5j everywhere: kernel time does not depend on the data
     results = {}
     try:
-        for tag, flags in (("chosen", 0), ("spectrum", G.FDC_PIPE_NO_POLY), ("all-banks", G.FDC_PIPE_WIDE_UNIFORM), ("no-block", G.FDC_PIPE_NO_BLOCK)):
+        for tag, flags in (("chosen", 0), ("spectrum", G.FDC_PIPE_NO_POLY), ("all-banks", G.FDC_PIPE_WIDE_UNIFORM), ("no-block", G.FDC_PIPE_NO_BLOCK),
+                           ("no-fused", G.FDC_PIPE_NO_FUSED)):
             p = G.Pipeline(n, R, plan, windowtype=1, max_blocks=nb, flags=flags, min_block_launch=96)
             what = p.describe()
             if tag != "chosen" and what == results["chosen"][1]:
@@ -234,3 +235,20 @@ def plans_at_shorter_blocks(n):
 @pytest.mark.parametrize("name", sorted(plans_at_shorter_blocks(32768)))
 def test_the_chosen_form_at_shorter_blocks(n, name):
     time_the_forms(n, plans_at_shorter_blocks(n)[name], 512 * 65536 // n, "N = %d, %s" % (n, name))
+
+
+def plans_at_4096():
+    """N = 4096 (round 6): the one-launch form with the spectrum in LDS against what FDC_PIPE_NO_FUSED / FDC_PIPE_NO_POLY leave (two-launch uniform form, spectrum path)."""
+    return {
+        "example flowgraph (256 / 512 / 1024 / 512)": [(100, 256, 0.8, 1.0), (700, 512, 0.8, 1.0), (1500, 1024, 0.8, 1.0), (3001, 512, 0.8, 1.0)],
+        "four 256-bin channels": [(300 + 901 * c, 256, 0.8, 1.0) for c in range(4)],
+        "full band of 256-bin channels": bank(256, range(16)),
+        "eight 512-bin channels": bank(512, range(8)),
+        "four 1024-bin channels": bank(1024, range(4)),
+        "one 256-bin channel": [(1234, 256, 0.8, 1.0)],
+    }
+
+
+@pytest.mark.parametrize("name", sorted(plans_at_4096()))
+def test_the_chosen_form_at_4096(name):
+    time_the_forms(4096, plans_at_4096()[name], 8192, "N = 4096, %s" % name)

@@ -5,7 +5,7 @@ set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../gr-fdc_amd/csrc"
 OBJS=""
-for f in fdc_kernels fdc_fast256 fdc_block256 fdc_block512 fdc_block1024 fdc_blocknarrow fdc_chanwide fdc_sinks_dev; do
+for f in fdc_kernels fdc_fast256 fdc_block256 fdc_block512 fdc_block1024 fdc_blocknarrow fdc_chanwide fdc_fused4096 fdc_sinks_dev; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result "$@" -c $f.hip -o /tmp/${f}_$TAG.o &
   OBJS="$OBJS /tmp/${f}_$TAG.o"
 done
