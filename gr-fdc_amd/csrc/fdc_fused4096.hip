@@ -27,7 +27,8 @@ namespace fdc {
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_f4[];
 
 // diagnostics (tools/build_variant.sh -DF4_EXP=bits): 1 = every input load from one cached line, 2 = every window load from one cached line,
-// 4 = no output stores (unless a value the data never takes): what each stream's latency costs the kernel (profiles/r06/NOTES.md section 8)
+// 4 = no output stores (unless a value the data never takes): what each stream's latency costs the kernel (profiles/r06/NOTES.md section 8);
+// 8 = three of the forward transform's five workgroup barriers left out (WRONG results): what they cost
 #ifndef F4_EXP
 #define F4_EXP 0
 #endif
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
 #pragma unroll
         for (int b = 0; b < 16; b++) u[b] = ld2(&tile[hi * 272 + b * 16 + lo]);      // thread = (a = lo, k0 = hi)
         dft16<false>(u);                                             // layer 2 over b: k1 in u[rev16(k1)]
+        if constexpr (F4_EXP & 8) __builtin_amdgcn_wave_barrier(); else
         __syncthreads();                                             // every read of exchange 1 is done
         {
             const cf s = ld2(&t4k[lo * 18 + hi]);                    // W_4096^(a k0)
@@ -137,10 +139,12 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
 #pragma unroll
             for (int k1 = 0; k1 < 16; k1++) st2(&tile[k1 * 257 + hi * 16 + (lo ^ hi)], cmul(u[rev16(k1)], k1 == 0 ? s : cmul(s, w[k1])));
         }
+        if constexpr (F4_EXP & 8) __builtin_amdgcn_wave_barrier(); else
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 16; a++) u[a] = ld2(&tile[hi * 257 + lo * 16 + (a ^ lo)]);   // thread = (k0 = lo, k1 = hi)
         dft16<false>(u);                                             // layer 3 over a: bin k0 + 16 k1 + 256 k2 in u[rev16(k2)]
+        if constexpr (F4_EXP & 8) __builtin_amdgcn_wave_barrier(); else
         __syncthreads();                                             // every read of exchange 2 is done
         // the shifted spectrum (fftshift: bin k at k + N/2; python/FrequencyDomainChannelizer.py:206 fft_vcc(..., shift = True)), times 1/N
 #pragma unroll
