@@ -524,38 +524,46 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     }
 }
 
-// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 256, 512 or 1024 bins wide.  A workgroup takes a pair of blocks; its
-// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256; their exchange areas
-// must fit the two tiles the spectra leave behind.  Always true for plans of up to 4096 bins in total; plans of channels that overlap to more stay on the
-// spectrum path.
+// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 64, 128, 256, 512 or 1024 bins wide.  A workgroup takes a pair of blocks; its
+// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256, 128 or 64; their exchange
+// areas must fit the two tiles the spectra leave behind.  Always true for plans of 256-bin and wider channels of up to 4096 bins in total; plans of channels
+// that overlap to more (or of more than 32 narrow channels) stay on the spectrum path.
+struct F4Class { int l, cls, per_wave, pitch; };
+constexpr F4Class kF4Classes[] = {{1024, 4, 2, 1056}, {512, 3, 4, 513}, {128, 5, 8, 136}, {64, 6, 8, 68}};   // (256: below; pitches: rows of a half-wave on different banks)
 bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
 {
     for (auto &w : p->f4_wave) w.clear();
     p->f4_cls = 0;
     if (p->N != 4096 || p->C == 0 || p->cfg_generic || (flags & (FDC_PIPE_NO_POLY | FDC_PIPE_NO_FUSED))) return false;
-    std::vector<int> by[3];                                       // rows of 1024, 512, 256 bins: the two blocks' rows of a channel side by side
+    std::map<int, std::vector<int>> by;                           // rows by width: the two blocks' rows of a channel side by side
     long long bins = 0;
     for (int c = 0; c < p->C; c++) {
         const int l = cfg->channels[c].l;
-        if ((l != 256 && l != 512 && l != 1024) || l % p->R) return false;
-        for (int k = 0; k < 2; k++) by[l == 1024 ? 0 : l == 512 ? 1 : 2].push_back(2 * c + k);
+        if ((l != 64 && l != 128 && l != 256 && l != 512 && l != 1024) || l % p->R) return false;
+        for (int k = 0; k < 2; k++) by[l].push_back(2 * c + k);
         bins += l;
     }
     // ONE 256-bin channel: the two launches are 9 % faster (0.063 against 0.069 ms per 8192 blocks; four such channels: 0.076 / 0.073; everything wider:
     // 1.3 - 1.6 x for this form, profiles/r06/plan_choice_4096.txt) — the forward transform alone is what both cost, and k_fft4096 has four workgroups per unit
     if (bins < 512 && !(flags & FDC_PIPE_WIDE_UNIFORM)) return false;
-    const int w1k = ((int)by[0].size() + 1) / 2, w512 = ((int)by[1].size() + 3) / 4, avail = 8 - w1k - w512, n256 = (int)by[2].size();
-    if (avail < 0 || n256 > 8 * avail) return false;
-    const long long pts = 1056ll * (long long)by[0].size() + 513ll * (long long)by[1].size() + 272ll * n256;   // the row pitches of k_c1024 / k_c512 / k_c256
-    if (pts > 2 * fdc::fused4096_tile_points()) return false;
     int w = 0;
     unsigned cls = 0;
-    for (size_t i = 0; i < by[0].size(); i += 2, w++) { for (size_t j = i; j < std::min(i + 2, by[0].size()); j++) p->f4_wave[w].push_back(by[0][j]); cls |= 4u << (4 * w); }
-    for (size_t i = 0; i < by[1].size(); i += 4, w++) { for (size_t j = i; j < std::min(i + 4, by[1].size()); j++) p->f4_wave[w].push_back(by[1][j]); cls |= 3u << (4 * w); }
+    long long pts = 272ll * (long long)by[256].size();
+    for (const F4Class &k : kF4Classes) {
+        const std::vector<int> &rows = by[k.l];
+        pts += (long long)k.pitch * (long long)rows.size();
+        for (size_t i = 0; i < rows.size(); i += (size_t)k.per_wave, w++) {
+            if (w >= 8) return false;
+            for (size_t j = i; j < std::min(i + (size_t)k.per_wave, rows.size()); j++) p->f4_wave[w].push_back(rows[j]);
+            cls |= (unsigned)k.cls << (4 * w);
+        }
+    }
+    const int avail = 8 - w, n256 = (int)by[256].size();
+    if (n256 > 8 * avail || pts > 2 * fdc::fused4096_tile_points()) { for (auto &v : p->f4_wave) v.clear(); return false; }
     if (n256) {
         // as few waves as one set of four rows each allows (a wave's instructions cost the same for one row as for four); two sets where that is not enough
         const int nw = n256 <= 4 * avail ? (n256 + 3) / 4 : avail;
-        for (int i = 0; i < n256; i++) p->f4_wave[w + i % nw].push_back(by[2][(size_t)i]);
+        for (int i = 0; i < n256; i++) p->f4_wave[w + i % nw].push_back(by[256][(size_t)i]);
         for (int k = 0; k < nw; k++) cls |= (p->f4_wave[w + k].size() > 4 ? 2u : 1u) << (4 * (w + k));
     }
     p->f4_cls = cls;
@@ -874,7 +882,7 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
         int xch = 0;
         for (int w = 0; w < 8; w++) {
             const unsigned cls = (p->f4_cls >> (4 * w)) & 0xfu;
-            const int L = cls == 4 ? 1024 : cls == 3 ? 512 : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : 272;
+            const int L = cls == 4 ? 1024 : cls == 3 ? 512 : cls == 5 ? 128 : cls == 6 ? 64 : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : cls == 5 ? 136 : cls == 6 ? 68 : 272;
             for (int k = 0; k < 8; k++) {
                 fdc::F4Row &r = rows[(size_t)(8 * w + k)];
                 r = fdc::F4Row{0, 0, 0, 0, L - L / R, 0, 0};

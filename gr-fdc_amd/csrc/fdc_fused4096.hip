@@ -13,6 +13,7 @@
 //       l =  256: 16 lanes x 16 points per row, up to eight rows (two sets of four) per wave   (the row machinery of k_c256)
 //       l =  512: 16 lanes x 32 points, up to four rows                                        (k_c512)
 //       l = 1024: 32 lanes x 32 points, up to two rows                                         (k_c1024)
+//       l =  128:  8 lanes x 16 points, eight rows; l = 64: 4 lanes x 16 points, eight rows    (DFT-16 over a, exchange inside the row, DFT-8 / DFT-4 over b)
 //     a row reads its slice from the LDS spectrum and its window row (phase counter in closed form) from memory, runs its first DFT
 //     layer in registers; ONE workgroup barrier (every slice has been read) and the tile is free for the rows' own exchanges, which stay
 //     inside a wave: no further barrier.  Sum of the rows' exchange areas <= the two tiles, at most eight waves of rows: plans with more
@@ -74,7 +75,8 @@ __device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, 
 }  // namespace
 
 // 512 threads: two teams of four waves, team t transforms block 2 pair + t; then wave w of the eight runs the rows the schedule gives it.
-// wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1)
+// wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1),
+// 5 = l = 128 (slots 0..7), 6 = l = 64 (slots 0..7)
 template <bool WIDE>
 __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per compute unit */) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
                                                   int mbase, int nb_call, int fbm /* (first block of the call + mbase) mod R */, const float2 *__restrict__ tw,
@@ -194,6 +196,19 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
             dft32<true>(v);                                          // over a: index p in v[pos32(p)]
         }
     }
+    if (cls == 5 || cls == 6) {
+        // l = 128 (8 lanes x 16 points per row, eight rows) and l = 64 (4 lanes x 16 points, eight rows on the first 32 lanes): slice 4a + b / 8a + b
+        const int lg = cls == 5 ? 3 : 2, b = lane & ((1 << lg) - 1);
+        r0 = wr[(lane >> lg) & 7];
+        a0 = row_at(r0, 16 << lg, m0, nb, mbase, fbm, R, wins, nb_call, tiles);
+        if (cls == 6 && lane >= 32) a0.on = false;
+        cf w[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) w[a] = ld2(a0.win + ((F4_EXP & 2) ? 0 : (a << lg)) + b);
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a ^ 8] = cmul(ld2(a0.spec + (a << lg) + b), w[a]);          // ifftshift of the slice: i -> i + l/2 = a -> a ^ 8
+        dft16<true>(reinterpret_cast<cf (&)[16]>(v[0]));             // over a: index p in v[rev16(p)]
+    }
     __syncthreads();                                                 // every slice has been read: the tiles belong to the rows' exchanges
     if (cls == 1 || cls == 2) {
         const int b = lane & 15;
@@ -281,6 +296,58 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
             }
         }
     }
+    if (cls == 5 || cls == 6) {
+        // y[t = p + 16 q] = sum_b W_l^(-b p) W_(l/16)^(-b q) (DFT-16 over a)[p]: twiddle W_l^(b p) = W_256^((256 / l) b p) from the 256 table, an exchange inside the
+        // row — element (b, p) at p * lanes + (b ^ (p mod lanes)) — then every lane runs the DFT-(l/16) over b for its 16 / lanes values of p
+        const int lg = cls == 5 ? 3 : 2, lanes = 1 << lg, b = lane & (lanes - 1);
+        cf w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = ld4(&t256[(b << (4 - lg)) * 18 + 2 * i]);
+            w[2 * i] = mk(t.x, t.y); w[2 * i + 1] = mk(t.z, t.w);
+        }
+        float2 *row = tiles + r0.xch;
+        if (a0.on) {
+#pragma unroll
+            for (int p = 0; p < 16; p++) st2(&row[(p << lg) + (b ^ (p & (lanes - 1)))], cmulc(v[rev16(p)], w[p]));
+        }
+        wave_sync();
+        if (cls == 5) {
+            // p = b and p = b + 8: two DFT-8 (dft8 leaves X[k0 + 2 k1] in [4 k0 + k1])
+#pragma unroll
+            for (int bb = 0; bb < 8; bb++) {
+                v[bb] = ld2(&row[(b << 3) + (bb ^ b)]);
+                v[8 + bb] = ld2(&row[((b + 8) << 3) + (bb ^ b)]);
+            }
+            dft8<true>(reinterpret_cast<cf (&)[8]>(v[0]));
+            dft8<true>(reinterpret_cast<cf (&)[8]>(v[8]));
+            const int skip = 128 - r0.lout;
+            if (a0.on) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int t0 = b + 16 * q, t1 = t0 + 8;
+                    if (t0 >= skip) out_st(out + a0.dst + t0, v[4 * (q & 1) + (q >> 1)] * 128.f);
+                    if (t1 >= skip) out_st(out + a0.dst + t1, v[8 + 4 * (q & 1) + (q >> 1)] * 128.f);
+                }
+            }
+        } else {
+            // p = b + 4 j, j < 4: four DFT-4
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) v[4 * j + bb] = ld2(&row[((b + 4 * j) << 2) + (bb ^ b)]);
+                dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            }
+            const int skip = 64 - r0.lout;
+            if (a0.on) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (b + 4 * j + 16 * q >= skip) out_st(out + a0.dst + b + 4 * j + 16 * q, v[4 * j + q] * 64.f);
+                }
+            }
+        }
+    }
 }
 
 hipError_t init_fused4096_kernels()
@@ -297,7 +364,7 @@ hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int
 {
     if (nb_chunk <= 0) return hipSuccess;
     bool wide = false;
-    for (int w = 0; w < 8; w++) wide = wide || ((wcls >> (4 * w)) & 0xfu) >= 3;
+    for (int w = 0; w < 8; w++) wide = wide || ((wcls >> (4 * w)) & 0xfu) == 3 || ((wcls >> (4 * w)) & 0xfu) == 4;
     const int npairs = (nb_chunk + 1) / 2;
     const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
     if (wide)

@@ -30,11 +30,16 @@ def plans():
         "eight 512": [(512 * c, 512, 0.8, 1.0) for c in range(8)],
         "four 1024": [(1024 * c, 1024, 0.8, 1.0) for c in range(4)],
         "five 256 (a second wave for one row)": [(700 * c + 3, 256, 0.8, 1.0) for c in range(5)],
+        "narrow channels: 128 and 64 bins beside the example": EXAMPLE + [(2000, 128, 0.8, 1.0), (2101, 64, 0.7, 0.9), (37, 128, 0.5, 0.8), (4032, 64, 0.8, 1.0)],
+        "full band of 128-bin channels": [(128 * c, 128, 0.88, 1.0) for c in range(32)],
+        "thirty-two 64-bin channels": [(int(f), 64, 0.8, 1.0) for f in rng.integers(0, N - 63, 32)],
+        "nine 128 + nine 64 + three 256": [(int(f), 128, 0.8, 1.0) for f in rng.integers(0, N - 127, 9)] + [(int(f), 64, 0.6, 0.9) for f in rng.integers(0, N - 63, 9)] +
+                                          [(int(f), 256, 0.8, 1.0) for f in rng.integers(0, N - 255, 3)],
         "the same slice twice and overlapping slices": [(500, 256, 0.8, 1.0), (500, 256, 0.8, 1.0), (600, 256, 0.5, 0.8), (400, 512, 0.8, 1.0), (650, 512, 0.8, 1.0)],
     }
 
 
-@pytest.mark.parametrize("R", [2, 4, 8])
+@pytest.mark.parametrize("R", [2, 4, 8, 16])
 def test_one_launch_form_vs_oracle_and_two_launch_form(oracle, R):
     H = N - N // R
     for name, chans in plans().items():

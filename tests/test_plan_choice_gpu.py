@@ -246,6 +246,10 @@ def plans_at_4096():
         "eight 512-bin channels": bank(512, range(8)),
         "four 1024-bin channels": bank(1024, range(4)),
         "one 256-bin channel": [(1234, 256, 0.8, 1.0)],
+        "full band of 128-bin channels": bank(128, range(32)),
+        "thirty-two 64-bin channels": bank(64, range(0, 64, 2)),
+        "example + two 128-bin + two 64-bin channels": [(100, 256, 0.8, 1.0), (700, 512, 0.8, 1.0), (1500, 1024, 0.8, 1.0), (3001, 512, 0.8, 1.0),
+                                                         (2600, 128, 0.8, 1.0), (2800, 128, 0.8, 1.0), (3600, 64, 0.8, 1.0), (3700, 64, 0.8, 1.0)],
     }
 
 
