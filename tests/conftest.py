@@ -17,6 +17,16 @@ for _k in ("FDC_FORCE_GENERIC", "FDC_NO_POLY", "FDC_NO_BLOCK", "FDC_NO_FUSED"): 
         _G.defaults[_k] = "1"
 
 
+@pytest.fixture(autouse=True)
+def _defaults_are_per_test():
+    """gr_fdc_amd.defaults as every test found it: a test that forces a path for a comparison (sets a key, deletes it afterwards) would otherwise take the
+    key of a forced-path run of the SUITE (FDC_TEST_FORCE) with it, and everything behind it would run unforced."""
+    saved = dict(_G.defaults)
+    yield
+    _G.defaults.clear()
+    _G.defaults.update(saved)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

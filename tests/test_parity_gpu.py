@@ -947,9 +947,12 @@ def test_uniform_banks_of_other_widths(oracle, N, L, R, wt):
         chans = [(L * c, L, 0.88, 1.0) for c in slots]
         # every width on request; by default only where it measured faster than the spectrum path (l = 128)
         # (FDC_PIPE_NO_BLOCK: l = 512 at N = 65536, R = 2 has a block kernel of its own, tested below)
-        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=3, flags=G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK)
+        # (round 6: N = 4096 has the one-launch form for this width, tests/test_fused4096_gpu.py; this test is about what FDC_PIPE_NO_FUSED leaves)
+        nf = G.FDC_PIPE_NO_FUSED if N == 4096 else 0
+        assert N != 4096 or G.defaults.get("FDC_NO_FUSED") or G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb).path() == 5
+        p = G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, chunk_blocks=3, flags=G.FDC_PIPE_WIDE_UNIFORM | G.FDC_PIPE_NO_BLOCK | nf)
         assert p.path() == 2
-        assert (G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK).path() == 2) == (L == 128)
+        assert (G.Pipeline(N, R, chans, windowtype=wt, max_blocks=nb, flags=G.FDC_PIPE_NO_BLOCK | nf).path() == 2) == (L == 128)
         outs = p.work(x)
         check = range(len(chans)) if len(chans) <= 16 else range(0, len(chans), max(1, len(chans) // 12))
         ref, _ = oracle.channelizer(N, R, wt, [chans[c] for c in check], x, nthreads=8)
