@@ -524,12 +524,12 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     }
 }
 
-// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 64, 128, 256, 512 or 1024 bins wide.  A workgroup takes a pair of blocks; its
-// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256, 128 or 64; their exchange
+// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 16 ... 1024 bins wide.  A workgroup takes a pair of blocks; its
+// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256 or less; their exchange
 // areas must fit the two tiles the spectra leave behind.  Always true for plans of 256-bin and wider channels of up to 4096 bins in total; plans of channels
 // that overlap to more (or of more than 32 narrow channels) stay on the spectrum path.
 struct F4Class { int l, cls, per_wave, pitch; };
-constexpr F4Class kF4Classes[] = {{1024, 4, 2, 1056}, {512, 3, 4, 513}, {128, 5, 8, 136}, {64, 6, 8, 68}};   // (256: below; pitches: rows of a half-wave on different banks)
+constexpr F4Class kF4Classes[] = {{1024, 4, 2, 1056}, {512, 3, 4, 513}, {128, 5, 8, 136}, {64, 6, 8, 68}, {32, 7, 8, 34}, {16, 8, 8, 17}};   // (256: below; pitches: rows of a half-wave on different banks)
 bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
 {
     for (auto &w : p->f4_wave) w.clear();
@@ -539,7 +539,7 @@ bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
     long long bins = 0;
     for (int c = 0; c < p->C; c++) {
         const int l = cfg->channels[c].l;
-        if ((l != 64 && l != 128 && l != 256 && l != 512 && l != 1024) || l % p->R) return false;
+        if (l < 16 || l > 1024 || (l & (l - 1)) || l % p->R) return false;
         for (int k = 0; k < 2; k++) by[l].push_back(2 * c + k);
         bins += l;
     }
@@ -882,7 +882,7 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
         int xch = 0;
         for (int w = 0; w < 8; w++) {
             const unsigned cls = (p->f4_cls >> (4 * w)) & 0xfu;
-            const int L = cls == 4 ? 1024 : cls == 3 ? 512 : cls == 5 ? 128 : cls == 6 ? 64 : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : cls == 5 ? 136 : cls == 6 ? 68 : 272;
+            const int L = cls == 4 ? 1024 : cls == 3 ? 512 : cls >= 5 ? 16 << (8 - (int)cls) : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : cls >= 5 ? L + L / 16 : 272;
             for (int k = 0; k < 8; k++) {
                 fdc::F4Row &r = rows[(size_t)(8 * w + k)];
                 r = fdc::F4Row{0, 0, 0, 0, L - L / R, 0, 0};

@@ -13,7 +13,7 @@
 //       l =  256: 16 lanes x 16 points per row, up to eight rows (two sets of four) per wave   (the row machinery of k_c256)
 //       l =  512: 16 lanes x 32 points, up to four rows                                        (k_c512)
 //       l = 1024: 32 lanes x 32 points, up to two rows                                         (k_c1024)
-//       l =  128:  8 lanes x 16 points, eight rows; l = 64: 4 lanes x 16 points, eight rows    (DFT-16 over a, exchange inside the row, DFT-8 / DFT-4 over b)
+//       l =  128:  8 lanes x 16 points, eight rows; l = 64 / 32 / 16: 4 / 2 / 1 lanes, eight rows   (DFT-16 over a, exchange inside the row, DFT-8 / 4 / 2 over b)
 //     a row reads its slice from the LDS spectrum and its window row (phase counter in closed form) from memory, runs its first DFT
 //     layer in registers; ONE workgroup barrier (every slice has been read) and the tile is free for the rows' own exchanges, which stay
 //     inside a wave: no further barrier.  Sum of the rows' exchange areas <= the two tiles, at most eight waves of rows: plans with more
@@ -76,7 +76,7 @@ __device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, 
 
 // 512 threads: two teams of four waves, team t transforms block 2 pair + t; then wave w of the eight runs the rows the schedule gives it.
 // wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1),
-// 5 = l = 128 (slots 0..7), 6 = l = 64 (slots 0..7)
+// 5 = l = 128, 6 = l = 64, 7 = l = 32, 8 = l = 16 (slots 0..7 each)
 template <bool WIDE>
 __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per compute unit */) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
                                                   int mbase, int nb_call, int fbm /* (first block of the call + mbase) mod R */, const float2 *__restrict__ tw,
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
             dft32<true>(v);                                          // over a: index p in v[pos32(p)]
         }
     }
-    if (cls == 5 || cls == 6) {
-        // l = 128 (8 lanes x 16 points per row, eight rows) and l = 64 (4 lanes x 16 points, eight rows on the first 32 lanes): slice 4a + b / 8a + b
-        const int lg = cls == 5 ? 3 : 2, b = lane & ((1 << lg) - 1);
+    if (cls >= 5) {
+        // l = 128 (8 lanes x 16 points per row), 64 (4 lanes), 32 (2 lanes), 16 (one lane): eight rows on the first 8 * lanes lanes of the wave; slice (a << lg) + b
+        const int lg = 8 - (int)cls, b = lane & ((1 << lg) - 1);
         r0 = wr[(lane >> lg) & 7];
         a0 = row_at(r0, 16 << lg, m0, nb, mbase, fbm, R, wins, nb_call, tiles);
-        if (cls == 6 && lane >= 32) a0.on = false;
+        if ((lane >> lg) >= 8) a0.on = false;
         cf w[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) w[a] = ld2(a0.win + ((F4_EXP & 2) ? 0 : (a << lg)) + b);
@@ -296,10 +296,10 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
             }
         }
     }
-    if (cls == 5 || cls == 6) {
+    if (cls >= 5) {
         // y[t = p + 16 q] = sum_b W_l^(-b p) W_(l/16)^(-b q) (DFT-16 over a)[p]: twiddle W_l^(b p) = W_256^((256 / l) b p) from the 256 table, an exchange inside the
         // row — element (b, p) at p * lanes + (b ^ (p mod lanes)) — then every lane runs the DFT-(l/16) over b for its 16 / lanes values of p
-        const int lg = cls == 5 ? 3 : 2, lanes = 1 << lg, b = lane & (lanes - 1);
+        const int lg = 8 - (int)cls, lanes = 1 << lg, b = lane & (lanes - 1);
         cf w[16];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -329,6 +329,30 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
                     if (t0 >= skip) out_st(out + a0.dst + t0, v[4 * (q & 1) + (q >> 1)] * 128.f);
                     if (t1 >= skip) out_st(out + a0.dst + t1, v[8 + 4 * (q & 1) + (q >> 1)] * 128.f);
                 }
+            }
+        } else if (cls == 7) {
+            // l = 32: p = b + 2 j, j < 8: eight DFT-2; y[t = p + 16 q], q < 2
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const cf e = ld2(&row[((b + 2 * j) << 1) + b]), o = ld2(&row[((b + 2 * j) << 1) + (1 ^ b)]);
+                v[2 * j] = e + o; v[2 * j + 1] = e - o;
+            }
+            const int skip = 32 - r0.lout;
+            if (a0.on) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) if (b + 2 * j + 16 * q >= skip) out_st(out + a0.dst + b + 2 * j + 16 * q, v[2 * j + q] * 32.f);
+                }
+            }
+        } else if (cls == 8) {
+            // l = 16: the DFT-16 over a is the whole transform (the trip through the row's exchange area only puts y[p] into register p)
+#pragma unroll
+            for (int p = 0; p < 16; p++) v[p] = ld2(&row[p]);
+            const int skip = 16 - r0.lout;
+            if (a0.on) {
+#pragma unroll
+                for (int p = 0; p < 16; p++) if (p >= skip) out_st(out + a0.dst + p, v[p] * 16.f);
             }
         } else {
             // p = b + 4 j, j < 4: four DFT-4

@@ -84,8 +84,8 @@ hipError_t launch_fft4096(const float2 *in, size_t in_stride, float2 *out, int n
 
 // N = 4096 in one launch (fdc_fused4096.hip): forward transform + every channel's slice / window / inverse transform, the spectrum stays in LDS.
 // A 512-thread workgroup takes a pair of blocks.  The schedule is the host's (fdc_api.hip plan_fused4096): rows[8 waves][8 slots], four bits per
-// wave in wcls (0 = no rows, 1 = l = 256 slots 0..3, 2 = l = 256 slots 0..7, 3 = l = 512 slots 0..3, 4 = l = 1024 slots 0..1, 5 = l = 128 slots 0..7,
-// 6 = l = 64 slots 0..7); valid = 0: no row,
+// wave in wcls (0 = no rows, 1 = l = 256 slots 0..3, 2 = l = 256 slots 0..7, 3 = l = 512 slots 0..3, 4 = l = 1024 slots 0..1, 5 / 6 / 7 / 8 = l = 128 / 64 / 32 / 16
+// slots 0..7); valid = 0: no row,
 // 1 + k: a row of the pair's block k; xch = the row's exchange area in the two tiles (points), rows disjoint, all inside 2 fused4096_tile_points().
 // Unused slots: everything 0 except lout.
 struct F4Row { int32_t f, win_off, shift, xch, lout, valid; long long out_off; };

@@ -194,8 +194,8 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * when the sum says so); fdc_pipeline_describe / fdc_pipeline_plan_preview say what was chosen.
  * 5 (round 6) = N = 4096 — the block length of the reference's example flowgraph — in ONE launch (csrc/fdc_fused4096.hip; ms[0]): forward transform, channel
  * slices, windows and inverse transforms with the spectrum in LDS, nothing but the new input samples and the output samples crosses the memory interface.
- * Every plan of 64- / 128- / 256- / 512- / 1024-bin channels (any offsets, windows, overlaps between them) of at least 512 and — about — at most 4096 bins in total
- * (exactly: the rows of a pair of blocks fit eight waves — two rows of 1024 bins, four of 512, eight of 256 / 128 / 64 per wave — and the two spectrum tiles);
+ * Every plan of channels 16 ... 1024 bins wide (any offsets, windows, overlaps between them) of at least 512 and — about — at most 4096 bins in total
+ * (exactly: the rows of a pair of blocks fit eight waves — two rows of 1024 bins, four of 512, eight of 256 or less per wave — and the two spectrum tiles);
  * a call that asks for the spectrum runs path 0 on the same handle.  FDC_PIPE_NO_FUSED / FDC_PIPE_NO_POLY: paths 0 / 2 as before.  plan_preview: every channel -1. */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 /* The same in words, for logs: which kernels the handle's plan was given ("N = 65536, R = 2, 512 channels; path 3: k_blknar, l = 128, bank of 511 half a

@@ -31,6 +31,9 @@ def plans():
         "four 1024": [(1024 * c, 1024, 0.8, 1.0) for c in range(4)],
         "five 256 (a second wave for one row)": [(700 * c + 3, 256, 0.8, 1.0) for c in range(5)],
         "narrow channels: 128 and 64 bins beside the example": EXAMPLE + [(2000, 128, 0.8, 1.0), (2101, 64, 0.7, 0.9), (37, 128, 0.5, 0.8), (4032, 64, 0.8, 1.0)],
+        "down to 16 bins": EXAMPLE[:2] + [(2000, 32, 0.8, 1.0), (2101, 16, 0.7, 0.9), (3, 32, 0.5, 0.8), (4080, 16, 0.8, 1.0), (777, 16, 1.0, 1.0), (1900, 64, 0.8, 1.0)],
+        "nine 32-bin and nine 16-bin channels beside a 1024-bin one": [(1000, 1024, 0.8, 1.0)] + [(int(f), 32, 0.8, 1.0) for f in rng.integers(0, N - 31, 9)] +
+                                                                    [(int(f), 16, 0.6, 0.9) for f in rng.integers(0, N - 15, 9)],
         "full band of 128-bin channels": [(128 * c, 128, 0.88, 1.0) for c in range(32)],
         "thirty-two 64-bin channels": [(int(f), 64, 0.8, 1.0) for f in rng.integers(0, N - 63, 32)],
         "nine 128 + nine 64 + three 256": [(int(f), 128, 0.8, 1.0) for f in rng.integers(0, N - 127, 9)] + [(int(f), 64, 0.6, 0.9) for f in rng.integers(0, N - 63, 9)] +

@@ -59,10 +59,10 @@ def check_structure(n, R, plan, flags=0):
     else:
         assert len(rem) == len(plan)
     if path == 5:     # the one-launch form of N = 4096 (fdc_fused4096.hip): every width has a row form, the rows of a pair of blocks fit eight waves and the two tiles
-        n = {l: sum(1 for c in plan if c[1] == l) for l in (1024, 512, 256, 128, 64)}
+        n = {l: sum(1 for c in plan if c[1] == l) for l in (1024, 512, 256, 128, 64, 32, 16)}
         assert sum(n.values()) == len(plan) and not flags & (G.FDC_PIPE_NO_POLY | G.FDC_PIPE_NO_FUSED | G.FDC_PIPE_FORCE_GENERIC)
-        waves = n[1024] + (n[512] + 1) // 2 + (n[128] + 3) // 4 + (n[64] + 3) // 4 + (n[256] + 3) // 4
-        assert waves <= 8 and 1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] <= 4352, text
+        waves = n[1024] + (n[512] + 1) // 2 + sum((n[l] + 3) // 4 for l in (256, 128, 64, 32, 16))
+        assert waves <= 8 and 1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] + 34 * n[32] + 17 * n[16] <= 4352, text
     if flags & G.FDC_PIPE_NO_POLY:
         assert path in (0, 1)
     if flags & G.FDC_PIPE_NO_BLOCK:
@@ -106,7 +106,7 @@ def test_the_one_launch_form_at_n_4096():
     assert check_structure(4096, 2, [(1234, 256, 0.8, 1.0)], G.FDC_PIPE_WIDE_UNIFORM)[0] == 5 and check_structure(4096, 2, [(1234, 512, 0.8, 1.0)])[0] == 5
     # widths without a row form, too many bins (channels that overlap), other block lengths: not this form
     assert check_structure(4096, 2, example + [(2000, 128, 0.8, 1.0)])[0] == 5 and "4 waves" in check_structure(4096, 2, example + [(2000, 128, 0.8, 1.0)])[1]
-    assert check_structure(4096, 2, example + [(2000, 32, 0.8, 1.0)])[0] == 0
+    assert check_structure(4096, 2, example + [(2000, 32, 0.8, 1.0), (2100, 16, 0.8, 1.0)])[0] == 5 and check_structure(4096, 2, example + [(2000, 8, 0.8, 1.0)])[0] == 0
     # narrow channels: eight rows of 128 or 64 bins per wave — up to 32 of them (a full band of 128-bin channels; half a band of 64-bin ones)
     assert check_structure(4096, 4, bank(128, range(32)))[0] == 5 and check_structure(4096, 2, bank(64, range(0, 64, 2)))[0] == 5
     assert check_structure(4096, 2, bank(64, range(33)))[0] in (0, 2) and check_structure(4096, 2, bank(64, range(4)))[0] in (0, 2)       # 33 rows x 2 blocks; under 512 bins

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box helper: randomised differential test of the one-launch form of N = 4096 (csrc/fdc_fused4096.hip, fdc_pipeline_path() = 5).  Every case draws a plan
-of 64- ... 1024-bin channels (any offsets, overlapping and repeated slices, two windows; sometimes a width without a row form, which must send the plan
+of 16- ... 1024-bin channels (any offsets, overlapping and repeated slices, two windows; sometimes a width without a row form, which must send the plan
 to the spectrum path), an overlap R, a window type, a call pattern and a launch-group size, runs it on dispatch and under FDC_PIPE_NO_FUSED and compares every
 output sample; every fourth case also against the oracle.  Usage: python tools/fuzz_fused4096.py [cases] [seed]"""
 import os
@@ -30,8 +30,8 @@ def main():
         R = int(rng.choice([2, 2, 4, 4, 8, 16]))
         H = N - N // R
         plan, left = [], int(rng.choice([1024, 2048, 4096, 4096, 5120]))
-        while left >= 64 and len(plan) < 24:
-            l = int(rng.choice([w for w in (64, 128, 256, 256, 512, 1024) if w <= left]))
+        while left >= 16 and len(plan) < 28:
+            l = int(rng.choice([w for w in (16, 32, 64, 128, 256, 256, 512, 1024) if w <= left]))
             win = [(0.88, 1.0), (0.6, 0.85)][int(rng.integers(0, 2))]
             plan.append((int(rng.integers(0, N - l + 1)), l) + win)
             left -= l
@@ -41,7 +41,7 @@ def main():
             plan.append(plan[int(rng.integers(0, len(plan)))])                  # the same slice again
         odd = rng.random() < 0.12
         if odd:
-            lo = int(rng.choice([16, 32, 2048]))
+            lo = int(rng.choice([4, 8, 2048]))
             plan.append((int(rng.integers(0, N - lo + 1)), lo, 0.8, 1.0))     # no row form: the whole plan on the spectrum path
         wt = int(rng.integers(0, 3))
         sizes = [int(v) for v in rng.integers(1, 70, size=int(rng.integers(1, 5)))]
@@ -49,9 +49,9 @@ def main():
         p = G.Pipeline(N, R, plan, windowtype=wt, max_blocks=max(sizes), chunk_blocks=chunk)
         q = G.Pipeline(N, R, plan, windowtype=wt, max_blocks=max(sizes), chunk_blocks=chunk, flags=G.FDC_PIPE_NO_FUSED)
         bins = sum(c[1] for c in plan)
-        n = {w: sum(1 for c in plan if c[1] == w) for w in (1024, 512, 256, 128, 64)}
-        fits = n[1024] + (n[512] + 1) // 2 + (n[128] + 3) // 4 + (n[64] + 3) // 4 + (n[256] + 3) // 4 <= 8 and \
-            1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] <= 4352
+        n = {w: sum(1 for c in plan if c[1] == w) for w in (1024, 512, 256, 128, 64, 32, 16)}
+        fits = n[1024] + (n[512] + 1) // 2 + sum((n[w] + 3) // 4 for w in (256, 128, 64, 32, 16)) <= 8 and \
+            1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] + 34 * n[32] + 17 * n[16] <= 4352
         if p.path() == 5:
             fused += 1
             assert not odd and bins >= 512 and fits, (plan, p.describe())
