@@ -188,6 +188,7 @@ struct fdc_pipeline {
     bool fused = false;
     std::vector<int> f4_wave[8];
     unsigned f4_cls = 0;
+    int f4_teams = 2;            // blocks per workgroup the schedule is made for
     fdc::F4Row *d_f4rows = nullptr;
     float2 *d_ftwq = nullptr, *d_fcbt = nullptr;
     float *d_fshn = nullptr;
@@ -534,40 +535,55 @@ bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
 {
     for (auto &w : p->f4_wave) w.clear();
     p->f4_cls = 0;
+    p->f4_teams = 2;
     if (p->N != 4096 || p->C == 0 || p->cfg_generic || (flags & (FDC_PIPE_NO_POLY | FDC_PIPE_NO_FUSED))) return false;
-    std::map<int, std::vector<int>> by;                           // rows by width: the two blocks' rows of a channel side by side
     long long bins = 0;
+    bool wide = false;
     for (int c = 0; c < p->C; c++) {
         const int l = cfg->channels[c].l;
         if (l < 16 || l > 1024 || (l & (l - 1)) || l % p->R) return false;
-        for (int k = 0; k < 2; k++) by[l].push_back(2 * c + k);
         bins += l;
+        wide = wide || l >= 512;
     }
     // ONE 256-bin channel: the two launches are 9 % faster (0.063 against 0.069 ms per 8192 blocks; four such channels: 0.076 / 0.073; everything wider:
     // 1.3 - 1.6 x for this form, profiles/r06/plan_choice_4096.txt) — the forward transform alone is what both cost, and k_fft4096 has four workgroups per unit
     if (bins < 512 && !(flags & FDC_PIPE_WIDE_UNIFORM)) return false;
-    int w = 0;
-    unsigned cls = 0;
-    long long pts = 272ll * (long long)by[256].size();
-    for (const F4Class &k : kF4Classes) {
-        const std::vector<int> &rows = by[k.l];
-        pts += (long long)k.pitch * (long long)rows.size();
-        for (size_t i = 0; i < rows.size(); i += (size_t)k.per_wave, w++) {
-            if (w >= 8) return false;
-            for (size_t j = i; j < std::min(i + (size_t)k.per_wave, rows.size()); j++) p->f4_wave[w].push_back(rows[j]);
-            cls |= (unsigned)k.cls << (4 * w);
+    // the schedule for T blocks per workgroup (4 T waves, T tiles): rows by width, the blocks' rows of a channel side by side
+    auto schedule = [&](int T) {
+        for (auto &w : p->f4_wave) w.clear();
+        std::map<int, std::vector<int>> by;
+        for (int c = 0; c < p->C; c++) for (int k = 0; k < T; k++) by[cfg->channels[c].l].push_back(2 * c + k);
+        int w = 0;
+        unsigned cls = 0;
+        long long pts = 272ll * (long long)by[256].size();
+        for (const F4Class &k : kF4Classes) {
+            const std::vector<int> &rows = by[k.l];
+            pts += (long long)k.pitch * (long long)rows.size();
+            for (size_t i = 0; i < rows.size(); i += (size_t)k.per_wave, w++) {
+                if (w >= 4 * T) return false;
+                for (size_t j = i; j < std::min(i + (size_t)k.per_wave, rows.size()); j++) p->f4_wave[w].push_back(rows[j]);
+                cls |= (unsigned)k.cls << (4 * w);
+            }
         }
-    }
-    const int avail = 8 - w, n256 = (int)by[256].size();
-    if (n256 > 8 * avail || pts > 2 * fdc::fused4096_tile_points()) { for (auto &v : p->f4_wave) v.clear(); return false; }
-    if (n256) {
-        // as few waves as one set of four rows each allows (a wave's instructions cost the same for one row as for four); two sets where that is not enough
-        const int nw = n256 <= 4 * avail ? (n256 + 3) / 4 : avail;
-        for (int i = 0; i < n256; i++) p->f4_wave[w + i % nw].push_back(by[256][(size_t)i]);
-        for (int k = 0; k < nw; k++) cls |= (p->f4_wave[w + k].size() > 4 ? 2u : 1u) << (4 * (w + k));
-    }
-    p->f4_cls = cls;
-    return true;
+        const int avail = 4 * T - w, n256 = (int)by[256].size();
+        if (n256 > 8 * avail || pts > (long long)T * fdc::fused4096_tile_points()) return false;
+        if (n256) {
+            // as few waves as one set of four rows each allows (a wave's instructions cost the same for one row as for four); two sets where that is not enough
+            const int nw = n256 <= 4 * avail ? (n256 + 3) / 4 : avail;
+            for (int i = 0; i < n256; i++) p->f4_wave[w + i % nw].push_back(by[256][(size_t)i]);
+            for (int k = 0; k < nw; k++) cls |= (p->f4_wave[w + k].size() > 4 ? 2u : 1u) << (4 * (w + k));
+        }
+        p->f4_cls = cls;
+        p->f4_teams = T;
+        return true;
+    };
+    // one block per workgroup (four independent workgroups on a unit) where no row is wide; else, or where that does not fit, a pair of blocks
+    static const int teams_env = [] { const char *e = fdc::debug_env("FDC_F4_TEAMS"); return e ? atoi(e) : 0; }();
+    if ((!wide || teams_env == 1) && teams_env != 2 && schedule(1)) return true;
+    if (schedule(2)) return true;
+    for (auto &w : p->f4_wave) w.clear();
+    p->f4_cls = 0;
+    return false;
 }
 
 void classify_plan(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
@@ -880,7 +896,7 @@ int build_device_state(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, const std::
     if (p->fused) {
         std::vector<fdc::F4Row> rows(64);
         int xch = 0;
-        for (int w = 0; w < 8; w++) {
+        for (int w = 0; w < 4 * p->f4_teams; w++) {
             const unsigned cls = (p->f4_cls >> (4 * w)) & 0xfu;
             const int L = cls == 4 ? 1024 : cls == 3 ? 512 : cls >= 5 ? 16 << (8 - (int)cls) : 256, pitch = cls == 4 ? 1056 : cls == 3 ? 513 : cls >= 5 ? L + L / 16 : 272;
             for (int k = 0; k < 8; k++) {
@@ -1075,7 +1091,8 @@ int32_t fdc_pipeline_describe(const fdc_pipeline *p, char *buf, int32_t n)
     if (p->fused) {
         int nw = 0;
         for (const auto &w : p->f4_wave) nw += !w.empty();
-        add("k_f4096, transform + %d channel transforms in one launch (spectrum in LDS, rows on %d wave%s)", p->C, nw, nw == 1 ? "" : "s");
+        add("k_f4096, transform + %d channel transforms in one launch (spectrum in LDS, %s per workgroup, rows on %d wave%s)", p->C,
+            p->f4_teams == 1 ? "one block" : "two blocks", nw, nw == 1 ? "" : "s");
     } else if (p->poly_block) {
         bool one_width = true, all256 = true;
         for (const auto &b : p->banks) { one_width = one_width && b.L == p->banks[0].L; all256 = all256 && b.L == 256; }
@@ -1286,7 +1303,7 @@ int fdc_pipeline_process_device(fdc_pipeline *p, const void *d_ring, int64_t fir
         if (p->fused && !d_spectrum) {
             // N = 4096: one launch, nothing but the input samples and the output samples crosses the memory interface
             if (tg) HIPCHK(hipEventRecord(p->events[span[0]], s));
-            HIPCHK(fdc::launch_fused4096(in0, (size_t)p->H, o, nb, p->R, m0, nblocks, first_block, p->d_tw, p->ntab, p->d_wins, p->d_f4rows, p->f4_cls, s));
+            HIPCHK(fdc::launch_fused4096(in0, (size_t)p->H, o, nb, p->R, m0, nblocks, first_block, p->d_tw, p->ntab, p->d_wins, p->d_f4rows, p->f4_cls, p->f4_teams, s));
             if (tg) { HIPCHK(hipEventRecord(p->events[span[1]], s)); span[2] = span[3] = span[1]; span[4] = kSpanBanks; p->ev_spans.push_back(span); }
             continue;
         }

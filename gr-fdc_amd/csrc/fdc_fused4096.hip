@@ -5,7 +5,7 @@
 // them back: python/FrequencyDomainChannelizer.py:206 (fft_vcc) -> :214-216 (vector_cut_vxx, phase_shifting_windowing_vcc) -> :218-226
 // (ifft, vector_cut_vxx, multiply_const) per channel.
 //
-//   one 512-thread workgroup per PAIR of input blocks: each team of four waves transforms one block (4096 points = 32 KiB, the same three
+//   one 512-thread workgroup per PAIR of input blocks (one 256-thread workgroup per block where that fills the waves as well): each team of four waves transforms one block (4096 points = 32 KiB, the same three
 //   DFT-16 layers as k_fft4096, fdc_chanwide.hip) and stores the shifted, 1/N-scaled spectrum to LDS over its exchange tile (32 KiB);
 //   every one of the eight WAVES then owns rows — (block of the pair, channel) — of ONE channel width: the plan's schedule, made by the
 //   host (fdc_api.hip, plan_fused4096).  Two blocks per workgroup because a wave's instructions cost the same for one row as for a full
@@ -35,16 +35,17 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_f4[];
 #endif
 namespace {
 constexpr int kF4TilePts = 16 * 272;                         // exchange tile of one block's forward transform; then its spectrum; then rows' exchanges
-constexpr int kF4Tiles = 2 * kF4TilePts * 8;                 // two blocks per workgroup
-constexpr int kF4OffT256 = kF4Tiles;                         // [x][y] = W_256^(x y), 16 x 18
-constexpr int kF4OffT4k = kF4OffT256 + 16 * 18 * 8;          // [x][y] = W_4096^(x y), 16 x 18
-constexpr int kF4OffRows = kF4OffT4k + 16 * 18 * 8;          // the schedule: [8 waves][8 slots] F4Row
-constexpr int kF4Lds = kF4OffRows + 64 * 32;                 // 76288
-constexpr int kF4OffW1k = kF4Lds;                            // [x][p] = W_1024^(x p), 16 x 34
-constexpr int kF4OffW64 = kF4OffW1k + 16 * 34 * 8;           // [c][p] = W_64^(c p), 2 x 34
-constexpr int kF4LdsWide = kF4OffW64 + 2 * 34 * 8;           // 81184: two 512-thread workgroups per compute unit, sixteen waves
+// LDS image for T blocks (teams of four waves) per workgroup: [T tiles][W_256^(x y) 16 x 18][W_4096^(x y) 16 x 18][schedule: 4 T waves x 8 slots]
+// and, with wide rows, [W_1024^(x p) 16 x 34][W_64^(c p) 2 x 34]
+constexpr int f4_off_t256(int T) { return T * kF4TilePts * 8; }
+constexpr int f4_off_t4k(int T) { return f4_off_t256(T) + 16 * 18 * 8; }
+constexpr int f4_off_rows(int T) { return f4_off_t4k(T) + 16 * 18 * 8; }
+constexpr int f4_lds(int T) { return f4_off_rows(T) + 32 * T * 32; }                 // T = 2: 76288 (two workgroups per unit); T = 1: 40448 (four)
+constexpr int f4_off_w1k(int T) { return f4_lds(T); }
+constexpr int f4_off_w64(int T) { return f4_off_w1k(T) + 16 * 34 * 8; }
+constexpr int f4_lds_wide(int T) { return f4_off_w64(T) + 2 * 34 * 8; }              // T = 2: 81184
 static_assert(sizeof(F4Row) == 32, "schedule rows are copied 16 bytes at a time");
-static_assert(2 * kF4LdsWide <= 160 * 1024, "LDS budget");
+static_assert(2 * f4_lds_wide(2) <= 160 * 1024 && 4 * f4_lds(1) <= 160 * 1024 && 3 * f4_lds_wide(1) <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ constexpr int pos32(int k) { return 16 * (k & 1) + rev16(k >> 1); }   // dft32 leaves X[k0 + 2 k1] in v[16 k0 + rev16(k1)]
 
@@ -74,34 +75,37 @@ __device__ __forceinline__ RowAt row_at(const F4Row &ri, int L, int m0, int nb, 
 }
 }  // namespace
 
-// 512 threads: two teams of four waves, team t transforms block 2 pair + t; then wave w of the eight runs the rows the schedule gives it.
+// TEAMS teams of four waves (256 TEAMS threads): team t transforms block TEAMS g + t of workgroup g's blocks; then every wave runs the rows the schedule gives it.
+// TEAMS = 2 wherever rows of ONE block would leave waves part empty (all wide rows: the reference's example fills its 1024- and 512-bin waves only with the
+// rows of two blocks); TEAMS = 1 — four independent workgroups per unit instead of two of twice the size — where the schedule of one block fits four waves.
 // wcls: four bits per wave: 0 = no rows, 1 = l = 256 (slots 0..3), 2 = l = 256 two sets (slots 0..7), 3 = l = 512 (slots 0..3), 4 = l = 1024 (slots 0..1),
 // 5 = l = 128, 6 = l = 64, 7 = l = 32, 8 = l = 16 (slots 0..7 each)
-template <bool WIDE>
-__global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per compute unit */) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
+template <bool WIDE, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS, 4 /* waves per SIMD */) void k_f4096(const float2 *__restrict__ in, size_t in_stride, float2 *__restrict__ out, int nb, int R,
                                                   int mbase, int nb_call, int fbm /* (first block of the call + mbase) mod R */, const float2 *__restrict__ tw,
                                                   int twstride /* ntab / 4096 */, const float2 *__restrict__ wins,
                                                   const F4Row *__restrict__ rows, unsigned wcls)
 {
     float2 *tiles = reinterpret_cast<float2 *>(fdc_smem_f4);
-    float2 *t256 = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffT256);
-    float2 *t4k = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffT4k);
-    const F4Row *srows = reinterpret_cast<const F4Row *>(fdc_smem_f4 + kF4OffRows);
-    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, lo = tid & 15, hi = tid >> 4;
+    float2 *t256 = reinterpret_cast<float2 *>(fdc_smem_f4 + f4_off_t256(TEAMS));
+    float2 *t4k = reinterpret_cast<float2 *>(fdc_smem_f4 + f4_off_t4k(TEAMS));
+    const F4Row *srows = reinterpret_cast<const F4Row *>(fdc_smem_f4 + f4_off_rows(TEAMS));
+    const int team = TEAMS == 1 ? 0 : threadIdx.x >> 8, tid = threadIdx.x & 255, lo = tid & 15, hi = tid >> 4;
     // neighbouring blocks share R - 1 of R input samples: workgroup ids go round the eight XCDs, so XCD x takes the x-th eighth of the launch
     // and the shared samples are hits in ITS L2
-    const int npairs = (nb + 1) >> 1, per = (npairs + 7) >> 3;
-    const int pair = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (pair >= npairs) return;
-    const int m0 = 2 * pair, m = m0 + team;
+    const int ngroups = (nb + TEAMS - 1) / TEAMS, per = (ngroups + 7) >> 3;
+    const int grp = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (grp >= ngroups) return;
+    const int m0 = TEAMS * grp, m = m0 + team;
     float2 *tile = tiles + team * kF4TilePts;
     if (team == 0) {
         t256[hi * 18 + lo] = tw[((16 * hi * lo) & 4095) * twstride];
         t4k[hi * 18 + lo] = tw[(hi * lo) * twstride];
-    } else {
-        if (tid < 128) reinterpret_cast<float4 *>(fdc_smem_f4 + kF4OffRows)[tid] = reinterpret_cast<const float4 *>(rows)[tid];
+    }
+    if (team == TEAMS - 1) {
+        if (tid < 64 * TEAMS) reinterpret_cast<float4 *>(fdc_smem_f4 + f4_off_rows(TEAMS))[tid] = reinterpret_cast<const float4 *>(rows)[tid];
         if constexpr (WIDE) {
-            float2 *w1k = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffW1k), *w64 = reinterpret_cast<float2 *>(fdc_smem_f4 + kF4OffW64);
+            float2 *w1k = reinterpret_cast<float2 *>(fdc_smem_f4 + f4_off_w1k(TEAMS)), *w64 = reinterpret_cast<float2 *>(fdc_smem_f4 + f4_off_w64(TEAMS));
             for (int i = tid; i < 512; i += 256) w1k[(i >> 5) * 34 + (i & 31)] = tw[((i >> 5) * (i & 31)) * (4 * twstride)];
             if (tid < 64) w64[(tid >> 5) * 34 + (tid & 31)] = tid < 32 ? make_float2(1.0f, 0.0f) : tw[(tid & 31) * (64 * twstride)];
         }
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
         // l = 1024: x = b; l = 512: W_512^(b p) = W_1024^(2 b p), x = 2 b
         if (cls == 3 || cls == 4) {
             const int lg = cls == 3 ? 4 : 5, b = lane & ((1 << lg) - 1), x = cls == 3 ? 2 * b : b;
-            const float2 *wa = reinterpret_cast<const float2 *>(fdc_smem_f4 + kF4OffW1k) + (x & 15) * 34;
-            const float2 *wb = reinterpret_cast<const float2 *>(fdc_smem_f4 + kF4OffW64) + (x >> 4) * 34;
+            const float2 *wa = reinterpret_cast<const float2 *>(fdc_smem_f4 + f4_off_w1k(TEAMS)) + (x & 15) * 34;
+            const float2 *wb = reinterpret_cast<const float2 *>(fdc_smem_f4 + f4_off_w64(TEAMS)) + (x >> 4) * 34;
             float2 *row = tiles + r0.xch;
             // element (b, p) of a row at p * lanes + (b ^ (p mod lanes)) (k_c1024, k_c512)
             if (a0.on) {
@@ -376,27 +380,36 @@ __global__ __launch_bounds__(512, 4 /* waves per SIMD: two workgroups per comput
 
 hipError_t init_fused4096_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kF4Lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, f4_lds(2));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kF4LdsWide);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, f4_lds(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, f4_lds_wide(1));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_f4096<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, f4_lds_wide(2));
 }
 
 int fused4096_tile_points() { return kF4TilePts; }
 
+// teams: blocks per workgroup the schedule was made for (1: rows[4 waves][8]; 2: rows[8 waves][8])
 hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int R, int mbase, int nb_call, int64_t first_block,
-                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, hipStream_t s)
+                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, int teams, hipStream_t s)
 {
     if (nb_chunk <= 0) return hipSuccess;
     bool wide = false;
     for (int w = 0; w < 8; w++) wide = wide || ((wcls >> (4 * w)) & 0xfu) == 3 || ((wcls >> (4 * w)) & 0xfu) == 4;
-    const int npairs = (nb_chunk + 1) / 2;
-    const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
-    if (wide)
-        hipLaunchKernelGGL(k_f4096<true>, grid, dim3(512), kF4LdsWide, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (int)((first_block + mbase) % R), tw,
-                           ntab / 4096, wins, rows, wcls);
+    if (teams != 2 && teams != 1) return hipErrorInvalidValue;
+    const int ngroups = (nb_chunk + teams - 1) / teams;
+    const dim3 grid((unsigned)(8 * ((ngroups + 7) / 8)));
+    const int fbm = (int)((first_block + mbase) % R);
+    if (wide && teams == 1)
+        hipLaunchKernelGGL((k_f4096<true, 1>), grid, dim3(256), f4_lds_wide(1), s, in, in_stride, out, nb_chunk, R, mbase, nb_call, fbm, tw, ntab / 4096, wins, rows, wcls);
+    else if (wide)
+        hipLaunchKernelGGL((k_f4096<true, 2>), grid, dim3(512), f4_lds_wide(2), s, in, in_stride, out, nb_chunk, R, mbase, nb_call, fbm, tw, ntab / 4096, wins, rows, wcls);
+    else if (teams == 2)
+        hipLaunchKernelGGL((k_f4096<false, 2>), grid, dim3(512), f4_lds(2), s, in, in_stride, out, nb_chunk, R, mbase, nb_call, fbm, tw, ntab / 4096, wins, rows, wcls);
     else
-        hipLaunchKernelGGL(k_f4096<false>, grid, dim3(512), kF4Lds, s, in, in_stride, out, nb_chunk, R, mbase, nb_call, (int)((first_block + mbase) % R), tw,
-                           ntab / 4096, wins, rows, wcls);
+        hipLaunchKernelGGL((k_f4096<false, 1>), grid, dim3(256), f4_lds(1), s, in, in_stride, out, nb_chunk, R, mbase, nb_call, fbm, tw, ntab / 4096, wins, rows, wcls);
     return hipGetLastError();
 }
 

@@ -92,7 +92,7 @@ struct F4Row { int32_t f, win_off, shift, xch, lout, valid; long long out_off; }
 hipError_t init_fused4096_kernels();
 int fused4096_tile_points();
 hipError_t launch_fused4096(const float2 *in, size_t in_stride, float2 *out, int nb_chunk, int R, int mbase, int nb_call, int64_t first_block,
-                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, hipStream_t s);
+                            const float2 *tw, int ntab, const float2 *wins, const F4Row *rows, unsigned wcls, int teams /* blocks per workgroup: 1 (rows[4][8], no wide rows) or 2 (rows[8][8]) */, hipStream_t s);
 
 // uniform plan (all channels l = 256, f = 256*slot, N = 256*N1): stage 1 + stage 2, no spectrum in memory.
 //   twq[n1][q] = W_N^(16*n1*q), cbt[n1][b] = (-1)^n1 W_N^(n1*b)  (16 entries per n1 each), shn[k2] = shape[k2]/N;

@@ -61,8 +61,13 @@ def check_structure(n, R, plan, flags=0):
     if path == 5:     # the one-launch form of N = 4096 (fdc_fused4096.hip): every width has a row form, the rows of a pair of blocks fit eight waves and the two tiles
         n = {l: sum(1 for c in plan if c[1] == l) for l in (1024, 512, 256, 128, 64, 32, 16)}
         assert sum(n.values()) == len(plan) and not flags & (G.FDC_PIPE_NO_POLY | G.FDC_PIPE_NO_FUSED | G.FDC_PIPE_FORCE_GENERIC)
-        waves = n[1024] + (n[512] + 1) // 2 + sum((n[l] + 3) // 4 for l in (256, 128, 64, 32, 16))
-        assert waves <= 8 and 1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] + 34 * n[32] + 17 * n[16] <= 4352, text
+        assert 1056 * n[1024] + 513 * n[512] + 272 * n[256] + 136 * n[128] + 68 * n[64] + 34 * n[32] + 17 * n[16] <= 4352, text
+
+        def fits(T):        # the rows of T blocks on 4 T waves: two rows of 1024 bins, four of 512, eight of anything narrower per wave (one width per wave)
+            w = -(-T * n[1024] // 2) + -(-T * n[512] // 4) + sum(-(-T * n[l] // 8) for l in (128, 64, 32, 16))
+            return w <= 4 * T and T * n[256] <= 8 * (4 * T - w)
+        one = not (n[1024] or n[512]) and fits(1)        # one block per workgroup (four workgroups on a unit) where no row is wide; else a pair of blocks
+        assert ("one block per workgroup" in text) == one and (one or fits(2)), text
     if flags & G.FDC_PIPE_NO_POLY:
         assert path in (0, 1)
     if flags & G.FDC_PIPE_NO_BLOCK:
@@ -91,16 +96,18 @@ def test_the_one_launch_form_at_n_4096():
     example = [(100, 256, 0.8, 1.0), (700, 512, 0.8, 1.0), (1500, 1024, 0.8, 1.0), (3000, 512, 0.8, 1.0)]     # examples/FDC_example.grc: l = 256 / 512 / 1024 / 512
     for R in (2, 4, 8):
         path, text, asg = check_structure(4096, R, example)
-        assert path == 5 and "k_f4096" in text and "3 waves" in text and asg == [-1] * 4, text
+        assert path == 5 and "k_f4096" in text and "two blocks per workgroup, rows on 3 waves" in text and asg == [-1] * 4, text
     assert check_structure(4096, 2, example, G.FDC_PIPE_NO_FUSED)[0] == 0 and check_structure(4096, 2, example, G.FDC_PIPE_NO_POLY)[0] == 0
     assert check_structure(4096, 2, example, G.FDC_PIPE_FORCE_GENERIC)[0] == 0 and check_structure(4096, 2, example, G.FDC_PIPE_NO_BLOCK)[0] == 5
-    # a full band of 256-bin channels: the two blocks of a workgroup fill its eight waves with four rows each; on its grid it was the two-launch form before
+    # a full band of 256-bin channels: one block per workgroup, four waves of four rows; on its grid it was the two-launch form before
     full = bank(256, range(16))
     path, text, _ = check_structure(4096, 2, full)
-    assert path == 5 and "8 waves" in text, text
+    assert path == 5 and "one block per workgroup, rows on 4 waves" in text, text
     assert check_structure(4096, 2, full, G.FDC_PIPE_NO_FUSED)[0] == 2
-    assert check_structure(4096, 2, bank(256, range(4)))[0] == 5 and "2 waves)" in check_structure(4096, 2, bank(256, range(4)))[1]
-    assert "1 wave)" in check_structure(4096, 2, bank(256, range(2)))[1]
+    assert check_structure(4096, 2, bank(256, range(4)))[0] == 5 and "1 wave)" in check_structure(4096, 2, bank(256, range(4)))[1]
+    # nine 128-bin + nine 64-bin channels take the four waves of one block; with a 256-bin channel more it is a pair of blocks on seven of eight waves
+    assert "one block per workgroup, rows on 4 waves" in check_structure(4096, 2, bank(128, range(9)) + bank(64, range(40, 49)))[1]
+    assert "two blocks per workgroup, rows on 7 waves" in check_structure(4096, 2, bank(128, range(9)) + bank(64, range(40, 49)) + bank(256, [15]))[1]
     # ONE 256-bin channel: the two launches measured 9 % faster; FDC_PIPE_WIDE_UNIFORM (every form without a spectrum in memory, whatever the rule says) keeps it
     assert check_structure(4096, 2, bank(256, [3]))[0] == 2 and check_structure(4096, 2, [(1234, 256, 0.8, 1.0)])[0] == 0
     assert check_structure(4096, 2, [(1234, 256, 0.8, 1.0)], G.FDC_PIPE_WIDE_UNIFORM)[0] == 5 and check_structure(4096, 2, [(1234, 512, 0.8, 1.0)])[0] == 5
