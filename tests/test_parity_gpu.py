@@ -592,8 +592,10 @@ def test_plans_that_read_part_of_the_band_leave_the_rest_unwritten(oracle, N):
                  (N - 1024, 1024, 0.88, 1.0)]
     x = noise(nb * (N - N // R), 91)
     ref, sref = oracle.channelizer(N, R, 1, chans, x, want_spectrum=True, nthreads=4)
-    part = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb).work(x)
-    full = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_FULL_SPECTRUM).work(x)
+    # (round 6: this plan at N = 4096 runs without a spectrum in memory by default; the test is about the spectrum path's partial writes)
+    nf = G.FDC_PIPE_NO_FUSED if N == 4096 else 0
+    part = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=nf).work(x)
+    full = G.Pipeline(N, R, chans, windowtype=1, max_blocks=nb, flags=G.FDC_PIPE_FULL_SPECTRUM | nf).work(x)
     for c in range(len(chans)):
         assert_close(part[c], ref[c], "channel %d" % c)
         assert (part[c] == full[c]).all(), c
