@@ -5,19 +5,20 @@
 // them back: python/FrequencyDomainChannelizer.py:206 (fft_vcc) -> :214-216 (vector_cut_vxx, phase_shifting_windowing_vcc) -> :218-226
 // (ifft, vector_cut_vxx, multiply_const) per channel.
 //
-//   one 512-thread workgroup per PAIR of input blocks (one 256-thread workgroup per block where that fills the waves as well): each team of four waves transforms one block (4096 points = 32 KiB, the same three
-//   DFT-16 layers as k_fft4096, fdc_chanwide.hip) and stores the shifted, 1/N-scaled spectrum to LDS over its exchange tile (32 KiB);
-//   every one of the eight WAVES then owns rows — (block of the pair, channel) — of ONE channel width: the plan's schedule, made by the
-//   host (fdc_api.hip, plan_fused4096).  Two blocks per workgroup because a wave's instructions cost the same for one row as for a full
-//   wave of them: the reference's example plan fills its 1024- and 512-bin waves only with the rows of two blocks.
+//   a workgroup takes T blocks, T teams of four waves: each team transforms one block (4096 points = 32 KiB, the same three DFT-16 layers as
+//   k_fft4096, fdc_chanwide.hip) and stores the shifted, 1/N-scaled spectrum to LDS over its exchange tile (32 KiB); every one of the 4 T
+//   WAVES then owns rows — (block of the workgroup, channel) — of ONE channel width: the plan's schedule, made by the host (fdc_api.hip,
+//   plan_fused4096).  T = 2 (512 threads, two workgroups on a unit) for plans with wide rows: a wave's instructions cost the same for one
+//   row as for a full wave of them, and the reference's example plan fills its 1024- and 512-bin waves only with the rows of two blocks;
+//   T = 1 (256 threads, FOUR workgroups on a unit: four barrier domains instead of two, 11 - 12 % faster) where no row is wide.
 //       l =  256: 16 lanes x 16 points per row, up to eight rows (two sets of four) per wave   (the row machinery of k_c256)
 //       l =  512: 16 lanes x 32 points, up to four rows                                        (k_c512)
 //       l = 1024: 32 lanes x 32 points, up to two rows                                         (k_c1024)
 //       l =  128:  8 lanes x 16 points, eight rows; l = 64 / 32 / 16: 4 / 2 / 1 lanes, eight rows   (DFT-16 over a, exchange inside the row, DFT-8 / 4 / 2 over b)
 //     a row reads its slice from the LDS spectrum and its window row (phase counter in closed form) from memory, runs its first DFT
 //     layer in registers; ONE workgroup barrier (every slice has been read) and the tile is free for the rows' own exchanges, which stay
-//     inside a wave: no further barrier.  Sum of the rows' exchange areas <= the two tiles, at most eight waves of rows: plans with more
-//     (channels that overlap to more than 4096 bins in total) stay on the spectrum path.
+//     inside a wave: no further barrier.  Sum of the rows' exchange areas <= the T tiles, at most 4 T waves of rows: plans with more
+//     (channels that overlap to more than 4096 bins in total, more than 32 narrow channels) stay on the spectrum path.
 // Bytes per block: H = N - N/R new input samples + sum(lout) output samples, nothing else (the window rows and tables are cache hits).
 #include "fdc_kernels.h"
 #include "fdc_radix16.hpp"
