@@ -14,7 +14,7 @@ make -C oracle SAN=1 -s CC="$CLANG -shared-libsan"      # one sanitizer runtime 
 mkdir -p gr-fdc_amd/_san /tmp/fdc_san
 SANF="-fsanitize=address,undefined -fno-omit-frame-pointer"
 cd gr-fdc_amd/csrc
-for f in fdc_api fdc_kernels fdc_fast256 fdc_block256 fdc_block512 fdc_block1024 fdc_blocknarrow fdc_chanwide fdc_sinks fdc_sinks_dev fdc_group; do
+for f in fdc_api fdc_kernels fdc_fast256 fdc_block256 fdc_block512 fdc_block1024 fdc_blocknarrow fdc_chanwide fdc_fused4096 fdc_sinks fdc_sinks_dev fdc_group; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined \
       -Xarch_host -fno-omit-frame-pointer -Wno-unused-result -c $f.hip -o /tmp/fdc_san/$f.o
 done
