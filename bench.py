@@ -615,7 +615,8 @@ def main():
         wl = "%s: %d-pt FFT, 1/%d overlap-save, %d fixed channels (l=%d, lout=%d), %d blocks/step/GPU" % (
             "configs[0] (example flowgraph plan)" if a.config == 1 else
             "configs[1]" if (N, R, C) == (65536, 2, 256) else "configs[3] per-GPU shape" if (N, R, C) == (262144, 2, 1024)
-            else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + (", offset %d bins" % a.offset if a.offset else "") + \
+            else "non-default shape", N, R, len(plan), params[0][1], params[0][2], nb) + \
+            (", widths l = %s as the reference's derivation gives them" % [p_[1] for p_ in params] if a.config == 1 else "") + (", offset %d bins" % a.offset if a.offset else "") + \
             (", %d input rings in rotation (cache-cold input)" % len(rings) if len(rings) > 1 else ", ONE input ring (stays in the memory-side cache)") + \
             (", MIXED widths l = %s" % sorted(set(p_[1] for p_ in params)) if a.mixed else "") + \
             (", TWO BANKS: 128 channels of 256 bins + 64 channels of 512 bins" if a.two_widths else "") + \
