@@ -196,7 +196,9 @@ int32_t fdc_pipeline_chunk_blocks(const fdc_pipeline *p);   /* blocks per intern
  * slices, windows and inverse transforms with the spectrum in LDS, nothing but the new input samples and the output samples crosses the memory interface.
  * Every plan of channels 16 ... 1024 bins wide (any offsets, windows, overlaps between them) of at least 512 and — about — at most 4096 bins in total
  * (exactly: the rows of a pair of blocks fit eight waves — two rows of 1024 bins, four of 512, eight of 256 or less per wave — and the two spectrum tiles);
- * a call that asks for the spectrum runs path 0 on the same handle.  FDC_PIPE_NO_FUSED / FDC_PIPE_NO_POLY: paths 0 / 2 as before.  plan_preview: every channel -1. */
+ * a call that asks for the spectrum runs path 0 on the same handle.  FDC_PIPE_NO_FUSED / FDC_PIPE_NO_POLY: paths 0 / 2 as before (FDC_PIPE_WIDE_UNIFORM: path 5 for
+ * plans under 512 bins too, which the two launches run a few per cent faster).  plan_preview: every channel -1.  The kernel takes one block per workgroup
+ * where no channel is wider than 256 bins and a pair of blocks where one is (fdc_pipeline_describe says which). */
 int32_t fdc_pipeline_path(const fdc_pipeline *p);
 /* The same in words, for logs: which kernels the handle's plan was given ("N = 65536, R = 2, 512 channels; path 3: k_blknar, l = 128, bank of 511 half a
  * channel off the grid + bank of 1 on the grid (two launches)").  Writes at most n bytes including the terminator; returns the untruncated length, -1 for
