@@ -34,6 +34,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_f4[];
 #ifndef F4_EXP
 #define F4_EXP 0
 #endif
+// streamed (nt) accesses: bit 0 = output stores, bit 1 = input loads (A/B: profiles/r06/NOTES.md section 8)
+#ifndef F4_NT
+#define F4_NT 1
+#endif
 namespace {
 constexpr int kF4TilePts = 16 * 272;                         // exchange tile of one block's forward transform; then its spectrum; then rows' exchanges
 // LDS image for T blocks (teams of four waves) per workgroup: [T tiles][W_256^(x y) 16 x 18][W_4096^(x y) 16 x 18][schedule: 4 T waves x 8 slots]
@@ -60,7 +64,11 @@ __device__ __forceinline__ void wave_sync()
 
 __device__ __forceinline__ void out_st(float2 *p, cf v)
 {
+#if F4_NT & 1
+    if (!(F4_EXP & 4) || v.x == 1.2345e30f) __builtin_nontemporal_store(v, reinterpret_cast<cf *>(p));
+#else
     if (!(F4_EXP & 4) || v.x == 1.2345e30f) st2(p, v);
+#endif
 }
 
 struct RowAt { const float2 *win; const float2 *spec; long long dst; bool on; };
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(256 * TEAMS, 4 /* waves per SIMD */) void k_f4096(c
     {
         cf (&u)[16] = reinterpret_cast<cf (&)[16]>(v[0]);
 #pragma unroll
-        for (int c = 0; c < 16; c++) u[c] = m < nb ? ld2(in + ((F4_EXP & 1) ? (size_t)(tid & 15) + 16 * c : (size_t)m * in_stride + (tid + 256 * c))) : mk(0.f, 0.f);
+        for (int c = 0; c < 16; c++) u[c] = m < nb ? ((F4_NT & 2) ? __builtin_nontemporal_load(reinterpret_cast<const cf *>(in + (size_t)m * in_stride + (tid + 256 * c)))
+                                                                   : ld2(in + ((F4_EXP & 1) ? (size_t)(tid & 15) + 16 * c : (size_t)m * in_stride + (tid + 256 * c)))) : mk(0.f, 0.f);
         __syncthreads();
         dft16<false>(u);                                             // layer 1 over c: k0 in u[rev16(k0)]; thread = (a = lo, b = hi)
         {
