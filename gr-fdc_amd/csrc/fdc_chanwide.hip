@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_c1024(const float2 *__restrict__ spe
 #pragma unroll
         for (int q = 0; q < 32; q++) {
             const int tt = b + 32 * q;
-            if (tt >= skip) st2(out + ri.dst + tt, v[pos32(q)] * 1024.f);       // overlap discard, multiply_const(l)
+            if (tt >= skip) st2_out(out + ri.dst + tt, v[pos32(q)] * 1024.f);       // overlap discard, multiply_const(l)
         }
     }
 }
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_c512(const float2 *__restrict__ spec
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int t0 = b + 32 * q, t1 = t0 + 16;
-            if (t0 >= skip) st2(out + ri.dst + t0, u0[rev16(q)] * 512.f);
-            if (t1 >= skip) st2(out + ri.dst + t1, u1[rev16(q)] * 512.f);
+            if (t0 >= skip) st2_out(out + ri.dst + t0, u0[rev16(q)] * 512.f);
+            if (t1 >= skip) st2_out(out + ri.dst + t1, u1[rev16(q)] * 512.f);
         }
     }
 }

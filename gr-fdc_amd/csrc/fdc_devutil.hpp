@@ -129,6 +129,19 @@ __device__ __forceinline__ void bst2t(__amdgpu_buffer_rsrc_t r, unsigned voff, c
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, NT ? 2 : 0);
 }
 __device__ __forceinline__ void st2(float2 *p, cf a) { *reinterpret_cast<cf *>(p) = a; }
+// output samples of the wide channel kernels (k_c512 / k_c1024): written once, read by nobody on the device: streamed (nt) stores, round 6:
+// -4 % on those kernels (profiles/r06/ch_nt_stores_ab.txt; -DFDC_CH_NT=0 builds the plain form)
+#ifndef FDC_CH_NT
+#define FDC_CH_NT 1
+#endif
+__device__ __forceinline__ void st2_out(float2 *p, cf a)
+{
+#if FDC_CH_NT
+    __builtin_nontemporal_store(a, reinterpret_cast<cf *>(p));
+#else
+    *reinterpret_cast<cf *>(p) = a;
+#endif
+}
 
 // 16-byte buffer store of two complex values (NT: streamed, aux bit 1)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -15,6 +15,11 @@
 #include "fdc_devutil.hpp"
 #include <cstdlib>
 
+// k_c256's output stores streamed (nt) like those of k_c512 / k_c1024 (fdc_devutil.hpp st2_out): -2 % on the channel kernels of a mixed plan, -1.3 % on the
+// example plan's, +1.4 % on a full band of 256-bin channels forced onto the spectrum path (profiles/r06/ch_nt_stores_ab.txt); -DFDC_C256_NT=0 builds the plain form
+#ifndef FDC_C256_NT
+#define FDC_C256_NT 1
+#endif
 namespace fdc {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fdc_smem_fast[];
@@ -187,7 +192,13 @@ __global__ __launch_bounds__(256, 4) void k_c256(const float2 *__restrict__ spec
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int tt = b + 16 * q;
-            if (tt >= skip) st2(out + ri.dst + tt, v[rev16(q)] * 256.f);
+            if (tt >= skip) {
+#if FDC_C256_NT
+                st2_out(out + ri.dst + tt, v[rev16(q)] * 256.f);
+#else
+                st2(out + ri.dst + tt, v[rev16(q)] * 256.f);
+#endif
+            }
         }
     }
 }
