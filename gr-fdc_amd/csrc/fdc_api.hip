@@ -525,10 +525,10 @@ bool bank_has_block_kernel(int N, int R, int L, int r, int flags)
     }
 }
 
-// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 16 ... 1024 bins wide.  A workgroup takes a pair of blocks; its
-// rows — (block of the pair, channel) — go to its eight waves, one width per wave: two rows of 1024 bins, four of 512, eight of 256 or less; their exchange
-// areas must fit the two tiles the spectra leave behind.  Always true for plans of 256-bin and wider channels of up to 4096 bins in total; plans of channels
-// that overlap to more (or of more than 32 narrow channels) stay on the spectrum path.
+// N = 4096: the whole plan as ONE launch (fdc_fused4096.hip) when every channel is 16 ... 1024 bins wide.  A workgroup takes T blocks (T = 1 where no channel
+// is wider than 256 bins, else 2); its rows — (block of the workgroup, channel) — go to its 4 T waves, one width per wave: two rows of 1024 bins, four of 512,
+// eight of 256 or less; their exchange areas must fit the T tiles the spectra leave behind.  Always true for plans of 256-bin and wider channels of up to 4096
+// bins in total; plans of channels that overlap to more (or of more than 32 narrow channels) stay on the spectrum path.
 struct F4Class { int l, cls, per_wave, pitch; };
 constexpr F4Class kF4Classes[] = {{1024, 4, 2, 1056}, {512, 3, 4, 513}, {128, 5, 8, 136}, {64, 6, 8, 68}, {32, 7, 8, 34}, {16, 8, 8, 17}};   // (256: below; pitches: rows of a half-wave on different banks)
 bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
@@ -545,8 +545,8 @@ bool plan_fused4096(fdc_pipeline *p, const fdc_pipeline_cfg *cfg, int flags)
         bins += l;
         wide = wide || l >= 512;
     }
-    // ONE 256-bin channel: the two launches are 9 % faster (0.063 against 0.069 ms per 8192 blocks; four such channels: 0.076 / 0.073; everything wider:
-    // 1.3 - 1.6 x for this form, profiles/r06/plan_choice_4096.txt) — the forward transform alone is what both cost, and k_fft4096 has four workgroups per unit
+    // ONE 256-bin channel: the two launches are as fast or a little faster (0.060 - 0.063 against 0.064 ms per 8192 blocks; four such channels: 0.075 / 0.064;
+    // everything wider: 1.3 - 2.8 x for this form, profiles/r06/plan_choice_4096.txt) — the forward transform alone is what both cost
     if (bins < 512 && !(flags & FDC_PIPE_WIDE_UNIFORM)) return false;
     // the schedule for T blocks per workgroup (4 T waves, T tiles): rows by width, the blocks' rows of a channel side by side
     auto schedule = [&](int T) {
